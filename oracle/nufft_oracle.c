@@ -1,0 +1,373 @@
+/* oracle/nufft_oracle.c -- CPU restatement of the reference's NUFFT hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE. Only tests/, the
+ * __graft_entry__.smoke() check and bench.py's `cpu_baseline` leg may load
+ * it. The shipped path (tensorflow-nufft_amd/) never links or calls it.
+ *
+ * What it restates: the FINUFFT-derived CPU plan of mrphys/tensorflow-nufft
+ * v0.12.0 (tensorflow_nufft/cc/kernels/nufft_plan.cc, nufft_plan.h,
+ * nufft_util.cc): parameter rules, exponential-of-semicircle kernel, bin sort,
+ * subproblem spreading, interpolation, deconvolution, and the transform
+ * driver. Each function cites the file:line it follows. Nothing is copied:
+ *  - the reference's generated Horner tables (kernel_horner_*.inc) are NOT
+ *    used; method 1 fits its own polynomials to the defining formula;
+ *  - the LGPL Gauss-Legendre routine (legendre_rule_fast.cc) is replaced by
+ *    a Newton iteration on the Legendre recurrence;
+ *  - FFTW (absent from this image) is replaced by a small mixed-radix FFT.
+ *
+ * Parity pinning. The reference cannot be built or imported here (it needs
+ * TensorFlow, FFTW3, protoc, Eigen: SURVEY.md section 8c) and its tests hold
+ * no stored golden vectors. This oracle is pinned by
+ *  (1) the reference tests' own numeric oracle, the dense NUDFT definition
+ *      (python/ops/nufft_ops.py:235-321), restated in oracle/nudft.py, and
+ *      their known-answer tests (interp(ones) = ones, spread mean = 1,
+ *      period invariance): tests/test_oracle.py;
+ *  (2) the two pieces of the reference that DO compile standalone from the
+ *      sources where they lie (oracle/Makefile -> oracle/_ref/): the
+ *      generated Horner kernel tables and the Gauss-Legendre rule, whose
+ *      outputs are stored as tests/golden/ref_*.npz and compared with this
+ *      file's kernel evaluation and quadrature.
+ *
+ * Build: see oracle/Makefile (gcc -O3 -fopenmp -shared).
+ */
+#include <math.h>
+#include <omp.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+#define ORACLE_MAX_W 16          /* kMaxKernelWidth, nufft_plan.h:68 */
+#define ORACLE_MAX_COEF 24
+#define ORACLE_RANGE_STRICT 0    /* PointsRange, nufft_options.proto */
+#define ORACLE_RANGE_EXTENDED 1
+#define ORACLE_RANGE_INFINITE 2
+
+enum {
+  ORACLE_OK = 0,
+  ORACLE_ERR_RANK = 1,
+  ORACLE_ERR_TYPE = 2,
+  ORACLE_ERR_GRID = 3,     /* spread-only grid not even/smooth/>=2w */
+  ORACLE_ERR_SIGMA = 4,
+  ORACLE_ERR_NTRANSF = 5
+};
+
+typedef struct {
+  int32_t type;          /* 1 or 2 */
+  int32_t rank;          /* 1..3 */
+  int64_t N[3];          /* modes, x fastest (FINUFFT order) */
+  int32_t iflag;         /* -1 forward, +1 backward (nufft_plan.h:126-129) */
+  int32_t ntransf;
+  double tol;            /* as given by the caller (float32 attr upstream) */
+  double sigma;          /* 0 = reference CPU rule; else forced */
+  int32_t w;             /* 0 = reference rule; else forced */
+  int32_t spread_only;
+  int32_t points_range;  /* ORACLE_RANGE_* */
+  int32_t kerevalmeth;   /* 0 formula, 1 own Horner fit */
+  int32_t nthreads;      /* 0 = all */
+} oracle_opts;
+
+typedef struct {
+  double sigma;
+  int32_t w;
+  int32_t ncoef;
+  double beta;
+  int64_t nf[3];
+} oracle_info;
+
+typedef struct {
+  int w, method, ncoef;
+  double beta, c, half_width, sigma;
+  double horner[ORACLE_MAX_COEF * ORACLE_MAX_W]; /* [k][j]: coeff of z^k, cell j */
+} kernel_params;
+
+/* ------------------------------------------------------------ parameters */
+
+/* Reference: next_smooth_integer nufft_plan.h:628-649 (same rule as
+ * next_smooth_int nufft_util.cc:119-133): smallest even integer >= n whose
+ * prime factors are <= 5. */
+int64_t oracle_next_smooth_even(int64_t n) {
+  if (n <= 2) return 2;
+  if (n % 2 == 1) n += 1;
+  for (;; n += 2) {
+    int64_t d = n;
+    while (d % 2 == 0) d /= 2;
+    while (d % 3 == 0) d /= 3;
+    while (d % 5 == 0) d /= 5;
+    if (d == 1) return n;
+  }
+}
+
+/* Gauss-Legendre nodes/weights on [-1,1], nodes descending (z[0] largest),
+ * by Newton iteration on the Legendre recurrence. Replaces
+ * legendre_compute_glr (legendre_rule_fast.cc:28, LGPL, not copied), which
+ * returns the same rule in ascending order; the rule is symmetric and the
+ * quadrature sum in oracle_kernel_fseries is order independent, so taking
+ * "the first q of 2q nodes" selects one half-interval either way.
+ * tests/test_oracle.py checks nodes and weights against the reference build. */
+void oracle_gauss_legendre(int n, double *z, double *w) {
+  for (int i = 0; i < n; ++i) {
+    double x = cos(M_PI * (i + 0.75) / (n + 0.5));
+    double dp = 1.0;
+    for (int it = 0; it < 100; ++it) {
+      double p0 = 1.0, p1 = x;
+      for (int k = 2; k <= n; ++k) {
+        double pk = ((2.0 * k - 1.0) * x * p1 - (k - 1.0) * p0) / k;
+        p0 = p1;
+        p1 = pk;
+      }
+      dp = n * (x * p1 - p0) / (x * x - 1.0);
+      double dx = p1 / dp;
+      x -= dx;
+      if (fabs(dx) < 1e-16) break;
+    }
+    /* recompute derivative at the converged node */
+    double p0 = 1.0, p1 = x;
+    for (int k = 2; k <= n; ++k) {
+      double pk = ((2.0 * k - 1.0) * x * p1 - (k - 1.0) * p0) / k;
+      p0 = p1;
+      p1 = pk;
+    }
+    dp = n * (x * p1 - p0) / (x * x - 1.0);
+    z[i] = x;
+    w[i] = 2.0 / ((1.0 - x * x) * dp * dp);
+  }
+}
+
+static double es_kernel_d(double x, const kernel_params *kp) {
+  if (fabs(x) >= kp->half_width) return 0.0;
+  return exp(kp->beta * sqrt(1.0 - kp->c * x * x));
+}
+
+/* Fit, for each stencil cell j, a degree-(nc-1) polynomial in z in [-1,1] to
+ * phi((z + 1 - w)/2 + j), by interpolation at Chebyshev nodes followed by
+ * conversion to monomial coefficients (all in double). This plays the role
+ * of the reference's generated tables kernel_horner_sigma2.inc /
+ * kernel_horner_sigma125.inc, whose degrees it matches approximately
+ * (nc = w + 3 for sigma 2, w + 2 otherwise, per SURVEY.md section 2 row 5 ...
+ * here we simply take a degree high enough for ~1e-10 relative error). */
+static void fit_horner_table(kernel_params *kp) {
+  const int w = kp->w;
+  int nc = w + 6;
+  if (nc > ORACLE_MAX_COEF) nc = ORACLE_MAX_COEF;
+  kp->ncoef = nc;
+  double node[ORACLE_MAX_COEF], val[ORACLE_MAX_COEF], cheb[ORACLE_MAX_COEF];
+  for (int j = 0; j < w; ++j) {
+    for (int i = 0; i < nc; ++i) {
+      node[i] = cos(M_PI * (i + 0.5) / nc);
+      double x1 = (node[i] + 1.0 - w) / 2.0;
+      double x = x1 + j;
+      /* the open-interval cutoff of evaluate_kernel only matters at the two
+       * end points |x| = w/2, where phi -> exp(0) = 1 continuously */
+      double t = 1.0 - kp->c * x * x;
+      val[i] = exp(kp->beta * sqrt(t > 0 ? t : 0));
+    }
+    for (int k = 0; k < nc; ++k) {
+      double s = 0;
+      for (int i = 0; i < nc; ++i) s += val[i] * cos(M_PI * k * (i + 0.5) / nc);
+      cheb[k] = s * (k == 0 ? 1.0 : 2.0) / nc;
+    }
+    /* Chebyshev -> monomial via T_{k+1} = 2 z T_k - T_{k-1} */
+    double mono[ORACLE_MAX_COEF] = {0};
+    double tkm1[ORACLE_MAX_COEF] = {0}, tk[ORACLE_MAX_COEF] = {0};
+    tkm1[0] = 1.0; /* T0 */
+    tk[1] = 1.0;   /* T1 */
+    for (int m = 0; m < nc; ++m) mono[m] += cheb[0] * tkm1[m];
+    if (nc > 1)
+      for (int m = 0; m < nc; ++m) mono[m] += cheb[1] * tk[m];
+    for (int k = 2; k < nc; ++k) {
+      double tn[ORACLE_MAX_COEF] = {0};
+      for (int m = 0; m < nc; ++m) {
+        if (m > 0) tn[m] += 2.0 * tk[m - 1];
+        tn[m] -= tkm1[m];
+      }
+      for (int m = 0; m < nc; ++m) {
+        mono[m] += cheb[k] * tn[m];
+        tkm1[m] = tk[m];
+        tk[m] = tn[m];
+      }
+    }
+    for (int k = 0; k < nc; ++k) kp->horner[k * ORACLE_MAX_W + j] = mono[k];
+  }
+}
+
+/* Parameter selection. Reference:
+ *  - tolerance clamp            nufft_plan.cc:189, nufft_plan.h:84-89
+ *  - sigma and kernel width     set_default_options nufft_plan.h:739-780
+ *  - beta, c, half width        setup_spreader nufft_plan.cc:885-947
+ *  - fine grid size             initialize_fine_grid nufft_plan.h:803-863
+ * `fbytes` selects the precision the rules are evaluated in (the reference
+ * evaluates them in FloatType, which changes w at tol = 1e-6 in float). */
+int oracle_setup(const oracle_opts *o, int fbytes, kernel_params *kp,
+                 int64_t N[3], int64_t nf[3], oracle_info *info) {
+  if (o->rank < 1 || o->rank > 3) return ORACLE_ERR_RANK;
+  if (o->type != 1 && o->type != 2) return ORACLE_ERR_TYPE;
+  if (o->ntransf < 1) return ORACLE_ERR_NTRANSF;
+  int64_t gsize = 1;
+  for (int d = 0; d < 3; ++d) {
+    N[d] = d < o->rank ? o->N[d] : 1;
+    nf[d] = 1;
+    gsize *= N[d];
+  }
+  double tol = o->tol;
+  if (fbytes == 4) {
+    float tf = (float)tol;
+    if (tf < 6e-08f) tf = 6e-08f;
+    tol = (double)tf;
+  } else if (tol < 1.1e-16) {
+    tol = 1.1e-16;
+  }
+  double sigma = o->sigma;
+  if (o->spread_only) sigma = 2.0;   /* nufft_kernels.cc:457-460 */
+  if (sigma == 0.0) {
+    sigma = 2.0;
+    if (tol >= (fbytes == 4 ? (double)1e-9f : 1e-9)) {
+      if ((o->rank == 1 && gsize > 10000000) ||
+          (o->rank == 2 && gsize > 300000) ||
+          (o->rank == 3 && gsize > 3000000))
+        sigma = 1.25;
+    }
+  } else if (sigma <= 1.0) {
+    return ORACLE_ERR_SIGMA;
+  }
+  int w = o->w;
+  if (w == 0) {
+    /* The reference writes `std::ceil(-log10(tol_ / FloatType(10.0)))` with an
+     * UNQUALIFIED log10 (nufft_plan.h:766, nufft_plan.cu.cc:3067). Compiled
+     * with this image's g++ 11 / glibc that resolves to ::log10(double) of the
+     * FloatType quotient (checked with a 6-line program; recorded in
+     * DESIGN.md), so in float tol = 1e-6 gives 6.99999999 -> w = 7, while in
+     * double the float32 attr 1e-6f = 9.99999997e-7 gives 7.000000001 -> 8. */
+    if (sigma == 2.0) {
+      if (fbytes == 4) w = (int)ceil(-log10((double)((float)tol / 10.0f)));
+      else w = (int)ceil(-log10(tol / 10.0));
+    } else {
+      if (fbytes == 4)
+        w = (int)ceil(-log((double)(float)tol) /
+                      ((double)(float)M_PI * sqrt(1.0 - 1.0 / sigma)));
+      else
+        w = (int)ceil(-log(tol) / (M_PI * sqrt(1.0 - 1.0 / sigma)));
+    }
+    if (w < 2) w = 2;
+    if (w > ORACLE_MAX_W) w = ORACLE_MAX_W;
+  }
+  double beta_over_w = 2.30;
+  if (w == 2) beta_over_w = 2.20;
+  if (w == 3) beta_over_w = 2.26;
+  if (w == 4) beta_over_w = 2.38;
+  if (sigma != 2.0) beta_over_w = 0.97 * M_PI * (1.0 - 1.0 / (2.0 * sigma));
+  memset(kp, 0, sizeof(*kp));
+  kp->w = w;
+  kp->sigma = sigma;
+  kp->method = o->kerevalmeth;
+  kp->beta = beta_over_w * w;
+  kp->c = 4.0 / ((double)w * w);
+  kp->half_width = w / 2.0;
+  if (kp->method == 1) fit_horner_table(kp);
+
+  for (int d = 0; d < o->rank; ++d) {
+    int64_t n = o->spread_only ? N[d] : (int64_t)((double)N[d] * sigma);
+    if (n < 2 * w) n = 2 * w;
+    n = oracle_next_smooth_even(n);
+    if (o->spread_only && n != N[d]) return ORACLE_ERR_GRID;
+    nf[d] = n;
+  }
+  if (info) {
+    info->sigma = sigma;
+    info->w = w;
+    info->ncoef = kp->ncoef;
+    info->beta = kp->beta;
+    for (int d = 0; d < 3; ++d) info->nf[d] = nf[d];
+  }
+  return ORACLE_OK;
+}
+
+/* Fourier series of the kernel on a grid of nf points, k = 0..nf/2.
+ * Reference: kernel_fseries_1d nufft_util.cc:71-117: q = floor(2 + 3 w/2)
+ * positive Gauss-Legendre nodes z_n scaled to (0, w/2), f_n = (w/2) wt_n
+ * phi(z_n), phihat[k] = sum_n 2 f_n Re exp(2 pi i k (nf/2 - z_n)/nf).
+ * The reference winds the phases by repeated complex multiplication in
+ * FloatType; here each phase is a direct double cos (more accurate, same
+ * definition). */
+void oracle_kernel_fseries(int64_t nf, const kernel_params *kp, double *out) {
+  const double hw = kp->half_width;
+  const int q = (int)(2 + 3.0 * hw);
+  double z[2 * 100], wt[2 * 100];
+  oracle_gauss_legendre(2 * q, z, wt);
+  double f[100], zn[100];
+  for (int n = 0; n < q; ++n) { /* first q nodes of ours are the positive ones */
+    zn[n] = z[n] * hw;
+    f[n] = hw * wt[n] * es_kernel_d(zn[n], kp);
+  }
+  for (int64_t k = 0; k <= nf / 2; ++k) {
+    double s = 0;
+    for (int n = 0; n < q; ++n)
+      s += 2.0 * f[n] *
+           cos(2.0 * M_PI * (double)k * ((double)(nf / 2) - zn[n]) / (double)nf);
+    out[k] = s;
+  }
+}
+
+void oracle_fseries(const oracle_opts *o, int fbytes, int64_t nf, double *out) {
+  kernel_params kp;
+  int64_t N[3], nfd[3];
+  oracle_info info;
+  if (oracle_setup(o, fbytes, &kp, N, nfd, &info)) return;
+  oracle_kernel_fseries(nf, &kp, out);
+}
+
+/* Spread-/interp-only normalisation. Reference: calculate_scale_factor
+ * nufft_util.cc:43-62 (100-interval rule on [-1,1] of exp(beta sqrt(1-x^2)),
+ * times w/2, to the power rank, inverted). */
+double oracle_scale_factor(int rank, const kernel_params *kp) {
+  const int n = 100;
+  const double h = 2.0 / n;
+  double x = -1.0, sum = 0.0;
+  for (int i = 1; i < n; ++i) {
+    x += h;
+    sum += exp(kp->beta * sqrt(1.0 - x * x));
+  }
+  sum += 1.0;
+  sum *= h;
+  sum *= sqrt(1.0 / kp->c);
+  double scale = sum;
+  if (rank > 1) scale *= sum;
+  if (rank > 2) scale *= sum;
+  return 1.0 / scale;
+}
+
+int oracle_query(const oracle_opts *o, int fbytes, oracle_info *info) {
+  kernel_params kp;
+  int64_t N[3], nf[3];
+  return oracle_setup(o, fbytes, &kp, N, nf, info);
+}
+
+/* ------------------------------------------- precision-specific bodies */
+
+#define FLT float
+#define SUF(name) name##_f32
+#define FABS fabsf
+#define EXP expf
+#define SQRT sqrtf
+#define CEIL ceilf
+#define FMOD fmodf
+#include "nufft_oracle_impl.h"
+#undef FLT
+#undef SUF
+#undef FABS
+#undef EXP
+#undef SQRT
+#undef CEIL
+#undef FMOD
+
+#define FLT double
+#define SUF(name) name##_f64
+#define FABS fabs
+#define EXP exp
+#define SQRT sqrt
+#define CEIL ceil
+#define FMOD fmod
+#include "nufft_oracle_impl.h"
