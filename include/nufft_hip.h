@@ -1,0 +1,180 @@
+/* include/nufft_hip.h -- C ABI of libnufft_hip.so, the MI355X (gfx950) NUFFT
+ * plan library. Plain pointers and sizes only: no TensorFlow, torch or C++
+ * types cross this boundary.
+ *
+ * It replaces, for the GPU device, the interface the reference's TensorFlow
+ * op kernels call (paths relative to the reference checkout,
+ * tensorflow_nufft/cc/kernels/):
+ *
+ *   Plan<GPUDevice,FloatType>::initialize   nufft_plan.h:223-231, nufft_plan.cu.cc:1808-2030
+ *   Plan<GPUDevice,FloatType>::set_points   nufft_plan.h:237-241, nufft_plan.cu.cc:2054-2111
+ *   Plan<GPUDevice,FloatType>::execute      nufft_plan.h:245,     nufft_plan.cu.cc:2113-2168
+ *   Plan<GPUDevice,FloatType>::interp       nufft_plan.h:250,     nufft_plan.cu.cc:2170-2196
+ *   Plan<GPUDevice,FloatType>::spread       nufft_plan.h:255,     nufft_plan.cu.cc:2198-2225
+ *   NUFFTBaseOp::Compute / ::Execute        nufft_kernels.cc:54-542 (op-level entry below)
+ *
+ * Conventions (same as the reference plan):
+ *  - grid dimensions are given x-fastest ("FINUFFT order" = the TF grid shape
+ *    reversed, nufft_kernels.cc:347-352); mode arrays f are [ntransf][N3][N2][N1]
+ *    contiguous with N1 fastest, CMCL mode order (index 0 = most negative mode);
+ *  - strengths c are [ntransf][M] interleaved complex;
+ *  - points are device arrays of the plan's real type, in radians/sample;
+ *  - iflag -1 = 'forward' (exp(-i k x)), +1 = 'backward' (nufft_plan.h:126-129);
+ *  - every pointer marked "device" must be valid on the plan's device; all work
+ *    is enqueued on the plan's stream and no call synchronises the device
+ *    unless stated.
+ * Unlike the reference, the points buffer is NOT modified (the reference folds
+ * and rescales it in place, nufft_plan.h:902-947).
+ *
+ * Thread safety: distinct plans may be used concurrently from distinct
+ * threads; one plan must not be used from two threads at once (the reference
+ * builds one Plan per Compute call, nufft_kernels.cc:474-475).
+ */
+#ifndef NUFFT_HIP_H_
+#define NUFFT_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NUFFT_HIP_ABI_VERSION 1
+
+/* Status codes. They map onto the tensorflow::errors the reference returns. */
+enum {
+  NUFFT_HIP_OK = 0,
+  NUFFT_HIP_INVALID_ARGUMENT = 3,    /* errors::InvalidArgument  */
+  NUFFT_HIP_RESOURCE_EXHAUSTED = 8,  /* errors::ResourceExhausted */
+  NUFFT_HIP_UNIMPLEMENTED = 12,      /* errors::Unimplemented    */
+  NUFFT_HIP_INTERNAL = 13            /* errors::Internal (HIP / rocFFT failure) */
+};
+
+enum { NUFFT_HIP_TYPE_1 = 1, NUFFT_HIP_TYPE_2 = 2 };
+enum { NUFFT_HIP_FORWARD = -1, NUFFT_HIP_BACKWARD = 1 };
+enum { NUFFT_HIP_F32 = 4, NUFFT_HIP_F64 = 8 };          /* bytes of the real type */
+/* PointsRange, tensorflow_nufft/proto/nufft_options.proto and nufft_plan.h:676-734 */
+enum { NUFFT_HIP_RANGE_STRICT = 0, NUFFT_HIP_RANGE_EXTENDED = 1, NUFFT_HIP_RANGE_INFINITE = 2 };
+/* spread_method: how type-1 spreading / type-2 interpolation run */
+enum {
+  NUFFT_HIP_METHOD_AUTO = 0,
+  NUFFT_HIP_METHOD_TILE_GENERIC = 1, /* LDS tile, one thread per point (any w, rank, precision) */
+  NUFFT_HIP_METHOD_TILE_WAVE = 2     /* LDS tile, one point per wavefront pass (specialised widths) */
+};
+enum { NUFFT_HIP_OP_NUFFT = 0, NUFFT_HIP_OP_INTERP = 1, NUFFT_HIP_OP_SPREAD = 2 };
+
+/* Options. The first four fields are the reference's user-visible Options
+ * (python/ops/nufft_options.py:222-273, proto/nufft_options.proto:27-32); the
+ * rest correspond to InternalOptions (nufft_options.h:92-162). Zero means
+ * "choose automatically" everywhere. Initialise with nufft_hip_default_options. */
+typedef struct nufft_hip_options {
+  int32_t max_batch_size;      /* Options.max_batch_size; 0 = auto */
+  int32_t points_range;        /* NUFFT_HIP_RANGE_*; default EXTENDED */
+  int32_t check_points_range;  /* debugging.check_points_range (costs one host sync) */
+  int32_t fftw_planning_rigor; /* accepted, ignored (rocFFT) */
+  int32_t spread_only;         /* Interp / Spread ops: no upsampling, no FFT */
+  int32_t kernel_width;        /* 0 = from tol */
+  double upsampling_factor;    /* 0 = 2.0 */
+  int32_t spread_method;       /* NUFFT_HIP_METHOD_* */
+  int32_t max_subproblem_size; /* points per workgroup pass; 0 = auto */
+  int32_t tile_dims[3];        /* fine-grid cells per tile, x fastest; 0 = auto */
+  int32_t reserved[8];
+} nufft_hip_options;
+
+typedef struct nufft_hip_plan_s* nufft_hip_plan;
+
+typedef struct nufft_hip_plan_info {
+  int32_t type, rank, precision, iflag, ntransf, batch_size;
+  int32_t kernel_width, ncoef, spread_method;
+  double upsampling_factor, beta, tol;
+  int64_t grid_dims[3], fine_dims[3];
+  int32_t tile_dims[3], num_tiles[3];
+  int32_t max_subproblem_size;
+  int64_t num_points;
+  int64_t workspace_bytes;
+} nufft_hip_plan_info;
+
+int nufft_hip_abi_version(void);
+void nufft_hip_default_options(nufft_hip_options* opts);
+
+/* = Plan::initialize. grid_dims has `rank` entries, x fastest. `stream` is a
+ * hipStream_t (NULL = the null stream). On failure *plan is NULL and, if
+ * errbuf is given, a message is written there. */
+int nufft_hip_plan_create(nufft_hip_plan* plan, int type, int rank,
+                          const int64_t* grid_dims, int iflag, int ntransf,
+                          double tol, int precision,
+                          const nufft_hip_options* opts, void* stream,
+                          char* errbuf, size_t errbuf_len);
+
+/* = Plan::set_points. x, y, z: device pointers (y, z ignored below rank 2, 3).
+ * `stride` is the element stride between consecutive points (1 for separate
+ * arrays; `rank` when x, y, z point into one [M, rank] array). */
+int nufft_hip_set_points(nufft_hip_plan plan, int64_t num_points,
+                         const void* x, const void* y, const void* z,
+                         int64_t stride);
+
+/* = Plan::execute. Type 1: reads c, writes f. Type 2: reads f, writes c. */
+int nufft_hip_execute(nufft_hip_plan plan, void* c, void* f);
+/* = Plan::spread / Plan::interp (plan created with opts.spread_only = 1):
+ * f is the [ntransf][grid] array itself (no upsampling). */
+int nufft_hip_spread(nufft_hip_plan plan, const void* c, void* f);
+int nufft_hip_interp(nufft_hip_plan plan, void* c, const void* f);
+
+int nufft_hip_plan_get_info(nufft_hip_plan plan, nufft_hip_plan_info* info);
+/* Host-only: runs every parameter rule of plan creation (kernel width, fine
+ * grid, tiles, polynomial degree, batch size, method) without touching a
+ * device, and reports the result. Same arguments / errors as plan_create. */
+int nufft_hip_plan_describe(int type, int rank, const int64_t* grid_dims, int iflag,
+                            int ntransf, double tol, int precision,
+                            const nufft_hip_options* opts, nufft_hip_plan_info* info,
+                            char* errbuf, size_t errbuf_len);
+int nufft_hip_plan_set_stream(nufft_hip_plan plan, void* stream);
+const char* nufft_hip_last_error(nufft_hip_plan plan);
+int nufft_hip_plan_destroy(nufft_hip_plan plan);
+
+/* Debug/test access to intermediate stages (device pointers, valid until the
+ * next call on the plan): the fine grid of the last batch, and the kernel
+ * Fourier-series reciprocals per dimension (host copy). */
+int nufft_hip_debug_fine_grid(nufft_hip_plan plan, void** fine, int64_t* count);
+int nufft_hip_debug_fseries(nufft_hip_plan plan, int dim, double* out, int64_t n);
+/* Evaluates the plan's piecewise-polynomial kernel on the host for n offsets
+ * x1 in [-w/2, -w/2+1] (out: n*w values, normalised so that phi(0) = 1). */
+int nufft_hip_debug_eval_kernel(nufft_hip_plan plan, int n, const double* x1, double* out);
+
+/* ---- Op-level entry: the host logic of NUFFTBaseOp::Compute/Execute --------
+ * (nufft_kernels.cc:54-542): validation with the reference's error messages,
+ * batch-shape broadcasting (dimensions where the points batch is 1 become
+ * num_transforms; the others become sequential set_points+execute calls),
+ * and the loop over calls. Shapes are in TensorFlow order (grid slowest first,
+ * points [..., M, rank] with the last axis ordered like the grid).
+ *
+ * Call nufft_hip_op_shape first to validate and obtain the output shape,
+ * allocate `target` (device), then nufft_hip_op_compute.                   */
+typedef struct nufft_hip_op_desc {
+  int32_t op_type;         /* NUFFT_HIP_OP_* */
+  int32_t transform_type;  /* NUFFT_HIP_TYPE_* */
+  int32_t fft_direction;   /* NUFFT_HIP_FORWARD / BACKWARD */
+  int32_t precision;       /* NUFFT_HIP_F32 / F64 */
+  double tol;              /* the op's `tol: float` attr (cc/ops/nufft_ops.cc:214) */
+  nufft_hip_options options;
+  int32_t source_ndim, points_ndim, grid_shape_len;
+  int64_t source_shape[12];
+  int64_t points_shape[12];
+  int64_t grid_shape[3];   /* the `grid_shape` input (type 1; TF order) */
+} nufft_hip_op_desc;
+
+int nufft_hip_op_shape(const nufft_hip_op_desc* desc, int32_t* target_ndim,
+                       int64_t* target_shape /* >= 12 entries */,
+                       char* errbuf, size_t errbuf_len);
+int nufft_hip_op_compute(const nufft_hip_op_desc* desc, const void* source,
+                         const void* points, void* target, void* stream,
+                         char* errbuf, size_t errbuf_len);
+/* Plans built by nufft_hip_op_compute are cached per configuration; this
+ * releases them (and their device memory). */
+void nufft_hip_op_clear_cache(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* NUFFT_HIP_H_ */

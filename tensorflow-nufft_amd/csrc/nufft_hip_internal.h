@@ -1,0 +1,91 @@
+// Internal declarations shared by the host plan (nufft_plan.cpp), the op-level
+// host logic (nufft_op.cpp) and the gfx950 kernels (nufft_kernels.hip).
+#ifndef NUFFT_HIP_INTERNAL_H_
+#define NUFFT_HIP_INTERNAL_H_
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "nufft_hip.h"
+
+namespace nufft_hip {
+
+constexpr int kMaxW = 16;        // kMaxKernelWidth, reference nufft_plan.h:68
+constexpr int kMaxCoef = 24;     // polynomial terms per stencil cell
+constexpr int kWaveCoef = 12;    // fixed term count of the wave-per-point kernels
+constexpr int kBlock = 256;      // threads per workgroup of the tile kernels
+
+// Geometry of one plan, passed by value to every kernel.
+struct Geom {
+  int rank;
+  int w;            // kernel width
+  int ncoef;        // polynomial terms
+  int nf[3];        // fine grid, x fastest
+  int tile[3];      // tile size in fine cells
+  int ntile[3];     // tiles per dimension
+  int ldim[3];      // LDS tile extent = tile + w - 1
+  int lstride;      // padded LDS row length (>= ldim[0])
+  int ntiles;       // product of ntile
+  int max_sub;      // points per subproblem
+  int nmodes[3];    // N, x fastest
+};
+
+// Per-point records in tile-sorted order (device arrays of length M).
+template <typename T>
+struct SortedPoints {
+  const uint32_t* loc;   // stencil start relative to the tile: l0 | l1<<10 | l2<<20
+  const T* z[3];         // Horner argument per dimension, in [-1, 1]
+  const int32_t* idx;    // original point index
+  const int32_t* tile_start;  // [ntiles + 1]
+  const int32_t* sub_start;   // [ntiles + 1] exclusive scan of ceil(count / max_sub)
+};
+
+struct PrepArgs {
+  const void* pts[3];
+  int64_t stride;
+  int64_t M;
+  int range_mode;
+  int check_range;
+  uint32_t* loc;
+  void* z[3];
+  int32_t* tile_of;
+  int32_t* rank_of;
+  int32_t* tile_count;
+  int32_t* bad_count;   // points outside the accepted range (debug check)
+};
+
+// Launchers (nufft_kernels.hip). All enqueue on `stream` and return hipGetLastError().
+template <typename T>
+hipError_t launch_prep(const Geom& g, const PrepArgs& a, hipStream_t stream);
+hipError_t launch_scan(const Geom& g, const int32_t* tile_count, int32_t* tile_start,
+                       int32_t* sub_start, hipStream_t stream);
+template <typename T>
+hipError_t launch_scatter(const Geom& g, int64_t M, const uint32_t* loc_in, T* const z_in[3],
+                          const int32_t* tile_of, const int32_t* rank_of,
+                          const int32_t* tile_start, uint32_t* loc_out, T* const z_out[3],
+                          int32_t* idx_out, hipStream_t stream);
+template <typename T>
+hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, int64_t M,
+                         const T* horner, const T* c, T* fw, int batch, int64_t c_stride,
+                         int64_t fw_stride, T scale, size_t lds_bytes, hipStream_t stream);
+template <typename T>
+hipError_t launch_interp(const Geom& g, int method, const SortedPoints<T>& sp, int64_t M,
+                         const T* horner, T* c, const T* fw, int batch, int64_t c_stride,
+                         int64_t fw_stride, T scale, hipStream_t stream);
+// dir 1: f = fw / phihat (type-1 step 3); dir 2: fw = f / phihat, zero elsewhere (type-2 step 1).
+template <typename T>
+hipError_t launch_deconvolve(const Geom& g, int dir, T* f, T* fw, const T* const rfser[3],
+                             int batch, hipStream_t stream);
+// Generic strided copy used by the op-level host code for batch-dimension permutes.
+hipError_t launch_permute(const void* src, void* dst, int elem_bytes, int ndim,
+                          const int64_t* out_shape, const int64_t* src_strides,
+                          hipStream_t stream);
+size_t spread_lds_bytes(const Geom& g, int method, int precision);
+bool wave_method_supported(const Geom& g, int precision);
+
+}  // namespace nufft_hip
+
+#endif  // NUFFT_HIP_INTERNAL_H_

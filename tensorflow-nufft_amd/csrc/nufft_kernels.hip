@@ -1,0 +1,742 @@
+// gfx950 (MI355X, CDNA4) kernels of the NUFFT plan: point preparation, tile
+// sort, exponential-of-semicircle spreading (type 1) and interpolation
+// (type 2), and the fused deconvolution / mode-reordering step.
+//
+// Replaces the CUDA kernels of the reference's
+// tensorflow_nufft/cc/kernels/nufft_plan.cu.cc (inventory: SURVEY.md 2.1):
+//   CalcBinSizeNoGhost*/CalcInvertofGlobalSortIdx*  (:160-296)  -> prep / scan / scatter
+//   CalcSubproblem / MapBinToSubproblem            (:304-320)  -> scan + in-kernel search
+//   SpreadSubproblem*                               (:530-960, :1295-1511) -> spread_tile_*
+//   InterpNuptsDriven* / InterpSubproblem*          (:653-704, :963-1187, :1513-1804) -> interp_tile_*
+//   Deconvolve* / Amplify*                          (:326-435)  -> deconvolve_kernel
+// None of it is a translation: the data layout (tile-local stencil starts +
+// fractional Horner arguments computed in double), the binning rule (by
+// stencil start, so the halo is one sided), the subproblem lookup (binary
+// search in a scanned array, no host sync) and the wavefront-per-point
+// scatter are specific to this build. Wavefront = 64 lanes throughout.
+#include "nufft_hip_internal.h"
+
+namespace nufft_hip {
+
+namespace {
+
+constexpr double kPiD = 3.14159265358979323846;
+
+// ----------------------------------------------------------------- helpers
+
+template <typename T>
+__device__ __forceinline__ T horner_cell(const T* __restrict__ tab, int nc, int j, T z) {
+  T acc = tab[(nc - 1) * kMaxW + j];
+  for (int k = nc - 2; k >= 0; --k) acc = fma(acc, z, tab[k * kMaxW + j]);
+  return acc;
+}
+
+__device__ __forceinline__ void lds_add(float* p, float v) { unsafeAtomicAdd(p, v); }
+__device__ __forceinline__ void lds_add(double* p, double v) { unsafeAtomicAdd(p, v); }
+__device__ __forceinline__ void glb_add(float* p, float v) { unsafeAtomicAdd(p, v); }
+__device__ __forceinline__ void glb_add(double* p, double v) { unsafeAtomicAdd(p, v); }
+
+// Which subproblem does workgroup `s` own? sub_start is the exclusive scan of
+// per-tile subproblem counts; returns the tile and the point range.
+__device__ __forceinline__ bool locate_subproblem(const Geom& g, const int32_t* __restrict__ tile_start,
+                                                  const int32_t* __restrict__ sub_start, int s,
+                                                  int* tile, int* p0, int* p1) {
+  const int nt = g.ntiles;
+  if (s >= sub_start[nt]) return false;
+  int lo = 0, hi = nt;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (sub_start[mid] <= s) lo = mid; else hi = mid;
+  }
+  const int chunk = s - sub_start[lo];
+  const int a = tile_start[lo] + chunk * g.max_sub;
+  const int e = tile_start[lo + 1];
+  *tile = lo;
+  *p0 = a;
+  *p1 = (a + g.max_sub < e) ? a + g.max_sub : e;
+  return true;
+}
+
+// ------------------------------------------------------------ prep + sort
+
+// One thread per point: fold + rescale in DOUBLE (reference FoldAndRescale,
+// nufft_plan.h:676-734, does it in FloatType, which costs ~eps*nf cells of
+// position error in float), split into integer stencil start i0 = ceil(x' -
+// w/2) (reference nufft_plan.cu.cc:838-841 / nufft_plan.cc:1496) and Horner
+// argument z = 2(i0 - x') + w - 1 in [-1, 1]; bin by the wrapped stencil start.
+template <typename T>
+__global__ __launch_bounds__(256) void prep_points_kernel(Geom g, PrepArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.M) return;
+  uint32_t loc = 0;
+  int tc[3] = {0, 0, 0};
+  bool bad = false;
+  for (int d = 0; d < g.rank; ++d) {
+    const double x = (double)((const T*)a.pts[d])[i * a.stride];
+    double s;
+    if (a.range_mode == NUFFT_HIP_RANGE_STRICT) {
+      bad |= !(x > -kPiD && x < kPiD);   // IsWithinRange, nufft_plan.h:866-898 (strict inequalities)
+      s = x + kPiD;
+    } else if (a.range_mode == NUFFT_HIP_RANGE_EXTENDED) {
+      bad |= !(x > -3.0 * kPiD && x < 3.0 * kPiD);
+      s = (x > kPiD) ? x - kPiD : ((x < -kPiD) ? x + 3.0 * kPiD : x + kPiD);
+    } else {
+      s = fmod(x + kPiD, 2.0 * kPiD);
+      if (s < 0.0) s += 2.0 * kPiD;
+    }
+    double xs = s * ((double)g.nf[d] * (1.0 / (2.0 * kPiD)));
+    if (!(xs > -1.0e15 && xs < 1.0e15)) xs = 0.0;   // NaN / inf / absurd: keep memory safe
+    const double i0f = ceil(xs - 0.5 * (double)g.w);
+    double zz = 2.0 * (i0f - xs) + (double)(g.w - 1);
+    zz = fmin(1.0, fmax(-1.0, zz));
+    long long i0 = (long long)i0f % g.nf[d];
+    if (i0 < 0) i0 += g.nf[d];
+    const int t = (int)i0 / g.tile[d];
+    const int l = (int)i0 - t * g.tile[d];
+    tc[d] = t;
+    loc |= (uint32_t)l << (10 * d);
+    ((T*)a.z[d])[i] = (T)zz;
+  }
+  const int tile = tc[0] + g.ntile[0] * (tc[1] + g.ntile[1] * tc[2]);
+  a.loc[i] = loc;
+  a.tile_of[i] = tile;
+  a.rank_of[i] = atomicAdd(&a.tile_count[tile], 1);
+  if (bad && a.check_range) atomicAdd(a.bad_count, 1);
+}
+
+// Single-workgroup exclusive scans over the tiles: point offsets and
+// subproblem offsets (ceil(count / max_sub) per tile).
+__global__ __launch_bounds__(1024) void scan_tiles_kernel(const int32_t* __restrict__ count, int n,
+                                                          int max_sub, int32_t* __restrict__ tile_start,
+                                                          int32_t* __restrict__ sub_start) {
+  __shared__ int sh_a[1024];
+  __shared__ int sh_b[1024];
+  const int tid = threadIdx.x;
+  const int per = (n + 1023) / 1024;
+  const int lo = tid * per;
+  const int hi = (lo + per < n) ? lo + per : n;
+  int sa = 0, sb = 0;
+  for (int i = lo; i < hi; ++i) {
+    const int c = count[i];
+    sa += c;
+    sb += (c + max_sub - 1) / max_sub;
+  }
+  sh_a[tid] = sa;
+  sh_b[tid] = sb;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int va = (tid >= off) ? sh_a[tid - off] : 0;
+    const int vb = (tid >= off) ? sh_b[tid - off] : 0;
+    __syncthreads();
+    sh_a[tid] += va;
+    sh_b[tid] += vb;
+    __syncthreads();
+  }
+  int ea = sh_a[tid] - sa, eb = sh_b[tid] - sb;
+  for (int i = lo; i < hi; ++i) {
+    const int c = count[i];
+    tile_start[i] = ea;
+    sub_start[i] = eb;
+    ea += c;
+    eb += (c + max_sub - 1) / max_sub;
+  }
+  if (tid == 1023) {
+    tile_start[n] = sh_a[1023];
+    sub_start[n] = sh_b[1023];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void scatter_points_kernel(int rank, int64_t M, const uint32_t* __restrict__ loc_in,
+                                                             const T* __restrict__ z0, const T* __restrict__ z1,
+                                                             const T* __restrict__ z2,
+                                                             const int32_t* __restrict__ tile_of,
+                                                             const int32_t* __restrict__ rank_of,
+                                                             const int32_t* __restrict__ tile_start,
+                                                             uint32_t* __restrict__ loc_out, T* __restrict__ o0,
+                                                             T* __restrict__ o1, T* __restrict__ o2,
+                                                             int32_t* __restrict__ idx_out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M) return;
+  const int pos = tile_start[tile_of[i]] + rank_of[i];
+  loc_out[pos] = loc_in[i];
+  idx_out[pos] = (int32_t)i;
+  o0[pos] = z0[i];
+  if (rank > 1) o1[pos] = z1[i];
+  if (rank > 2) o2[pos] = z2[i];
+}
+
+// ------------------------------------------------- spread: generic tile path
+
+// One workgroup per subproblem (<= max_sub points of one tile) and transform.
+// LDS tile of (tile + w - 1)^rank interleaved complex cells; one thread per
+// point, w^rank LDS atomic adds per component; then the tile is added to the
+// periodic fine grid with global float atomics (executed at the memory side
+// on gfx950). Works for any w <= 16, rank, precision.
+template <typename T, int RANK>
+__global__ __launch_bounds__(kBlock) void spread_tile_generic_kernel(
+    Geom g, SortedPoints<T> sp, const T* __restrict__ horner, const T* __restrict__ c,
+    T* __restrict__ fw, int64_t c_stride, int64_t fw_stride, T scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* tile = reinterpret_cast<T*>(smem_raw);
+  int tb, p0, p1;
+  if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1)) return;
+  const int tid = threadIdx.x;
+  const int w = g.w, nc = g.ncoef;
+  const int L0 = g.ldim[0], LS = g.lstride;
+  const int L1 = RANK > 1 ? g.ldim[1] : 1;
+  const int L2 = RANK > 2 ? g.ldim[2] : 1;
+  const int ncell_padded = LS * L1 * L2;
+  for (int i = tid; i < 2 * ncell_padded; i += kBlock) tile[i] = (T)0;
+  __syncthreads();
+
+  const T* cc = c + 2 * (int64_t)blockIdx.y * c_stride;
+  for (int j = p0 + tid; j < p1; j += kBlock) {
+    const uint32_t loc = sp.loc[j];
+    const int idx = sp.idx[j];
+    const T re = cc[2 * (int64_t)idx] * scale;
+    const T im = cc[2 * (int64_t)idx + 1] * scale;
+    T kx[kMaxW];
+    const T z0 = sp.z[0][j];
+#pragma unroll
+    for (int q = 0; q < kMaxW; ++q) kx[q] = (q < w) ? horner_cell(horner, nc, q, z0) : (T)0;
+    const int l0 = loc & 1023;
+    if (RANK == 1) {
+#pragma unroll
+      for (int q = 0; q < kMaxW; ++q)
+        if (q < w) {
+          lds_add(&tile[2 * (l0 + q)], re * kx[q]);
+          lds_add(&tile[2 * (l0 + q) + 1], im * kx[q]);
+        }
+    } else if (RANK == 2) {
+      const int l1 = (loc >> 10) & 1023;
+      const T z1 = sp.z[1][j];
+      for (int dy = 0; dy < w; ++dy) {
+        const T ky = horner_cell(horner, nc, dy, z1);
+        const T vre = re * ky, vim = im * ky;
+        T* row = tile + 2 * ((l1 + dy) * LS + l0);
+#pragma unroll
+        for (int q = 0; q < kMaxW; ++q)
+          if (q < w) {
+            lds_add(&row[2 * q], vre * kx[q]);
+            lds_add(&row[2 * q + 1], vim * kx[q]);
+          }
+      }
+    } else {
+      const int l1 = (loc >> 10) & 1023;
+      const int l2 = (loc >> 20) & 1023;
+      const T z1 = sp.z[1][j];
+      const T z2 = sp.z[2][j];
+      for (int dz = 0; dz < w; ++dz) {
+        const T kz = horner_cell(horner, nc, dz, z2);
+        for (int dy = 0; dy < w; ++dy) {
+          const T kyz = kz * horner_cell(horner, nc, dy, z1);
+          const T vre = re * kyz, vim = im * kyz;
+          T* row = tile + 2 * (((l2 + dz) * L1 + (l1 + dy)) * LS + l0);
+#pragma unroll
+          for (int q = 0; q < kMaxW; ++q)
+            if (q < w) {
+              lds_add(&row[2 * q], vre * kx[q]);
+              lds_add(&row[2 * q + 1], vim * kx[q]);
+            }
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // tile -> periodic fine grid
+  const int t0 = tb % g.ntile[0];
+  const int t1 = (tb / g.ntile[0]) % g.ntile[1];
+  const int t2 = tb / (g.ntile[0] * g.ntile[1]);
+  const int o0 = t0 * g.tile[0], o1 = t1 * g.tile[1], o2 = t2 * g.tile[2];
+  T* out = fw + 2 * (int64_t)blockIdx.y * fw_stride;
+  const int ncell = L0 * L1 * L2;
+  for (int i = tid; i < ncell; i += kBlock) {
+    const int a0 = i % L0;
+    const int a1 = (i / L0) % L1;
+    const int a2 = i / (L0 * L1);
+    const int li = (a2 * L1 + a1) * LS + a0;
+    const T vre = tile[2 * li], vim = tile[2 * li + 1];
+    if (vre != (T)0 || vim != (T)0) {
+      const int64_t g0 = (o0 + a0) % g.nf[0];
+      const int64_t g1 = RANK > 1 ? (o1 + a1) % g.nf[1] : 0;
+      const int64_t g2 = RANK > 2 ? (o2 + a2) % g.nf[2] : 0;
+      const int64_t gi = g0 + (int64_t)g.nf[0] * (g1 + (int64_t)g.nf[1] * g2);
+      glb_add(&out[2 * gi], vre);
+      glb_add(&out[2 * gi + 1], vim);
+    }
+  }
+}
+
+// --------------------------------- spread: wavefront-per-point path (2D, w=8)
+
+// Tile 32x32 fine cells (+7 one-sided halo) held as two PLANAR fp32 planes
+// with a row stride of 40 words. A wavefront handles one point per pass: lane
+// (dy, dx) = (lane >> 3, lane & 7) owns one of the 8x8 stencil cells, so a
+// pass is exactly two ds_add_f32 wave-instructions (re, im). With the row
+// stride = 8 (mod 32) the 32 lanes of each half-wave (4 stencil rows x 8
+// cells) fall in 32 distinct banks: conflict free by construction, for every
+// point position. Kernel values are produced 64 points at a time (one point
+// per lane, Horner in registers) and handed to the per-point passes through
+// a small LDS staging area read with broadcast loads.
+constexpr int kWT = 32;              // tile edge
+constexpr int kWW = 8;               // kernel width
+constexpr int kWL = kWT + kWW - 1;   // 39 rows/cols used
+constexpr int kWS = 40;              // row stride in words: 8 mod 32
+constexpr int kWPlane = kWS * kWL;   // 1560 words per plane
+constexpr int kWaves = kBlock / 64;
+constexpr int kStageWords = 64 * kWW * 3;  // per wave: kx[64][8] + (ky*re, ky*im)[64][8]
+
+__global__ __launch_bounds__(kBlock) void spread_2d_w8_wave_kernel(
+    Geom g, SortedPoints<float> sp, const float* __restrict__ horner, const float* __restrict__ c,
+    float* __restrict__ fw, int64_t c_stride, int64_t fw_stride, float scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* plane_re = reinterpret_cast<float*>(smem_raw);
+  float* plane_im = plane_re + kWPlane;
+  float* stage_all = plane_im + kWPlane;
+  int tb, p0, p1;
+  if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1)) return;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  for (int i = tid; i < 2 * kWPlane; i += kBlock) plane_re[i] = 0.f;
+  __syncthreads();
+
+  float* kxs = stage_all + wave * kStageWords;        // [64][8]
+  float2* kyc = reinterpret_cast<float2*>(kxs + 64 * kWW);  // [64][8] (ky*re, ky*im)
+  const int dx = lane & 7, dy = lane >> 3;
+  const int cell = dy * kWS + dx;
+  const float* cc = c + 2 * (int64_t)blockIdx.y * c_stride;
+
+  // coefficients of the piecewise polynomial: uniform loads, kept in SGPRs/VGPRs
+  for (int base = p0 + wave * 64; base < p1; base += kWaves * 64) {
+    const int j = base + lane;
+    const bool valid = j < p1;
+    int off = 0;
+    float kx[kWW], kyr[kWW], kyi[kWW];
+    if (valid) {
+      const uint32_t loc = sp.loc[j];
+      const int idx = sp.idx[j];
+      const float zx = sp.z[0][j], zy = sp.z[1][j];
+      const float2 cv = reinterpret_cast<const float2*>(cc)[idx];
+      const float re = cv.x * scale, im = cv.y * scale;
+      off = ((loc >> 10) & 1023) * kWS + (loc & 1023);
+#pragma unroll
+      for (int q = 0; q < kWW; ++q) {
+        float ax = horner[(kWaveCoef - 1) * kMaxW + q];
+        float ay = ax;
+#pragma unroll
+        for (int k = kWaveCoef - 2; k >= 0; --k) {
+          const float t = horner[k * kMaxW + q];
+          ax = fmaf(ax, zx, t);
+          ay = fmaf(ay, zy, t);
+        }
+        kx[q] = ax;
+        kyr[q] = ay * re;
+        kyi[q] = ay * im;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < kWW; ++q) { kx[q] = 0.f; kyr[q] = 0.f; kyi[q] = 0.f; }
+    }
+    // stage: each lane writes its point's 8 + 16 values
+    {
+      float4* d4 = reinterpret_cast<float4*>(kxs + lane * kWW);
+      d4[0] = make_float4(kx[0], kx[1], kx[2], kx[3]);
+      d4[1] = make_float4(kx[4], kx[5], kx[6], kx[7]);
+      float4* e4 = reinterpret_cast<float4*>(kyc + lane * kWW);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        e4[q] = make_float4(kyr[2 * q], kyi[2 * q], kyr[2 * q + 1], kyi[2 * q + 1]);
+    }
+    // (same wave reads what it wrote: LDS ops of one wave are processed in order)
+    int npts = p1 - base;
+    if (npts > 64) npts = 64;
+    const int nround = (npts + 3) & ~3;   // padded lanes hold zeros and off = 0
+    for (int q = 0; q < nround; q += 4) {
+      float a[4];
+      float2 b[4];
+      int o[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a[u] = kxs[(q + u) * kWW + dx];
+        b[u] = kyc[(q + u) * kWW + dy];
+        o[u] = __builtin_amdgcn_readlane(off, q + u) + cell;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        lds_add(&plane_re[o[u]], a[u] * b[u].x);
+        lds_add(&plane_im[o[u]], a[u] * b[u].y);
+      }
+    }
+  }
+  __syncthreads();
+
+  const int t0 = tb % g.ntile[0];
+  const int t1 = tb / g.ntile[0];
+  const int o0 = t0 * kWT, o1 = t1 * kWT;
+  float* out = fw + 2 * (int64_t)blockIdx.y * fw_stride;
+  for (int i = tid; i < kWPlane; i += kBlock) {
+    const int a0 = i % kWS, a1 = i / kWS;
+    if (a0 < kWL) {
+      const float vre = plane_re[i], vim = plane_im[i];
+      if (vre != 0.f || vim != 0.f) {
+        int g0 = o0 + a0; if (g0 >= g.nf[0]) g0 -= g.nf[0];
+        int g1 = o1 + a1; if (g1 >= g.nf[1]) g1 -= g.nf[1];
+        const int64_t gi = g0 + (int64_t)g.nf[0] * g1;
+        glb_add(&out[2 * gi], vre);
+        glb_add(&out[2 * gi + 1], vim);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------ interp: generic tile path
+
+// One workgroup per subproblem, one thread per point, gathering w^rank fine
+// cells straight from global memory (tile-sorted points keep the working set
+// in the XCD's L2).
+template <typename T, int RANK>
+__global__ __launch_bounds__(kBlock) void interp_tile_generic_kernel(
+    Geom g, SortedPoints<T> sp, const T* __restrict__ horner, T* __restrict__ c,
+    const T* __restrict__ fw, int64_t c_stride, int64_t fw_stride, T scale) {
+  int tb, p0, p1;
+  if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1)) return;
+  const int w = g.w, nc = g.ncoef;
+  const int t0 = tb % g.ntile[0];
+  const int t1 = (tb / g.ntile[0]) % g.ntile[1];
+  const int t2 = tb / (g.ntile[0] * g.ntile[1]);
+  const int o0 = t0 * g.tile[0], o1 = t1 * g.tile[1], o2 = t2 * g.tile[2];
+  const T* in = fw + 2 * (int64_t)blockIdx.y * fw_stride;
+  T* cc = c + 2 * (int64_t)blockIdx.y * c_stride;
+  for (int j = p0 + (int)threadIdx.x; j < p1; j += kBlock) {
+    const uint32_t loc = sp.loc[j];
+    const int idx = sp.idx[j];
+    T kx[kMaxW];
+    int gx[kMaxW];
+    const T z0 = sp.z[0][j];
+    const int b0 = o0 + (int)(loc & 1023);
+#pragma unroll
+    for (int q = 0; q < kMaxW; ++q) {
+      kx[q] = (q < w) ? horner_cell(horner, nc, q, z0) : (T)0;
+      gx[q] = (b0 + q) % g.nf[0];
+    }
+    T sre = 0, sim = 0;
+    if (RANK == 1) {
+#pragma unroll
+      for (int q = 0; q < kMaxW; ++q)
+        if (q < w) {
+          sre = fma(in[2 * (int64_t)gx[q]], kx[q], sre);
+          sim = fma(in[2 * (int64_t)gx[q] + 1], kx[q], sim);
+        }
+    } else if (RANK == 2) {
+      const int b1 = o1 + (int)((loc >> 10) & 1023);
+      const T z1 = sp.z[1][j];
+      for (int dy = 0; dy < w; ++dy) {
+        const T ky = horner_cell(horner, nc, dy, z1);
+        const int64_t ro = (int64_t)g.nf[0] * ((b1 + dy) % g.nf[1]);
+        T lre = 0, lim = 0;
+#pragma unroll
+        for (int q = 0; q < kMaxW; ++q)
+          if (q < w) {
+            lre = fma(in[2 * (ro + gx[q])], kx[q], lre);
+            lim = fma(in[2 * (ro + gx[q]) + 1], kx[q], lim);
+          }
+        sre = fma(ky, lre, sre);
+        sim = fma(ky, lim, sim);
+      }
+    } else {
+      const int b1 = o1 + (int)((loc >> 10) & 1023);
+      const int b2 = o2 + (int)((loc >> 20) & 1023);
+      const T z1 = sp.z[1][j];
+      const T z2 = sp.z[2][j];
+      for (int dz = 0; dz < w; ++dz) {
+        const T kz = horner_cell(horner, nc, dz, z2);
+        const int64_t zo = (int64_t)g.nf[1] * ((b2 + dz) % g.nf[2]);
+        for (int dy = 0; dy < w; ++dy) {
+          const T kyz = kz * horner_cell(horner, nc, dy, z1);
+          const int64_t ro = (int64_t)g.nf[0] * (zo + (b1 + dy) % g.nf[1]);
+          T lre = 0, lim = 0;
+#pragma unroll
+          for (int q = 0; q < kMaxW; ++q)
+            if (q < w) {
+              lre = fma(in[2 * (ro + gx[q])], kx[q], lre);
+              lim = fma(in[2 * (ro + gx[q]) + 1], kx[q], lim);
+            }
+          sre = fma(kyz, lre, sre);
+          sim = fma(kyz, lim, sim);
+        }
+      }
+    }
+    cc[2 * (int64_t)idx] = sre * scale;
+    cc[2 * (int64_t)idx + 1] = sim * scale;
+  }
+}
+
+// -------------------------------------------------------------- deconvolve
+
+// dir 1 (type-1 step 3): f[k] = fw[k mod nf] * rf0[|k0|] rf1[|k1|] rf2[|k2|],
+//   one thread per output mode, CMCL order (index 0 = most negative mode):
+//   fuses fftshift + truncation nf -> N + division by the kernel's Fourier
+//   series (reference Deconvolve{1,2,3}DKernel nufft_plan.cu.cc:326-379;
+//   CPU deconvolve_*d nufft_plan.cc:729-881).
+// dir 2 (type-2 step 1): one thread per FINE cell writes either the amplified
+//   mode or zero -- the zero-fill of the whole fine batch the reference does
+//   with a separate memset (nufft_plan.cu.cc:2855-2858) is fused in.
+// rf* hold RECIPROCALS of the Fourier series (computed in double on the host).
+template <typename T>
+__global__ __launch_bounds__(256) void deconvolve_kernel(Geom g, int dir, T* __restrict__ f,
+                                                         T* __restrict__ fw, const T* __restrict__ rf0,
+                                                         const T* __restrict__ rf1,
+                                                         const T* __restrict__ rf2) {
+  const int64_t N0 = g.nmodes[0], N1 = g.nmodes[1], N2 = g.nmodes[2];
+  const int64_t nf0 = g.nf[0], nf1 = g.nf[1], nf2 = g.nf[2];
+  const int64_t ntot = N0 * N1 * N2, nftot = nf0 * nf1 * nf2;
+  T* fb = f + 2 * (int64_t)blockIdx.y * ntot;
+  T* fwb = fw + 2 * (int64_t)blockIdx.y * nftot;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (dir == 1) {
+    if (i >= ntot) return;
+    const int64_t a0 = i % N0, a1 = (i / N0) % N1, a2 = i / (N0 * N1);
+    const int64_t k0 = a0 - N0 / 2, k1 = a1 - N1 / 2, k2 = a2 - N2 / 2;
+    const int64_t w0 = k0 >= 0 ? k0 : nf0 + k0;
+    const int64_t w1 = k1 >= 0 ? k1 : nf1 + k1;
+    const int64_t w2 = k2 >= 0 ? k2 : nf2 + k2;
+    T r = rf0[k0 < 0 ? -k0 : k0];
+    if (g.rank > 1) r *= rf1[k1 < 0 ? -k1 : k1];
+    if (g.rank > 2) r *= rf2[k2 < 0 ? -k2 : k2];
+    const int64_t wi = w0 + nf0 * (w1 + nf1 * w2);
+    fb[2 * i] = fwb[2 * wi] * r;
+    fb[2 * i + 1] = fwb[2 * wi + 1] * r;
+  } else {
+    if (i >= nftot) return;
+    const int64_t w0 = i % nf0, w1 = (i / nf0) % nf1, w2 = i / (nf0 * nf1);
+    // kept modes: k in [-(N/2), (N-1)/2]
+    int64_t k0 = w0 <= (N0 - 1) / 2 ? w0 : w0 - nf0;
+    int64_t k1 = w1 <= (N1 - 1) / 2 ? w1 : w1 - nf1;
+    int64_t k2 = w2 <= (N2 - 1) / 2 ? w2 : w2 - nf2;
+    const bool keep = k0 >= -(N0 / 2) && k1 >= -(N1 / 2) && k2 >= -(N2 / 2);
+    T vre = 0, vim = 0;
+    if (keep) {
+      T r = rf0[k0 < 0 ? -k0 : k0];
+      if (g.rank > 1) r *= rf1[k1 < 0 ? -k1 : k1];
+      if (g.rank > 2) r *= rf2[k2 < 0 ? -k2 : k2];
+      const int64_t fi = (k0 + N0 / 2) + N0 * ((k1 + N1 / 2) + N1 * (k2 + N2 / 2));
+      vre = fb[2 * fi] * r;
+      vim = fb[2 * fi + 1] * r;
+    }
+    fwb[2 * i] = vre;
+    fwb[2 * i + 1] = vim;
+  }
+}
+
+// ------------------------------------------------------------------ permute
+
+struct PermuteArgs {
+  int ndim;
+  int64_t shape[12];
+  int64_t stride[12];
+  int64_t total;
+};
+
+template <typename V>
+__global__ __launch_bounds__(256) void permute_kernel(const V* __restrict__ src, V* __restrict__ dst,
+                                                      PermuteArgs a) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.total) return;
+  int64_t rem = i, so = 0;
+  for (int d = a.ndim - 1; d >= 0; --d) {
+    const int64_t q = rem % a.shape[d];
+    rem /= a.shape[d];
+    so += q * a.stride[d];
+  }
+  dst[i] = src[so];
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ launchers
+
+static inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
+
+template <typename T>
+hipError_t launch_prep(const Geom& g, const PrepArgs& a, hipStream_t stream) {
+  if (a.M == 0) return hipSuccess;
+  prep_points_kernel<T><<<blocks_for(a.M, 256), 256, 0, stream>>>(g, a);
+  return hipGetLastError();
+}
+template hipError_t launch_prep<float>(const Geom&, const PrepArgs&, hipStream_t);
+template hipError_t launch_prep<double>(const Geom&, const PrepArgs&, hipStream_t);
+
+hipError_t launch_scan(const Geom& g, const int32_t* tile_count, int32_t* tile_start,
+                       int32_t* sub_start, hipStream_t stream) {
+  scan_tiles_kernel<<<1, 1024, 0, stream>>>(tile_count, g.ntiles, g.max_sub, tile_start, sub_start);
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_scatter(const Geom& g, int64_t M, const uint32_t* loc_in, T* const z_in[3],
+                          const int32_t* tile_of, const int32_t* rank_of,
+                          const int32_t* tile_start, uint32_t* loc_out, T* const z_out[3],
+                          int32_t* idx_out, hipStream_t stream) {
+  if (M == 0) return hipSuccess;
+  scatter_points_kernel<T><<<blocks_for(M, 256), 256, 0, stream>>>(
+      g.rank, M, loc_in, z_in[0], z_in[1], z_in[2], tile_of, rank_of, tile_start, loc_out,
+      z_out[0], z_out[1], z_out[2], idx_out);
+  return hipGetLastError();
+}
+template hipError_t launch_scatter<float>(const Geom&, int64_t, const uint32_t*, float* const[3],
+                                          const int32_t*, const int32_t*, const int32_t*, uint32_t*,
+                                          float* const[3], int32_t*, hipStream_t);
+template hipError_t launch_scatter<double>(const Geom&, int64_t, const uint32_t*, double* const[3],
+                                           const int32_t*, const int32_t*, const int32_t*, uint32_t*,
+                                           double* const[3], int32_t*, hipStream_t);
+
+bool wave_method_supported(const Geom& g, int precision) {
+  return precision == NUFFT_HIP_F32 && g.rank == 2 && g.w == kWW && g.ncoef <= kWaveCoef &&
+         g.tile[0] == kWT && g.tile[1] == kWT;
+}
+
+size_t spread_lds_bytes(const Geom& g, int method, int precision) {
+  if (method == NUFFT_HIP_METHOD_TILE_WAVE)
+    return sizeof(float) * (2 * kWPlane + kWaves * kStageWords);
+  size_t cells = (size_t)g.lstride;
+  for (int d = 1; d < g.rank; ++d) cells *= (size_t)g.ldim[d];
+  return cells * 2 * (size_t)precision;
+}
+
+// Upper bound on the number of subproblems, known without reading the device:
+// sum_b ceil(n_b / S) <= ntiles + M / S.
+static inline unsigned subproblem_grid(const Geom& g, int64_t M) {
+  return (unsigned)((int64_t)g.ntiles + M / g.max_sub);
+}
+
+template <typename K>
+static hipError_t ensure_lds(K kernel, size_t bytes) {
+  if (bytes > 64 * 1024)
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  return hipSuccess;
+}
+
+template <typename T>
+hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, int64_t M,
+                         const T* horner, const T* c, T* fw, int batch, int64_t c_stride,
+                         int64_t fw_stride, T scale, size_t lds_bytes, hipStream_t stream) {
+  if (M == 0) return hipSuccess;
+  dim3 grid(subproblem_grid(g, M), (unsigned)batch);
+  hipError_t e = hipSuccess;
+  if (method == NUFFT_HIP_METHOD_TILE_WAVE) {
+    if constexpr (sizeof(T) == 4) {
+      spread_2d_w8_wave_kernel<<<grid, kBlock, lds_bytes, stream>>>(
+          g, sp, horner, c, fw, c_stride, fw_stride, scale);
+      return hipGetLastError();
+    } else {
+      return hipErrorInvalidValue;
+    }
+  }
+  switch (g.rank) {
+    case 1:
+      e = ensure_lds(spread_tile_generic_kernel<T, 1>, lds_bytes);
+      if (e != hipSuccess) return e;
+      spread_tile_generic_kernel<T, 1><<<grid, kBlock, lds_bytes, stream>>>(
+          g, sp, horner, c, fw, c_stride, fw_stride, scale);
+      break;
+    case 2:
+      e = ensure_lds(spread_tile_generic_kernel<T, 2>, lds_bytes);
+      if (e != hipSuccess) return e;
+      spread_tile_generic_kernel<T, 2><<<grid, kBlock, lds_bytes, stream>>>(
+          g, sp, horner, c, fw, c_stride, fw_stride, scale);
+      break;
+    default:
+      e = ensure_lds(spread_tile_generic_kernel<T, 3>, lds_bytes);
+      if (e != hipSuccess) return e;
+      spread_tile_generic_kernel<T, 3><<<grid, kBlock, lds_bytes, stream>>>(
+          g, sp, horner, c, fw, c_stride, fw_stride, scale);
+      break;
+  }
+  return hipGetLastError();
+}
+template hipError_t launch_spread<float>(const Geom&, int, const SortedPoints<float>&, int64_t,
+                                         const float*, const float*, float*, int, int64_t, int64_t,
+                                         float, size_t, hipStream_t);
+template hipError_t launch_spread<double>(const Geom&, int, const SortedPoints<double>&, int64_t,
+                                          const double*, const double*, double*, int, int64_t,
+                                          int64_t, double, size_t, hipStream_t);
+
+template <typename T>
+hipError_t launch_interp(const Geom& g, int method, const SortedPoints<T>& sp, int64_t M,
+                         const T* horner, T* c, const T* fw, int batch, int64_t c_stride,
+                         int64_t fw_stride, T scale, hipStream_t stream) {
+  (void)method;
+  if (M == 0) return hipSuccess;
+  dim3 grid(subproblem_grid(g, M), (unsigned)batch);
+  switch (g.rank) {
+    case 1:
+      interp_tile_generic_kernel<T, 1><<<grid, kBlock, 0, stream>>>(g, sp, horner, c, fw, c_stride,
+                                                                    fw_stride, scale);
+      break;
+    case 2:
+      interp_tile_generic_kernel<T, 2><<<grid, kBlock, 0, stream>>>(g, sp, horner, c, fw, c_stride,
+                                                                    fw_stride, scale);
+      break;
+    default:
+      interp_tile_generic_kernel<T, 3><<<grid, kBlock, 0, stream>>>(g, sp, horner, c, fw, c_stride,
+                                                                    fw_stride, scale);
+      break;
+  }
+  return hipGetLastError();
+}
+template hipError_t launch_interp<float>(const Geom&, int, const SortedPoints<float>&, int64_t,
+                                         const float*, float*, const float*, int, int64_t, int64_t,
+                                         float, hipStream_t);
+template hipError_t launch_interp<double>(const Geom&, int, const SortedPoints<double>&, int64_t,
+                                          const double*, double*, const double*, int, int64_t,
+                                          int64_t, double, hipStream_t);
+
+template <typename T>
+hipError_t launch_deconvolve(const Geom& g, int dir, T* f, T* fw, const T* const rfser[3],
+                             int batch, hipStream_t stream) {
+  int64_t n = 1;
+  for (int d = 0; d < 3; ++d) n *= (dir == 1) ? g.nmodes[d] : g.nf[d];
+  if (n == 0 || batch == 0) return hipSuccess;
+  dim3 grid(blocks_for(n, 256), (unsigned)batch);
+  deconvolve_kernel<T><<<grid, 256, 0, stream>>>(g, dir, f, fw, rfser[0], rfser[1], rfser[2]);
+  return hipGetLastError();
+}
+template hipError_t launch_deconvolve<float>(const Geom&, int, float*, float*, const float* const[3],
+                                             int, hipStream_t);
+template hipError_t launch_deconvolve<double>(const Geom&, int, double*, double*,
+                                              const double* const[3], int, hipStream_t);
+
+hipError_t launch_permute(const void* src, void* dst, int elem_bytes, int ndim,
+                          const int64_t* out_shape, const int64_t* src_strides,
+                          hipStream_t stream) {
+  PermuteArgs a;
+  a.ndim = ndim;
+  a.total = 1;
+  for (int d = 0; d < ndim; ++d) {
+    a.shape[d] = out_shape[d];
+    a.stride[d] = src_strides[d];
+    a.total *= out_shape[d];
+  }
+  if (a.total == 0) return hipSuccess;
+  const unsigned nb = blocks_for(a.total, 256);
+  switch (elem_bytes) {
+    case 4:
+      permute_kernel<float><<<nb, 256, 0, stream>>>((const float*)src, (float*)dst, a);
+      break;
+    case 8:
+      permute_kernel<double><<<nb, 256, 0, stream>>>((const double*)src, (double*)dst, a);
+      break;
+    case 16:
+      permute_kernel<double2><<<nb, 256, 0, stream>>>((const double2*)src, (double2*)dst, a);
+      break;
+    default:
+      return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace nufft_hip

@@ -1,0 +1,372 @@
+// Op-level host logic behind nufft_hip_op_shape / nufft_hip_op_compute: what
+// the reference's TensorFlow kernel does around the plan
+// (tensorflow_nufft/cc/kernels/nufft_kernels.cc, NUFFTBaseOp::Compute :54-379
+// and ::Execute :381-542; shape function cc/ops/nufft_ops.cc:27-103), restated
+// over plain shapes and device pointers so that the TF glue, the ctypes
+// binding and any other host can share it.
+//
+// Differences by design: points are consumed in their [.., M, rank]
+// layout through a strided read instead of being reversed and transposed into
+// a temporary (reference :276-303); plans are cached per configuration instead
+// of being rebuilt on every call (reference :474-478).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <list>
+#include <mutex>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "nufft_hip_internal.h"
+
+namespace {
+
+using nufft_hip::launch_permute;
+
+std::string shape_str(const int64_t* s, int n) {   // TensorShape::DebugString format
+  std::string r = "[";
+  for (int i = 0; i < n; ++i) {
+    if (i) r += ",";
+    r += std::to_string((long long)s[i]);
+  }
+  return r + "]";
+}
+
+struct Analysis {
+  int rank = 0;
+  int64_t num_points = 0;
+  std::vector<int64_t> grid;            // TF order
+  std::vector<int64_t> source_batch;    // padded to common batch rank
+  std::vector<int64_t> points_batch;
+  std::vector<int64_t> out_batch;       // broadcast
+  std::vector<int> outer, inner;        // batch dims with points dim != 1 / == 1
+  int64_t num_transforms = 1, num_calls = 1;
+  int source_elem_rank = 1;
+  bool transpose = false;
+  std::vector<int64_t> target_shape;
+};
+
+int fail(char* errbuf, size_t n, int code, const std::string& msg) {
+  if (errbuf && n) snprintf(errbuf, n, "%s", msg.c_str());
+  return code;
+}
+
+// Validation + shape algebra of NUFFTBaseOp::Compute (nufft_kernels.cc:58-274)
+// and NUFFTBaseShapeFn (nufft_ops.cc:27-103). Error strings are the reference's.
+int analyze(const nufft_hip_op_desc* d, Analysis* a, std::string* err) {
+  if (d->points_ndim < 2 || d->points_ndim > 12 || d->source_ndim < 1 || d->source_ndim > 12) {
+    *err = "Input `points` must have rank of at least 2, but got shape: " +
+           shape_str(d->points_shape, std::max(0, d->points_ndim));
+    return NUFFT_HIP_INVALID_ARGUMENT;
+  }
+  const int64_t rank = d->points_shape[d->points_ndim - 1];
+  if (rank < 1 || rank > 3) {
+    *err = "Dimension must be 1, 2 or 3, but is " + std::to_string((long long)rank);
+    return NUFFT_HIP_INVALID_ARGUMENT;
+  }
+  a->rank = (int)rank;
+  a->num_points = d->points_shape[d->points_ndim - 2];
+  const bool t1 = d->transform_type == NUFFT_HIP_TYPE_1;
+  if (d->transform_type != NUFFT_HIP_TYPE_1 && d->transform_type != NUFFT_HIP_TYPE_2) {
+    *err = "transform_type attr must be 'type_1' or 'type_2'";
+    return NUFFT_HIP_INVALID_ARGUMENT;
+  }
+  if (t1) {
+    if (d->grid_shape_len != rank) {
+      *err = "grid_shape must have length " + std::to_string((long long)rank) + " for a " +
+             std::to_string((long long)rank) + "D transform (as inferred from points), but got length: " +
+             std::to_string(d->grid_shape_len);
+      return NUFFT_HIP_INVALID_ARGUMENT;
+    }
+    for (int i = 0; i < rank; ++i) {
+      if (d->grid_shape[i] < 0) {
+        *err = "Dimension " + std::to_string((long long)d->grid_shape[i]) + " must be >= 0";
+        return NUFFT_HIP_INVALID_ARGUMENT;
+      }
+      a->grid.push_back(d->grid_shape[i]);
+    }
+    if (d->source_shape[d->source_ndim - 1] != a->num_points) {
+      *err = "source and points must have equal samples dimensions for type-1 transforms, but got "
+             "source.shape[-1] = " + std::to_string((long long)d->source_shape[d->source_ndim - 1]) +
+             " and points.shape[-2] = " + std::to_string((long long)a->num_points);
+      return NUFFT_HIP_INVALID_ARGUMENT;
+    }
+    a->source_elem_rank = 1;
+  } else {
+    if (d->source_ndim < rank) {
+      *err = "Input `source` must have rank of at least " + std::to_string((long long)rank) +
+             " but received shape: " + shape_str(d->source_shape, d->source_ndim);
+      return NUFFT_HIP_INVALID_ARGUMENT;
+    }
+    for (int i = d->source_ndim - (int)rank; i < d->source_ndim; ++i) a->grid.push_back(d->source_shape[i]);
+    a->source_elem_rank = (int)rank;
+  }
+  std::vector<int64_t> sb(d->source_shape, d->source_shape + d->source_ndim - a->source_elem_rank);
+  std::vector<int64_t> pb(d->points_shape, d->points_shape + d->points_ndim - 2);
+  while (sb.size() < pb.size()) sb.insert(sb.begin(), 1);
+  while (pb.size() < sb.size()) pb.insert(pb.begin(), 1);
+  const int nb = (int)sb.size();
+  a->out_batch.resize(nb);
+  for (int i = 0; i < nb; ++i) {
+    if (sb[i] != pb[i] && sb[i] != 1 && pb[i] != 1) {
+      *err = "Incompatible shapes: " + shape_str(d->source_shape, d->source_ndim) + " vs. " +
+             shape_str(d->points_shape, d->points_ndim);
+      return NUFFT_HIP_INVALID_ARGUMENT;
+    }
+    a->out_batch[i] = std::max(sb[i], pb[i]);
+    if (sb[i] == 0 || pb[i] == 0) a->out_batch[i] = 0;
+  }
+  a->source_batch = sb;
+  a->points_batch = pb;
+  for (int i = 0; i < nb; ++i) {
+    if (pb[i] == 1) {
+      a->inner.push_back(i);
+      a->num_transforms *= sb[i];
+    } else {
+      a->outer.push_back(i);
+      a->num_calls *= pb[i];
+    }
+  }
+  // transposition is needed iff some inner dim precedes an outer dim
+  std::vector<int> perm(a->outer);
+  perm.insert(perm.end(), a->inner.begin(), a->inner.end());
+  for (int i = 0; i < nb; ++i)
+    if (perm[i] != i) a->transpose = true;
+  a->target_shape = a->out_batch;
+  if (t1) a->target_shape.insert(a->target_shape.end(), a->grid.begin(), a->grid.end());
+  else a->target_shape.push_back(a->num_points);
+  return NUFFT_HIP_OK;
+}
+
+// ----------------------------------------------------------- plan cache
+
+struct CachedPlan {
+  std::string key;
+  nufft_hip_plan plan;
+};
+std::mutex g_cache_mu;
+std::list<CachedPlan> g_cache;    // most recently returned at the front
+constexpr size_t kMaxCached = 8;
+
+std::string plan_key(const nufft_hip_op_desc* d, const Analysis& a, int type, int ntransf,
+                     double tol, void* stream, int device) {
+  std::string k;
+  char buf[256];
+  snprintf(buf, sizeof(buf), "op%d t%d r%d n%d f%d p%d tol%.17g dev%d s%p|", d->op_type, type, a.rank,
+           ntransf, d->fft_direction, d->precision, tol, device, stream);
+  k = buf;
+  for (auto g : a.grid) k += std::to_string((long long)g) + ",";
+  k.append(reinterpret_cast<const char*>(&d->options), sizeof(d->options));
+  return k;
+}
+
+nufft_hip_plan cache_take(const std::string& key) {
+  std::lock_guard<std::mutex> lk(g_cache_mu);
+  for (auto it = g_cache.begin(); it != g_cache.end(); ++it)
+    if (it->key == key) {
+      nufft_hip_plan p = it->plan;
+      g_cache.erase(it);
+      return p;
+    }
+  return nullptr;
+}
+
+void cache_give(const std::string& key, nufft_hip_plan p) {
+  nufft_hip_plan evict = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    g_cache.push_front({key, p});
+    if (g_cache.size() > kMaxCached) {
+      evict = g_cache.back().plan;
+      g_cache.pop_back();
+    }
+  }
+  if (evict) nufft_hip_plan_destroy(evict);
+}
+
+}  // namespace
+
+extern "C" {
+
+int nufft_hip_op_shape(const nufft_hip_op_desc* desc, int32_t* target_ndim, int64_t* target_shape,
+                       char* errbuf, size_t errbuf_len) {
+  if (!desc || !target_ndim || !target_shape)
+    return fail(errbuf, errbuf_len, NUFFT_HIP_INVALID_ARGUMENT, "null argument");
+  Analysis a;
+  std::string err;
+  int rc = analyze(desc, &a, &err);
+  if (rc) return fail(errbuf, errbuf_len, rc, err);
+  if (a.target_shape.size() > 12)
+    return fail(errbuf, errbuf_len, NUFFT_HIP_INVALID_ARGUMENT, "too many dimensions");
+  *target_ndim = (int32_t)a.target_shape.size();
+  for (size_t i = 0; i < a.target_shape.size(); ++i) target_shape[i] = a.target_shape[i];
+  return NUFFT_HIP_OK;
+}
+
+int nufft_hip_op_compute(const nufft_hip_op_desc* desc, const void* source, const void* points,
+                         void* target, void* stream_v, char* errbuf, size_t errbuf_len) {
+  if (!desc) return fail(errbuf, errbuf_len, NUFFT_HIP_INVALID_ARGUMENT, "null desc");
+  Analysis a;
+  std::string err;
+  int rc = analyze(desc, &a, &err);
+  if (rc) return fail(errbuf, errbuf_len, rc, err);
+  hipStream_t stream = (hipStream_t)stream_v;
+  const int rank = a.rank;
+  const bool t1 = desc->transform_type == NUFFT_HIP_TYPE_1;
+  const int nb = (int)a.source_batch.size();
+  const size_t csize = 2 * (size_t)desc->precision;   // bytes per complex
+  int64_t num_coeffs = 1;
+  for (auto g : a.grid) num_coeffs *= g;
+  int64_t out_elems = 1;
+  for (auto s : a.target_shape) out_elems *= s;
+  if (out_elems == 0) return NUFFT_HIP_OK;   // empty batch: nothing to do
+
+  // grid dims reversed to x-fastest (nufft_kernels.cc:347-352)
+  int64_t dims[3] = {1, 1, 1};
+  for (int d = 0; d < rank; ++d) dims[d] = a.grid[rank - 1 - d];
+
+  nufft_hip_options opts = desc->options;
+  if (desc->op_type != NUFFT_HIP_OP_NUFFT) {   // nufft_kernels.cc:457-460
+    opts.spread_only = 1;
+    opts.upsampling_factor = 2.0;
+  }
+  const double tol = (double)(float)desc->tol;   // `tol: float` attr cast to FloatType (:361)
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(errbuf, errbuf_len, NUFFT_HIP_INTERNAL,
+                "no HIP device available (this library has no CPU fallback)");
+  }
+  const std::string key = plan_key(desc, a, desc->transform_type, (int)a.num_transforms, tol, stream_v, device);
+  nufft_hip_plan plan = cache_take(key);
+  if (!plan) {
+    char pe[512] = {0};
+    rc = nufft_hip_plan_create(&plan, desc->transform_type, rank, dims, desc->fft_direction,
+                               (int)a.num_transforms, tol, desc->precision, &opts, stream_v, pe, sizeof(pe));
+    if (rc) return fail(errbuf, errbuf_len, rc, pe);
+  }
+
+  // Source / target with batch dims permuted to [outer..., inner..., element...]
+  // when the original order interleaves them (nufft_kernels.cc:241-345,372-378).
+  const void* psource = source;
+  void* ptarget = target;
+  void *tsource = nullptr, *ttarget = nullptr;
+  std::vector<int> perm(a.outer);
+  perm.insert(perm.end(), a.inner.begin(), a.inner.end());
+  const int s_nd = nb + a.source_elem_rank;
+  const int t_nd = (int)a.target_shape.size();
+  std::vector<int64_t> sshape(a.source_batch);
+  for (int i = desc->source_ndim - a.source_elem_rank; i < desc->source_ndim; ++i) sshape.push_back(desc->source_shape[i]);
+  auto contiguous_strides = [](const std::vector<int64_t>& s) {
+    std::vector<int64_t> st(s.size(), 1);
+    for (int i = (int)s.size() - 2; i >= 0; --i) st[i] = st[i + 1] * s[i + 1];
+    return st;
+  };
+  auto cleanup = [&]() {
+    if (tsource) (void)hipFree(tsource);
+    if (ttarget) (void)hipFree(ttarget);
+  };
+  auto hip_fail = [&](hipError_t e) {
+    cleanup();
+    nufft_hip_plan_destroy(plan);
+    return fail(errbuf, errbuf_len, NUFFT_HIP_INTERNAL, std::string("HIP error: ") + hipGetErrorString(e));
+  };
+  std::vector<int64_t> tperm_shape, tt_strides_for_back;
+  if (a.transpose) {
+    // tsource[outer.., inner.., elem..] = source[perm]
+    std::vector<int64_t> sst = contiguous_strides(sshape), oshape(s_nd), ostr(s_nd);
+    for (int i = 0; i < s_nd; ++i) {
+      const int src_dim = i < nb ? perm[i] : i;
+      oshape[i] = sshape[src_dim];
+      ostr[i] = sst[src_dim];
+    }
+    int64_t n = 1;
+    for (auto v : oshape) n *= v;
+    hipError_t e = hipMalloc(&tsource, std::max<size_t>(16, (size_t)n * csize));
+    if (e != hipSuccess) return hip_fail(e);
+    e = launch_permute(source, tsource, (int)csize, s_nd, oshape.data(), ostr.data(), stream);
+    if (e != hipSuccess) return hip_fail(e);
+    psource = tsource;
+    e = hipMalloc(&ttarget, std::max<size_t>(16, (size_t)out_elems * csize));
+    if (e != hipSuccess) return hip_fail(e);
+    ptarget = ttarget;
+  }
+
+  // Loop over calls (nufft_kernels.cc:491-540). Batch dims in `outer` order.
+  std::vector<int64_t> src_outer, pts_outer;
+  for (int i : a.outer) { src_outer.push_back(a.source_batch[i]); pts_outer.push_back(a.points_batch[i]); }
+  const int no = (int)a.outer.size();
+  std::vector<int64_t> sfac(no, 1), pfac(no, 1);
+  for (int d2 = no - 2; d2 >= 0; --d2) {
+    sfac[d2] = sfac[d2 + 1] * src_outer[d2 + 1];
+    pfac[d2] = pfac[d2 + 1] * pts_outer[d2 + 1];
+  }
+  const size_t rsize = (size_t)desc->precision;
+  for (int64_t call = 0; call < a.num_calls; ++call) {
+    const char* pb = (const char*)points + (size_t)call * (size_t)a.num_points * rank * rsize;
+    // x = LAST coordinate of each point (reverse of the last axis, :282-286)
+    const void* px = pb + (size_t)(rank - 1) * rsize;
+    const void* py = rank > 1 ? pb + (size_t)(rank - 2) * rsize : nullptr;
+    const void* pz = rank > 2 ? pb + (size_t)(rank - 3) * rsize : nullptr;
+    rc = nufft_hip_set_points(plan, a.num_points, px, py, pz, rank);
+    if (rc) break;
+    int64_t source_index = 0, tmp = call;
+    for (int d2 = 0; d2 < no; ++d2) {
+      int64_t ix = tmp / pfac[d2];
+      tmp %= pfac[d2];
+      if (src_outer[d2] == 1) ix = 0;
+      source_index += ix * sfac[d2];
+    }
+    const int64_t target_index = call;
+    const int64_t c_index = t1 ? source_index : target_index;
+    const int64_t f_index = t1 ? target_index : source_index;
+    char* cbase = (char*)(t1 ? const_cast<void*>(psource) : ptarget);
+    char* fbase = (char*)(t1 ? ptarget : const_cast<void*>(psource));
+    void* c = cbase + (size_t)c_index * (size_t)a.num_transforms * (size_t)a.num_points * csize;
+    void* f = fbase + (size_t)f_index * (size_t)a.num_transforms * (size_t)num_coeffs * csize;
+    switch (desc->op_type) {
+      case NUFFT_HIP_OP_NUFFT: rc = nufft_hip_execute(plan, c, f); break;
+      case NUFFT_HIP_OP_INTERP: rc = nufft_hip_interp(plan, c, f); break;
+      case NUFFT_HIP_OP_SPREAD: rc = nufft_hip_spread(plan, c, f); break;
+      default: rc = NUFFT_HIP_INVALID_ARGUMENT;
+    }
+    if (rc) break;
+  }
+  if (rc) {
+    const std::string msg = nufft_hip_last_error(plan);
+    cleanup();
+    nufft_hip_plan_destroy(plan);
+    return fail(errbuf, errbuf_len, rc, msg);
+  }
+  if (a.transpose) {
+    // target[original order] = ttarget[outer.., inner.., elem..]: for output dim j
+    // (original position), its stride in ttarget is that of position iperm[j].
+    std::vector<int64_t> tshape_perm(t_nd);
+    for (int i = 0; i < t_nd; ++i) tshape_perm[i] = a.target_shape[i < nb ? perm[i] : i];
+    std::vector<int64_t> tst = contiguous_strides(tshape_perm), ostr(t_nd);
+    std::vector<int> iperm(t_nd);
+    for (int i = 0; i < t_nd; ++i) iperm[i < nb ? perm[i] : i] = i;
+    for (int j = 0; j < t_nd; ++j) ostr[j] = tst[iperm[j]];
+    hipError_t e = launch_permute(ttarget, target, (int)csize, t_nd, a.target_shape.data(), ostr.data(), stream);
+    if (e != hipSuccess) return hip_fail(e);
+    e = hipStreamSynchronize(stream);   // temporaries are freed below
+    if (e != hipSuccess) return hip_fail(e);
+  }
+  cleanup();
+  cache_give(key, plan);
+  return NUFFT_HIP_OK;
+}
+
+void nufft_hip_op_clear_cache(void) {
+  std::list<CachedPlan> tmp;
+  {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    tmp.swap(g_cache);
+  }
+  for (auto& c : tmp) nufft_hip_plan_destroy(c.plan);
+}
+
+}  // extern "C"

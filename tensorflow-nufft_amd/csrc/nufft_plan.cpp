@@ -1,0 +1,811 @@
+// Host side of the gfx950 NUFFT plan: parameter rules, kernel tables, device
+// workspace, rocFFT plan, and the stage sequencing of set_points / execute /
+// spread / interp behind the C ABI of include/nufft_hip.h.
+//
+// Replaces Plan<GPUDevice, FloatType> of the reference
+// (tensorflow_nufft/cc/kernels/nufft_plan.cu.cc: initialize :1808-2030,
+// set_points :2054-2111, execute :2113-2168, interp/spread :2170-2225,
+// setup_spreader :3040-3099, set_grid_size :3166-3204) together with the
+// shared rules in nufft_plan.h:739-863 and nufft_util.cc:43-117.
+#include <hip/hip_runtime.h>
+#include <rocfft/rocfft.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "nufft_hip_internal.h"
+
+using namespace nufft_hip;
+
+namespace {
+
+constexpr double kPi = 3.14159265358979323846;
+constexpr int64_t kMaxArraySize = 2000000000;  // reference nufft_plan.h:62
+
+std::string format(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  return std::string(buf);
+}
+
+// ------------------------------------------------------------- numerics
+
+// Smallest even integer >= n with no prime factor above 5
+// (reference next_smooth_integer, nufft_plan.h:628-649).
+int64_t next_smooth_even(int64_t n) {
+  if (n <= 2) return 2;
+  if (n & 1) ++n;
+  for (;; n += 2) {
+    int64_t d = n;
+    while (d % 2 == 0) d /= 2;
+    while (d % 3 == 0) d /= 3;
+    while (d % 5 == 0) d /= 5;
+    if (d == 1) return n;
+  }
+}
+
+struct KernelSpec {
+  int w = 0;
+  double beta = 0, c = 0, sigma = 2.0;
+  // Normalised exponential-of-semicircle kernel, phi(0) = 1:
+  //   phi(x) = exp(beta (sqrt(1 - c x^2) - 1)),  |x| <= w/2.
+  // The reference leaves it unnormalised (exp(beta) ~ 1e8 at w = 8,
+  // nufft_util.cc:64-69); the constant cancels in the deconvolution, and the
+  // normalised form cannot overflow float in 3D at large w.
+  double eval(double x) const {
+    const double t = 1.0 - c * x * x;
+    return t <= 0.0 ? (std::fabs(x) <= 0.5 * w ? std::exp(-beta) : 0.0)
+                    : std::exp(beta * (std::sqrt(t) - 1.0));
+  }
+};
+
+// Gauss-Legendre rule by Newton iteration on the Legendre recurrence (own code;
+// the reference uses the LGPL legendre_compute_glr, legendre_rule_fast.cc:28).
+void gauss_legendre(int n, std::vector<double>& z, std::vector<double>& wt) {
+  z.resize(n);
+  wt.resize(n);
+  for (int i = 0; i < n; ++i) {
+    double x = std::cos(kPi * (i + 0.75) / (n + 0.5));
+    double dp = 1.0;
+    for (int it = 0; it < 100; ++it) {
+      double p0 = 1.0, p1 = x;
+      for (int k = 2; k <= n; ++k) {
+        const double pk = ((2.0 * k - 1.0) * x * p1 - (k - 1.0) * p0) / k;
+        p0 = p1;
+        p1 = pk;
+      }
+      dp = n * (x * p1 - p0) / (x * x - 1.0);
+      const double dx = p1 / dp;
+      x -= dx;
+      if (std::fabs(dx) < 1e-16) break;
+    }
+    double p0 = 1.0, p1 = x;
+    for (int k = 2; k <= n; ++k) {
+      const double pk = ((2.0 * k - 1.0) * x * p1 - (k - 1.0) * p0) / k;
+      p0 = p1;
+      p1 = pk;
+    }
+    dp = n * (x * p1 - p0) / (x * x - 1.0);
+    z[i] = x;
+    wt[i] = 2.0 / ((1.0 - x * x) * dp * dp);
+  }
+}
+
+// Fourier series of the kernel on an nf-point grid, k = 0..nf/2, including the
+// (-1)^k that cancels the +pi shift of the fold (reference kernel_fseries_1d,
+// nufft_util.cc:71-117; q = floor(2 + 3 w / 2) positive nodes). Always double.
+void kernel_fseries(const KernelSpec& ks, int64_t nf, std::vector<double>& out) {
+  const double hw = 0.5 * ks.w;
+  const int q = (int)(2 + 3.0 * hw);
+  std::vector<double> z, wt;
+  gauss_legendre(2 * q, z, wt);
+  out.assign(nf / 2 + 1, 0.0);
+  for (int64_t k = 0; k <= nf / 2; ++k) {
+    double s = 0.0;
+    for (int n = 0; n < q; ++n) {
+      const double zn = z[n] * hw;
+      s += 2.0 * hw * wt[n] * ks.eval(zn) *
+           std::cos(2.0 * kPi * (double)k * ((double)(nf / 2) - zn) / (double)nf);
+    }
+    out[k] = s;
+  }
+}
+
+// Spread-/interp-only normalisation (reference calculate_scale_factor,
+// nufft_util.cc:43-62), for the NORMALISED kernel: the reference multiplies by
+// 1 / (h (1 + sum exp(beta sqrt(1 - t_i^2))) w/2)^rank with its unnormalised
+// kernel, so ours carries an extra exp(beta)^rank.
+double spread_only_scale(const KernelSpec& ks, int rank) {
+  const int n = 100;
+  const double h = 2.0 / n;
+  double x = -1.0, sum = 0.0;
+  for (int i = 1; i < n; ++i) {
+    x += h;
+    sum += std::exp(ks.beta * (std::sqrt(1.0 - x * x) - 1.0));
+  }
+  sum += std::exp(-ks.beta);
+  sum *= h;
+  sum *= std::sqrt(1.0 / ks.c);
+  double scale = sum;
+  if (rank > 1) scale *= sum;
+  if (rank > 2) scale *= sum;
+  return 1.0 / scale;
+}
+
+// Piecewise polynomial (one per stencil cell j) in z in [-1, 1]:
+// P_j(z) ~ phi((z + 1 - w)/2 + j). Chebyshev interpolation -> monomial
+// coefficients, all in double. Plays the role of the reference's generated
+// kernel_horner_*.inc tables (not copied; any sigma works). Returns the max
+// error over a dense sample.
+double fit_horner(const KernelSpec& ks, int nc, double* tab /* [kMaxCoef][kMaxW] */) {
+  const int w = ks.w;
+  std::vector<double> node(nc), val(nc), cheb(nc);
+  for (int i = 0; i < kMaxCoef * kMaxW; ++i) tab[i] = 0.0;
+  for (int j = 0; j < w; ++j) {
+    for (int i = 0; i < nc; ++i) {
+      node[i] = std::cos(kPi * (i + 0.5) / nc);
+      val[i] = ks.eval((node[i] + 1.0 - w) / 2.0 + j);
+    }
+    for (int k = 0; k < nc; ++k) {
+      double s = 0;
+      for (int i = 0; i < nc; ++i) s += val[i] * std::cos(kPi * k * (i + 0.5) / nc);
+      cheb[k] = s * (k == 0 ? 1.0 : 2.0) / nc;
+    }
+    std::vector<double> mono(nc, 0.0), tkm1(nc, 0.0), tk(nc, 0.0), tn(nc, 0.0);
+    tkm1[0] = 1.0;
+    if (nc > 1) tk[1] = 1.0;
+    for (int m = 0; m < nc; ++m) mono[m] += cheb[0] * tkm1[m];
+    if (nc > 1)
+      for (int m = 0; m < nc; ++m) mono[m] += cheb[1] * tk[m];
+    for (int k = 2; k < nc; ++k) {
+      for (int m = 0; m < nc; ++m) tn[m] = (m > 0 ? 2.0 * tk[m - 1] : 0.0) - tkm1[m];
+      for (int m = 0; m < nc; ++m) {
+        mono[m] += cheb[k] * tn[m];
+        tkm1[m] = tk[m];
+        tk[m] = tn[m];
+      }
+    }
+    for (int k = 0; k < nc; ++k) tab[k * kMaxW + j] = mono[k];
+  }
+  double err = 0.0;
+  for (int s = 0; s <= 64; ++s) {
+    const double z = -1.0 + 2.0 * s / 64.0;
+    for (int j = 0; j < w; ++j) {
+      double acc = tab[(nc - 1) * kMaxW + j];
+      for (int k = nc - 2; k >= 0; --k) acc = acc * z + tab[k * kMaxW + j];
+      err = std::max(err, std::fabs(acc - ks.eval((z + 1.0 - w) / 2.0 + j)));
+    }
+  }
+  return err;
+}
+
+std::once_flag g_rocfft_once;
+
+}  // namespace
+
+// ------------------------------------------------------------------ plan
+
+struct nufft_hip_plan_s {
+  int type = 0, rank = 0, iflag = 0, ntransf = 0, precision = 0;
+  double tol = 0;
+  nufft_hip_options opts;
+  Geom g;
+  KernelSpec ks;
+  int method = NUFFT_HIP_METHOD_TILE_GENERIC;
+  int batch_size = 1;
+  size_t lds_bytes = 0;
+  hipStream_t stream = nullptr;
+  int device = 0;
+  double spread_scale = 1.0;
+
+  std::vector<double> horner_h;      // [kMaxCoef][kMaxW]
+  std::vector<double> fser_h[3];     // phi-hat per dimension
+  void* d_horner = nullptr;
+  void* d_rfser[3] = {nullptr, nullptr, nullptr};
+  void* d_fine = nullptr;
+  int64_t fine_elems = 0, grid_elems = 0;
+  std::map<int, rocfft_plan> fft_plans;   // by batch count
+  rocfft_execution_info fft_info = nullptr;
+  void* fft_work = nullptr;
+  size_t fft_work_bytes = 0;
+
+  int64_t M = 0, cap = 0;
+  uint32_t *loc_tmp = nullptr, *loc = nullptr;
+  void *z_tmp[3] = {nullptr, nullptr, nullptr}, *z[3] = {nullptr, nullptr, nullptr};
+  int32_t *tile_of = nullptr, *rank_of = nullptr, *idx = nullptr;
+  int32_t *tile_count = nullptr, *tile_start = nullptr, *sub_start = nullptr, *bad_count = nullptr;
+  int64_t workspace_bytes = 0;
+  bool points_set = false;
+  std::string err;
+};
+
+namespace {
+
+#define HIP_TRY(p, expr)                                                              \
+  do {                                                                                \
+    hipError_t e_ = (expr);                                                           \
+    if (e_ != hipSuccess) {                                                           \
+      (p)->err = format("HIP error %d (%s) at %s:%d", (int)e_, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                          \
+      return NUFFT_HIP_INTERNAL;                                                      \
+    }                                                                                 \
+  } while (0)
+
+#define FFT_TRY(p, expr)                                                      \
+  do {                                                                        \
+    rocfft_status s_ = (expr);                                                \
+    if (s_ != rocfft_status_success) {                                        \
+      (p)->err = format("rocFFT error %d at %s:%d", (int)s_, __FILE__, __LINE__); \
+      return NUFFT_HIP_INTERNAL;                                              \
+    }                                                                         \
+  } while (0)
+
+int dev_alloc(nufft_hip_plan p, void** ptr, size_t bytes) {
+  *ptr = nullptr;
+  if (bytes == 0) bytes = 16;
+  hipError_t e = hipMalloc(ptr, bytes);
+  if (e != hipSuccess) {
+    p->err = format("out of device memory allocating %zu bytes (%s)", bytes, hipGetErrorString(e));
+    (void)hipGetLastError();
+    return NUFFT_HIP_RESOURCE_EXHAUSTED;
+  }
+  p->workspace_bytes += (int64_t)bytes;
+  return NUFFT_HIP_OK;
+}
+
+void dev_free(void* p) {
+  if (p) (void)hipFree(p);
+}
+
+int get_fft_plan(nufft_hip_plan p, int batch, rocfft_plan* out) {
+  auto it = p->fft_plans.find(batch);
+  if (it != p->fft_plans.end()) {
+    *out = it->second;
+    return NUFFT_HIP_OK;
+  }
+  std::call_once(g_rocfft_once, [] { rocfft_setup(); });
+  size_t lengths[3];
+  for (int d = 0; d < p->rank; ++d) lengths[d] = (size_t)p->g.nf[d];
+  rocfft_plan plan = nullptr;
+  FFT_TRY(p, rocfft_plan_create(
+                 &plan, rocfft_placement_inplace,
+                 p->iflag < 0 ? rocfft_transform_type_complex_forward
+                              : rocfft_transform_type_complex_inverse,
+                 p->precision == NUFFT_HIP_F32 ? rocfft_precision_single : rocfft_precision_double,
+                 (size_t)p->rank, lengths, (size_t)batch, nullptr));
+  size_t wb = 0;
+  FFT_TRY(p, rocfft_plan_get_work_buffer_size(plan, &wb));
+  if (!p->fft_info) FFT_TRY(p, rocfft_execution_info_create(&p->fft_info));
+  if (wb > p->fft_work_bytes) {
+    HIP_TRY(p, hipStreamSynchronize(p->stream));
+    dev_free(p->fft_work);
+    int rc = dev_alloc(p, &p->fft_work, wb);
+    if (rc) return rc;
+    p->fft_work_bytes = wb;
+  }
+  if (p->fft_work_bytes)
+    FFT_TRY(p, rocfft_execution_info_set_work_buffer(p->fft_info, p->fft_work, p->fft_work_bytes));
+  FFT_TRY(p, rocfft_execution_info_set_stream(p->fft_info, p->stream));
+  p->fft_plans[batch] = plan;
+  *out = plan;
+  return NUFFT_HIP_OK;
+}
+
+template <typename T>
+int upload_tables(nufft_hip_plan p) {
+  std::vector<T> tmp(kMaxCoef * kMaxW);
+  for (size_t i = 0; i < tmp.size(); ++i) tmp[i] = (T)p->horner_h[i];
+  int rc = dev_alloc(p, &p->d_horner, tmp.size() * sizeof(T));
+  if (rc) return rc;
+  HIP_TRY(p, hipMemcpy(p->d_horner, tmp.data(), tmp.size() * sizeof(T), hipMemcpyHostToDevice));
+  for (int d = 0; d < p->rank; ++d) {
+    const size_t n = p->fser_h[d].size();
+    std::vector<T> r(n);
+    for (size_t k = 0; k < n; ++k) r[k] = (T)(1.0 / p->fser_h[d][k]);
+    rc = dev_alloc(p, &p->d_rfser[d], n * sizeof(T));
+    if (rc) return rc;
+    HIP_TRY(p, hipMemcpy(p->d_rfser[d], r.data(), n * sizeof(T), hipMemcpyHostToDevice));
+  }
+  return NUFFT_HIP_OK;
+}
+
+int ensure_point_capacity(nufft_hip_plan p, int64_t M) {
+  if (M <= p->cap) return NUFFT_HIP_OK;
+  HIP_TRY(p, hipStreamSynchronize(p->stream));
+  const size_t fb = (size_t)p->precision;
+  dev_free(p->loc_tmp); dev_free(p->loc); dev_free(p->tile_of); dev_free(p->rank_of); dev_free(p->idx);
+  for (int d = 0; d < 3; ++d) { dev_free(p->z_tmp[d]); dev_free(p->z[d]); p->z_tmp[d] = p->z[d] = nullptr; }
+  p->loc_tmp = p->loc = nullptr; p->tile_of = p->rank_of = p->idx = nullptr;
+  p->cap = 0;
+  int rc;
+  if ((rc = dev_alloc(p, (void**)&p->loc_tmp, M * 4))) return rc;
+  if ((rc = dev_alloc(p, (void**)&p->loc, M * 4))) return rc;
+  if ((rc = dev_alloc(p, (void**)&p->tile_of, M * 4))) return rc;
+  if ((rc = dev_alloc(p, (void**)&p->rank_of, M * 4))) return rc;
+  if ((rc = dev_alloc(p, (void**)&p->idx, M * 4))) return rc;
+  for (int d = 0; d < p->rank; ++d) {
+    if ((rc = dev_alloc(p, &p->z_tmp[d], M * fb))) return rc;
+    if ((rc = dev_alloc(p, &p->z[d], M * fb))) return rc;
+  }
+  p->cap = M;
+  return NUFFT_HIP_OK;
+}
+
+template <typename T>
+int set_points_impl(nufft_hip_plan p, int64_t M, const void* x, const void* y, const void* z,
+                    int64_t stride) {
+  int rc = ensure_point_capacity(p, M);
+  if (rc) return rc;
+  p->M = M;
+  HIP_TRY(p, hipMemsetAsync(p->tile_count, 0, sizeof(int32_t) * (size_t)p->g.ntiles, p->stream));
+  HIP_TRY(p, hipMemsetAsync(p->bad_count, 0, sizeof(int32_t) * 4, p->stream));
+  PrepArgs a;
+  a.pts[0] = x; a.pts[1] = y; a.pts[2] = z;
+  a.stride = stride;
+  a.M = M;
+  a.range_mode = p->opts.points_range;
+  a.check_range = p->opts.check_points_range;
+  a.loc = p->loc_tmp;
+  for (int d = 0; d < 3; ++d) a.z[d] = p->z_tmp[d];
+  a.tile_of = p->tile_of;
+  a.rank_of = p->rank_of;
+  a.tile_count = p->tile_count;
+  a.bad_count = p->bad_count;
+  HIP_TRY(p, launch_prep<T>(p->g, a, p->stream));
+  HIP_TRY(p, launch_scan(p->g, p->tile_count, p->tile_start, p->sub_start, p->stream));
+  T* zin[3] = {(T*)p->z_tmp[0], (T*)p->z_tmp[1], (T*)p->z_tmp[2]};
+  T* zout[3] = {(T*)p->z[0], (T*)p->z[1], (T*)p->z[2]};
+  HIP_TRY(p, launch_scatter<T>(p->g, M, p->loc_tmp, zin, p->tile_of, p->rank_of, p->tile_start,
+                               p->loc, zout, p->idx, p->stream));
+  if (p->opts.check_points_range && p->opts.points_range != NUFFT_HIP_RANGE_INFINITE) {
+    int32_t bad = 0;
+    HIP_TRY(p, hipMemcpyAsync(&bad, p->bad_count, sizeof(int32_t), hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(p, hipStreamSynchronize(p->stream));
+    if (bad > 0) {
+      const double b = p->opts.points_range == NUFFT_HIP_RANGE_STRICT ? kPi : 3.0 * kPi;
+      // message of reference check_points_within_range, nufft_plan.h:889-893
+      p->err = format(
+          "Found points outside expected range. Valid range is [%g, %g]. Check your points "
+          "and/or set a less restrictive value for options.points_range.", -b, b);
+      return NUFFT_HIP_INVALID_ARGUMENT;
+    }
+  }
+  p->points_set = true;
+  return NUFFT_HIP_OK;
+}
+
+template <typename T>
+SortedPoints<T> sorted_view(nufft_hip_plan p) {
+  SortedPoints<T> sp;
+  sp.loc = p->loc;
+  for (int d = 0; d < 3; ++d) sp.z[d] = (const T*)p->z[d];
+  sp.idx = p->idx;
+  sp.tile_start = p->tile_start;
+  sp.sub_start = p->sub_start;
+  return sp;
+}
+
+// type 1: c -> fine grid (spread) -> FFT -> deconvolve -> f
+// type 2: f -> amplify into fine grid -> FFT -> interpolate -> c
+// batched over min(ntransf, batch_size) transforms per pass (one launch per
+// stage and pass; the reference launches per transform, nufft_plan.cu.cc:2469-2571).
+template <typename T>
+int execute_impl(nufft_hip_plan p, void* c, void* f) {
+  if (!p->points_set) {
+    p->err = "set_points must be called before execute";
+    return NUFFT_HIP_INVALID_ARGUMENT;
+  }
+  const SortedPoints<T> sp = sorted_view<T>(p);
+  const T* rf[3] = {(const T*)p->d_rfser[0], (const T*)p->d_rfser[1], (const T*)p->d_rfser[2]};
+  for (int b0 = 0; b0 < p->ntransf; b0 += p->batch_size) {
+    const int nb = std::min(p->batch_size, p->ntransf - b0);
+    T* cb = (T*)c + 2 * (int64_t)b0 * p->M;
+    T* fb = (T*)f + 2 * (int64_t)b0 * p->grid_elems;
+    T* fw = (T*)p->d_fine;
+    rocfft_plan fft;
+    int rc = get_fft_plan(p, nb, &fft);
+    if (rc) return rc;
+    void* bufs[1] = {fw};
+    if (p->type == NUFFT_HIP_TYPE_1) {
+      HIP_TRY(p, hipMemsetAsync(fw, 0, sizeof(T) * 2 * (size_t)p->fine_elems * nb, p->stream));
+      HIP_TRY(p, launch_spread<T>(p->g, p->method, sp, p->M, (const T*)p->d_horner, cb, fw, nb,
+                                  p->M, p->fine_elems, (T)1, p->lds_bytes, p->stream));
+      FFT_TRY(p, rocfft_execute(fft, bufs, nullptr, p->fft_info));
+      HIP_TRY(p, launch_deconvolve<T>(p->g, 1, fb, fw, rf, nb, p->stream));
+    } else {
+      HIP_TRY(p, launch_deconvolve<T>(p->g, 2, fb, fw, rf, nb, p->stream));
+      FFT_TRY(p, rocfft_execute(fft, bufs, nullptr, p->fft_info));
+      HIP_TRY(p, launch_interp<T>(p->g, p->method, sp, p->M, (const T*)p->d_horner, cb, fw, nb,
+                                  p->M, p->fine_elems, (T)1, p->stream));
+    }
+  }
+  return NUFFT_HIP_OK;
+}
+
+template <typename T>
+int spread_interp_impl(nufft_hip_plan p, int dir, void* c, void* f) {
+  if (!p->opts.spread_only) {
+    p->err = "spread/interp require a plan created with options.spread_only = 1";
+    return NUFFT_HIP_INVALID_ARGUMENT;
+  }
+  if (!p->points_set) {
+    p->err = "set_points must be called before spread/interp";
+    return NUFFT_HIP_INVALID_ARGUMENT;
+  }
+  const SortedPoints<T> sp = sorted_view<T>(p);
+  const T scale = (T)p->spread_scale;
+  // The op output IS the grid here; batch over all transforms in one launch
+  // group of at most 65535 (grid.y limit).
+  for (int b0 = 0; b0 < p->ntransf; b0 += 32768) {
+    const int nb = std::min(32768, p->ntransf - b0);
+    T* cb = (T*)c + 2 * (int64_t)b0 * p->M;
+    T* fb = (T*)f + 2 * (int64_t)b0 * p->fine_elems;
+    if (dir == 1) {
+      HIP_TRY(p, hipMemsetAsync(fb, 0, sizeof(T) * 2 * (size_t)p->fine_elems * nb, p->stream));
+      HIP_TRY(p, launch_spread<T>(p->g, p->method, sp, p->M, (const T*)p->d_horner, cb, fb, nb,
+                                  p->M, p->fine_elems, scale, p->lds_bytes, p->stream));
+    } else {
+      HIP_TRY(p, launch_interp<T>(p->g, p->method, sp, p->M, (const T*)p->d_horner, cb, fb, nb,
+                                  p->M, p->fine_elems, scale, p->stream));
+    }
+  }
+  return NUFFT_HIP_OK;
+}
+
+void destroy(nufft_hip_plan p) {
+  if (!p) return;
+  if (p->stream || true) (void)hipStreamSynchronize(p->stream);
+  for (auto& kv : p->fft_plans) rocfft_plan_destroy(kv.second);
+  if (p->fft_info) rocfft_execution_info_destroy(p->fft_info);
+  dev_free(p->fft_work);
+  dev_free(p->d_horner);
+  for (int d = 0; d < 3; ++d) { dev_free(p->d_rfser[d]); dev_free(p->z_tmp[d]); dev_free(p->z[d]); }
+  dev_free(p->d_fine);
+  dev_free(p->loc_tmp); dev_free(p->loc); dev_free(p->tile_of); dev_free(p->rank_of); dev_free(p->idx);
+  dev_free(p->tile_count); dev_free(p->tile_start); dev_free(p->sub_start); dev_free(p->bad_count);
+  delete p;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ C ABI
+
+extern "C" {
+
+int nufft_hip_abi_version(void) { return NUFFT_HIP_ABI_VERSION; }
+
+void nufft_hip_default_options(nufft_hip_options* o) {
+  if (!o) return;
+  std::memset(o, 0, sizeof(*o));
+  o->points_range = NUFFT_HIP_RANGE_EXTENDED;   // reference default, nufft_options.py
+}
+
+// Host-only part of plan creation: argument checks and every parameter rule.
+// On success returns a plan object with no device state.
+static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* grid_dims,
+                     int iflag, int ntransf, double tol, int precision,
+                     const nufft_hip_options* opts_in, void* stream, std::string* errmsg) {
+  auto fail = [&](int code, const std::string& msg) {
+    *errmsg = msg;
+    *out = nullptr;
+    return code;
+  };
+  // argument checks: reference Plan::initialize nufft_plan.cc:174-183 / nufft_plan.cu.cc:1833-1843
+  if (type != NUFFT_HIP_TYPE_1 && type != NUFFT_HIP_TYPE_2)
+    return fail(NUFFT_HIP_UNIMPLEMENTED, "type-3 transforms are not implemented");
+  if (rank < 1 || rank > 3)
+    return fail(NUFFT_HIP_UNIMPLEMENTED, format("rank %d is not implemented", rank));
+  if (ntransf < 1) return fail(NUFFT_HIP_INVALID_ARGUMENT, "num_transforms must be >= 1");
+  if (precision != NUFFT_HIP_F32 && precision != NUFFT_HIP_F64)
+    return fail(NUFFT_HIP_INVALID_ARGUMENT, "precision must be 4 (float) or 8 (double)");
+  if (iflag != NUFFT_HIP_FORWARD && iflag != NUFFT_HIP_BACKWARD)
+    return fail(NUFFT_HIP_INVALID_ARGUMENT, "iflag must be -1 (forward) or +1 (backward)");
+  if (!grid_dims) return fail(NUFFT_HIP_INVALID_ARGUMENT, "grid_dims is null");
+
+  nufft_hip_plan p = new nufft_hip_plan_s();
+  if (opts_in) p->opts = *opts_in; else nufft_hip_default_options(&p->opts);
+  p->type = type; p->rank = rank; p->iflag = iflag; p->ntransf = ntransf; p->precision = precision;
+  p->stream = (hipStream_t)stream;
+  // tolerance clamp: reference nufft_plan.h:84-89, nufft_plan.cu.cc:3062-3064
+  const double eps = precision == NUFFT_HIP_F32 ? 6e-8 : 1.1e-16;
+  p->tol = std::max(tol, eps);
+
+  Geom& g = p->g;
+  std::memset(&g, 0, sizeof(g));
+  g.rank = rank;
+  p->grid_elems = 1;
+  for (int d = 0; d < 3; ++d) {
+    g.nmodes[d] = d < rank ? (int)grid_dims[d] : 1;
+    if (d < rank && (grid_dims[d] < 1 || grid_dims[d] > kMaxArraySize)) {
+      delete p;
+      return fail(NUFFT_HIP_INVALID_ARGUMENT, format("invalid grid dimension %lld", (long long)grid_dims[d]));
+    }
+    p->grid_elems *= g.nmodes[d];
+  }
+
+  // Upsampling factor: 2.0 always on the GPU path (reference nufft_plan.cu.cc:1854-1857).
+  double sigma = p->opts.upsampling_factor;
+  if (sigma == 0.0) sigma = 2.0;
+  if (sigma <= 1.0) {
+    delete p;
+    return fail(NUFFT_HIP_INVALID_ARGUMENT, format("upsampling_factor must be > 1.0, but got: %g", sigma));
+  }
+  // Kernel width. Reference rule: w = ceil(-log10(tol / 10)) at sigma = 2
+  // (nufft_plan.h:762-777), whose value at exact powers of ten depends on the
+  // compiler's log10 overload (7 or 8 at tol = 1e-6). This build
+  // takes the safe side: one more cell whenever the rule lands within 1e-5 of
+  // an integer, so tol = 1e-6 -> 8, 1e-4 -> 6 in either precision.
+  int w = p->opts.kernel_width;
+  if (w == 0) {
+    if (sigma == 2.0) w = (int)std::ceil(-std::log10(p->tol / 10.0) + 1e-5);
+    else w = (int)std::ceil(-std::log(p->tol) / (kPi * std::sqrt(1.0 - 1.0 / sigma)) + 1e-5);
+    w = std::max(2, std::min(w, kMaxW));
+  }
+  if (w < 2 || w > kMaxW) {
+    delete p;
+    return fail(NUFFT_HIP_INVALID_ARGUMENT, format("kernel_width must be in [2, %d], but got: %d", kMaxW, w));
+  }
+  // ES kernel parameters: reference setup_spreader nufft_plan.cc:923-940, nufft_plan.cu.cc:3078-3093
+  double beta_over_w = 2.30;
+  if (w == 2) beta_over_w = 2.20;
+  if (w == 3) beta_over_w = 2.26;
+  if (w == 4) beta_over_w = 2.38;
+  if (sigma != 2.0) beta_over_w = 0.97 * kPi * (1.0 - 1.0 / (2.0 * sigma));
+  p->ks.w = w; p->ks.sigma = sigma; p->ks.beta = beta_over_w * w; p->ks.c = 4.0 / ((double)w * w);
+  g.w = w;
+
+  // Fine grid: reference initialize_fine_grid nufft_plan.h:803-863, set_grid_size nufft_plan.cu.cc:3166-3204
+  p->fine_elems = 1;
+  for (int d = 0; d < 3; ++d) g.nf[d] = 1;
+  for (int d = 0; d < rank; ++d) {
+    int64_t n = p->opts.spread_only ? g.nmodes[d] : (int64_t)((double)g.nmodes[d] * sigma);
+    if (n < 2 * w) n = 2 * w;
+    n = next_smooth_even(n);
+    if (p->opts.spread_only && n != g.nmodes[d]) {
+      const int bad = g.nmodes[d];
+      delete p;
+      return fail(NUFFT_HIP_INVALID_ARGUMENT,
+                  format("Invalid grid dimension size: %d. Grid dimension must be even, larger than "
+                         "the kernel (%d) and have no prime factors larger than 5.", bad, 2 * w));
+    }
+    g.nf[d] = (int)n;
+    p->fine_elems *= n;
+  }
+  // batch size: reference nufft_plan.cu.cc:1923-1928 (min(ntransf, 8) unless set)
+  p->batch_size = p->opts.max_batch_size > 0 ? std::min(p->opts.max_batch_size, ntransf)
+                                             : std::min(ntransf, 8);
+  if (p->fine_elems * p->batch_size > kMaxArraySize) {
+    const long long sz = (long long)(p->fine_elems * p->batch_size);
+    delete p;
+    return fail(NUFFT_HIP_INVALID_ARGUMENT, format("Fine grid is too big: size %lld > %lld", sz, (long long)kMaxArraySize));
+  }
+
+  // Tiles (bins). Defaults: 1024 | 32 x 32 | 16 x 16 x 4 fine cells; shrunk
+  // until the LDS tile fits.
+  const int def_tile[3][3] = {{1024, 1, 1}, {32, 32, 1}, {16, 16, 4}};
+  for (int d = 0; d < 3; ++d) {
+    int t = d < rank ? (p->opts.tile_dims[d] > 0 ? p->opts.tile_dims[d] : def_tile[rank - 1][d]) : 1;
+    t = std::max(1, std::min(t, 1024));
+    if (d < rank) t = std::min(t, g.nf[d]);
+    g.tile[d] = t;
+  }
+  const size_t lds_limit = 96 * 1024;
+  for (;;) {
+    g.ntiles = 1;
+    for (int d = 0; d < 3; ++d) {
+      g.ntile[d] = d < rank ? (g.nf[d] + g.tile[d] - 1) / g.tile[d] : 1;
+      g.ldim[d] = d < rank ? g.tile[d] + w - 1 : 1;
+      g.ntiles *= g.ntile[d];
+    }
+    g.lstride = g.ldim[0];
+    if (spread_lds_bytes(g, NUFFT_HIP_METHOD_TILE_GENERIC, precision) <= lds_limit) break;
+    int big = 0;
+    for (int d = 1; d < rank; ++d)
+      if (g.tile[d] > g.tile[big]) big = d;
+    if (g.tile[big] == 1) break;
+    g.tile[big] = (g.tile[big] + 1) / 2;
+  }
+  if (spread_lds_bytes(g, NUFFT_HIP_METHOD_TILE_GENERIC, precision) > 160 * 1024) {
+    delete p;
+    return fail(NUFFT_HIP_RESOURCE_EXHAUSTED, "kernel too wide for an LDS tile");  // cf. nufft_plan.cu.cc:2458-2463
+  }
+
+  // Polynomial kernel table. The fit error falls geometrically with the term
+  // count until it reaches a plateau set by the kernel's square-root end-point
+  // singularity (~5e-(w+1) of the peak, reached near w + 2 terms); more terms
+  // buy nothing. Take the smallest count within 1.3x of that plateau, or below
+  // the precision floor.
+  p->horner_h.assign(kMaxCoef * kMaxW, 0.0);
+  const double floor_err = precision == NUFFT_HIP_F32 ? 2e-8 : 1e-15;
+  const double plateau = fit_horner(p->ks, std::min(kMaxCoef, w + 3), p->horner_h.data());
+  const double want = std::max(floor_err, 1.3 * plateau);
+  int nc = std::max(3, w / 2 + 1);
+  for (; nc < kMaxCoef; ++nc)
+    if (fit_horner(p->ks, nc, p->horner_h.data()) <= want) break;
+  if (nc == kMaxCoef) fit_horner(p->ks, nc, p->horner_h.data());
+  g.ncoef = nc;
+
+  g.max_sub = p->opts.max_subproblem_size > 0 ? p->opts.max_subproblem_size : 1024;
+  int method = p->opts.spread_method;
+  if (method == NUFFT_HIP_METHOD_AUTO)
+    method = wave_method_supported(g, precision) ? NUFFT_HIP_METHOD_TILE_WAVE : NUFFT_HIP_METHOD_TILE_GENERIC;
+  if (method == NUFFT_HIP_METHOD_TILE_WAVE && !wave_method_supported(g, precision)) {
+    delete p;
+    return fail(NUFFT_HIP_INVALID_ARGUMENT,
+                "spread_method TILE_WAVE needs rank 2, kernel width 8, float precision and 32x32 tiles");
+  }
+  p->method = method;
+  if (method == NUFFT_HIP_METHOD_TILE_WAVE) g.lstride = 40;
+  p->lds_bytes = spread_lds_bytes(g, method, precision);
+
+  for (int d = 0; d < rank; ++d) kernel_fseries(p->ks, g.nf[d], p->fser_h[d]);
+  p->spread_scale = p->opts.spread_only ? spread_only_scale(p->ks, rank) : 1.0;
+
+  *out = p;
+  return NUFFT_HIP_OK;
+}
+
+int nufft_hip_plan_create(nufft_hip_plan* out, int type, int rank, const int64_t* grid_dims,
+                          int iflag, int ntransf, double tol, int precision,
+                          const nufft_hip_options* opts_in, void* stream, char* errbuf,
+                          size_t errbuf_len) {
+  auto fail = [&](int code, const std::string& msg) {
+    if (errbuf && errbuf_len) snprintf(errbuf, errbuf_len, "%s", msg.c_str());
+    if (out) *out = nullptr;
+    return code;
+  };
+  if (!out) return NUFFT_HIP_INVALID_ARGUMENT;
+  nufft_hip_plan p = nullptr;
+  std::string msg;
+  int rc0 = configure(&p, type, rank, grid_dims, iflag, ntransf, tol, precision, opts_in, stream, &msg);
+  if (rc0) return fail(rc0, msg);
+  if (hipGetDevice(&p->device) != hipSuccess) {
+    delete p;
+    (void)hipGetLastError();
+    return fail(NUFFT_HIP_INTERNAL, "no HIP device available (this library has no CPU fallback)");
+  }
+  Geom& g = p->g;
+  // device state
+  int rc = precision == NUFFT_HIP_F32 ? upload_tables<float>(p) : upload_tables<double>(p);
+  if (!rc) rc = dev_alloc(p, (void**)&p->tile_count, sizeof(int32_t) * (size_t)g.ntiles);
+  if (!rc) rc = dev_alloc(p, (void**)&p->tile_start, sizeof(int32_t) * ((size_t)g.ntiles + 1));
+  if (!rc) rc = dev_alloc(p, (void**)&p->sub_start, sizeof(int32_t) * ((size_t)g.ntiles + 1));
+  if (!rc) rc = dev_alloc(p, (void**)&p->bad_count, sizeof(int32_t) * 4);
+  if (!rc && !p->opts.spread_only)
+    rc = dev_alloc(p, &p->d_fine, (size_t)precision * 2 * (size_t)p->fine_elems * p->batch_size);
+  if (!rc && !p->opts.spread_only) {
+    rocfft_plan dummy;
+    rc = get_fft_plan(p, p->batch_size, &dummy);
+  }
+  if (rc) {
+    const std::string msg = p->err;
+    destroy(p);
+    return fail(rc, msg);
+  }
+  *out = p;
+  return NUFFT_HIP_OK;
+}
+
+
+int nufft_hip_plan_describe(int type, int rank, const int64_t* grid_dims, int iflag, int ntransf,
+                            double tol, int precision, const nufft_hip_options* opts,
+                            nufft_hip_plan_info* info, char* errbuf, size_t errbuf_len) {
+  nufft_hip_plan p = nullptr;
+  std::string msg;
+  int rc = configure(&p, type, rank, grid_dims, iflag, ntransf, tol, precision, opts, nullptr, &msg);
+  if (rc) {
+    if (errbuf && errbuf_len) snprintf(errbuf, errbuf_len, "%s", msg.c_str());
+    return rc;
+  }
+  rc = nufft_hip_plan_get_info(p, info);
+  delete p;
+  return rc;
+}
+
+int nufft_hip_set_points(nufft_hip_plan p, int64_t M, const void* x, const void* y, const void* z,
+                         int64_t stride) {
+  if (!p) return NUFFT_HIP_INVALID_ARGUMENT;
+  if (M < 0 || M > kMaxArraySize) {
+    p->err = format("invalid number of points %lld", (long long)M);
+    return NUFFT_HIP_INVALID_ARGUMENT;
+  }
+  if (M > 0 && (!x || (p->rank > 1 && !y) || (p->rank > 2 && !z))) {
+    p->err = "null points pointer";
+    return NUFFT_HIP_INVALID_ARGUMENT;
+  }
+  if (stride < 1) stride = 1;
+  return p->precision == NUFFT_HIP_F32 ? set_points_impl<float>(p, M, x, y, z, stride)
+                                       : set_points_impl<double>(p, M, x, y, z, stride);
+}
+
+int nufft_hip_execute(nufft_hip_plan p, void* c, void* f) {
+  if (!p) return NUFFT_HIP_INVALID_ARGUMENT;
+  if (p->opts.spread_only) {
+    p->err = "execute is not available on a spread_only plan";
+    return NUFFT_HIP_INVALID_ARGUMENT;
+  }
+  return p->precision == NUFFT_HIP_F32 ? execute_impl<float>(p, c, f) : execute_impl<double>(p, c, f);
+}
+
+int nufft_hip_spread(nufft_hip_plan p, const void* c, void* f) {
+  if (!p) return NUFFT_HIP_INVALID_ARGUMENT;
+  return p->precision == NUFFT_HIP_F32 ? spread_interp_impl<float>(p, 1, const_cast<void*>(c), f)
+                                       : spread_interp_impl<double>(p, 1, const_cast<void*>(c), f);
+}
+
+int nufft_hip_interp(nufft_hip_plan p, void* c, const void* f) {
+  if (!p) return NUFFT_HIP_INVALID_ARGUMENT;
+  return p->precision == NUFFT_HIP_F32 ? spread_interp_impl<float>(p, 2, c, const_cast<void*>(f))
+                                       : spread_interp_impl<double>(p, 2, c, const_cast<void*>(f));
+}
+
+int nufft_hip_plan_get_info(nufft_hip_plan p, nufft_hip_plan_info* info) {
+  if (!p || !info) return NUFFT_HIP_INVALID_ARGUMENT;
+  std::memset(info, 0, sizeof(*info));
+  info->type = p->type; info->rank = p->rank; info->precision = p->precision; info->iflag = p->iflag;
+  info->ntransf = p->ntransf; info->batch_size = p->batch_size;
+  info->kernel_width = p->g.w; info->ncoef = p->g.ncoef; info->spread_method = p->method;
+  info->upsampling_factor = p->ks.sigma; info->beta = p->ks.beta; info->tol = p->tol;
+  for (int d = 0; d < 3; ++d) {
+    info->grid_dims[d] = p->g.nmodes[d]; info->fine_dims[d] = p->g.nf[d];
+    info->tile_dims[d] = p->g.tile[d]; info->num_tiles[d] = p->g.ntile[d];
+  }
+  info->max_subproblem_size = p->g.max_sub;
+  info->num_points = p->M;
+  info->workspace_bytes = p->workspace_bytes;
+  return NUFFT_HIP_OK;
+}
+
+int nufft_hip_plan_set_stream(nufft_hip_plan p, void* stream) {
+  if (!p) return NUFFT_HIP_INVALID_ARGUMENT;
+  p->stream = (hipStream_t)stream;
+  if (p->fft_info) FFT_TRY(p, rocfft_execution_info_set_stream(p->fft_info, p->stream));
+  return NUFFT_HIP_OK;
+}
+
+const char* nufft_hip_last_error(nufft_hip_plan p) { return p ? p->err.c_str() : "null plan"; }
+
+int nufft_hip_plan_destroy(nufft_hip_plan p) {
+  destroy(p);
+  return NUFFT_HIP_OK;
+}
+
+int nufft_hip_debug_fine_grid(nufft_hip_plan p, void** fine, int64_t* count) {
+  if (!p || !fine || !count) return NUFFT_HIP_INVALID_ARGUMENT;
+  *fine = p->d_fine;
+  *count = p->fine_elems * p->batch_size;
+  return NUFFT_HIP_OK;
+}
+
+int nufft_hip_debug_fseries(nufft_hip_plan p, int dim, double* out, int64_t n) {
+  if (!p || dim < 0 || dim >= p->rank || !out) return NUFFT_HIP_INVALID_ARGUMENT;
+  const int64_t m = std::min<int64_t>(n, (int64_t)p->fser_h[dim].size());
+  for (int64_t k = 0; k < m; ++k) out[k] = p->fser_h[dim][k];
+  return NUFFT_HIP_OK;
+}
+
+int nufft_hip_debug_eval_kernel(nufft_hip_plan p, int n, const double* x1, double* out) {
+  if (!p || !x1 || !out) return NUFFT_HIP_INVALID_ARGUMENT;
+  const int w = p->g.w, nc = p->g.ncoef;
+  for (int i = 0; i < n; ++i) {
+    const double z = 2.0 * x1[i] + w - 1.0;
+    for (int j = 0; j < w; ++j) {
+      double acc = p->horner_h[(nc - 1) * kMaxW + j];
+      for (int k = nc - 2; k >= 0; --k) acc = acc * z + p->horner_h[k * kMaxW + j];
+      out[(size_t)i * w + j] = acc;
+    }
+  }
+  return NUFFT_HIP_OK;
+}
+
+}  // extern "C"

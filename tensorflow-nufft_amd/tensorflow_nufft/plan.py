@@ -1,0 +1,133 @@
+"""`Plan`: thin Python handle on the C-ABI plan (create / set_points / execute),
+for callers that reuse one plan across many executions (benchmarks, iterative
+reconstruction). Mirrors the reference's C++ `Plan` interface
+(cc/kernels/nufft_plan.h:223-256)."""
+import ctypes
+
+import torch
+
+from tensorflow_nufft import _lib
+from tensorflow_nufft.nufft_ops import _options_struct
+
+
+class Plan:
+  """grid_shape is in array (TensorFlow) order; points are [M, rank] with the
+  last axis ordered like grid_shape."""
+
+  def __init__(self, transform_type, grid_shape, fft_direction='forward', num_transforms=1,
+               tol=1e-6, dtype=torch.complex64, options=None, device=None, spread_only=False,
+               **internal):
+    self._handle = None
+    self.lib = _lib.lib()
+    self.rank = len(grid_shape)
+    self.grid_shape = [int(g) for g in grid_shape]
+    self.type = transform_type
+    self.ntransf = int(num_transforms)
+    self.cdtype = dtype
+    self.rdtype = torch.float32 if dtype == torch.complex64 else torch.float64
+    self.device = torch.device(device if device is not None else 'cuda')
+    if self.device.index is None:
+      self.device = torch.device('cuda', torch.cuda.current_device())
+    o = _options_struct(options)
+    o.spread_only = int(spread_only)
+    for k, v in internal.items():
+      if k == 'tile_dims':
+        for i, t in enumerate(v):
+          o.tile_dims[i] = int(t)
+      else:
+        setattr(o, k, v)
+    dims = (ctypes.c_int64 * 3)(*([self.grid_shape[self.rank - 1 - d] for d in range(self.rank)] +
+                                  [1] * (3 - self.rank)))
+    err = ctypes.create_string_buffer(1024)
+    h = ctypes.c_void_p()
+    with torch.cuda.device(self.device):
+      stream = torch.cuda.current_stream(self.device).cuda_stream
+      rc = self.lib.nufft_hip_plan_create(
+          ctypes.byref(h), 1 if transform_type == 'type_1' else 2, self.rank, dims,
+          -1 if fft_direction == 'forward' else 1, self.ntransf, float(tol),
+          4 if dtype == torch.complex64 else 8, ctypes.byref(o), ctypes.c_void_p(stream), err, len(err))
+    _lib.raise_for_status(rc, err.value)
+    self._handle = h
+    self.M = 0
+    self._points = None
+
+  def _check(self, rc):
+    if rc:
+      _lib.raise_for_status(rc, self.lib.nufft_hip_last_error(self._handle))
+
+  def info(self):
+    i = _lib.PlanInfo()
+    self._check(self.lib.nufft_hip_plan_get_info(self._handle, ctypes.byref(i)))
+    return i
+
+  def set_points(self, points):
+    points = points.to(self.device, self.rdtype).contiguous()
+    assert points.dim() == 2 and points.shape[1] == self.rank
+    self._points = points   # keep alive until the sort kernels have consumed it
+    self.M = points.shape[0]
+    es = points.element_size()
+    base = points.data_ptr()
+    r = self.rank
+    with torch.cuda.device(self.device):
+      self._check(self.lib.nufft_hip_set_points(
+          self._handle, self.M, base + (r - 1) * es,
+          base + (r - 2) * es if r > 1 else None,
+          base + (r - 3) * es if r > 2 else None, r))
+
+  def execute(self, source, out=None):
+    source = source.to(self.device, self.cdtype).contiguous()
+    lead = [self.ntransf] if self.ntransf > 1 or source.dim() > (1 if self.type == 'type_1' else self.rank) else []
+    if self.type == 'type_1':
+      if out is None:
+        out = torch.empty(lead + self.grid_shape, dtype=self.cdtype, device=self.device)
+      c, f = source, out
+    else:
+      if out is None:
+        out = torch.empty(lead + [self.M], dtype=self.cdtype, device=self.device)
+      c, f = out, source
+    with torch.cuda.device(self.device):
+      self._check(self.lib.nufft_hip_execute(self._handle, c.data_ptr(), f.data_ptr()))
+    return out
+
+  def spread(self, c, out=None):
+    c = c.to(self.device, self.cdtype).contiguous()
+    lead = [self.ntransf] if self.ntransf > 1 or c.dim() > 1 else []
+    if out is None:
+      out = torch.empty(lead + self.grid_shape, dtype=self.cdtype, device=self.device)
+    with torch.cuda.device(self.device):
+      self._check(self.lib.nufft_hip_spread(self._handle, c.data_ptr(), out.data_ptr()))
+    return out
+
+  def interp(self, f, out=None):
+    f = f.to(self.device, self.cdtype).contiguous()
+    lead = [self.ntransf] if self.ntransf > 1 or f.dim() > self.rank else []
+    if out is None:
+      out = torch.empty(lead + [self.M], dtype=self.cdtype, device=self.device)
+    with torch.cuda.device(self.device):
+      self._check(self.lib.nufft_hip_interp(self._handle, out.data_ptr(), f.data_ptr()))
+    return out
+
+  def fine_grid(self):
+    """Copy of the fine (oversampled) grid of the last batch, array order."""
+    ptr = ctypes.c_void_p()
+    n = ctypes.c_int64()
+    self._check(self.lib.nufft_hip_debug_fine_grid(self._handle, ctypes.byref(ptr), ctypes.byref(n)))
+    i = self.info()
+    shape = [i.batch_size] + [int(i.fine_dims[self.rank - 1 - d]) for d in range(self.rank)]
+    out = torch.empty(shape, dtype=self.cdtype, device=self.device)
+    torch.cuda.current_stream(self.device).synchronize()
+    import ctypes as _c
+    hip = _c.CDLL('libamdhip64.so')
+    hip.hipMemcpy(_c.c_void_p(out.data_ptr()), ptr, _c.c_size_t(out.numel() * out.element_size()), 3)
+    return out
+
+  def close(self):
+    if self._handle is not None:
+      self.lib.nufft_hip_plan_destroy(self._handle)
+      self._handle = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:  # pylint: disable=broad-except
+      pass

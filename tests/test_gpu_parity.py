@@ -1,0 +1,300 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against
+the CPU oracle and the committed NUDFT golden vectors. Tolerances are stated
+per test; `tol` is the transform's requested precision (north star: rel-l2
+<= tol, default 1e-6, vs the reference CPU path / fp64 truth)."""
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def tfft():
+  import torch
+  assert torch.cuda.is_available()
+  import tensorflow_nufft as t
+  from tensorflow_nufft import _lib
+  _lib.lib()   # the HIP library must be the thing that runs: fail loudly if missing
+  return t
+
+
+def _dev(a):
+  import torch
+  return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _cases(golden, fname):
+  g = golden(fname)
+  for name in g['names']:
+    name = str(name)
+    _, tt1, tt2, fd = name.rsplit('_', 3)
+    grid = [int(v) for v in name.split('_')[0][1:].split('x')]
+    yield name, grid, f'{tt1}_{tt2}', fd, g[name + '_points'], g[name + '_source'], g[name + '_target']
+
+
+@pytest.mark.parametrize('fname', ['nudft_cases.npz', 'nudft_mid.npz'])
+def test_golden_nudft_f32(tfft, golden, fname):
+  # complex64 at the default tol = 1e-6: rel-l2 <= 1e-6 against float64 NUDFT
+  for name, grid, tt, fd, pts, src, target in _cases(golden, fname):
+    out = tfft.nufft(_dev(src), _dev(pts), grid_shape=grid if tt == 'type_1' else None,
+                     transform_type=tt, fft_direction=fd, tol=1e-6).cpu().numpy()
+    assert out.shape == target.shape
+    assert rel_l2(out, target) < 1e-6, (name, rel_l2(out, target))
+
+
+@pytest.mark.parametrize('fname', ['nudft_cases.npz', 'nudft_mid.npz'])
+@pytest.mark.parametrize('tol', [1e-3, 1e-6, 1e-9, 1e-12])
+def test_golden_nudft_f64(tfft, golden, fname, tol):
+  for name, grid, tt, fd, pts, src, target in _cases(golden, fname):
+    out = tfft.nufft(_dev(src.astype(np.complex128)), _dev(pts.astype(np.float64)),
+                     grid_shape=grid if tt == 'type_1' else None,
+                     transform_type=tt, fft_direction=fd, tol=tol).cpu().numpy()
+    assert rel_l2(out, target) < tol, (name, tol, rel_l2(out, target))
+
+
+@pytest.mark.parametrize('tol', [1e-1, 1e-2, 1e-3, 1e-4, 1e-5, 1e-6])
+def test_tolerance_sweep_f32(tfft, golden, tol):
+  g = golden('nudft_mid.npz')
+  for name in ('g64x64_type_1_forward', 'g64x64_type_2_backward', 'g16x20x24_type_1_forward',
+               'g200_type_2_backward'):
+    grid = [int(v) for v in name.split('_')[0][1:].split('x')]
+    tt = 'type_1' if 'type_1' in name else 'type_2'
+    fd = name.rsplit('_', 1)[1]
+    out = tfft.nufft(_dev(g[name + '_source']), _dev(g[name + '_points']),
+                     grid_shape=grid if tt == 'type_1' else None, transform_type=tt,
+                     fft_direction=fd, tol=tol).cpu().numpy()
+    assert rel_l2(out, g[name + '_target']) < tol, (name, tol)
+
+
+@pytest.mark.parametrize('method', [1, 2])
+def test_wave_and_generic_spreaders_agree_with_oracle(tfft, method):
+  # 2D, w = 8, float: both spreading paths against the fp64 oracle (tol 1e-12)
+  import torch
+  from oracle import oracle
+  rng = np.random.default_rng(21)
+  grid = [96, 80]
+  M = 50000
+  pts = rng.uniform(-np.pi, np.pi, (M, 2)).astype(np.float32)
+  c = (rng.uniform(-.5, .5, M) + 1j * rng.uniform(-.5, .5, M)).astype(np.complex64)
+  truth = oracle.nufft(c.astype(np.complex128), pts, grid, 'type_1', 'forward', tol=1e-12)
+  plan = tfft.Plan('type_1', grid, 'forward', tol=1e-6, dtype=torch.complex64, spread_method=method)
+  assert plan.info().spread_method == method and plan.info().kernel_width == 8
+  plan.set_points(_dev(pts))
+  out = plan.execute(_dev(c)).cpu().numpy()
+  assert rel_l2(out, truth) < 1e-6, rel_l2(out, truth)
+  plan.close()
+
+
+def test_headline_shape_small_m_vs_oracle(tfft):
+  # BASELINE config 2 geometry (1024^2 modes, 2048^2 fine grid) with M = 2e5 so
+  # the oracle (fp64, sigma 2, tol 1e-12) finishes in seconds
+  from oracle import oracle
+  rng = np.random.default_rng(2)
+  grid = [1024, 1024]
+  M = 200000
+  pts = rng.uniform(-np.pi, np.pi, (M, 2)).astype(np.float32)
+  c = (rng.uniform(-.5, .5, M) + 1j * rng.uniform(-.5, .5, M)).astype(np.complex64)
+  truth = oracle.nufft(c.astype(np.complex128), pts, grid, 'type_1', 'forward', tol=1e-12, sigma=2.0)
+  out = tfft.nufft(_dev(c), _dev(pts), grid_shape=grid, transform_type='type_1', tol=1e-6).cpu().numpy()
+  err = rel_l2(out, truth)
+  assert err < 1e-6, err
+  # type 2 on the same geometry
+  f = (rng.uniform(-.5, .5, grid) + 1j * rng.uniform(-.5, .5, grid)).astype(np.complex64)
+  truth2 = oracle.nufft(f.astype(np.complex128), pts, None, 'type_2', 'forward', tol=1e-12, sigma=2.0)
+  out2 = tfft.nufft(_dev(f), _dev(pts), transform_type='type_2', tol=1e-6).cpu().numpy()
+  assert rel_l2(out2, truth2) < 1e-6, rel_l2(out2, truth2)
+
+
+def test_3d_config4_shape_small(tfft):
+  # config 4 flavour: 3D, tol 1e-4 (w = 6), reduced to 64^3 / 2e5 points
+  from oracle import oracle
+  rng = np.random.default_rng(4)
+  grid = [64, 64, 64]
+  M = 200000
+  pts = rng.uniform(-np.pi, np.pi, (M, 3)).astype(np.float32)
+  c = (rng.uniform(-.5, .5, M) + 1j * rng.uniform(-.5, .5, M)).astype(np.complex64)
+  truth = oracle.nufft(c.astype(np.complex128), pts, grid, 'type_1', 'forward', tol=1e-12)
+  out = tfft.nufft(_dev(c), _dev(pts), grid_shape=grid, transform_type='type_1', tol=1e-4).cpu().numpy()
+  assert rel_l2(out, truth) < 1e-4, rel_l2(out, truth)
+
+
+def test_1d_config1_shape_f64(tfft):
+  # BASELINE config 1: 1D type 1, N = 4096, M = 1e5, tol 1e-6, fp64
+  from oracle import oracle
+  rng = np.random.default_rng(1)
+  M = 100000
+  x = rng.uniform(-np.pi, np.pi, (M, 1))
+  c = rng.uniform(-.5, .5, M) + 1j * rng.uniform(-.5, .5, M)
+  ref = oracle.nufft(c, x, [4096], 'type_1', 'forward', tol=1e-6)       # reference CPU rule
+  truth = oracle.nufft(c, x, [4096], 'type_1', 'forward', tol=1e-13)
+  out = tfft.nufft(_dev(c), _dev(x), grid_shape=[4096], transform_type='type_1', tol=1e-6).cpu().numpy()
+  assert rel_l2(out, truth) < 1e-6
+  assert rel_l2(out, ref) < 1e-6 + rel_l2(ref, truth)
+
+
+def test_batch_broadcasting(tfft):
+  # batch-shape semantics of nufft_kernels.cc:146-259: shared points => transforms,
+  # per-item points => calls, mixed ranks (nufft_ops_test.py:351-417)
+  import torch
+  rng = np.random.default_rng(6)
+  grid = [24, 24]
+  M = 576
+  for sb, pb in ([[2, 4], [1]], [[1], [2, 4]], [[3], [3]], [[2, 1, 3], [2, 4, 1]], [[4], []], [[], [4]],
+                 [[2, 3], [3]], [[3, 1], [3, 2]]):
+    pts = rng.uniform(-np.pi, np.pi, pb + [M, 2]).astype(np.float32)
+    src = (rng.uniform(-.5, .5, sb + [M]) + 1j * rng.uniform(-.5, .5, sb + [M])).astype(np.complex64)
+    out = tfft.nufft(_dev(src), _dev(pts), grid_shape=grid, transform_type='type_1', fft_direction='backward')
+    ref = tfft.nudft(_dev(src.astype(np.complex128)), _dev(pts.astype(np.float64)), grid_shape=grid,
+                     transform_type='type_1', fft_direction='backward')
+    assert list(out.shape) == list(ref.shape), (sb, pb)
+    assert rel_l2(out.cpu().numpy(), ref.cpu().numpy()) < 1e-6, (sb, pb)
+    src2 = (rng.uniform(-.5, .5, sb + grid) + 1j * rng.uniform(-.5, .5, sb + grid)).astype(np.complex64)
+    out = tfft.nufft(_dev(src2), _dev(pts), transform_type='type_2')
+    ref = tfft.nudft(_dev(src2.astype(np.complex128)), _dev(pts.astype(np.float64)), transform_type='type_2')
+    assert list(out.shape) == list(ref.shape), (sb, pb)
+    assert rel_l2(out.cpu().numpy(), ref.cpu().numpy()) < 1e-6, (sb, pb)
+
+
+def test_options_batch_size_and_rigor_do_not_change_results(tfft):
+  # nufft_ops_test.py:65-84
+  rng = np.random.default_rng(7)
+  pts = rng.uniform(-np.pi, np.pi, (400, 2)).astype(np.float32)
+  src = (rng.standard_normal((8, 400)) + 1j * rng.standard_normal((8, 400))).astype(np.complex64)
+  base = tfft.nufft(_dev(src), _dev(pts), grid_shape=[20, 20], transform_type='type_1').cpu().numpy()
+  o = tfft.Options()
+  o.max_batch_size = 2
+  o.fftw.planning_rigor = tfft.FftwPlanningRigor.PATIENT
+  out = tfft.nufft(_dev(src), _dev(pts), grid_shape=[20, 20], transform_type='type_1', options=o).cpu().numpy()
+  assert rel_l2(out, base) < 1e-6
+
+
+@pytest.mark.parametrize('grid', [[128, 128], [128, 128, 128], [64, 96]])
+def test_kat_interp_ones(tfft, grid):
+  # nufft_ops_test.py:224-252, 287-316
+  rng = np.random.default_rng(8)
+  pts = rng.uniform(-np.pi, np.pi, (100, len(grid))).astype(np.float32)
+  out = tfft.interp(_dev(np.ones(grid, np.complex64)), _dev(pts), tol=1e-4).cpu().numpy()
+  np.testing.assert_allclose(out, np.ones(100), rtol=1e-4, atol=1e-4)
+  out = tfft.interp(_dev(1j * np.ones([3] + grid, np.complex64)), _dev(pts)).cpu().numpy()
+  np.testing.assert_allclose(out, 1j * np.ones((3, 100)), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('grid', [[64, 64], [64, 64, 64]])
+def test_kat_spread_ones(tfft, grid):
+  # nufft_ops_test.py:255-284, 319-348
+  from oracle import oracle
+  rng = np.random.default_rng(9)
+  M = int(np.prod(grid))
+  pts = rng.uniform(-np.pi, np.pi, (M, len(grid))).astype(np.float32)
+  out = tfft.spread(_dev(np.ones(M, np.complex64)), _dev(pts), grid).cpu().numpy()
+  assert out.real.min() >= 0.0 and out.real.max() <= 3.0
+  assert abs(out.mean() - 1.0) < 1e-4
+  ref = oracle.nufft(np.ones(M, np.complex128), pts, grid, 'type_1', op='spread')
+  assert rel_l2(out, ref) < 2e-6
+  outb = tfft.spread(_dev(1j * np.ones((2, M), np.complex64)), _dev(pts), grid).cpu().numpy()
+  assert abs(outb.mean() - 1j) < 1e-4
+
+
+def test_interp_3d_many_points(tfft):
+  # nufft_ops_test.py:420-435 (3e6 points on 128^3, repeated)
+  import torch
+  pts = (torch.rand((3000000, 3), device='cuda') * 2 - 1) * np.pi
+  src = torch.ones((128, 128, 128), dtype=torch.complex64, device='cuda')
+  for _ in range(3):
+    out = tfft.interp(src, pts)
+    assert torch.allclose(out, torch.ones_like(out), rtol=1e-3, atol=1e-3)
+
+
+def test_points_range_and_check(tfft):
+  # nufft_ops_test.py:506-620
+  rng = np.random.default_rng(10)
+  grid = [10, 16]
+  pts = rng.uniform(-np.pi, np.pi, (80, 2)).astype(np.float64)
+  src = rng.standard_normal(80) + 1j * rng.standard_normal(80)
+  base = tfft.nufft(_dev(src), _dev(pts), grid_shape=grid, transform_type='type_1', tol=1e-9).cpu().numpy()
+  for rng_name, k in (('EXTENDED', 1), ('INFINITE', 5)):
+    o = tfft.Options()
+    o.points_range = getattr(tfft.PointsRange, rng_name)
+    sh = pts + 2 * np.pi * rng.integers(-k, k + 1, size=(80, 1))
+    out = tfft.nufft(_dev(src), _dev(sh), grid_shape=grid, transform_type='type_1', tol=1e-9, options=o).cpu().numpy()
+    assert rel_l2(out, base) < 1e-8
+  o = tfft.Options()
+  o.debugging.check_points_range = True
+  o.points_range = tfft.PointsRange.STRICT
+  bad = pts.copy()
+  bad[3, 1] = 4.0
+  with pytest.raises(tfft.InvalidArgumentError, match='outside expected range'):
+    tfft.nufft(_dev(src), _dev(bad), grid_shape=grid, transform_type='type_1', options=o)
+  tfft.nufft(_dev(src), _dev(pts), grid_shape=grid, transform_type='type_1', options=o)   # in range: fine
+
+
+def test_error_messages(tfft):
+  # nufft_ops_test.py:438-503
+  pts = np.zeros((10, 2), np.float32)
+  src = np.zeros(10, np.complex64)
+  with pytest.raises(ValueError, match='grid_shape must be provided for type-1 transforms'):
+    tfft.nufft(_dev(src), _dev(pts), transform_type='type_1')
+  with pytest.raises(tfft.InvalidArgumentError, match='grid_shape must have length 2'):
+    tfft.nufft(_dev(src), _dev(pts), grid_shape=[8], transform_type='type_1')
+  with pytest.raises(tfft.InvalidArgumentError, match='must have equal samples dimensions'):
+    tfft.nufft(_dev(np.zeros(11, np.complex64)), _dev(pts), grid_shape=[8, 8], transform_type='type_1')
+  with pytest.raises(tfft.InvalidArgumentError, match='Dimension must be 1, 2 or 3'):
+    tfft.nufft(_dev(src), _dev(np.zeros((10, 4), np.float32)), grid_shape=[8, 8, 8, 8], transform_type='type_1')
+  tfft.nufft(_dev(np.zeros((8, 8), np.complex64)), _dev(pts), transform_type='type_2')   # no grid_shape needed
+
+
+def test_empty_and_tiny_inputs(tfft):
+  pts = np.zeros((0, 2), np.float32)
+  out = tfft.nufft(_dev(np.zeros(0, np.complex64)), _dev(pts), grid_shape=[8, 8], transform_type='type_1')
+  assert out.shape == (8, 8) and float(out.abs().max()) == 0.0
+  out = tfft.nufft(_dev(np.ones((8, 8), np.complex64)), _dev(pts), transform_type='type_2')
+  assert out.shape == (0,)
+  # a single point
+  one = np.array([[0.3, -1.2]], np.float32)
+  out = tfft.nufft(_dev(np.array([1 + 2j], np.complex64)), _dev(one), grid_shape=[6, 8], transform_type='type_1').cpu().numpy()
+  ref = tfft.nudft(np.array([1 + 2j]), one.astype(np.float64), grid_shape=[6, 8], transform_type='type_1')
+  assert rel_l2(out, ref) < 1e-6
+
+
+def test_clustered_points_many_subproblems(tfft):
+  # all points inside one tile => many subproblems of the same tile
+  from oracle import oracle
+  rng = np.random.default_rng(12)
+  M = 30000
+  pts = (0.02 * rng.standard_normal((M, 2)) + 0.5).astype(np.float32)
+  c = (rng.standard_normal(M) + 1j * rng.standard_normal(M)).astype(np.complex64)
+  truth = oracle.nufft(c.astype(np.complex128), pts, [64, 64], 'type_1', 'forward', tol=1e-12)
+  out = tfft.nufft(_dev(c), _dev(pts), grid_shape=[64, 64], transform_type='type_1').cpu().numpy()
+  assert rel_l2(out, truth) < 1e-6
+
+
+def test_linearity_and_adjointness_full_size(tfft):
+  # size-independent properties at BASELINE config 2/3 size (M = 1e7, 1024^2):
+  # <A c, f> == <c, A^H f> where type 2 with the opposite sign is the adjoint
+  import torch
+  M = 10_000_000
+  g = torch.Generator(device='cuda').manual_seed(2)
+  pts = (torch.rand((M, 2), generator=g, device='cuda') * 2 - 1) * np.pi
+  c = torch.complex(torch.rand(M, generator=g, device='cuda') - .5, torch.rand(M, generator=g, device='cuda') - .5)
+  f = torch.complex(torch.rand((1024, 1024), generator=g, device='cuda') - .5,
+                    torch.rand((1024, 1024), generator=g, device='cuda') - .5)
+  Ac = tfft.nufft(c, pts, grid_shape=[1024, 1024], transform_type='type_1', fft_direction='forward')
+  AHf = tfft.nufft(f, pts, transform_type='type_2', fft_direction='backward')
+  lhs = torch.vdot(f.reshape(-1).to(torch.complex128), Ac.reshape(-1).to(torch.complex128))
+  rhs = torch.vdot(AHf.to(torch.complex128), c.to(torch.complex128))
+  assert abs(lhs - rhs) / abs(lhs) < 2e-6, (lhs, rhs)
+  # linearity
+  A2c = tfft.nufft(2.5 * c, pts, grid_shape=[1024, 1024], transform_type='type_1', fft_direction='forward')
+  assert float((A2c - 2.5 * Ac).abs().max() / Ac.abs().max()) < 1e-5
+  # a 64x64 low-frequency corner of the result against the dense NUDFT of the same inputs
+  k = torch.arange(-32, 32, device='cuda', dtype=torch.float64)
+  sub = torch.zeros((64, 64), dtype=torch.complex128, device='cuda')
+  for s in range(0, M, 1_000_000):
+    p = pts[s:s + 1_000_000].to(torch.float64)
+    e0 = torch.exp(-1j * p[:, 0:1] * k)
+    e1 = torch.exp(-1j * p[:, 1:2] * k)
+    sub += torch.einsum('j,ja,jb->ab', c[s:s + 1_000_000].to(torch.complex128), e0, e1)
+  got = Ac[512 - 32:512 + 32, 512 - 32:512 + 32].to(torch.complex128)
+  assert float(torch.linalg.norm(got - sub) / torch.linalg.norm(sub)) < 1e-6
