@@ -31,7 +31,6 @@ __device__ __forceinline__ T horner_cell(const T* __restrict__ tab, int nc, int 
   return acc;
 }
 
-__device__ __forceinline__ void lds_add(float* p, float v) { unsafeAtomicAdd(p, v); }
 __device__ __forceinline__ void lds_add(double* p, double v) { unsafeAtomicAdd(p, v); }
 __device__ __forceinline__ void glb_add(float* p, float v) { unsafeAtomicAdd(p, v); }
 __device__ __forceinline__ void glb_add(double* p, double v) { unsafeAtomicAdd(p, v); }
@@ -173,12 +172,18 @@ __global__ __launch_bounds__(256) void scatter_points_kernel(int rank, int64_t M
 // point, w^rank LDS atomic adds per component; then the tile is added to the
 // periodic fine grid with global float atomics (executed at the memory side
 // on gfx950). Works for any w <= 16, rank, precision.
+//
+// The LDS tile is DOUBLE for both precisions: measured on MI355X
+// (tools/ubench/lds_atomic_bench.hip, profiles/r01_lds_atomic_ubench.txt)
+// ds_add_f32 is serialised at ~193 cycles per wave-instruction per CU
+// whatever the occupancy, while ds_add_f64 takes ~8.6 -- 22x faster -- so
+// fp32 strengths are accumulated in fp64 and rounded once on the way out.
 template <typename T, int RANK>
 __global__ __launch_bounds__(kBlock) void spread_tile_generic_kernel(
     Geom g, SortedPoints<T> sp, const T* __restrict__ horner, const T* __restrict__ c,
     T* __restrict__ fw, int64_t c_stride, int64_t fw_stride, T scale) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* tile = reinterpret_cast<T*>(smem_raw);
+  double* tile = reinterpret_cast<double*>(smem_raw);
   int tb, p0, p1;
   if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1)) return;
   const int tid = threadIdx.x;
@@ -187,7 +192,7 @@ __global__ __launch_bounds__(kBlock) void spread_tile_generic_kernel(
   const int L1 = RANK > 1 ? g.ldim[1] : 1;
   const int L2 = RANK > 2 ? g.ldim[2] : 1;
   const int ncell_padded = LS * L1 * L2;
-  for (int i = tid; i < 2 * ncell_padded; i += kBlock) tile[i] = (T)0;
+  for (int i = tid; i < 2 * ncell_padded; i += kBlock) tile[i] = 0.0;
   __syncthreads();
 
   const T* cc = c + 2 * (int64_t)blockIdx.y * c_stride;
@@ -205,8 +210,8 @@ __global__ __launch_bounds__(kBlock) void spread_tile_generic_kernel(
 #pragma unroll
       for (int q = 0; q < kMaxW; ++q)
         if (q < w) {
-          lds_add(&tile[2 * (l0 + q)], re * kx[q]);
-          lds_add(&tile[2 * (l0 + q) + 1], im * kx[q]);
+          lds_add(&tile[2 * (l0 + q)], (double)(re * kx[q]));
+          lds_add(&tile[2 * (l0 + q) + 1], (double)(im * kx[q]));
         }
     } else if (RANK == 2) {
       const int l1 = (loc >> 10) & 1023;
@@ -214,12 +219,12 @@ __global__ __launch_bounds__(kBlock) void spread_tile_generic_kernel(
       for (int dy = 0; dy < w; ++dy) {
         const T ky = horner_cell(horner, nc, dy, z1);
         const T vre = re * ky, vim = im * ky;
-        T* row = tile + 2 * ((l1 + dy) * LS + l0);
+        double* row = tile + 2 * ((l1 + dy) * LS + l0);
 #pragma unroll
         for (int q = 0; q < kMaxW; ++q)
           if (q < w) {
-            lds_add(&row[2 * q], vre * kx[q]);
-            lds_add(&row[2 * q + 1], vim * kx[q]);
+            lds_add(&row[2 * q], (double)(vre * kx[q]));
+            lds_add(&row[2 * q + 1], (double)(vim * kx[q]));
           }
       }
     } else {
@@ -232,12 +237,12 @@ __global__ __launch_bounds__(kBlock) void spread_tile_generic_kernel(
         for (int dy = 0; dy < w; ++dy) {
           const T kyz = kz * horner_cell(horner, nc, dy, z1);
           const T vre = re * kyz, vim = im * kyz;
-          T* row = tile + 2 * (((l2 + dz) * L1 + (l1 + dy)) * LS + l0);
+          double* row = tile + 2 * (((l2 + dz) * L1 + (l1 + dy)) * LS + l0);
 #pragma unroll
           for (int q = 0; q < kMaxW; ++q)
             if (q < w) {
-              lds_add(&row[2 * q], vre * kx[q]);
-              lds_add(&row[2 * q + 1], vim * kx[q]);
+              lds_add(&row[2 * q], (double)(vre * kx[q]));
+              lds_add(&row[2 * q + 1], (double)(vim * kx[q]));
             }
         }
       }
@@ -257,7 +262,7 @@ __global__ __launch_bounds__(kBlock) void spread_tile_generic_kernel(
     const int a1 = (i / L0) % L1;
     const int a2 = i / (L0 * L1);
     const int li = (a2 * L1 + a1) * LS + a0;
-    const T vre = tile[2 * li], vim = tile[2 * li + 1];
+    const T vre = (T)tile[2 * li], vim = (T)tile[2 * li + 1];
     if (vre != (T)0 || vim != (T)0) {
       const int64_t g0 = (o0 + a0) % g.nf[0];
       const int64_t g1 = RANK > 1 ? (o1 + a1) % g.nf[1] : 0;
@@ -271,13 +276,14 @@ __global__ __launch_bounds__(kBlock) void spread_tile_generic_kernel(
 
 // --------------------------------- spread: wavefront-per-point path (2D, w=8)
 
-// Tile 32x32 fine cells (+7 one-sided halo) held as two PLANAR fp32 planes
-// with a row stride of 40 words. A wavefront handles one point per pass: lane
-// (dy, dx) = (lane >> 3, lane & 7) owns one of the 8x8 stencil cells, so a
-// pass is exactly two ds_add_f32 wave-instructions (re, im). With the row
-// stride = 8 (mod 32) the 32 lanes of each half-wave (4 stencil rows x 8
-// cells) fall in 32 distinct banks: conflict free by construction, for every
-// point position. Kernel values are produced 64 points at a time (one point
+// Tile 32x32 fine cells (+7 one-sided halo) held as two PLANAR fp64 planes
+// with a row stride of 40 elements. A wavefront handles one point per pass:
+// lane (dy, dx) = (lane >> 3, lane & 7) owns one of the 8x8 stencil cells, so a
+// pass is exactly two ds_add_f64 wave-instructions (re, im; fp64 because
+// ds_add_f32 is ~22x slower on gfx950, see the generic kernel). With the row
+// stride = 8 (mod 32) elements, i.e. 16 (mod 64) words, the 32 lanes of each
+// half-wave (4 stencil rows x 8 cells x 2 words) cover all 64 banks exactly
+// once: conflict free by construction, for every point position. Kernel values are produced 64 points at a time (one point
 // per lane, Horner in registers) and handed to the per-point passes through
 // a small LDS staging area read with broadcast loads.
 constexpr int kWT = 32;              // tile edge
@@ -292,15 +298,15 @@ __global__ __launch_bounds__(kBlock) void spread_2d_w8_wave_kernel(
     Geom g, SortedPoints<float> sp, const float* __restrict__ horner, const float* __restrict__ c,
     float* __restrict__ fw, int64_t c_stride, int64_t fw_stride, float scale) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  float* plane_re = reinterpret_cast<float*>(smem_raw);
-  float* plane_im = plane_re + kWPlane;
-  float* stage_all = plane_im + kWPlane;
+  double* plane_re = reinterpret_cast<double*>(smem_raw);
+  double* plane_im = plane_re + kWPlane;
+  float* stage_all = reinterpret_cast<float*>(plane_im + kWPlane);
   int tb, p0, p1;
   if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1)) return;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  for (int i = tid; i < 2 * kWPlane; i += kBlock) plane_re[i] = 0.f;
+  for (int i = tid; i < 2 * kWPlane; i += kBlock) plane_re[i] = 0.0;
   __syncthreads();
 
   float* kxs = stage_all + wave * kStageWords;        // [64][8]
@@ -366,8 +372,8 @@ __global__ __launch_bounds__(kBlock) void spread_2d_w8_wave_kernel(
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        lds_add(&plane_re[o[u]], a[u] * b[u].x);
-        lds_add(&plane_im[o[u]], a[u] * b[u].y);
+        lds_add(&plane_re[o[u]], (double)(a[u] * b[u].x));
+        lds_add(&plane_im[o[u]], (double)(a[u] * b[u].y));
       }
     }
   }
@@ -380,7 +386,7 @@ __global__ __launch_bounds__(kBlock) void spread_2d_w8_wave_kernel(
   for (int i = tid; i < kWPlane; i += kBlock) {
     const int a0 = i % kWS, a1 = i / kWS;
     if (a0 < kWL) {
-      const float vre = plane_re[i], vim = plane_im[i];
+      const float vre = (float)plane_re[i], vim = (float)plane_im[i];
       if (vre != 0.f || vim != 0.f) {
         int g0 = o0 + a0; if (g0 >= g.nf[0]) g0 -= g.nf[0];
         int g1 = o1 + a1; if (g1 >= g.nf[1]) g1 -= g.nf[1];
@@ -599,11 +605,12 @@ bool wave_method_supported(const Geom& g, int precision) {
 }
 
 size_t spread_lds_bytes(const Geom& g, int method, int precision) {
+  (void)precision;   // LDS tiles are double for both precisions
   if (method == NUFFT_HIP_METHOD_TILE_WAVE)
-    return sizeof(float) * (2 * kWPlane + kWaves * kStageWords);
+    return sizeof(double) * 2 * kWPlane + sizeof(float) * kWaves * kStageWords;
   size_t cells = (size_t)g.lstride;
   for (int d = 1; d < g.rank; ++d) cells *= (size_t)g.ldim[d];
-  return cells * 2 * (size_t)precision;
+  return cells * 2 * sizeof(double);
 }
 
 // Upper bound on the number of subproblems, known without reading the device:

@@ -1,0 +1,27 @@
+"""Small driver for rocprofv3: K x (set_points + execute) of one config."""
+import os, sys
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tensorflow-nufft_amd'))
+import numpy as np, torch
+import tensorflow_nufft as tfft
+import argparse
+ap = argparse.ArgumentParser()
+ap.add_argument('--type', default='type_1'); ap.add_argument('--grid', default='1024,1024')
+ap.add_argument('--M', type=float, default=1e7); ap.add_argument('--tol', type=float, default=1e-6)
+ap.add_argument('--method', type=int, default=0); ap.add_argument('--S', type=int, default=0)
+ap.add_argument('--steps', type=int, default=5); ap.add_argument('--ntransf', type=int, default=1)
+a = ap.parse_args()
+grid = [int(g) for g in a.grid.split(',')]; M = int(a.M); rank = len(grid)
+g = torch.Generator(device='cuda').manual_seed(2)
+pts = (torch.rand((M, rank), generator=g, device='cuda') * 2 - 1) * np.pi
+lead = [a.ntransf] if a.ntransf > 1 else []
+if a.type == 'type_1':
+  src = torch.complex(torch.rand(lead + [M], generator=g, device='cuda') - .5, torch.rand(lead + [M], generator=g, device='cuda') - .5)
+else:
+  src = torch.complex(torch.rand(lead + grid, generator=g, device='cuda') - .5, torch.rand(lead + grid, generator=g, device='cuda') - .5)
+plan = tfft.Plan(a.type, grid, 'forward', num_transforms=a.ntransf, tol=a.tol, spread_method=a.method, max_subproblem_size=a.S)
+for _ in range(a.steps):
+  plan.set_points(pts)
+  out = plan.execute(src)
+torch.cuda.synchronize()
+print('done', out.shape)
