@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Headline benchmark: BASELINE.json `configs[1]` -- 2D type-1 NUFFT, 1024 x 1024
+modes, M = 1e7 random points, tol = 1e-6, fp32, on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic input already
+resident in HBM: `set_points` (fold + tile sort) followed by `execute`
+(spread -> rocFFT -> deconvolve) on a plan that is reused across steps, i.e.
+what one `tfft.nufft(source, points, grid_shape, 'type_1')` call costs once its
+plan is cached. With N > 1 (launched by torch.distributed.run, one rank per
+GPU) every rank runs the same workload on its own points/strengths -- the
+transforms of a batch are independent, so the path shards with no data-path
+collective ("weak" scaling); RCCL is used only for the barrier and the
+max-over-ranks time.
+
+Rank 0 prints ONE JSON line with the contract fields plus
+  roofline      dominant kernel (spread) against the HBM roofline, from HIP
+                events recorded on the plan's stream inside the timed region
+  cpu_baseline  the CPU oracle (a port of the reference CPU path, NOT the
+                upstream binary) timed on this host's cores, rank 0 at N = 1
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tensorflow-nufft_amd'))
+
+import numpy as np   # noqa: E402
+import torch         # noqa: E402
+
+GRID = [1024, 1024]
+M = 10_000_000
+TOL = 1e-6
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def algorithmic_spread_bytes(m, nf, rank):
+  # read each point's coordinates + complex strength once,
+  # write each fine-grid cell once: M (4 d + 8) + 8 nf^d   [fp32]
+  cells = 1
+  for n in nf:
+    cells *= n
+  return m * (4 * rank + 8) + 8 * cells
+
+
+def cpu_baseline(args):
+  """Times the CPU oracle on a bounded sample of the same workload."""
+  from oracle import oracle
+  cores = os.cpu_count() or 1
+  m = args.cpu_points
+  rng = np.random.default_rng(2)
+  pts = rng.uniform(-np.pi, np.pi, (m, 2)).astype(np.float32)
+  c = (rng.uniform(-.5, .5, m) + 1j * rng.uniform(-.5, .5, m)).astype(np.complex64)
+  # reference CPU rule for this config: sigma = 1.25, w = 10,
+  # float arithmetic, own piecewise-polynomial kernel (kerevalmeth 1), all cores
+  best = float('inf')
+  total = 0.0
+  runs = 0
+  while runs < 3 and total < 30.0:
+    t0 = time.perf_counter()
+    oracle.nufft(c, pts, GRID, 'type_1', 'forward', tol=TOL, kerevalmeth=1, nthreads=cores)
+    dt = time.perf_counter() - t0
+    best = min(best, dt)
+    total += dt
+    runs += 1
+  sigma, w, _, nf = oracle.query(2, GRID, float(np.float32(TOL)), 'f32')
+  return {
+      'value': round(m / best / 1e6, 3), 'unit': 'Mpts/s', 'cores': cores, 'kind': 'port',
+      'sample': f'full type-1 transform (sort+spread+FFT+deconvolve) of {m} of the {M} points on the '
+                f'same 1024x1024 grid, reference CPU rule sigma={sigma} w={w} fine grid {nf[0]}x{nf[1]}, '
+                f'fp32, {cores} OpenMP threads, best of {runs} runs, {best:.2f} s each',
+  }
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=50)
+  ap.add_argument('--warmup', type=int, default=5)
+  ap.add_argument('--points', type=int, default=M)
+  ap.add_argument('--cpu-points', type=int, default=M)
+  ap.add_argument('--no-cpu-baseline', action='store_true')
+  args = ap.parse_args()
+
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  rank = int(os.environ.get('RANK', '0'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  if not torch.cuda.is_available():
+    raise SystemExit('bench.py needs a ROCm GPU (the HIP path has no CPU fallback)')
+  torch.cuda.set_device(local_rank)
+  dev = torch.device('cuda', local_rank)
+  dist = None
+  if world > 1:
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    dist.init_process_group('nccl', device_id=dev)   # "nccl" is RCCL on ROCm
+
+  import tensorflow_nufft as tfft
+  m = args.points
+  # synthetic inputs: points ~ U(-pi, pi)^2,
+  # strengths ~ U(-.5,.5) + i U(-.5,.5); seed 2 (+rank so shards differ)
+  g = torch.Generator(device=dev).manual_seed(2 + rank)
+  pts = (torch.rand((m, 2), generator=g, device=dev) * 2 - 1) * np.pi
+  c = torch.complex(torch.rand(m, generator=g, device=dev) - .5,
+                    torch.rand(m, generator=g, device=dev) - .5)
+  plan = tfft.Plan('type_1', GRID, 'forward', tol=TOL, dtype=torch.complex64, device=dev)
+  info = plan.info()
+  out = torch.empty(GRID, dtype=torch.complex64, device=dev)
+
+  def step():
+    plan.set_points(pts)
+    plan.execute(c, out=out)
+
+  for _ in range(args.warmup):
+    step()
+  plan.set_timing(True)     # HIP events around each stage, on the plan's stream
+  plan.get_timing()
+  if dist is not None:
+    dist.barrier()
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    step()
+  torch.cuda.synchronize()
+  if dist is not None:
+    dist.barrier()
+  elapsed = time.perf_counter() - t0
+  stages = plan.get_timing()
+  if dist is not None:
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+  # exec-only rate (set_points amortised), same plan
+  plan.set_timing(False)
+  torch.cuda.synchronize()
+  t1 = time.perf_counter()
+  for _ in range(args.steps):
+    plan.execute(c, out=out)
+  torch.cuda.synchronize()
+  exec_only = (time.perf_counter() - t1) / args.steps
+
+  if rank == 0:
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * m / (elapsed / args.steps) / 1e6
+    nf = [int(info.fine_dims[1]), int(info.fine_dims[0])]
+    spread_ms = stages['spread'][0] / max(stages['spread'][1], 1)
+    algo = algorithmic_spread_bytes(m, nf, 2)
+    achieved = algo / (spread_ms * 1e-3) / 1e9
+    result = {
+        'metric': 'non-uniform pts/s, 2D type-1 1024^2 tol=1e-6 (set_points + execute)',
+        'value': round(value, 2), 'unit': 'Mpts/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {
+            'workload': 'BASELINE configs[1]: 2D type-1, 1024x1024 modes, M=1e7 uniform random points, '
+                        'tol=1e-6, complex64; per GPU one independent transform per step',
+            'points_per_gpu': m, 'grid': GRID, 'fine_grid': nf, 'kernel_width': int(info.kernel_width),
+            'upsampling_factor': info.upsampling_factor, 'spread_method': int(info.spread_method),
+            'exec_only_Mpts_s': round(m / exec_only / 1e6, 2),
+            'stage_us': {k: round(v[0] / max(v[1], 1) * 1e3, 1) for k, v in stages.items() if v[1]},
+        },
+        'roofline': {
+            'bound': 'hbm', 'kernel': 'spread_2d_w8_wave_kernel', 'achieved': round(achieved, 1),
+            'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
+            'traffic': None, 'algorithmic_bytes': algo, 'kernel_ms': round(spread_ms, 4),
+            'note': 'the kernel is bound by the LDS atomic pipe (2 ds_add_f64 + 2 broadcast reads per '
+                    'point-pass per CU), not by HBM: DESIGN.md section 5',
+        },
+    }
+    if world == 1 and not args.no_cpu_baseline:
+      result['cpu_baseline'] = cpu_baseline(args)
+    print(json.dumps(result))
+  if dist is not None:
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

@@ -130,6 +130,14 @@ int nufft_hip_plan_describe(int type, int rank, const int64_t* grid_dims, int if
                             const nufft_hip_options* opts, nufft_hip_plan_info* info,
                             char* errbuf, size_t errbuf_len);
 int nufft_hip_plan_set_stream(nufft_hip_plan plan, void* stream);
+/* Per-stage timing with HIP events recorded on the plan's stream around each
+ * stage (no synchronisation while enabled). get_timing synchronises the
+ * stream, returns accumulated milliseconds and call counts per stage since the
+ * last get, and resets them. Stage order (NUFFT_HIP_STAGE_*): sort-count,
+ * sort-scan, sort-scatter, zero, spread, fft, deconvolve, interp. */
+#define NUFFT_HIP_NUM_STAGES 8
+int nufft_hip_plan_set_timing(nufft_hip_plan plan, int enable);
+int nufft_hip_plan_get_timing(nufft_hip_plan plan, double* ms, int32_t* calls, int n);
 const char* nufft_hip_last_error(nufft_hip_plan plan);
 int nufft_hip_plan_destroy(nufft_hip_plan plan);
 

@@ -81,7 +81,8 @@ typedef struct {
 typedef struct {
   int w, method, ncoef;
   double beta, c, half_width, sigma;
-  double horner[ORACLE_MAX_COEF * ORACLE_MAX_W]; /* [k][j]: coeff of z^k, cell j */
+  double horner_f64[ORACLE_MAX_COEF * ORACLE_MAX_W]; /* [k][j]: coeff of z^k, cell j */
+  float horner_f32[ORACLE_MAX_COEF * ORACLE_MAX_W];
 } kernel_params;
 
 /* ------------------------------------------------------------ parameters */
@@ -146,12 +147,12 @@ static double es_kernel_d(double x, const kernel_params *kp) {
  * phi((z + 1 - w)/2 + j), by interpolation at Chebyshev nodes followed by
  * conversion to monomial coefficients (all in double). This plays the role
  * of the reference's generated tables kernel_horner_sigma2.inc /
- * kernel_horner_sigma125.inc, whose degrees it matches approximately
- * (nc = w + 3 for sigma 2, w + 2 otherwise, per SURVEY.md section 2 row 5 ...
- * here we simply take a degree high enough for ~1e-10 relative error). */
+ * kernel_horner_sigma125.inc, whose term counts it matches: w + 3 terms at
+ * sigma = 2 and w + 2 otherwise (counted in the reference tables: 11 terms at
+ * w = 8 sigma 2, 10 at w = 8 sigma 1.25). */
 static void fit_horner_table(kernel_params *kp) {
   const int w = kp->w;
-  int nc = w + 6;
+  int nc = (kp->sigma == 2.0) ? w + 3 : w + 2;
   if (nc > ORACLE_MAX_COEF) nc = ORACLE_MAX_COEF;
   kp->ncoef = nc;
   double node[ORACLE_MAX_COEF], val[ORACLE_MAX_COEF], cheb[ORACLE_MAX_COEF];
@@ -190,7 +191,10 @@ static void fit_horner_table(kernel_params *kp) {
         tk[m] = tn[m];
       }
     }
-    for (int k = 0; k < nc; ++k) kp->horner[k * ORACLE_MAX_W + j] = mono[k];
+    for (int k = 0; k < nc; ++k) {
+      kp->horner_f64[k * ORACLE_MAX_W + j] = mono[k];
+      kp->horner_f32[k * ORACLE_MAX_W + j] = (float)mono[k];
+    }
   }
 }
 

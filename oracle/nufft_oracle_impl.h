@@ -35,12 +35,13 @@ static inline void SUF(eval_kernel_vec)(FLT *ker, FLT x1,
   } else {
     const FLT z = (FLT)2 * x1 + (FLT)w - (FLT)1;
     const int nc = kp->ncoef;
-    for (int j = 0; j < w; ++j) {
-      FLT acc = (FLT)kp->horner[(nc - 1) * ORACLE_MAX_W + j];
-      for (int k = nc - 2; k >= 0; --k)
-        acc = acc * z + (FLT)kp->horner[k * ORACLE_MAX_W + j];
-      ker[j] = acc;
-    }
+    FLT acc[ORACLE_MAX_W];
+    const FLT *tab = kp->SUF(horner);          /* table in the working precision */
+    for (int j = 0; j < ORACLE_MAX_W; ++j) acc[j] = tab[(nc - 1) * ORACLE_MAX_W + j];
+    for (int k = nc - 2; k >= 0; --k)          /* j loop vectorises (reference pads to 4) */
+      for (int j = 0; j < ORACLE_MAX_W; ++j)
+        acc[j] = acc[j] * z + tab[k * ORACLE_MAX_W + j];
+    for (int j = 0; j < w; ++j) ker[j] = acc[j];
   }
 }
 

@@ -33,40 +33,73 @@ struct Geom {
   int nmodes[3];    // N, x fastest
 };
 
-// Per-point records in tile-sorted order (device arrays of length M).
+// Per-point record in tile-sorted order. float: 16 bytes, one dwordx4 access;
+// the original point index shares the slot of the unused third coordinate in
+// 1D/2D (3D keeps it in a side array). double: 32 bytes.
+template <typename T> struct Rec;
+template <> struct alignas(16) Rec<float> {
+  uint32_t loc;              // stencil start relative to the tile: l0 | l1<<10 | l2<<20
+  float z0, z1;              // Horner arguments in [-1, 1]
+  union { float z2; int32_t idx; };
+};
+template <> struct alignas(16) Rec<double> {
+  uint32_t loc;
+  int32_t idx;
+  double z0, z1, z2;
+};
+
 template <typename T>
 struct SortedPoints {
-  const uint32_t* loc;   // stencil start relative to the tile: l0 | l1<<10 | l2<<20
-  const T* z[3];         // Horner argument per dimension, in [-1, 1]
-  const int32_t* idx;    // original point index
+  const Rec<T>* rec;          // [M] tile-sorted
+  const int32_t* idx3;        // [M] original index (float, rank 3 only)
   const int32_t* tile_start;  // [ntiles + 1]
   const int32_t* sub_start;   // [ntiles + 1] exclusive scan of ceil(count / max_sub)
 };
+template <typename T>
+struct SortedOut {
+  Rec<T>* rec;
+  int32_t* idx3;
+};
 
-struct PrepArgs {
+struct PointsIn {
   const void* pts[3];
   int64_t stride;
   int64_t M;
   int range_mode;
   int check_range;
-  uint32_t* loc;
-  void* z[3];
-  int32_t* tile_of;
-  int32_t* rank_of;
-  int32_t* tile_count;
-  int32_t* bad_count;   // points outside the accepted range (debug check)
+};
+
+struct SortWork {
+  int32_t* hist;        // [nblk][ntiles] (LDS-histogram path)
+  int32_t* tile_of;     // [M] (global-counter path)
+  int32_t* rank_of;     // [M]
+  int32_t* tile_count;  // [ntiles]
+  int32_t* tile_start;  // [ntiles + 1]
+  int32_t* sub_start;   // [ntiles + 1]
+  int32_t* bad_count;
+};
+
+constexpr int kMaxLdsTiles = 16384;   // 64 KiB of LDS counters
+
+enum Stage {
+  STAGE_SORT_COUNT = 0, STAGE_SORT_SCAN, STAGE_SORT_SCATTER, STAGE_ZERO, STAGE_SPREAD,
+  STAGE_FFT, STAGE_DECONVOLVE, STAGE_INTERP, STAGE_COUNT
+};
+// Optional per-stage HIP-event timing (bench / profiling); no-ops when disabled.
+struct StageHook {
+  void* ctx = nullptr;
+  void (*begin_fn)(void*, int) = nullptr;
+  void (*end_fn)(void*, int) = nullptr;
+  void begin(int s) const { if (begin_fn) begin_fn(ctx, s); }
+  void end(int s) const { if (end_fn) end_fn(ctx, s); }
 };
 
 // Launchers (nufft_kernels.hip). All enqueue on `stream` and return hipGetLastError().
+int sort_blocks(const Geom& g, int64_t M, int64_t* per_block);
+bool sort_uses_lds(const Geom& g);
 template <typename T>
-hipError_t launch_prep(const Geom& g, const PrepArgs& a, hipStream_t stream);
-hipError_t launch_scan(const Geom& g, const int32_t* tile_count, int32_t* tile_start,
-                       int32_t* sub_start, hipStream_t stream);
-template <typename T>
-hipError_t launch_scatter(const Geom& g, int64_t M, const uint32_t* loc_in, T* const z_in[3],
-                          const int32_t* tile_of, const int32_t* rank_of,
-                          const int32_t* tile_start, uint32_t* loc_out, T* const z_out[3],
-                          int32_t* idx_out, hipStream_t stream);
+hipError_t launch_sort(const Geom& g, const PointsIn& in, const SortWork& w, const SortedOut<T>& out,
+                       hipStream_t stream, const StageHook& hook);
 template <typename T>
 hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, int64_t M,
                          const T* horner, const T* c, T* fw, int batch, int64_t c_stride,

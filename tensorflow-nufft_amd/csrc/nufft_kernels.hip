@@ -35,6 +35,20 @@ __device__ __forceinline__ void lds_add(double* p, double v) { unsafeAtomicAdd(p
 __device__ __forceinline__ void glb_add(float* p, float v) { unsafeAtomicAdd(p, v); }
 __device__ __forceinline__ void glb_add(double* p, double v) { unsafeAtomicAdd(p, v); }
 
+template <typename T>
+__device__ __forceinline__ int rec_idx(const SortedPoints<T>& sp, int rank, int j, const Rec<T>& r);
+template <>
+__device__ __forceinline__ int rec_idx<float>(const SortedPoints<float>& sp, int rank, int j,
+                                              const Rec<float>& r) {
+  return rank < 3 ? r.idx : sp.idx3[j];
+}
+template <>
+__device__ __forceinline__ int rec_idx<double>(const SortedPoints<double>& sp, int rank, int j,
+                                               const Rec<double>& r) {
+  (void)sp; (void)rank; (void)j;
+  return r.idx;
+}
+
 // Which subproblem does workgroup `s` own? sub_start is the exclusive scan of
 // per-tile subproblem counts; returns the tile and the point range.
 __device__ __forceinline__ bool locate_subproblem(const Geom& g, const int32_t* __restrict__ tile_start,
@@ -58,26 +72,27 @@ __device__ __forceinline__ bool locate_subproblem(const Geom& g, const int32_t* 
 
 // ------------------------------------------------------------ prep + sort
 
-// One thread per point: fold + rescale in DOUBLE (reference FoldAndRescale,
+// Fold + rescale one point in DOUBLE (reference FoldAndRescale,
 // nufft_plan.h:676-734, does it in FloatType, which costs ~eps*nf cells of
-// position error in float), split into integer stencil start i0 = ceil(x' -
-// w/2) (reference nufft_plan.cu.cc:838-841 / nufft_plan.cc:1496) and Horner
-// argument z = 2(i0 - x') + w - 1 in [-1, 1]; bin by the wrapped stencil start.
+// position error in float), split into the integer stencil start
+// i0 = ceil(x' - w/2) (reference nufft_plan.cu.cc:838-841 / nufft_plan.cc:1496)
+// and the Horner argument z = 2(i0 - x') + w - 1 in [-1, 1]. Points are binned
+// by the WRAPPED STENCIL START, so a tile's halo is one sided (w - 1 cells).
+// Returns the tile index; fills the record (without idx).
 template <typename T>
-__global__ __launch_bounds__(256) void prep_points_kernel(Geom g, PrepArgs a) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.M) return;
+__device__ __forceinline__ int fold_point(const Geom& g, const PointsIn& in, int64_t i, Rec<T>* r,
+                                          bool* bad) {
   uint32_t loc = 0;
   int tc[3] = {0, 0, 0};
-  bool bad = false;
+  T zz3[3] = {(T)0, (T)0, (T)0};
   for (int d = 0; d < g.rank; ++d) {
-    const double x = (double)((const T*)a.pts[d])[i * a.stride];
+    const double x = (double)((const T*)in.pts[d])[i * in.stride];
     double s;
-    if (a.range_mode == NUFFT_HIP_RANGE_STRICT) {
-      bad |= !(x > -kPiD && x < kPiD);   // IsWithinRange, nufft_plan.h:866-898 (strict inequalities)
+    if (in.range_mode == NUFFT_HIP_RANGE_STRICT) {
+      *bad |= !(x > -kPiD && x < kPiD);   // IsWithinRange, nufft_plan.h:866-898 (strict inequalities)
       s = x + kPiD;
-    } else if (a.range_mode == NUFFT_HIP_RANGE_EXTENDED) {
-      bad |= !(x > -3.0 * kPiD && x < 3.0 * kPiD);
+    } else if (in.range_mode == NUFFT_HIP_RANGE_EXTENDED) {
+      *bad |= !(x > -3.0 * kPiD && x < 3.0 * kPiD);
       s = (x > kPiD) ? x - kPiD : ((x < -kPiD) ? x + 3.0 * kPiD : x + kPiD);
     } else {
       s = fmod(x + kPiD, 2.0 * kPiD);
@@ -94,13 +109,137 @@ __global__ __launch_bounds__(256) void prep_points_kernel(Geom g, PrepArgs a) {
     const int l = (int)i0 - t * g.tile[d];
     tc[d] = t;
     loc |= (uint32_t)l << (10 * d);
-    ((T*)a.z[d])[i] = (T)zz;
+    zz3[d] = (T)zz;
   }
-  const int tile = tc[0] + g.ntile[0] * (tc[1] + g.ntile[1] * tc[2]);
-  a.loc[i] = loc;
-  a.tile_of[i] = tile;
-  a.rank_of[i] = atomicAdd(&a.tile_count[tile], 1);
-  if (bad && a.check_range) atomicAdd(a.bad_count, 1);
+  r->loc = loc;
+  r->z0 = zz3[0];
+  r->z1 = zz3[1];
+  r->z2 = zz3[2];
+  return tc[0] + g.ntile[0] * (tc[1] + g.ntile[1] * tc[2]);
+}
+
+template <typename T>
+__device__ __forceinline__ void store_record(const SortedOut<T>& out, int rank, int pos, Rec<T> r,
+                                             int32_t idx);
+template <>
+__device__ __forceinline__ void store_record<float>(const SortedOut<float>& out, int rank, int pos,
+                                                    Rec<float> r, int32_t idx) {
+  if (rank < 3) r.idx = idx; else out.idx3[pos] = idx;
+  out.rec[pos] = r;   // one 16-byte store
+}
+template <>
+__device__ __forceinline__ void store_record<double>(const SortedOut<double>& out, int rank, int pos,
+                                                     Rec<double> r, int32_t idx) {
+  (void)rank;
+  r.idx = idx;
+  out.rec[pos] = r;   // 32 bytes
+}
+
+// --- path A (ntiles <= kMaxLdsTiles): counting sort with per-workgroup LDS
+// histograms. No global atomics, deterministic tile order. Three passes over
+// the raw points (hist, scatter) + two tiny scans.
+constexpr int kSortBlock = 1024;
+
+template <typename T>
+__global__ __launch_bounds__(kSortBlock) void hist_lds_kernel(Geom g, PointsIn in, int64_t per_block,
+                                                              int32_t* __restrict__ hist,
+                                                              int32_t* __restrict__ bad_count) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  int* h = reinterpret_cast<int*>(smem_raw);
+  const int nt = g.ntiles;
+  for (int t = threadIdx.x; t < nt; t += kSortBlock) h[t] = 0;
+  __syncthreads();
+  const int64_t lo = (int64_t)blockIdx.x * per_block;
+  const int64_t hi = (lo + per_block < in.M) ? lo + per_block : in.M;
+  bool bad = false;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += kSortBlock) {
+    Rec<T> r;
+    const int tile = fold_point<T>(g, in, i, &r, &bad);
+    atomicAdd(&h[tile], 1);
+  }
+  if (bad && in.check_range) atomicAdd(bad_count, 1);
+  __syncthreads();
+  int32_t* out = hist + (int64_t)blockIdx.x * nt;
+  for (int t = threadIdx.x; t < nt; t += kSortBlock) out[t] = h[t];
+}
+
+// hist[b][t] -> exclusive prefix over b (per tile), totals -> tile_count[t]
+__global__ __launch_bounds__(256) void colscan_kernel(int nt, int nblk, int32_t* __restrict__ hist,
+                                                      int32_t* __restrict__ tile_count) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nt) return;
+  int run = 0;
+  int b = 0;
+  for (; b + 4 <= nblk; b += 4) {
+    int32_t* p = hist + (int64_t)b * nt + t;
+    const int v0 = p[0], v1 = p[nt], v2 = p[2 * (int64_t)nt], v3 = p[3 * (int64_t)nt];
+    p[0] = run; run += v0;
+    p[nt] = run; run += v1;
+    p[2 * (int64_t)nt] = run; run += v2;
+    p[3 * (int64_t)nt] = run; run += v3;
+  }
+  for (; b < nblk; ++b) {
+    int32_t* p = hist + (int64_t)b * nt + t;
+    const int v = p[0];
+    p[0] = run;
+    run += v;
+  }
+  tile_count[t] = run;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kSortBlock) void scatter_lds_kernel(Geom g, PointsIn in, int64_t per_block,
+                                                                 const int32_t* __restrict__ hist,
+                                                                 const int32_t* __restrict__ tile_start,
+                                                                 SortedOut<T> out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  int* cur = reinterpret_cast<int*>(smem_raw);
+  const int nt = g.ntiles;
+  const int32_t* hb = hist + (int64_t)blockIdx.x * nt;
+  for (int t = threadIdx.x; t < nt; t += kSortBlock) cur[t] = tile_start[t] + hb[t];
+  __syncthreads();
+  const int64_t lo = (int64_t)blockIdx.x * per_block;
+  const int64_t hi = (lo + per_block < in.M) ? lo + per_block : in.M;
+  bool bad = false;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += kSortBlock) {
+    Rec<T> r;
+    const int tile = fold_point<T>(g, in, i, &r, &bad);
+    const int pos = atomicAdd(&cur[tile], 1);
+    store_record<T>(out, g.rank, pos, r, (int32_t)i);
+  }
+}
+
+// --- path B (many tiles): per-point rank from a global counter (the
+// reference's scheme, nufft_plan.cu.cc:160-296), then scatter.
+template <typename T>
+__global__ __launch_bounds__(256) void count_global_kernel(Geom g, PointsIn in,
+                                                           int32_t* __restrict__ tile_of,
+                                                           int32_t* __restrict__ rank_of,
+                                                           int32_t* __restrict__ tile_count,
+                                                           int32_t* __restrict__ bad_count) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= in.M) return;
+  Rec<T> r;
+  bool bad = false;
+  const int tile = fold_point<T>(g, in, i, &r, &bad);
+  tile_of[i] = tile;
+  rank_of[i] = atomicAdd(&tile_count[tile], 1);
+  if (bad && in.check_range) atomicAdd(bad_count, 1);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void scatter_global_kernel(Geom g, PointsIn in,
+                                                             const int32_t* __restrict__ tile_of,
+                                                             const int32_t* __restrict__ rank_of,
+                                                             const int32_t* __restrict__ tile_start,
+                                                             SortedOut<T> out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= in.M) return;
+  Rec<T> r;
+  bool bad = false;
+  fold_point<T>(g, in, i, &r, &bad);
+  const int pos = tile_start[tile_of[i]] + rank_of[i];
+  store_record<T>(out, g.rank, pos, r, (int32_t)i);
 }
 
 // Single-workgroup exclusive scans over the tiles: point offsets and
@@ -145,26 +284,6 @@ __global__ __launch_bounds__(1024) void scan_tiles_kernel(const int32_t* __restr
   }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void scatter_points_kernel(int rank, int64_t M, const uint32_t* __restrict__ loc_in,
-                                                             const T* __restrict__ z0, const T* __restrict__ z1,
-                                                             const T* __restrict__ z2,
-                                                             const int32_t* __restrict__ tile_of,
-                                                             const int32_t* __restrict__ rank_of,
-                                                             const int32_t* __restrict__ tile_start,
-                                                             uint32_t* __restrict__ loc_out, T* __restrict__ o0,
-                                                             T* __restrict__ o1, T* __restrict__ o2,
-                                                             int32_t* __restrict__ idx_out) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= M) return;
-  const int pos = tile_start[tile_of[i]] + rank_of[i];
-  loc_out[pos] = loc_in[i];
-  idx_out[pos] = (int32_t)i;
-  o0[pos] = z0[i];
-  if (rank > 1) o1[pos] = z1[i];
-  if (rank > 2) o2[pos] = z2[i];
-}
-
 // ------------------------------------------------- spread: generic tile path
 
 // One workgroup per subproblem (<= max_sub points of one tile) and transform.
@@ -197,12 +316,13 @@ __global__ __launch_bounds__(kBlock) void spread_tile_generic_kernel(
 
   const T* cc = c + 2 * (int64_t)blockIdx.y * c_stride;
   for (int j = p0 + tid; j < p1; j += kBlock) {
-    const uint32_t loc = sp.loc[j];
-    const int idx = sp.idx[j];
+    const Rec<T> rec = sp.rec[j];
+    const uint32_t loc = rec.loc;
+    const int idx = rec_idx<T>(sp, RANK, j, rec);
     const T re = cc[2 * (int64_t)idx] * scale;
     const T im = cc[2 * (int64_t)idx + 1] * scale;
     T kx[kMaxW];
-    const T z0 = sp.z[0][j];
+    const T z0 = rec.z0;
 #pragma unroll
     for (int q = 0; q < kMaxW; ++q) kx[q] = (q < w) ? horner_cell(horner, nc, q, z0) : (T)0;
     const int l0 = loc & 1023;
@@ -215,7 +335,7 @@ __global__ __launch_bounds__(kBlock) void spread_tile_generic_kernel(
         }
     } else if (RANK == 2) {
       const int l1 = (loc >> 10) & 1023;
-      const T z1 = sp.z[1][j];
+      const T z1 = rec.z1;
       for (int dy = 0; dy < w; ++dy) {
         const T ky = horner_cell(horner, nc, dy, z1);
         const T vre = re * ky, vim = im * ky;
@@ -230,8 +350,8 @@ __global__ __launch_bounds__(kBlock) void spread_tile_generic_kernel(
     } else {
       const int l1 = (loc >> 10) & 1023;
       const int l2 = (loc >> 20) & 1023;
-      const T z1 = sp.z[1][j];
-      const T z2 = sp.z[2][j];
+      const T z1 = rec.z1;
+      const T z2 = rec.z2;
       for (int dz = 0; dz < w; ++dz) {
         const T kz = horner_cell(horner, nc, dz, z2);
         for (int dy = 0; dy < w; ++dy) {
@@ -322,9 +442,10 @@ __global__ __launch_bounds__(kBlock) void spread_2d_w8_wave_kernel(
     int off = 0;
     float kx[kWW], kyr[kWW], kyi[kWW];
     if (valid) {
-      const uint32_t loc = sp.loc[j];
-      const int idx = sp.idx[j];
-      const float zx = sp.z[0][j], zy = sp.z[1][j];
+      const Rec<float> rec = sp.rec[j];   // one 16-byte load: loc, zx, zy, idx
+      const uint32_t loc = rec.loc;
+      const int idx = rec.idx;
+      const float zx = rec.z0, zy = rec.z1;
       const float2 cv = reinterpret_cast<const float2*>(cc)[idx];
       const float re = cv.x * scale, im = cv.y * scale;
       off = ((loc >> 10) & 1023) * kWS + (loc & 1023);
@@ -417,11 +538,12 @@ __global__ __launch_bounds__(kBlock) void interp_tile_generic_kernel(
   const T* in = fw + 2 * (int64_t)blockIdx.y * fw_stride;
   T* cc = c + 2 * (int64_t)blockIdx.y * c_stride;
   for (int j = p0 + (int)threadIdx.x; j < p1; j += kBlock) {
-    const uint32_t loc = sp.loc[j];
-    const int idx = sp.idx[j];
+    const Rec<T> rec = sp.rec[j];
+    const uint32_t loc = rec.loc;
+    const int idx = rec_idx<T>(sp, RANK, j, rec);
     T kx[kMaxW];
     int gx[kMaxW];
-    const T z0 = sp.z[0][j];
+    const T z0 = rec.z0;
     const int b0 = o0 + (int)(loc & 1023);
 #pragma unroll
     for (int q = 0; q < kMaxW; ++q) {
@@ -438,7 +560,7 @@ __global__ __launch_bounds__(kBlock) void interp_tile_generic_kernel(
         }
     } else if (RANK == 2) {
       const int b1 = o1 + (int)((loc >> 10) & 1023);
-      const T z1 = sp.z[1][j];
+      const T z1 = rec.z1;
       for (int dy = 0; dy < w; ++dy) {
         const T ky = horner_cell(horner, nc, dy, z1);
         const int64_t ro = (int64_t)g.nf[0] * ((b1 + dy) % g.nf[1]);
@@ -455,8 +577,8 @@ __global__ __launch_bounds__(kBlock) void interp_tile_generic_kernel(
     } else {
       const int b1 = o1 + (int)((loc >> 10) & 1023);
       const int b2 = o2 + (int)((loc >> 20) & 1023);
-      const T z1 = sp.z[1][j];
-      const T z2 = sp.z[2][j];
+      const T z1 = rec.z1;
+      const T z2 = rec.z2;
       for (int dz = 0; dz < w; ++dz) {
         const T kz = horner_cell(horner, nc, dz, z2);
         const int64_t zo = (int64_t)g.nf[1] * ((b2 + dz) % g.nf[2]);
@@ -566,38 +688,62 @@ __global__ __launch_bounds__(256) void permute_kernel(const V* __restrict__ src,
 
 static inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
 
-template <typename T>
-hipError_t launch_prep(const Geom& g, const PrepArgs& a, hipStream_t stream) {
-  if (a.M == 0) return hipSuccess;
-  prep_points_kernel<T><<<blocks_for(a.M, 256), 256, 0, stream>>>(g, a);
-  return hipGetLastError();
-}
-template hipError_t launch_prep<float>(const Geom&, const PrepArgs&, hipStream_t);
-template hipError_t launch_prep<double>(const Geom&, const PrepArgs&, hipStream_t);
-
-hipError_t launch_scan(const Geom& g, const int32_t* tile_count, int32_t* tile_start,
-                       int32_t* sub_start, hipStream_t stream) {
-  scan_tiles_kernel<<<1, 1024, 0, stream>>>(tile_count, g.ntiles, g.max_sub, tile_start, sub_start);
-  return hipGetLastError();
+int sort_blocks(const Geom& g, int64_t M, int64_t* per_block) {
+  // at most 1024 workgroups, at least 4096 points each
+  int64_t pb = (M + 1023) / 1024;
+  if (pb < 4096) pb = 4096;
+  *per_block = pb;
+  (void)g;
+  return (int)((M + pb - 1) / pb);
 }
 
+bool sort_uses_lds(const Geom& g) { return g.ntiles <= kMaxLdsTiles; }
+
 template <typename T>
-hipError_t launch_scatter(const Geom& g, int64_t M, const uint32_t* loc_in, T* const z_in[3],
-                          const int32_t* tile_of, const int32_t* rank_of,
-                          const int32_t* tile_start, uint32_t* loc_out, T* const z_out[3],
-                          int32_t* idx_out, hipStream_t stream) {
-  if (M == 0) return hipSuccess;
-  scatter_points_kernel<T><<<blocks_for(M, 256), 256, 0, stream>>>(
-      g.rank, M, loc_in, z_in[0], z_in[1], z_in[2], tile_of, rank_of, tile_start, loc_out,
-      z_out[0], z_out[1], z_out[2], idx_out);
+hipError_t launch_sort(const Geom& g, const PointsIn& in, const SortWork& w, const SortedOut<T>& out,
+                       hipStream_t stream, const StageHook& hook) {
+  hipError_t e;
+  if (in.M == 0) {
+    e = hipMemsetAsync(w.tile_count, 0, sizeof(int32_t) * (size_t)g.ntiles, stream);
+    if (e != hipSuccess) return e;
+    scan_tiles_kernel<<<1, 1024, 0, stream>>>(w.tile_count, g.ntiles, g.max_sub, w.tile_start, w.sub_start);
+    return hipGetLastError();
+  }
+  if (sort_uses_lds(g)) {
+    int64_t per_block;
+    const int nblk = sort_blocks(g, in.M, &per_block);
+    const size_t lds = sizeof(int) * (size_t)g.ntiles;
+    hook.begin(STAGE_SORT_COUNT);
+    hist_lds_kernel<T><<<nblk, kSortBlock, lds, stream>>>(g, in, per_block, w.hist, w.bad_count);
+    hook.end(STAGE_SORT_COUNT);
+    hook.begin(STAGE_SORT_SCAN);
+    colscan_kernel<<<(g.ntiles + 255) / 256, 256, 0, stream>>>(g.ntiles, nblk, w.hist, w.tile_count);
+    scan_tiles_kernel<<<1, 1024, 0, stream>>>(w.tile_count, g.ntiles, g.max_sub, w.tile_start, w.sub_start);
+    hook.end(STAGE_SORT_SCAN);
+    hook.begin(STAGE_SORT_SCATTER);
+    scatter_lds_kernel<T><<<nblk, kSortBlock, lds, stream>>>(g, in, per_block, w.hist, w.tile_start, out);
+    hook.end(STAGE_SORT_SCATTER);
+    return hipGetLastError();
+  }
+  e = hipMemsetAsync(w.tile_count, 0, sizeof(int32_t) * (size_t)g.ntiles, stream);
+  if (e != hipSuccess) return e;
+  hook.begin(STAGE_SORT_COUNT);
+  count_global_kernel<T><<<blocks_for(in.M, 256), 256, 0, stream>>>(g, in, w.tile_of, w.rank_of,
+                                                                    w.tile_count, w.bad_count);
+  hook.end(STAGE_SORT_COUNT);
+  hook.begin(STAGE_SORT_SCAN);
+  scan_tiles_kernel<<<1, 1024, 0, stream>>>(w.tile_count, g.ntiles, g.max_sub, w.tile_start, w.sub_start);
+  hook.end(STAGE_SORT_SCAN);
+  hook.begin(STAGE_SORT_SCATTER);
+  scatter_global_kernel<T><<<blocks_for(in.M, 256), 256, 0, stream>>>(g, in, w.tile_of, w.rank_of,
+                                                                      w.tile_start, out);
+  hook.end(STAGE_SORT_SCATTER);
   return hipGetLastError();
 }
-template hipError_t launch_scatter<float>(const Geom&, int64_t, const uint32_t*, float* const[3],
-                                          const int32_t*, const int32_t*, const int32_t*, uint32_t*,
-                                          float* const[3], int32_t*, hipStream_t);
-template hipError_t launch_scatter<double>(const Geom&, int64_t, const uint32_t*, double* const[3],
-                                           const int32_t*, const int32_t*, const int32_t*, uint32_t*,
-                                           double* const[3], int32_t*, hipStream_t);
+template hipError_t launch_sort<float>(const Geom&, const PointsIn&, const SortWork&,
+                                       const SortedOut<float>&, hipStream_t, const StageHook&);
+template hipError_t launch_sort<double>(const Geom&, const PointsIn&, const SortWork&,
+                                        const SortedOut<double>&, hipStream_t, const StageHook&);
 
 bool wave_method_supported(const Geom& g, int precision) {
   return precision == NUFFT_HIP_F32 && g.rank == 2 && g.w == kWW && g.ncoef <= kWaveCoef &&

@@ -220,13 +220,24 @@ struct nufft_hip_plan_s {
   size_t fft_work_bytes = 0;
 
   int64_t M = 0, cap = 0;
-  uint32_t *loc_tmp = nullptr, *loc = nullptr;
-  void *z_tmp[3] = {nullptr, nullptr, nullptr}, *z[3] = {nullptr, nullptr, nullptr};
-  int32_t *tile_of = nullptr, *rank_of = nullptr, *idx = nullptr;
+  void* rec = nullptr;           // Rec<T>[cap], tile-sorted
+  int32_t* idx3 = nullptr;       // float rank-3 only
+  int32_t *hist = nullptr;       // LDS-histogram sort: [nblk][ntiles]
+  int64_t hist_elems = 0;
+  int32_t *tile_of = nullptr, *rank_of = nullptr;   // global-counter sort
   int32_t *tile_count = nullptr, *tile_start = nullptr, *sub_start = nullptr, *bad_count = nullptr;
   int64_t workspace_bytes = 0;
   bool points_set = false;
   std::string err;
+
+  // optional per-stage timing with HIP events on the plan's stream
+  bool timing = false;
+  struct Pending { int stage; hipEvent_t e0, e1; };
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> free_events;
+  hipEvent_t open_event[STAGE_COUNT] = {};
+  double stage_ms[STAGE_COUNT] = {};
+  int stage_calls[STAGE_COUNT] = {};
 };
 
 namespace {
@@ -319,23 +330,64 @@ int upload_tables(nufft_hip_plan p) {
   return NUFFT_HIP_OK;
 }
 
+hipEvent_t take_event(nufft_hip_plan p) {
+  if (!p->free_events.empty()) {
+    hipEvent_t e = p->free_events.back();
+    p->free_events.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+void stage_begin(void* ctx, int stage) {
+  nufft_hip_plan p = (nufft_hip_plan)ctx;
+  hipEvent_t e = take_event(p);
+  (void)hipEventRecord(e, p->stream);
+  p->open_event[stage] = e;
+}
+void stage_end(void* ctx, int stage) {
+  nufft_hip_plan p = (nufft_hip_plan)ctx;
+  hipEvent_t e = take_event(p);
+  (void)hipEventRecord(e, p->stream);
+  p->pending.push_back({stage, p->open_event[stage], e});
+}
+StageHook make_hook(nufft_hip_plan p) {
+  StageHook h;
+  if (p->timing) {
+    h.ctx = p;
+    h.begin_fn = stage_begin;
+    h.end_fn = stage_end;
+  }
+  return h;
+}
+
 int ensure_point_capacity(nufft_hip_plan p, int64_t M) {
+  int rc;
+  if (sort_uses_lds(p->g)) {
+    int64_t per_block;
+    const int64_t need = (int64_t)sort_blocks(p->g, M, &per_block) * p->g.ntiles;
+    if (need > p->hist_elems) {
+      HIP_TRY(p, hipStreamSynchronize(p->stream));
+      dev_free(p->hist);
+      p->hist = nullptr;
+      p->hist_elems = 0;
+      if ((rc = dev_alloc(p, (void**)&p->hist, sizeof(int32_t) * (size_t)need))) return rc;
+      p->hist_elems = need;
+    }
+  }
   if (M <= p->cap) return NUFFT_HIP_OK;
   HIP_TRY(p, hipStreamSynchronize(p->stream));
-  const size_t fb = (size_t)p->precision;
-  dev_free(p->loc_tmp); dev_free(p->loc); dev_free(p->tile_of); dev_free(p->rank_of); dev_free(p->idx);
-  for (int d = 0; d < 3; ++d) { dev_free(p->z_tmp[d]); dev_free(p->z[d]); p->z_tmp[d] = p->z[d] = nullptr; }
-  p->loc_tmp = p->loc = nullptr; p->tile_of = p->rank_of = p->idx = nullptr;
+  dev_free(p->rec); dev_free(p->idx3); dev_free(p->tile_of); dev_free(p->rank_of);
+  p->rec = nullptr; p->idx3 = nullptr; p->tile_of = p->rank_of = nullptr;
   p->cap = 0;
-  int rc;
-  if ((rc = dev_alloc(p, (void**)&p->loc_tmp, M * 4))) return rc;
-  if ((rc = dev_alloc(p, (void**)&p->loc, M * 4))) return rc;
-  if ((rc = dev_alloc(p, (void**)&p->tile_of, M * 4))) return rc;
-  if ((rc = dev_alloc(p, (void**)&p->rank_of, M * 4))) return rc;
-  if ((rc = dev_alloc(p, (void**)&p->idx, M * 4))) return rc;
-  for (int d = 0; d < p->rank; ++d) {
-    if ((rc = dev_alloc(p, &p->z_tmp[d], M * fb))) return rc;
-    if ((rc = dev_alloc(p, &p->z[d], M * fb))) return rc;
+  const size_t rec_bytes = p->precision == NUFFT_HIP_F32 ? sizeof(Rec<float>) : sizeof(Rec<double>);
+  if ((rc = dev_alloc(p, &p->rec, (size_t)M * rec_bytes))) return rc;
+  if (p->precision == NUFFT_HIP_F32 && p->rank == 3)
+    if ((rc = dev_alloc(p, (void**)&p->idx3, (size_t)M * 4))) return rc;
+  if (!sort_uses_lds(p->g)) {
+    if ((rc = dev_alloc(p, (void**)&p->tile_of, (size_t)M * 4))) return rc;
+    if ((rc = dev_alloc(p, (void**)&p->rank_of, (size_t)M * 4))) return rc;
   }
   p->cap = M;
   return NUFFT_HIP_OK;
@@ -347,27 +399,23 @@ int set_points_impl(nufft_hip_plan p, int64_t M, const void* x, const void* y, c
   int rc = ensure_point_capacity(p, M);
   if (rc) return rc;
   p->M = M;
-  HIP_TRY(p, hipMemsetAsync(p->tile_count, 0, sizeof(int32_t) * (size_t)p->g.ntiles, p->stream));
-  HIP_TRY(p, hipMemsetAsync(p->bad_count, 0, sizeof(int32_t) * 4, p->stream));
-  PrepArgs a;
-  a.pts[0] = x; a.pts[1] = y; a.pts[2] = z;
-  a.stride = stride;
-  a.M = M;
-  a.range_mode = p->opts.points_range;
-  a.check_range = p->opts.check_points_range;
-  a.loc = p->loc_tmp;
-  for (int d = 0; d < 3; ++d) a.z[d] = p->z_tmp[d];
-  a.tile_of = p->tile_of;
-  a.rank_of = p->rank_of;
-  a.tile_count = p->tile_count;
-  a.bad_count = p->bad_count;
-  HIP_TRY(p, launch_prep<T>(p->g, a, p->stream));
-  HIP_TRY(p, launch_scan(p->g, p->tile_count, p->tile_start, p->sub_start, p->stream));
-  T* zin[3] = {(T*)p->z_tmp[0], (T*)p->z_tmp[1], (T*)p->z_tmp[2]};
-  T* zout[3] = {(T*)p->z[0], (T*)p->z[1], (T*)p->z[2]};
-  HIP_TRY(p, launch_scatter<T>(p->g, M, p->loc_tmp, zin, p->tile_of, p->rank_of, p->tile_start,
-                               p->loc, zout, p->idx, p->stream));
-  if (p->opts.check_points_range && p->opts.points_range != NUFFT_HIP_RANGE_INFINITE) {
+  const bool check = p->opts.check_points_range && p->opts.points_range != NUFFT_HIP_RANGE_INFINITE;
+  if (check) HIP_TRY(p, hipMemsetAsync(p->bad_count, 0, sizeof(int32_t) * 4, p->stream));
+  PointsIn in;
+  in.pts[0] = x; in.pts[1] = y; in.pts[2] = z;
+  in.stride = stride;
+  in.M = M;
+  in.range_mode = p->opts.points_range;
+  in.check_range = check ? 1 : 0;
+  SortWork w;
+  w.hist = p->hist; w.tile_of = p->tile_of; w.rank_of = p->rank_of;
+  w.tile_count = p->tile_count; w.tile_start = p->tile_start; w.sub_start = p->sub_start;
+  w.bad_count = p->bad_count;
+  SortedOut<T> out;
+  out.rec = (Rec<T>*)p->rec;
+  out.idx3 = p->idx3;
+  HIP_TRY(p, launch_sort<T>(p->g, in, w, out, p->stream, make_hook(p)));
+  if (check) {
     int32_t bad = 0;
     HIP_TRY(p, hipMemcpyAsync(&bad, p->bad_count, sizeof(int32_t), hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(p, hipStreamSynchronize(p->stream));
@@ -387,9 +435,8 @@ int set_points_impl(nufft_hip_plan p, int64_t M, const void* x, const void* y, c
 template <typename T>
 SortedPoints<T> sorted_view(nufft_hip_plan p) {
   SortedPoints<T> sp;
-  sp.loc = p->loc;
-  for (int d = 0; d < 3; ++d) sp.z[d] = (const T*)p->z[d];
-  sp.idx = p->idx;
+  sp.rec = (const Rec<T>*)p->rec;
+  sp.idx3 = p->idx3;
   sp.tile_start = p->tile_start;
   sp.sub_start = p->sub_start;
   return sp;
@@ -416,17 +463,32 @@ int execute_impl(nufft_hip_plan p, void* c, void* f) {
     int rc = get_fft_plan(p, nb, &fft);
     if (rc) return rc;
     void* bufs[1] = {fw};
+    const StageHook hook = make_hook(p);
     if (p->type == NUFFT_HIP_TYPE_1) {
+      hook.begin(STAGE_ZERO);
       HIP_TRY(p, hipMemsetAsync(fw, 0, sizeof(T) * 2 * (size_t)p->fine_elems * nb, p->stream));
+      hook.end(STAGE_ZERO);
+      hook.begin(STAGE_SPREAD);
       HIP_TRY(p, launch_spread<T>(p->g, p->method, sp, p->M, (const T*)p->d_horner, cb, fw, nb,
                                   p->M, p->fine_elems, (T)1, p->lds_bytes, p->stream));
+      hook.end(STAGE_SPREAD);
+      hook.begin(STAGE_FFT);
       FFT_TRY(p, rocfft_execute(fft, bufs, nullptr, p->fft_info));
+      hook.end(STAGE_FFT);
+      hook.begin(STAGE_DECONVOLVE);
       HIP_TRY(p, launch_deconvolve<T>(p->g, 1, fb, fw, rf, nb, p->stream));
+      hook.end(STAGE_DECONVOLVE);
     } else {
+      hook.begin(STAGE_DECONVOLVE);
       HIP_TRY(p, launch_deconvolve<T>(p->g, 2, fb, fw, rf, nb, p->stream));
+      hook.end(STAGE_DECONVOLVE);
+      hook.begin(STAGE_FFT);
       FFT_TRY(p, rocfft_execute(fft, bufs, nullptr, p->fft_info));
+      hook.end(STAGE_FFT);
+      hook.begin(STAGE_INTERP);
       HIP_TRY(p, launch_interp<T>(p->g, p->method, sp, p->M, (const T*)p->d_horner, cb, fw, nb,
                                   p->M, p->fine_elems, (T)1, p->stream));
+      hook.end(STAGE_INTERP);
     }
   }
   return NUFFT_HIP_OK;
@@ -450,13 +512,20 @@ int spread_interp_impl(nufft_hip_plan p, int dir, void* c, void* f) {
     const int nb = std::min(32768, p->ntransf - b0);
     T* cb = (T*)c + 2 * (int64_t)b0 * p->M;
     T* fb = (T*)f + 2 * (int64_t)b0 * p->fine_elems;
+    const StageHook hook = make_hook(p);
     if (dir == 1) {
+      hook.begin(STAGE_ZERO);
       HIP_TRY(p, hipMemsetAsync(fb, 0, sizeof(T) * 2 * (size_t)p->fine_elems * nb, p->stream));
+      hook.end(STAGE_ZERO);
+      hook.begin(STAGE_SPREAD);
       HIP_TRY(p, launch_spread<T>(p->g, p->method, sp, p->M, (const T*)p->d_horner, cb, fb, nb,
                                   p->M, p->fine_elems, scale, p->lds_bytes, p->stream));
+      hook.end(STAGE_SPREAD);
     } else {
+      hook.begin(STAGE_INTERP);
       HIP_TRY(p, launch_interp<T>(p->g, p->method, sp, p->M, (const T*)p->d_horner, cb, fb, nb,
                                   p->M, p->fine_elems, scale, p->stream));
+      hook.end(STAGE_INTERP);
     }
   }
   return NUFFT_HIP_OK;
@@ -469,9 +538,11 @@ void destroy(nufft_hip_plan p) {
   if (p->fft_info) rocfft_execution_info_destroy(p->fft_info);
   dev_free(p->fft_work);
   dev_free(p->d_horner);
-  for (int d = 0; d < 3; ++d) { dev_free(p->d_rfser[d]); dev_free(p->z_tmp[d]); dev_free(p->z[d]); }
+  for (int d = 0; d < 3; ++d) dev_free(p->d_rfser[d]);
   dev_free(p->d_fine);
-  dev_free(p->loc_tmp); dev_free(p->loc); dev_free(p->tile_of); dev_free(p->rank_of); dev_free(p->idx);
+  dev_free(p->rec); dev_free(p->idx3); dev_free(p->hist); dev_free(p->tile_of); dev_free(p->rank_of);
+  for (auto& pe : p->pending) { (void)hipEventDestroy(pe.e0); (void)hipEventDestroy(pe.e1); }
+  for (auto e : p->free_events) (void)hipEventDestroy(e);
   dev_free(p->tile_count); dev_free(p->tile_start); dev_free(p->sub_start); dev_free(p->bad_count);
   delete p;
 }
@@ -770,6 +841,33 @@ int nufft_hip_plan_set_stream(nufft_hip_plan p, void* stream) {
   if (!p) return NUFFT_HIP_INVALID_ARGUMENT;
   p->stream = (hipStream_t)stream;
   if (p->fft_info) FFT_TRY(p, rocfft_execution_info_set_stream(p->fft_info, p->stream));
+  return NUFFT_HIP_OK;
+}
+
+int nufft_hip_plan_set_timing(nufft_hip_plan p, int enable) {
+  if (!p) return NUFFT_HIP_INVALID_ARGUMENT;
+  p->timing = enable != 0;
+  return NUFFT_HIP_OK;
+}
+
+int nufft_hip_plan_get_timing(nufft_hip_plan p, double* ms, int32_t* calls, int n) {
+  if (!p) return NUFFT_HIP_INVALID_ARGUMENT;
+  HIP_TRY(p, hipStreamSynchronize(p->stream));
+  for (auto& pe : p->pending) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, pe.e0, pe.e1) == hipSuccess) {
+      p->stage_ms[pe.stage] += t;
+      p->stage_calls[pe.stage] += 1;
+    }
+    p->free_events.push_back(pe.e0);
+    p->free_events.push_back(pe.e1);
+  }
+  p->pending.clear();
+  for (int s2 = 0; s2 < n && s2 < STAGE_COUNT; ++s2) {
+    if (ms) ms[s2] = p->stage_ms[s2];
+    if (calls) calls[s2] = p->stage_calls[s2];
+  }
+  for (int s2 = 0; s2 < STAGE_COUNT; ++s2) { p->stage_ms[s2] = 0; p->stage_calls[s2] = 0; }
   return NUFFT_HIP_OK;
 }
 

@@ -20,6 +20,7 @@ FORWARD, BACKWARD = -1, 1
 F32, F64 = 4, 8
 OP_NUFFT, OP_INTERP, OP_SPREAD = 0, 1, 2
 METHOD_AUTO, METHOD_TILE_GENERIC, METHOD_TILE_WAVE = 0, 1, 2
+STAGES = ('sort_count', 'sort_scan', 'sort_scatter', 'zero', 'spread', 'fft', 'deconvolve', 'interp')
 
 
 class InvalidArgumentError(ValueError):
@@ -96,6 +97,9 @@ SYMBOLS = {
         ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.POINTER(OptionsStruct),
         ctypes.POINTER(PlanInfo), ctypes.c_char_p, ctypes.c_size_t]),
     'nufft_hip_plan_set_stream': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    'nufft_hip_plan_set_timing': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    'nufft_hip_plan_get_timing': (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32), ctypes.c_int]),
     'nufft_hip_last_error': (ctypes.c_char_p, [ctypes.c_void_p]),
     'nufft_hip_plan_destroy': (ctypes.c_int, [ctypes.c_void_p]),
     'nufft_hip_debug_fine_grid': (ctypes.c_int, [

@@ -121,6 +121,17 @@ class Plan:
     hip.hipMemcpy(_c.c_void_p(out.data_ptr()), ptr, _c.c_size_t(out.numel() * out.element_size()), 3)
     return out
 
+  def set_timing(self, enable=True):
+    self._check(self.lib.nufft_hip_plan_set_timing(self._handle, int(enable)))
+
+  def get_timing(self):
+    """{stage: (total_ms, calls)} since the last call; synchronises the stream."""
+    n = len(_lib.STAGES)
+    ms = (ctypes.c_double * n)()
+    calls = (ctypes.c_int32 * n)()
+    self._check(self.lib.nufft_hip_plan_get_timing(self._handle, ms, calls, n))
+    return {name: (ms[i], calls[i]) for i, name in enumerate(_lib.STAGES)}
+
   def close(self):
     if self._handle is not None:
       self.lib.nufft_hip_plan_destroy(self._handle)

@@ -1,0 +1,155 @@
+"""CPU-side checks of the C ABI (no GPU, no compute calls): the library loads,
+exports every symbol include/nufft_hip.h declares, its structs have the layout
+the Python binding assumes, the host-only parameter rules give the sizes of
+SURVEY.md section 8, and validation errors carry the reference's messages."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from tensorflow_nufft import _lib
+
+
+def _describe(rank, dims, tol, prec, ttype=1, ntransf=1, **opts):
+  lib = _lib.lib()
+  o = _lib.OptionsStruct()
+  lib.nufft_hip_default_options(ctypes.byref(o))
+  for k, v in opts.items():
+    setattr(o, k, v)
+  info = _lib.PlanInfo()
+  err = ctypes.create_string_buffer(512)
+  d = (ctypes.c_int64 * 3)(*(list(dims) + [1] * (3 - rank)))
+  rc = lib.nufft_hip_plan_describe(ttype, rank, d, -1, ntransf, float(tol), prec, ctypes.byref(o),
+                                   ctypes.byref(info), err, 512)
+  return rc, err.value.decode(), info
+
+
+def test_library_exports_every_declared_symbol():
+  header = open(os.path.join(ROOT, 'include', 'nufft_hip.h')).read()
+  declared = set(re.findall(r'\b(nufft_hip_[a-z_0-9]+)\s*\(', header))
+  assert len(declared) >= 20
+  handle = ctypes.CDLL(_lib.LIB_PATH)
+  missing = [n for n in sorted(declared) if not hasattr(handle, n)]
+  assert not missing, missing
+  assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+  assert _lib.lib().nufft_hip_abi_version() == 1
+
+
+def test_default_options_and_struct_layout():
+  o = _lib.OptionsStruct()
+  _lib.lib().nufft_hip_default_options(ctypes.byref(o))
+  assert o.points_range == 1 and o.max_batch_size == 0 and o.check_points_range == 0
+  assert ctypes.sizeof(_lib.OptionsStruct) == 88
+  # plan_describe echoes fields through the C struct: checks PlanInfo's layout
+  rc, _, i = _describe(2, [1024, 1024], 1e-6, 4, ntransf=3)
+  assert rc == 0 and (i.type, i.rank, i.precision, i.iflag, i.ntransf) == (1, 2, 4, -1, 3)
+  assert list(i.grid_dims) == [1024, 1024, 1]
+
+
+@pytest.mark.parametrize('rank,dims,tol,prec,w,nf,method', [
+    (2, [1024, 1024], float(np.float32(1e-6)), 4, 8, [2048, 2048, 1], 2),   # BASELINE config 2/3
+    (3, [256, 256, 256], float(np.float32(1e-4)), 4, 6, [512, 512, 512], 1),  # config 4
+    (2, [512, 512], float(np.float32(1e-6)), 4, 8, [1024, 1024, 1], 2),     # config 5
+    (1, [4096], float(np.float32(1e-6)), 8, 8, [8192, 1, 1], 1),            # config 1 (fp64)
+    (2, [6, 8], 1e-6, 4, 8, [16, 16, 1], 1),                                # fine grid >= 2 w
+])
+def test_parameter_rules(rank, dims, tol, prec, w, nf, method):
+  rc, err, i = _describe(rank, dims, tol, prec)
+  assert rc == 0, err
+  assert i.kernel_width == w and list(i.fine_dims) == nf and i.upsampling_factor == 2.0
+  assert i.spread_method == method
+  assert abs(i.beta - 2.30 * w) < 1e-12
+  for d in range(rank):
+    assert i.num_tiles[d] * i.tile_dims[d] >= i.fine_dims[d]
+
+
+def test_kernel_width_rule_safe_side():
+  # w = ceil(log10(10 / tol)) with exact powers of ten rounded UP
+  for tol, w in ((1e-1, 3), (1e-2, 4), (1e-3, 5), (1e-4, 6), (1e-5, 7), (1e-6, 8), (2e-6, 7),
+                 (1e-9, 11), (1e-12, 14), (1e-14, 16), (1e-16, 16)):
+    rc, _, i = _describe(2, [64, 64], tol, 8)
+    assert rc == 0 and i.kernel_width == w, (tol, i.kernel_width)
+  # float clamps tol at 6e-8 (nufft_plan.h:84-89)
+  assert _describe(2, [64, 64], 1e-12, 4)[2].kernel_width == 9
+
+
+def test_batch_size_rule():
+  assert _describe(2, [64, 64], 1e-6, 4, ntransf=20)[2].batch_size == 8   # nufft_plan.cu.cc:1923-1928
+  assert _describe(2, [64, 64], 1e-6, 4, ntransf=3)[2].batch_size == 3
+  assert _describe(2, [64, 64], 1e-6, 4, ntransf=20, max_batch_size=2)[2].batch_size == 2
+
+
+def test_create_argument_errors():
+  assert _describe(4, [8, 8, 8], 1e-6, 4)[0] == _lib.UNIMPLEMENTED
+  rc, err, _ = _describe(2, [64, 64], 1e-6, 4, ttype=3)
+  assert rc == _lib.UNIMPLEMENTED and 'type-3' in err
+  rc, err, _ = _describe(2, [64, 64], 1e-6, 4, ntransf=0)
+  assert rc == _lib.INVALID_ARGUMENT and 'num_transforms must be >= 1' in err
+  rc, err, _ = _describe(2, [14, 64], 1e-6, 4, spread_only=1)
+  assert rc == _lib.INVALID_ARGUMENT and 'Invalid grid dimension size: 14' in err
+  rc, err, _ = _describe(2, [64, 64], 1e-6, 4, upsampling_factor=0.5)
+  assert rc == _lib.INVALID_ARGUMENT and 'upsampling_factor must be > 1.0' in err
+
+
+def _op_shape(op, ttype, prec, source_shape, points_shape, grid_shape=()):
+  d = _lib.OpDesc()
+  d.op_type, d.transform_type, d.fft_direction, d.precision, d.tol = op, ttype, -1, prec, 1e-6
+  _lib.lib().nufft_hip_default_options(ctypes.byref(d.options))
+  d.source_ndim, d.points_ndim, d.grid_shape_len = len(source_shape), len(points_shape), len(grid_shape)
+  for i, s in enumerate(source_shape):
+    d.source_shape[i] = s
+  for i, s in enumerate(points_shape):
+    d.points_shape[i] = s
+  for i, s in enumerate(grid_shape[:3]):
+    d.grid_shape[i] = s
+  nd = ctypes.c_int32()
+  shp = (ctypes.c_int64 * 12)()
+  err = ctypes.create_string_buffer(512)
+  rc = _lib.lib().nufft_hip_op_shape(ctypes.byref(d), ctypes.byref(nd), shp, err, 512)
+  return rc, err.value.decode(), [shp[i] for i in range(nd.value)]
+
+
+def test_op_shape_inference_and_errors():
+  # nufft_ops_test.py:667-725 (static shapes) and :438-503 (error messages)
+  assert _op_shape(0, 1, 4, [100], [100, 2], [8, 6])[2] == [8, 6]
+  assert _op_shape(0, 2, 4, [8, 6], [100, 2])[2] == [100]
+  assert _op_shape(0, 1, 4, [2, 4, 100], [1, 100, 2], [24, 24])[2] == [2, 4, 24, 24]
+  assert _op_shape(0, 1, 4, [1, 100], [2, 4, 100, 2], [24, 24])[2] == [2, 4, 24, 24]
+  assert _op_shape(0, 2, 4, [5, 1, 8, 8, 8], [3, 50, 3])[2] == [5, 3, 50]
+  assert _op_shape(1, 2, 8, [3, 64, 96], [100, 2])[2] == [3, 100]        # Interp
+  assert _op_shape(2, 1, 8, [100], [100, 3], [4, 8, 6])[2] == [4, 8, 6]  # Spread
+  rc, err, _ = _op_shape(0, 1, 4, [100], [100, 2], [8])
+  assert rc == _lib.INVALID_ARGUMENT and 'grid_shape must have length 2' in err
+  rc, err, _ = _op_shape(0, 1, 4, [99], [100, 2], [8, 8])
+  assert rc == _lib.INVALID_ARGUMENT and 'must have equal samples dimensions' in err
+  rc, err, _ = _op_shape(0, 1, 4, [100], [100, 4], [8, 8, 8])
+  assert rc == _lib.INVALID_ARGUMENT and 'Dimension must be 1, 2 or 3' in err
+  rc, err, _ = _op_shape(0, 1, 4, [3, 100], [2, 100, 2], [8, 8])
+  assert rc == _lib.INVALID_ARGUMENT and 'Incompatible shapes: [3,100] vs. [2,100,2]' in err
+  rc, err, _ = _op_shape(0, 2, 4, [8], [100, 2])
+  assert rc == _lib.INVALID_ARGUMENT and 'must have rank of at least 2' in err
+
+
+def test_product_package_does_not_import_the_oracle():
+  # the shipped path must never route through oracle/ (or any CPU fallback)
+  pkg = os.path.join(ROOT, 'tensorflow-nufft_amd')
+  for dirpath, _, files in os.walk(pkg):
+    for f in files:
+      if f.endswith(('.py', '.cpp', '.hip', '.h', '.cc')):
+        text = open(os.path.join(dirpath, f), errors='replace').read()
+        assert 'import oracle' not in text and 'from oracle' not in text, f
+        assert 'nufft_oracle' not in text, f
+
+
+def test_python_surface_fails_loudly_without_gpu():
+  import torch
+  if torch.cuda.device_count() > 0:
+    pytest.skip('GPU present')
+  import tensorflow_nufft as tfft
+  with pytest.raises(RuntimeError, match='no CPU kernels'):
+    tfft.nufft(np.zeros(4, np.complex64), np.zeros((4, 1), np.float32), grid_shape=[8], transform_type='type_1')
+  with pytest.raises(ValueError, match='grid_shape must be provided for type-1 transforms'):
+    tfft.nufft(np.zeros(4, np.complex64), np.zeros((4, 1), np.float32), transform_type='type_1')

@@ -20,12 +20,17 @@ def main():
   pts = (torch.rand((M, 2), generator=g, device='cuda') * 2 - 1) * np.pi
   c = torch.complex(torch.rand(M, generator=g, device='cuda') - .5, torch.rand(M, generator=g, device='cuda') - .5)
   for method in (2, 1):
-    for S in (512, 1024, 2048, 4096):
+    for S in (1024, 4096):
       plan = tfft.Plan('type_1', [1024, 1024], 'forward', tol=1e-6, spread_method=method, max_subproblem_size=S)
       i = plan.info()
       t_set = timeit(lambda: plan.set_points(pts))
       out = plan.execute(c)
       t_exec = timeit(lambda: plan.execute(c, out=out))
+      plan.set_timing(True)
+      for _ in range(5):
+        plan.set_points(pts); plan.execute(c, out=out)
+      tm = plan.get_timing()
+      print('   stages(us):', ' '.join(f'{k}={v[0]/max(v[1],1)*1e3:.0f}' for k, v in tm.items() if v[1]))
       print(f'method {method} S {S} w {i.kernel_width} nc {i.ncoef}: set_points {t_set*1e3:.3f} ms  execute {t_exec*1e3:.3f} ms  '
             f'-> {M/(t_set+t_exec)/1e6:.1f} Mpts/s total, {M/t_exec/1e6:.1f} Mpts/s exec')
       plan.close()
