@@ -117,6 +117,8 @@ hipError_t launch_permute(const void* src, void* dst, int elem_bytes, int ndim,
                           const int64_t* out_shape, const int64_t* src_strides,
                           hipStream_t stream);
 size_t spread_lds_bytes(const Geom& g, int method, int precision);
+size_t interp_lds_bytes(const Geom& g, int method, int precision);
+int wave_lstride(int rank);
 bool wave_method_supported(const Geom& g, int precision);
 
 }  // namespace nufft_hip

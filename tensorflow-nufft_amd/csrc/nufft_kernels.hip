@@ -519,6 +519,306 @@ __global__ __launch_bounds__(kBlock) void spread_2d_w8_wave_kernel(
   }
 }
 
+// ----------------- spread: wavefront-per-point path, any w <= 8, rank 2 or 3
+
+// Generalisation of the kernel above. Lanes are laid out as an 8 x 8 (dy, dx)
+// patch of which the w x w sub-patch is active; rank 3 loops over dz with the
+// same patch (2 ds_add_f64 per point and z-plane). The LDS row stride must be
+// 8 or 24 (mod 32) fp64 elements so that the four rows of a half-wave land in
+// disjoint bank groups (2-D: tile 32x32, stride 40; 3-D: tile 16x16x4, stride
+// 24). Staging per point: kx[8], ky[8] (rank 3), and the last dimension's
+// kernel values multiplied by the strength, (k*re, k*im)[8].
+template <typename T> struct Pair;
+template <> struct Pair<float> { using type = float2; };
+template <> struct Pair<double> { using type = double2; };
+
+template <typename T, int RANK, int NW, int CH>
+__global__ __launch_bounds__(NW * 64) void spread_wave_kernel(
+    Geom g, SortedPoints<T> sp, const T* __restrict__ horner, const T* __restrict__ c,
+    T* __restrict__ fw, int64_t c_stride, int64_t fw_stride, T scale) {
+  using T2 = typename Pair<T>::type;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int LS = g.lstride;
+  const int L0 = g.ldim[0], L1 = g.ldim[1];
+  const int L2 = RANK > 2 ? g.ldim[2] : 1;
+  const int PS = LS * L1;              // z-plane stride (elements)
+  const int plane = PS * L2;           // elements per component plane
+  double* plane_re = reinterpret_cast<double*>(smem_raw);
+  double* plane_im = plane_re + plane;
+  constexpr int kPer = (RANK == 2) ? (8 + 16) : (8 + 8 + 16);   // T words per staged point
+  T* stage_all = reinterpret_cast<T*>(plane_im + plane);
+  int tb, p0, p1;
+  if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1)) return;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  for (int i = tid; i < 2 * plane; i += NW * 64) plane_re[i] = 0.0;
+  __syncthreads();
+
+  const int w = g.w, nc = g.ncoef;
+  T* st = stage_all + wave * (CH * kPer);
+  T* kxs = st;                                   // [CH][8]
+  T* kys = st + CH * 8;                          // [CH][8]   (rank 3 only)
+  T2* klc = reinterpret_cast<T2*>(st + CH * (RANK == 2 ? 8 : 16));   // [CH][8] (k_last*re, k_last*im)
+  const int dx = lane & 7, dy = lane >> 3;
+  const bool active = dx < w && dy < w;
+  const int cell = dy * LS + dx;
+  const T* cc = c + 2 * (int64_t)blockIdx.y * c_stride;
+
+  for (int base = p0 + wave * CH; base < p1; base += NW * CH) {
+    const int j = base + lane;
+    const bool valid = lane < CH && j < p1;
+    int off = 0;
+    if (lane < CH) {
+      T kx[8], k2[8], klr[8], kli[8];
+      if (valid) {
+        const Rec<T> rec = sp.rec[j];
+        const uint32_t loc = rec.loc;
+        const int idx = rec_idx<T>(sp, RANK, j, rec);
+        const T re = cc[2 * (int64_t)idx] * scale, im = cc[2 * (int64_t)idx + 1] * scale;
+        off = (int)(loc & 1023) + (int)((loc >> 10) & 1023) * LS + (RANK > 2 ? (int)((loc >> 20) & 1023) * PS : 0);
+        const T zl = RANK == 2 ? rec.z1 : rec.z2;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          T a0 = (T)0, a1 = (T)0, al = (T)0;
+          if (q < w) {
+            a0 = horner[(nc - 1) * kMaxW + q];
+            a1 = a0;
+            al = a0;
+            for (int k = nc - 2; k >= 0; --k) {
+              const T t = horner[k * kMaxW + q];
+              a0 = fma(a0, rec.z0, t);
+              if (RANK > 2) a1 = fma(a1, rec.z1, t);
+              al = fma(al, zl, t);
+            }
+          }
+          kx[q] = a0; k2[q] = a1; klr[q] = al * re; kli[q] = al * im;
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { kx[q] = (T)0; k2[q] = (T)0; klr[q] = (T)0; kli[q] = (T)0; }
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        kxs[lane * 8 + q] = kx[q];
+        if (RANK > 2) kys[lane * 8 + q] = k2[q];
+        T2 v; v.x = klr[q]; v.y = kli[q];
+        klc[lane * 8 + q] = v;
+      }
+    }
+    int npts = p1 - base;
+    if (npts > CH) npts = CH;
+    if (RANK == 2) {
+      const int nround = (npts + 3) & ~3;
+      for (int q = 0; q < nround; q += 4) {
+        T a[4]; T2 b[4]; int o[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          a[u] = kxs[(q + u) * 8 + dx];
+          b[u] = klc[(q + u) * 8 + dy];
+          o[u] = __builtin_amdgcn_readlane(off, q + u) + cell;
+        }
+        if (active) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            lds_add(&plane_re[o[u]], (double)(a[u] * b[u].x));
+            lds_add(&plane_im[o[u]], (double)(a[u] * b[u].y));
+          }
+        }
+      }
+    } else {
+      for (int q = 0; q < npts; ++q) {
+        const T a = kxs[q * 8 + dx] * kys[q * 8 + dy];
+        const int o = __builtin_amdgcn_readlane(off, q) + cell;
+#pragma unroll
+        for (int dz = 0; dz < 8; ++dz) {
+          if (dz < w) {
+            const T2 b = klc[q * 8 + dz];
+            if (active) {
+              lds_add(&plane_re[o + dz * PS], (double)(a * b.x));
+              lds_add(&plane_im[o + dz * PS], (double)(a * b.y));
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  const int t0 = tb % g.ntile[0];
+  const int t1 = (tb / g.ntile[0]) % g.ntile[1];
+  const int t2 = tb / (g.ntile[0] * g.ntile[1]);
+  const int o0 = t0 * g.tile[0], o1 = t1 * g.tile[1], o2 = t2 * g.tile[2];
+  T* out = fw + 2 * (int64_t)blockIdx.y * fw_stride;
+  for (int i = tid; i < plane; i += NW * 64) {
+    const int a0 = i % LS, a1 = (i / LS) % L1, a2 = i / PS;
+    if (a0 < L0) {
+      const T vre = (T)plane_re[i], vim = (T)plane_im[i];
+      if (vre != (T)0 || vim != (T)0) {
+        const int64_t g0 = (o0 + a0) % g.nf[0];
+        const int64_t g1 = (o1 + a1) % g.nf[1];
+        const int64_t g2 = RANK > 2 ? (o2 + a2) % g.nf[2] : 0;
+        const int64_t gi = g0 + (int64_t)g.nf[0] * (g1 + (int64_t)g.nf[1] * g2);
+        glb_add(&out[2 * gi], vre);
+        glb_add(&out[2 * gi + 1], vim);
+      }
+    }
+  }
+}
+
+// ------------------- interp: LDS-tiled path, any w <= 8, rank 2 or 3 (type 2)
+
+// Sum over an aligned group of 8 lanes, result valid in the group's first lane.
+__device__ __forceinline__ float red8(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x104, 0xf, 0xf, true));  // row_shl:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x102, 0xf, 0xf, true));  // row_shl:2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, true));  // row_shl:1
+  return v;
+}
+__device__ __forceinline__ double red8(double v) {
+  v += __shfl_down(v, 4, 8);
+  v += __shfl_down(v, 2, 8);
+  v += __shfl_down(v, 1, 8);
+  return v;
+}
+
+// One workgroup per subproblem: the fine-grid tile (+ one-sided halo) is staged
+// in LDS as interleaved complex; kernel values are produced one point per lane
+// and staged; then 8 points are gathered per wavefront pass, lane (p, dx)
+// accumulating column dx of point p over dy (and dz), followed by an 8-lane
+// DPP reduction. Replaces the reference's InterpSubproblem* kernels
+// (nufft_plan.cu.cc:1041-1187, 1608-1804); its default is the untiled
+// InterpNuptsDriven* (:963-1038), kept here as the generic kernel below.
+template <typename T, int RANK>
+__global__ __launch_bounds__(256) void interp_wave_kernel(
+    Geom g, SortedPoints<T> sp, const T* __restrict__ horner, T* __restrict__ c,
+    const T* __restrict__ fw, int64_t c_stride, int64_t fw_stride, T scale) {
+  using T2 = typename Pair<T>::type;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int LS = g.lstride;
+  const int L0 = g.ldim[0], L1 = g.ldim[1];
+  const int L2 = RANK > 2 ? g.ldim[2] : 1;
+  const int PS = LS * L1;
+  const int ncell = PS * L2;
+  T2* tile = reinterpret_cast<T2*>(smem_raw);
+  constexpr int kPer = (RANK == 2) ? 16 : 24;
+  T* stage_all = reinterpret_cast<T*>(tile + ncell);
+  int2* meta_all = reinterpret_cast<int2*>(stage_all + 4 * 64 * kPer);   // (off, idx) per staged point
+  int tb, p0, p1;
+  if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1)) return;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int t0 = tb % g.ntile[0];
+  const int t1 = (tb / g.ntile[0]) % g.ntile[1];
+  const int t2 = tb / (g.ntile[0] * g.ntile[1]);
+  const int o0 = t0 * g.tile[0], o1 = t1 * g.tile[1], o2 = t2 * g.tile[2];
+  const T2* in = reinterpret_cast<const T2*>(fw) + (int64_t)blockIdx.y * fw_stride;
+  for (int i = tid; i < ncell; i += 256) {
+    const int a0 = i % LS, a1 = (i / LS) % L1, a2 = i / PS;
+    T2 v; v.x = (T)0; v.y = (T)0;
+    if (a0 < L0) {
+      const int64_t g0 = (o0 + a0) % g.nf[0];
+      const int64_t g1 = (o1 + a1) % g.nf[1];
+      const int64_t g2 = RANK > 2 ? (o2 + a2) % g.nf[2] : 0;
+      v = in[g0 + (int64_t)g.nf[0] * (g1 + (int64_t)g.nf[1] * g2)];
+    }
+    tile[i] = v;
+  }
+  __syncthreads();
+
+  const int w = g.w, nc = g.ncoef;
+  T* st = stage_all + wave * (64 * kPer);
+  T* kxs = st;                 // [64][8]
+  T* kys = st + 64 * 8;        // [64][8]
+  T* kzs = st + 64 * 16;       // [64][8] (rank 3)
+  int2* meta = meta_all + wave * 64;
+  const int dx = lane & 7, pg = lane >> 3;
+  T* cc = c + 2 * (int64_t)blockIdx.y * c_stride;
+
+  for (int base = p0 + wave * 64; base < p1; base += 4 * 64) {
+    const int j = base + lane;
+    {
+      T kx[8], ky[8], kz[8];
+      int off = 0, idx = -1;
+      if (j < p1) {
+        const Rec<T> rec = sp.rec[j];
+        const uint32_t loc = rec.loc;
+        idx = rec_idx<T>(sp, RANK, j, rec);
+        off = (int)(loc & 1023) + (int)((loc >> 10) & 1023) * LS + (RANK > 2 ? (int)((loc >> 20) & 1023) * PS : 0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          T a0 = (T)0, a1 = (T)0, a2 = (T)0;
+          if (q < w) {
+            a0 = horner[(nc - 1) * kMaxW + q];
+            a1 = a0;
+            a2 = a0;
+            for (int k = nc - 2; k >= 0; --k) {
+              const T t = horner[k * kMaxW + q];
+              a0 = fma(a0, rec.z0, t);
+              a1 = fma(a1, rec.z1, t);
+              if (RANK > 2) a2 = fma(a2, rec.z2, t);
+            }
+          }
+          kx[q] = a0; ky[q] = a1; kz[q] = a2;
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { kx[q] = (T)0; ky[q] = (T)0; kz[q] = (T)0; }
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        kxs[lane * 8 + q] = kx[q];
+        kys[lane * 8 + q] = ky[q];
+        if (RANK > 2) kzs[lane * 8 + q] = kz[q];
+      }
+      meta[lane] = make_int2(off, idx);
+    }
+    int npts = p1 - base;
+    if (npts > 64) npts = 64;
+    for (int q0 = 0; q0 < npts; q0 += 8) {
+      const int q = q0 + pg;                 // this lane group's point
+      const int2 m = meta[q];
+      const T kxv = kxs[q * 8 + dx];
+      T sre = (T)0, sim = (T)0;
+      const T2* tp = tile + m.x + dx;
+      if (RANK == 2) {
+#pragma unroll
+        for (int dy = 0; dy < 8; ++dy) {
+          if (dy < w) {
+            const T kyv = kys[q * 8 + dy];
+            const T2 v = tp[dy * LS];
+            sre = fma(kyv, v.x, sre);
+            sim = fma(kyv, v.y, sim);
+          }
+        }
+      } else {
+        for (int dz = 0; dz < w; ++dz) {
+          const T kzv = kzs[q * 8 + dz];
+          T lre = (T)0, lim = (T)0;
+#pragma unroll
+          for (int dy = 0; dy < 8; ++dy) {
+            if (dy < w) {
+              const T kyv = kys[q * 8 + dy];
+              const T2 v = tp[dz * PS + dy * LS];
+              lre = fma(kyv, v.x, lre);
+              lim = fma(kyv, v.y, lim);
+            }
+          }
+          sre = fma(kzv, lre, sre);
+          sim = fma(kzv, lim, sim);
+        }
+      }
+      sre = red8(sre * kxv);
+      sim = red8(sim * kxv);
+      if (dx == 0 && m.y >= 0) {
+        T2 r; r.x = sre * scale; r.y = sim * scale;
+        reinterpret_cast<T2*>(cc)[m.y] = r;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------ interp: generic tile path
 
 // One workgroup per subproblem, one thread per point, gathering w^rank fine
@@ -745,18 +1045,44 @@ template hipError_t launch_sort<float>(const Geom&, const PointsIn&, const SortW
 template hipError_t launch_sort<double>(const Geom&, const PointsIn&, const SortWork&,
                                         const SortedOut<double>&, hipStream_t, const StageHook&);
 
-bool wave_method_supported(const Geom& g, int precision) {
+// Specialised 2-D w = 8 float kernel applicable?
+static bool wave8_supported(const Geom& g, int precision) {
   return precision == NUFFT_HIP_F32 && g.rank == 2 && g.w == kWW && g.ncoef <= kWaveCoef &&
-         g.tile[0] == kWT && g.tile[1] == kWT;
+         g.tile[0] == kWT && g.tile[1] == kWT && g.lstride == kWS;
 }
 
+// Wavefront-per-point kernels need w <= 8, rank 2/3 and the tile geometry that
+// makes their LDS accesses conflict free.
+bool wave_method_supported(const Geom& g, int precision) {
+  (void)precision;
+  if (g.w > 8) return false;
+  if (g.rank == 2) return g.tile[0] == 32 && g.tile[1] == 32;
+  if (g.rank == 3) return g.tile[0] == 16 && g.tile[1] == 16 && g.tile[2] == 4;
+  return false;
+}
+int wave_lstride(int rank) { return rank == 2 ? 40 : 24; }
+
+template <typename T> static constexpr int wave3d_nw() { return sizeof(T) == 4 ? 8 : 4; }
+
 size_t spread_lds_bytes(const Geom& g, int method, int precision) {
-  (void)precision;   // LDS tiles are double for both precisions
-  if (method == NUFFT_HIP_METHOD_TILE_WAVE)
-    return sizeof(double) * 2 * kWPlane + sizeof(float) * kWaves * kStageWords;
+  // LDS tiles are double for both precisions
   size_t cells = (size_t)g.lstride;
   for (int d = 1; d < g.rank; ++d) cells *= (size_t)g.ldim[d];
+  if (method == NUFFT_HIP_METHOD_TILE_WAVE) {
+    if (wave8_supported(g, precision))
+      return sizeof(double) * 2 * kWPlane + sizeof(float) * kWaves * kStageWords;
+    if (g.rank == 2) return cells * 2 * sizeof(double) + (size_t)precision * 4 * 64 * 24;
+    const int nw = precision == NUFFT_HIP_F32 ? 8 : 4;
+    return cells * 2 * sizeof(double) + (size_t)precision * nw * 32 * 32;
+  }
   return cells * 2 * sizeof(double);
+}
+
+size_t interp_lds_bytes(const Geom& g, int method, int precision) {
+  if (method != NUFFT_HIP_METHOD_TILE_WAVE) return 0;
+  size_t cells = (size_t)g.lstride;
+  for (int d = 1; d < g.rank; ++d) cells *= (size_t)g.ldim[d];
+  return cells * 2 * (size_t)precision + (size_t)precision * 4 * 64 * (g.rank == 2 ? 16 : 24) + 4 * 64 * 8;
 }
 
 // Upper bound on the number of subproblems, known without reading the device:
@@ -782,12 +1108,25 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
   hipError_t e = hipSuccess;
   if (method == NUFFT_HIP_METHOD_TILE_WAVE) {
     if constexpr (sizeof(T) == 4) {
-      spread_2d_w8_wave_kernel<<<grid, kBlock, lds_bytes, stream>>>(
-          g, sp, horner, c, fw, c_stride, fw_stride, scale);
-      return hipGetLastError();
-    } else {
-      return hipErrorInvalidValue;
+      if (wave8_supported(g, 4)) {
+        spread_2d_w8_wave_kernel<<<grid, kBlock, lds_bytes, stream>>>(
+            g, sp, horner, c, fw, c_stride, fw_stride, scale);
+        return hipGetLastError();
+      }
     }
+    if (g.rank == 2) {
+      e = ensure_lds(spread_wave_kernel<T, 2, 4, 64>, lds_bytes);
+      if (e != hipSuccess) return e;
+      spread_wave_kernel<T, 2, 4, 64><<<grid, 256, lds_bytes, stream>>>(g, sp, horner, c, fw, c_stride,
+                                                                        fw_stride, scale);
+    } else {
+      constexpr int nw = wave3d_nw<T>();
+      e = ensure_lds(spread_wave_kernel<T, 3, nw, 32>, lds_bytes);
+      if (e != hipSuccess) return e;
+      spread_wave_kernel<T, 3, nw, 32><<<grid, nw * 64, lds_bytes, stream>>>(g, sp, horner, c, fw, c_stride,
+                                                                             fw_stride, scale);
+    }
+    return hipGetLastError();
   }
   switch (g.rank) {
     case 1:
@@ -822,9 +1161,22 @@ template <typename T>
 hipError_t launch_interp(const Geom& g, int method, const SortedPoints<T>& sp, int64_t M,
                          const T* horner, T* c, const T* fw, int batch, int64_t c_stride,
                          int64_t fw_stride, T scale, hipStream_t stream) {
-  (void)method;
   if (M == 0) return hipSuccess;
   dim3 grid(subproblem_grid(g, M), (unsigned)batch);
+  if (method == NUFFT_HIP_METHOD_TILE_WAVE) {
+    const size_t lds = interp_lds_bytes(g, method, (int)sizeof(T));
+    hipError_t e;
+    if (g.rank == 2) {
+      e = ensure_lds(interp_wave_kernel<T, 2>, lds);
+      if (e != hipSuccess) return e;
+      interp_wave_kernel<T, 2><<<grid, 256, lds, stream>>>(g, sp, horner, c, fw, c_stride, fw_stride, scale);
+    } else {
+      e = ensure_lds(interp_wave_kernel<T, 3>, lds);
+      if (e != hipSuccess) return e;
+      interp_wave_kernel<T, 3><<<grid, 256, lds, stream>>>(g, sp, horner, c, fw, c_stride, fw_stride, scale);
+    }
+    return hipGetLastError();
+  }
   switch (g.rank) {
     case 1:
       interp_tile_generic_kernel<T, 1><<<grid, kBlock, 0, stream>>>(g, sp, horner, c, fw, c_stride,

@@ -713,11 +713,21 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
   if (method == NUFFT_HIP_METHOD_TILE_WAVE && !wave_method_supported(g, precision)) {
     delete p;
     return fail(NUFFT_HIP_INVALID_ARGUMENT,
-                "spread_method TILE_WAVE needs rank 2, kernel width 8, float precision and 32x32 tiles");
+                "spread_method TILE_WAVE needs rank 2 or 3, kernel width <= 8 and the default tile sizes");
   }
   p->method = method;
-  if (method == NUFFT_HIP_METHOD_TILE_WAVE) g.lstride = 40;
+  if (method == NUFFT_HIP_METHOD_TILE_WAVE) g.lstride = wave_lstride(rank);
   p->lds_bytes = spread_lds_bytes(g, method, precision);
+  if (p->lds_bytes > 160 * 1024 || interp_lds_bytes(g, method, precision) > 160 * 1024) {
+    // does not fit (e.g. 3-D double at w = 8): fall back to the generic tile path
+    if (p->opts.spread_method == NUFFT_HIP_METHOD_TILE_WAVE) {
+      delete p;
+      return fail(NUFFT_HIP_RESOURCE_EXHAUSTED, "spread_method TILE_WAVE does not fit in LDS for this configuration");
+    }
+    p->method = method = NUFFT_HIP_METHOD_TILE_GENERIC;
+    g.lstride = g.ldim[0];
+    p->lds_bytes = spread_lds_bytes(g, method, precision);
+  }
 
   for (int d = 0; d < rank; ++d) kernel_fseries(p->ks, g.nf[d], p->fser_h[d]);
   p->spread_scale = p->opts.spread_only ? spread_only_scale(p->ks, rank) : 1.0;

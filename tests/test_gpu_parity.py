@@ -87,6 +87,38 @@ def test_wave_and_generic_spreaders_agree_with_oracle(tfft, method):
   plan.close()
 
 
+@pytest.mark.parametrize('rank,grid,tol,dtype', [
+    (2, [96, 80], 1e-3, 'c64'), (2, [96, 80], 1e-5, 'c64'), (2, [50, 64], 1e-6, 'c128'),
+    (3, [40, 48, 36], 1e-4, 'c64'), (3, [40, 48, 36], 1e-6, 'c64'), (3, [24, 20, 28], 1e-5, 'c128'),
+])
+@pytest.mark.parametrize('ttype', ['type_1', 'type_2'])
+def test_wave_kernels_all_widths_vs_generic_and_oracle(tfft, rank, grid, tol, dtype, ttype):
+  # wavefront-per-point kernels (method 2) for w < 8, 3-D and double, against the
+  # generic tile kernels (method 1) and the fp64 oracle
+  import torch
+  from oracle import oracle
+  rng = np.random.default_rng(31)
+  M = 30000
+  cdt = np.complex64 if dtype == 'c64' else np.complex128
+  rdt = np.float32 if dtype == 'c64' else np.float64
+  pts = rng.uniform(-np.pi, np.pi, (M, rank)).astype(rdt)
+  if ttype == 'type_1':
+    src = (rng.uniform(-.5, .5, M) + 1j * rng.uniform(-.5, .5, M)).astype(cdt)
+  else:
+    src = (rng.uniform(-.5, .5, grid) + 1j * rng.uniform(-.5, .5, grid)).astype(cdt)
+  truth = oracle.nufft(src.astype(np.complex128), pts, grid, ttype, 'forward', tol=1e-13)
+  outs = {}
+  for method in (1, 2):
+    plan = tfft.Plan(ttype, grid, 'forward', tol=tol, dtype=torch.complex64 if dtype == 'c64' else torch.complex128,
+                     spread_method=method)
+    assert plan.info().spread_method == method and plan.info().kernel_width <= 8
+    plan.set_points(_dev(pts))
+    outs[method] = plan.execute(_dev(src)).cpu().numpy()
+    plan.close()
+    assert rel_l2(outs[method], truth) < tol, (method, rel_l2(outs[method], truth))
+  assert rel_l2(outs[2], outs[1]) < max(1e-6, 1e-3 * tol)
+
+
 def test_headline_shape_small_m_vs_oracle(tfft):
   # BASELINE config 2 geometry (1024^2 modes, 2048^2 fine grid) with M = 2e5 so
   # the oracle (fp64, sigma 2, tol 1e-12) finishes in seconds
