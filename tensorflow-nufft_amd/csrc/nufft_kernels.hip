@@ -500,21 +500,22 @@ __global__ __launch_bounds__(kBlock) void spread_2d_w8_wave_kernel(
   }
   __syncthreads();
 
+  // Write-out: consecutive lanes take (re, im) of consecutive cells, so one
+  // global_atomic_add_f32 wave-instruction covers 256 contiguous bytes of a
+  // fine-grid row (the shape the memory-side atomic units want).
   const int t0 = tb % g.ntile[0];
   const int t1 = tb / g.ntile[0];
   const int o0 = t0 * kWT, o1 = t1 * kWT;
   float* out = fw + 2 * (int64_t)blockIdx.y * fw_stride;
-  for (int i = tid; i < kWPlane; i += kBlock) {
-    const int a0 = i % kWS, a1 = i / kWS;
-    if (a0 < kWL) {
-      const float vre = (float)plane_re[i], vim = (float)plane_im[i];
-      if (vre != 0.f || vim != 0.f) {
-        int g0 = o0 + a0; if (g0 >= g.nf[0]) g0 -= g.nf[0];
-        int g1 = o1 + a1; if (g1 >= g.nf[1]) g1 -= g.nf[1];
-        const int64_t gi = g0 + (int64_t)g.nf[0] * g1;
-        glb_add(&out[2 * gi], vre);
-        glb_add(&out[2 * gi + 1], vim);
-      }
+  for (int i = tid; i < 2 * kWL * kWL; i += kBlock) {
+    const int comp = i & 1;
+    const int cellid = i >> 1;
+    const int a0 = cellid % kWL, a1 = cellid / kWL;
+    const float v = (float)(comp ? plane_im : plane_re)[a1 * kWS + a0];
+    if (v != 0.f) {
+      int g0 = o0 + a0; if (g0 >= g.nf[0]) g0 -= g.nf[0];
+      int g1 = o1 + a1; if (g1 >= g.nf[1]) g1 -= g.nf[1];
+      glb_add(&out[2 * (g0 + (int64_t)g.nf[0] * g1) + comp], v);
     }
   }
 }
@@ -528,6 +529,16 @@ __global__ __launch_bounds__(kBlock) void spread_2d_w8_wave_kernel(
 // disjoint bank groups (2-D: tile 32x32, stride 40; 3-D: tile 16x16x4, stride
 // 24). Staging per point: kx[8], ky[8] (rank 3), and the last dimension's
 // kernel values multiplied by the strength, (k*re, k*im)[8].
+__device__ __forceinline__ float bcast_lane(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+__device__ __forceinline__ double bcast_lane(double v, int lane) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), lane);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+
 template <typename T> struct Pair;
 template <> struct Pair<float> { using type = float2; };
 template <> struct Pair<double> { using type = double2; };
@@ -569,8 +580,11 @@ __global__ __launch_bounds__(NW * 64) void spread_wave_kernel(
     const int j = base + lane;
     const bool valid = lane < CH && j < p1;
     int off = 0;
+    T klr[8], kli[8];   // (k_last * re, k_last * im) of this lane's point
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { klr[q] = (T)0; kli[q] = (T)0; }
     if (lane < CH) {
-      T kx[8], k2[8], klr[8], kli[8];
+      T kx[8], k2[8];
       if (valid) {
         const Rec<T> rec = sp.rec[j];
         const uint32_t loc = rec.loc;
@@ -596,14 +610,16 @@ __global__ __launch_bounds__(NW * 64) void spread_wave_kernel(
         }
       } else {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { kx[q] = (T)0; k2[q] = (T)0; klr[q] = (T)0; kli[q] = (T)0; }
+        for (int q = 0; q < 8; ++q) { kx[q] = (T)0; k2[q] = (T)0; }
       }
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         kxs[lane * 8 + q] = kx[q];
         if (RANK > 2) kys[lane * 8 + q] = k2[q];
-        T2 v; v.x = klr[q]; v.y = kli[q];
-        klc[lane * 8 + q] = v;
+        if (RANK == 2) {
+          T2 v; v.x = klr[q]; v.y = kli[q];
+          klc[lane * 8 + q] = v;
+        }
       }
     }
     int npts = p1 - base;
@@ -627,16 +643,24 @@ __global__ __launch_bounds__(NW * 64) void spread_wave_kernel(
         }
       }
     } else {
+      // kx*ky is lane dependent (two staging reads, next point's prefetched);
+      // the z factor times the strength is the same for all lanes of a pass, so
+      // it comes straight from the owning lane's registers through v_readlane
+      // (scalar broadcast) instead of LDS.
+      T a_n = kxs[dx] * kys[dy];
       for (int q = 0; q < npts; ++q) {
-        const T a = kxs[q * 8 + dx] * kys[q * 8 + dy];
+        const T a = a_n;
+        const int qn = (q + 1 < npts) ? q + 1 : q;
+        a_n = kxs[qn * 8 + dx] * kys[qn * 8 + dy];
         const int o = __builtin_amdgcn_readlane(off, q) + cell;
 #pragma unroll
         for (int dz = 0; dz < 8; ++dz) {
           if (dz < w) {
-            const T2 b = klc[q * 8 + dz];
+            const T br = bcast_lane(klr[dz], q);
+            const T bi = bcast_lane(kli[dz], q);
             if (active) {
-              lds_add(&plane_re[o + dz * PS], (double)(a * b.x));
-              lds_add(&plane_im[o + dz * PS], (double)(a * b.y));
+              lds_add(&plane_re[o + dz * PS], (double)(a * br));
+              lds_add(&plane_im[o + dz * PS], (double)(a * bi));
             }
           }
         }
@@ -650,18 +674,138 @@ __global__ __launch_bounds__(NW * 64) void spread_wave_kernel(
   const int t2 = tb / (g.ntile[0] * g.ntile[1]);
   const int o0 = t0 * g.tile[0], o1 = t1 * g.tile[1], o2 = t2 * g.tile[2];
   T* out = fw + 2 * (int64_t)blockIdx.y * fw_stride;
-  for (int i = tid; i < plane; i += NW * 64) {
-    const int a0 = i % LS, a1 = (i / LS) % L1, a2 = i / PS;
-    if (a0 < L0) {
-      const T vre = (T)plane_re[i], vim = (T)plane_im[i];
-      if (vre != (T)0 || vim != (T)0) {
-        const int64_t g0 = (o0 + a0) % g.nf[0];
-        const int64_t g1 = (o1 + a1) % g.nf[1];
-        const int64_t g2 = RANK > 2 ? (o2 + a2) % g.nf[2] : 0;
-        const int64_t gi = g0 + (int64_t)g.nf[0] * (g1 + (int64_t)g.nf[1] * g2);
-        glb_add(&out[2 * gi], vre);
-        glb_add(&out[2 * gi + 1], vim);
+  const int ncomp = 2 * L0 * L1 * L2;   // (re, im) of consecutive cells on consecutive lanes
+  for (int i = tid; i < ncomp; i += NW * 64) {
+    const int comp = i & 1;
+    const int cellid = i >> 1;
+    const int a0 = cellid % L0, a1 = (cellid / L0) % L1, a2 = cellid / (L0 * L1);
+    const T v = (T)(comp ? plane_im : plane_re)[a2 * PS + a1 * LS + a0];
+    if (v != (T)0) {
+      const int64_t g0 = (o0 + a0) % g.nf[0];
+      const int64_t g1 = (o1 + a1) % g.nf[1];
+      const int64_t g2 = RANK > 2 ? (o2 + a2) % g.nf[2] : 0;
+      glb_add(&out[2 * (g0 + (int64_t)g.nf[0] * (g1 + (int64_t)g.nf[1] * g2)) + comp], v);
+    }
+  }
+}
+
+// ------------------------- spread: 3-D wavefront path with compile-time width
+
+// Same scheme as spread_wave_kernel<T, 3, ...> with the kernel width W as a
+// template parameter: the per-point body is straight-line code (2 v_readlane,
+// 2 multiplies, 2 conversions, 2 ds_add_f64 per z-plane), so the only LDS wait
+// in the loop is a counted one on the prefetched kx/ky reads and the atomics
+// of consecutive points stream back to back. (With a run-time width the
+// compiler drains the LDS queue, lgkmcnt(0), after every point: measured 45 %
+// LDS-array activity against 82 % for the 2-D kernel, profiles/r01_pmc_*.)
+template <typename T, int W, int NW, int CH>
+__global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
+    Geom g, SortedPoints<T> sp, const T* __restrict__ horner, const T* __restrict__ c,
+    T* __restrict__ fw, int64_t c_stride, int64_t fw_stride, T scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int LS = g.lstride;
+  const int L0 = g.ldim[0], L1 = g.ldim[1], L2 = g.ldim[2];
+  const int PS = LS * L1;
+  const int plane = PS * L2;
+  double* plane_re = reinterpret_cast<double*>(smem_raw);
+  double* plane_im = plane_re + plane;
+  T* stage_all = reinterpret_cast<T*>(plane_im + plane);
+  int tb, p0, p1;
+  if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1)) return;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  for (int i = tid; i < 2 * plane; i += NW * 64) plane_re[i] = 0.0;
+  __syncthreads();
+
+  const int nc = g.ncoef;
+  T* kxs = stage_all + wave * (CH * 16);   // [CH][8]
+  T* kys = kxs + CH * 8;                   // [CH][8]
+  const int dx = lane & 7, dy = lane >> 3;
+  const bool active = dx < W && dy < W;
+  const int cell = dy * LS + dx;
+  const T* cc = c + 2 * (int64_t)blockIdx.y * c_stride;
+
+  for (int base = p0 + wave * CH; base < p1; base += NW * CH) {
+    const int j = base + lane;
+    int off = 0;
+    T klr[W], kli[W];
+#pragma unroll
+    for (int q = 0; q < W; ++q) { klr[q] = (T)0; kli[q] = (T)0; }
+    if (lane < CH) {
+      T kx[W], ky[W];
+#pragma unroll
+      for (int q = 0; q < W; ++q) { kx[q] = (T)0; ky[q] = (T)0; }
+      if (j < p1) {
+        const Rec<T> rec = sp.rec[j];
+        const uint32_t loc = rec.loc;
+        const int idx = rec_idx<T>(sp, 3, j, rec);
+        const T re = cc[2 * (int64_t)idx] * scale, im = cc[2 * (int64_t)idx + 1] * scale;
+        off = (int)(loc & 1023) + (int)((loc >> 10) & 1023) * LS + (int)((loc >> 20) & 1023) * PS;
+#pragma unroll
+        for (int q = 0; q < W; ++q) {
+          T a0 = horner[(nc - 1) * kMaxW + q];
+          T a1 = a0, a2 = a0;
+          for (int k = nc - 2; k >= 0; --k) {
+            const T t = horner[k * kMaxW + q];
+            a0 = fma(a0, rec.z0, t);
+            a1 = fma(a1, rec.z1, t);
+            a2 = fma(a2, rec.z2, t);
+          }
+          kx[q] = a0; ky[q] = a1; klr[q] = a2 * re; kli[q] = a2 * im;
+        }
       }
+#pragma unroll
+      for (int q = 0; q < W; ++q) {
+        kxs[lane * 8 + q] = kx[q];
+        kys[lane * 8 + q] = ky[q];
+      }
+    }
+    int npts = p1 - base;
+    if (npts > CH) npts = CH;
+    // z factor x strength: same for every lane of a pass -> v_readlane from the
+    // owning lane's registers (all lanes execute the readlanes; only the w x w
+    // patch issues atomics)
+    T a_n = (T)0;
+    if (active) a_n = kxs[dx] * kys[dy];
+    for (int q = 0; q < npts; ++q) {
+      const T a = a_n;
+      const int qn = (q + 1 < npts) ? q + 1 : q;
+      if (active) a_n = kxs[qn * 8 + dx] * kys[qn * 8 + dy];
+      const int o = __builtin_amdgcn_readlane(off, q) + cell;
+      T br[W], bi[W];
+#pragma unroll
+      for (int dz = 0; dz < W; ++dz) {
+        br[dz] = bcast_lane(klr[dz], q);
+        bi[dz] = bcast_lane(kli[dz], q);
+      }
+      if (active) {
+#pragma unroll
+        for (int dz = 0; dz < W; ++dz) {
+          lds_add(&plane_re[o + dz * PS], (double)(a * br[dz]));
+          lds_add(&plane_im[o + dz * PS], (double)(a * bi[dz]));
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  const int t0 = tb % g.ntile[0];
+  const int t1 = (tb / g.ntile[0]) % g.ntile[1];
+  const int t2 = tb / (g.ntile[0] * g.ntile[1]);
+  const int o0 = t0 * g.tile[0], o1 = t1 * g.tile[1], o2 = t2 * g.tile[2];
+  T* out = fw + 2 * (int64_t)blockIdx.y * fw_stride;
+  const int ncomp = 2 * L0 * L1 * L2;
+  for (int i = tid; i < ncomp; i += NW * 64) {
+    const int comp = i & 1;
+    const int cellid = i >> 1;
+    const int a0 = cellid % L0, a1 = (cellid / L0) % L1, a2 = cellid / (L0 * L1);
+    const T v = (T)(comp ? plane_im : plane_re)[a2 * PS + a1 * LS + a0];
+    if (v != (T)0) {
+      const int64_t g0 = (o0 + a0) % g.nf[0];
+      const int64_t g1 = (o1 + a1) % g.nf[1];
+      const int64_t g2 = (o2 + a2) % g.nf[2];
+      glb_add(&out[2 * (g0 + (int64_t)g.nf[0] * (g1 + (int64_t)g.nf[1] * g2)) + comp], v);
     }
   }
 }
@@ -1062,7 +1206,7 @@ bool wave_method_supported(const Geom& g, int precision) {
 }
 int wave_lstride(int rank) { return rank == 2 ? 40 : 24; }
 
-template <typename T> static constexpr int wave3d_nw() { return sizeof(T) == 4 ? 8 : 4; }
+template <typename T> static constexpr int wave3d_nw() { return sizeof(T) == 4 ? 16 : 8; }
 
 size_t spread_lds_bytes(const Geom& g, int method, int precision) {
   // LDS tiles are double for both precisions
@@ -1072,8 +1216,8 @@ size_t spread_lds_bytes(const Geom& g, int method, int precision) {
     if (wave8_supported(g, precision))
       return sizeof(double) * 2 * kWPlane + sizeof(float) * kWaves * kStageWords;
     if (g.rank == 2) return cells * 2 * sizeof(double) + (size_t)precision * 4 * 64 * 24;
-    const int nw = precision == NUFFT_HIP_F32 ? 8 : 4;
-    return cells * 2 * sizeof(double) + (size_t)precision * nw * 32 * 32;
+    const int nw = precision == NUFFT_HIP_F32 ? 16 : 8;
+    return cells * 2 * sizeof(double) + (size_t)precision * nw * 32 * 16;
   }
   return cells * 2 * sizeof(double);
 }
@@ -1121,10 +1265,19 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
                                                                         fw_stride, scale);
     } else {
       constexpr int nw = wave3d_nw<T>();
-      e = ensure_lds(spread_wave_kernel<T, 3, nw, 32>, lds_bytes);
-      if (e != hipSuccess) return e;
-      spread_wave_kernel<T, 3, nw, 32><<<grid, nw * 64, lds_bytes, stream>>>(g, sp, horner, c, fw, c_stride,
-                                                                             fw_stride, scale);
+#define NUFFT_LAUNCH_W3(WW)                                                                      \
+  case WW:                                                                                       \
+    e = ensure_lds(spread_wave3_kernel<T, WW, nw, 32>, lds_bytes);                               \
+    if (e != hipSuccess) return e;                                                               \
+    spread_wave3_kernel<T, WW, nw, 32><<<grid, nw * 64, lds_bytes, stream>>>(g, sp, horner, c, fw, \
+                                                                           c_stride, fw_stride, scale); \
+    break;
+      switch (g.w) {
+        NUFFT_LAUNCH_W3(2) NUFFT_LAUNCH_W3(3) NUFFT_LAUNCH_W3(4) NUFFT_LAUNCH_W3(5)
+        NUFFT_LAUNCH_W3(6) NUFFT_LAUNCH_W3(7) NUFFT_LAUNCH_W3(8)
+        default: return hipErrorInvalidValue;
+      }
+#undef NUFFT_LAUNCH_W3
     }
     return hipGetLastError();
   }
