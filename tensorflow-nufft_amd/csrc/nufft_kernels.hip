@@ -14,6 +14,9 @@
 // stencil start, so the halo is one sided), the subproblem lookup (binary
 // search in a scanned array, no host sync) and the wavefront-per-point
 // scatter are specific to this build. Wavefront = 64 lanes throughout.
+#include <cstdio>
+#include <cstdlib>
+
 #include "nufft_hip_internal.h"
 
 namespace nufft_hip {
@@ -163,28 +166,34 @@ __global__ __launch_bounds__(kSortBlock) void hist_lds_kernel(Geom g, PointsIn i
   for (int t = threadIdx.x; t < nt; t += kSortBlock) out[t] = h[t];
 }
 
-// hist[b][t] -> exclusive prefix over b (per tile), totals -> tile_count[t]
-__global__ __launch_bounds__(256) void colscan_kernel(int nt, int nblk, int32_t* __restrict__ hist,
-                                                      int32_t* __restrict__ tile_count) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= nt) return;
+// hist[b][t] -> exclusive prefix over b (per tile), totals -> tile_count[t].
+// A workgroup owns 64 tile columns; its 16 waves each take a band of rows
+// (coalesced 256-byte row segments), band sums are combined through LDS, then
+// each wave rewrites its band with the running prefix.
+__global__ __launch_bounds__(1024) void colscan_kernel(int nt, int nblk, int32_t* __restrict__ hist,
+                                                       int32_t* __restrict__ tile_count) {
+  __shared__ int part[16][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int t = blockIdx.x * 64 + tx;
+  const int rpg = (nblk + 15) / 16;
+  const int r0 = ty * rpg;
+  const int r1 = (r0 + rpg < nblk) ? r0 + rpg : nblk;
+  int sum = 0;
+  if (t < nt)
+    for (int r = r0; r < r1; ++r) sum += hist[(int64_t)r * nt + t];
+  part[ty][tx] = sum;
+  __syncthreads();
   int run = 0;
-  int b = 0;
-  for (; b + 4 <= nblk; b += 4) {
-    int32_t* p = hist + (int64_t)b * nt + t;
-    const int v0 = p[0], v1 = p[nt], v2 = p[2 * (int64_t)nt], v3 = p[3 * (int64_t)nt];
-    p[0] = run; run += v0;
-    p[nt] = run; run += v1;
-    p[2 * (int64_t)nt] = run; run += v2;
-    p[3 * (int64_t)nt] = run; run += v3;
+  for (int k = 0; k < ty; ++k) run += part[k][tx];
+  if (t < nt) {
+    for (int r = r0; r < r1; ++r) {
+      int32_t* p = hist + (int64_t)r * nt + t;
+      const int v = *p;
+      *p = run;
+      run += v;
+    }
+    if (ty == 15) tile_count[t] = run;
   }
-  for (; b < nblk; ++b) {
-    int32_t* p = hist + (int64_t)b * nt + t;
-    const int v = p[0];
-    p[0] = run;
-    run += v;
-  }
-  tile_count[t] = run;
 }
 
 template <typename T>
@@ -411,10 +420,9 @@ constexpr int kWW = 8;               // kernel width
 constexpr int kWL = kWT + kWW - 1;   // 39 rows/cols used
 constexpr int kWS = 40;              // row stride in words: 8 mod 32
 constexpr int kWPlane = kWS * kWL;   // 1560 words per plane
-constexpr int kWaves = kBlock / 64;
-constexpr int kStageWords = 64 * kWW * 3;  // per wave: kx[64][8] + (ky*re, ky*im)[64][8]
 
-__global__ __launch_bounds__(kBlock) void spread_2d_w8_wave_kernel(
+template <int NW, int CH>
+__global__ __launch_bounds__(NW * 64) void spread_2d_w8_wave_kernel(
     Geom g, SortedPoints<float> sp, const float* __restrict__ horner, const float* __restrict__ c,
     float* __restrict__ fw, int64_t c_stride, int64_t fw_stride, float scale) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -426,19 +434,19 @@ __global__ __launch_bounds__(kBlock) void spread_2d_w8_wave_kernel(
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  for (int i = tid; i < 2 * kWPlane; i += kBlock) plane_re[i] = 0.0;
+  for (int i = tid; i < 2 * kWPlane; i += NW * 64) plane_re[i] = 0.0;
   __syncthreads();
 
-  float* kxs = stage_all + wave * kStageWords;        // [64][8]
-  float2* kyc = reinterpret_cast<float2*>(kxs + 64 * kWW);  // [64][8] (ky*re, ky*im)
+  float* kxs = stage_all + wave * (CH * kWW * 3);   // [CH][8]
+  float2* kyc = reinterpret_cast<float2*>(kxs + CH * kWW);  // [CH][8] (ky*re, ky*im)
   const int dx = lane & 7, dy = lane >> 3;
   const int cell = dy * kWS + dx;
   const float* cc = c + 2 * (int64_t)blockIdx.y * c_stride;
 
   // coefficients of the piecewise polynomial: uniform loads, kept in SGPRs/VGPRs
-  for (int base = p0 + wave * 64; base < p1; base += kWaves * 64) {
+  for (int base = p0 + wave * CH; base < p1; base += NW * CH) {
     const int j = base + lane;
-    const bool valid = j < p1;
+    const bool valid = lane < CH && j < p1;
     int off = 0;
     float kx[kWW], kyr[kWW], kyi[kWW];
     if (valid) {
@@ -468,7 +476,7 @@ __global__ __launch_bounds__(kBlock) void spread_2d_w8_wave_kernel(
       for (int q = 0; q < kWW; ++q) { kx[q] = 0.f; kyr[q] = 0.f; kyi[q] = 0.f; }
     }
     // stage: each lane writes its point's 8 + 16 values
-    {
+    if (lane < CH) {
       float4* d4 = reinterpret_cast<float4*>(kxs + lane * kWW);
       d4[0] = make_float4(kx[0], kx[1], kx[2], kx[3]);
       d4[1] = make_float4(kx[4], kx[5], kx[6], kx[7]);
@@ -479,7 +487,7 @@ __global__ __launch_bounds__(kBlock) void spread_2d_w8_wave_kernel(
     }
     // (same wave reads what it wrote: LDS ops of one wave are processed in order)
     int npts = p1 - base;
-    if (npts > 64) npts = 64;
+    if (npts > CH) npts = CH;
     const int nround = (npts + 3) & ~3;   // padded lanes hold zeros and off = 0
     for (int q = 0; q < nround; q += 4) {
       float a[4];
@@ -507,7 +515,7 @@ __global__ __launch_bounds__(kBlock) void spread_2d_w8_wave_kernel(
   const int t1 = tb / g.ntile[0];
   const int o0 = t0 * kWT, o1 = t1 * kWT;
   float* out = fw + 2 * (int64_t)blockIdx.y * fw_stride;
-  for (int i = tid; i < 2 * kWL * kWL; i += kBlock) {
+  for (int i = tid; i < 2 * kWL * kWL; i += NW * 64) {
     const int comp = i & 1;
     const int cellid = i >> 1;
     const int a0 = cellid % kWL, a1 = cellid / kWL;
@@ -1133,8 +1141,14 @@ __global__ __launch_bounds__(256) void permute_kernel(const V* __restrict__ src,
 static inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
 
 int sort_blocks(const Geom& g, int64_t M, int64_t* per_block) {
-  // at most 1024 workgroups, at least 4096 points each
-  int64_t pb = (M + 1023) / 1024;
+  // at most 512 workgroups (longer per-tile runs per workgroup => better write
+  // combining in the scatter; measured r01), at least 4096 points each
+  static int maxblk = 0;
+  if (!maxblk) {
+    maxblk = 512;
+    if (const char* e = getenv("NUFFT_HIP_SORT_BLOCKS")) maxblk = atoi(e) > 0 ? atoi(e) : 512;
+  }
+  int64_t pb = (M + maxblk - 1) / maxblk;
   if (pb < 4096) pb = 4096;
   *per_block = pb;
   (void)g;
@@ -1161,7 +1175,7 @@ hipError_t launch_sort(const Geom& g, const PointsIn& in, const SortWork& w, con
     hist_lds_kernel<T><<<nblk, kSortBlock, lds, stream>>>(g, in, per_block, w.hist, w.bad_count);
     hook.end(STAGE_SORT_COUNT);
     hook.begin(STAGE_SORT_SCAN);
-    colscan_kernel<<<(g.ntiles + 255) / 256, 256, 0, stream>>>(g.ntiles, nblk, w.hist, w.tile_count);
+    colscan_kernel<<<(g.ntiles + 63) / 64, 1024, 0, stream>>>(g.ntiles, nblk, w.hist, w.tile_count);
     scan_tiles_kernel<<<1, 1024, 0, stream>>>(w.tile_count, g.ntiles, g.max_sub, w.tile_start, w.sub_start);
     hook.end(STAGE_SORT_SCAN);
     hook.begin(STAGE_SORT_SCATTER);
@@ -1189,6 +1203,18 @@ template hipError_t launch_sort<float>(const Geom&, const PointsIn&, const SortW
 template hipError_t launch_sort<double>(const Geom&, const PointsIn&, const SortWork&,
                                         const SortedOut<double>&, hipStream_t, const StageHook&);
 
+// Launch shape of the specialised kernel (waves per workgroup, points per
+// staging chunk); NUFFT_HIP_W8_SHAPE = "NWxCH" overrides for experiments.
+static int g_w8_nw = 0, g_w8_ch = 0;
+static void wave8_shape_init() {
+  if (g_w8_nw) return;
+  int nw = 4, ch = 64;
+  if (const char* e = getenv("NUFFT_HIP_W8_SHAPE")) sscanf(e, "%dx%d", &nw, &ch);
+  g_w8_nw = nw; g_w8_ch = ch;
+}
+static int wave8_nw() { wave8_shape_init(); return g_w8_nw; }
+static int wave8_ch() { wave8_shape_init(); return g_w8_ch; }
+
 // Specialised 2-D w = 8 float kernel applicable?
 static bool wave8_supported(const Geom& g, int precision) {
   return precision == NUFFT_HIP_F32 && g.rank == 2 && g.w == kWW && g.ncoef <= kWaveCoef &&
@@ -1214,7 +1240,7 @@ size_t spread_lds_bytes(const Geom& g, int method, int precision) {
   for (int d = 1; d < g.rank; ++d) cells *= (size_t)g.ldim[d];
   if (method == NUFFT_HIP_METHOD_TILE_WAVE) {
     if (wave8_supported(g, precision))
-      return sizeof(double) * 2 * kWPlane + sizeof(float) * kWaves * kStageWords;
+      return sizeof(double) * 2 * kWPlane + sizeof(float) * wave8_nw() * wave8_ch() * kWW * 3;
     if (g.rank == 2) return cells * 2 * sizeof(double) + (size_t)precision * 4 * 64 * 24;
     const int nw = precision == NUFFT_HIP_F32 ? 16 : 8;
     return cells * 2 * sizeof(double) + (size_t)precision * nw * 32 * 16;
@@ -1253,8 +1279,21 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
   if (method == NUFFT_HIP_METHOD_TILE_WAVE) {
     if constexpr (sizeof(T) == 4) {
       if (wave8_supported(g, 4)) {
-        spread_2d_w8_wave_kernel<<<grid, kBlock, lds_bytes, stream>>>(
-            g, sp, horner, c, fw, c_stride, fw_stride, scale);
+        const int shape = wave8_nw() * 100 + wave8_ch();
+#define NUFFT_LAUNCH_W8(NWV, CHV)                                                              \
+  case NWV * 100 + CHV:                                                                        \
+    e = ensure_lds(spread_2d_w8_wave_kernel<NWV, CHV>, lds_bytes);                             \
+    if (e != hipSuccess) return e;                                                             \
+    spread_2d_w8_wave_kernel<NWV, CHV><<<grid, NWV * 64, lds_bytes, stream>>>(                 \
+        g, sp, horner, c, fw, c_stride, fw_stride, scale);                                     \
+    break;
+        switch (shape) {
+          NUFFT_LAUNCH_W8(4, 64) NUFFT_LAUNCH_W8(4, 32) NUFFT_LAUNCH_W8(8, 64) NUFFT_LAUNCH_W8(8, 32)
+          NUFFT_LAUNCH_W8(2, 64) NUFFT_LAUNCH_W8(2, 32) NUFFT_LAUNCH_W8(16, 32) NUFFT_LAUNCH_W8(4, 16)
+          NUFFT_LAUNCH_W8(8, 16)
+          default: return hipErrorInvalidValue;
+        }
+#undef NUFFT_LAUNCH_W8
         return hipGetLastError();
       }
     }

@@ -707,6 +707,7 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
   g.ncoef = nc;
 
   g.max_sub = p->opts.max_subproblem_size > 0 ? p->opts.max_subproblem_size : 1024;
+  bool auto_sub = p->opts.max_subproblem_size <= 0;
   int method = p->opts.spread_method;
   if (method == NUFFT_HIP_METHOD_AUTO)
     method = wave_method_supported(g, precision) ? NUFFT_HIP_METHOD_TILE_WAVE : NUFFT_HIP_METHOD_TILE_GENERIC;
@@ -717,6 +718,8 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
   }
   p->method = method;
   if (method == NUFFT_HIP_METHOD_TILE_WAVE) g.lstride = wave_lstride(rank);
+  // 2-D wavefront kernels: one subproblem per typical tile measured fastest (r01 sweep)
+  if (method == NUFFT_HIP_METHOD_TILE_WAVE && rank == 2 && auto_sub) g.max_sub = 4096;
   p->lds_bytes = spread_lds_bytes(g, method, precision);
   if (p->lds_bytes > 160 * 1024 || interp_lds_bytes(g, method, precision) > 160 * 1024) {
     // does not fit (e.g. 3-D double at w = 8): fall back to the generic tile path

@@ -330,3 +330,73 @@ def test_linearity_and_adjointness_full_size(tfft):
     sub += torch.einsum('j,ja,jb->ab', c[s:s + 1_000_000].to(torch.complex128), e0, e1)
   got = Ac[512 - 32:512 + 32, 512 - 32:512 + 32].to(torch.complex128)
   assert float(torch.linalg.norm(got - sub) / torch.linalg.norm(sub)) < 1e-6
+
+
+@pytest.mark.parametrize('grid', [[8], [6, 8], [4, 8, 6]])
+@pytest.mark.parametrize('ttype', ['type_1', 'type_2'])
+@pytest.mark.parametrize('fd', ['forward', 'backward'])
+def test_gradients_match_dense_nudft(tfft, grid, ttype, fd):
+  # reference test_nufft gradient checks (nufft_ops_test.py:182-212): d/dsource and
+  # d/dpoints of nufft == those of the dense nudft, with an upstream multiplier
+  import torch
+  rank = len(grid)
+  M = int(np.prod(grid))
+  g = torch.Generator(device='cuda').manual_seed(11)
+  for sb, pb in ([[], []], [[3], [1]], [[2], [2]]):
+    pts = ((torch.rand(pb + [M, rank], generator=g, device='cuda', dtype=torch.float64) * 2 - 1) * np.pi)
+    shp = sb + ([M] if ttype == 'type_1' else grid)
+    src = torch.complex(torch.rand(shp, generator=g, device='cuda', dtype=torch.float64) - .5,
+                        torch.rand(shp, generator=g, device='cuda', dtype=torch.float64) - .5)
+    res = {}
+    for name, fn in (('nufft', lambda s, p: tfft.nufft(s, p, grid_shape=grid if ttype == 'type_1' else None,
+                                                        transform_type=ttype, fft_direction=fd, tol=1e-10)),
+                     ('nudft', lambda s, p: tfft.nudft(s, p, grid_shape=grid if ttype == 'type_1' else None,
+                                                       transform_type=ttype, fft_direction=fd))):
+      s = src.clone().requires_grad_(True)
+      p = pts.clone().requires_grad_(True)
+      out = fn(s, p)
+      mult = torch.complex(torch.linspace(0.5, 1.5, out.numel(), device='cuda', dtype=torch.float64),
+                           torch.linspace(-1.0, 1.0, out.numel(), device='cuda', dtype=torch.float64)).reshape(out.shape)
+      loss = (out * mult).abs().pow(2).sum() + (out * mult).real.sum()
+      gs, gp = torch.autograd.grad(loss, [s, p])
+      res[name] = (out.detach(), gs, gp)
+    assert rel_l2(res['nufft'][0].cpu().numpy(), res['nudft'][0].cpu().numpy()) < 1e-9
+    assert rel_l2(res['nufft'][1].cpu().numpy(), res['nudft'][1].cpu().numpy()) < 1e-8, (sb, pb, 'dsource')
+    assert rel_l2(res['nufft'][2].cpu().numpy(), res['nudft'][2].cpu().numpy()) < 1e-8, (sb, pb, 'dpoints')
+
+
+def test_concurrent_calls_are_reentrant(tfft):
+  # nufft_ops_test.py:623-664 (tf.map_fn with parallel_iterations=4): Compute must be re-entrant
+  import threading
+  import torch
+  rng = np.random.default_rng(13)
+  grid = [24, 24]
+  items = []
+  for _ in range(8):
+    pts = rng.uniform(-np.pi, np.pi, (300, 2)).astype(np.float32)
+    c = (rng.standard_normal(300) + 1j * rng.standard_normal(300)).astype(np.complex64)
+    items.append((pts, c, tfft.nudft(c.astype(np.complex128), pts.astype(np.float64), grid_shape=grid,
+                                      transform_type='type_1', fft_direction='backward')))
+  results = [None] * 8
+  errors = []
+
+  def work(i):
+    try:
+      s = torch.cuda.Stream()
+      with torch.cuda.stream(s):
+        for _ in range(5):
+          out = tfft.nufft(_dev(items[i][1]), _dev(items[i][0]), grid_shape=grid, transform_type='type_1',
+                           fft_direction='backward')
+        s.synchronize()
+        results[i] = out.cpu().numpy()
+    except Exception as e:  # pylint: disable=broad-except
+      errors.append(e)
+
+  threads = [threading.Thread(target=work, args=(i,)) for i in range(8)]
+  for t in threads:
+    t.start()
+  for t in threads:
+    t.join()
+  assert not errors, errors
+  for i in range(8):
+    assert rel_l2(results[i], items[i][2]) < 1e-6
