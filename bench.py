@@ -48,6 +48,21 @@ def algorithmic_spread_bytes(m, nf, rank):
   return m * (4 * rank + 8) + 8 * cells
 
 
+def pmc_traffic(kernel_name, m):
+  """HBM-side bytes per launch of the spread kernel from the PMC passes committed
+  under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs,
+  corrected as MI355X_MICROARCH.md prescribes: 2*FETCH_SIZE + WRITE_SIZE).
+  bench.py cannot run the profiler on itself, so the figure is the one measured
+  offline for the same kernel and point count; None when it does not apply."""
+  try:
+    d = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_spread_traffic.json')))
+    if d.get('points') == m and kernel_name in d.get('kernel', ''):
+      return int(d['traffic_bytes_corrected'])
+  except (OSError, ValueError):
+    pass
+  return None
+
+
 def cpu_baseline(args):
   """Times the CPU oracle on a bounded sample of the same workload."""
   from oracle import oracle
@@ -85,6 +100,8 @@ def main():
   ap.add_argument('--points', type=int, default=M)
   ap.add_argument('--cpu-points', type=int, default=M)
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--dist-backend', default='nccl', help='nccl (= RCCL, default) | gloo (testing)')
+  ap.add_argument('--device', type=int, default=None, help='force a device index (testing)')
   args = ap.parse_args()
 
   world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -92,13 +109,18 @@ def main():
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
   if not torch.cuda.is_available():
     raise SystemExit('bench.py needs a ROCm GPU (the HIP path has no CPU fallback)')
+  if args.device is not None:
+    local_rank = args.device
   torch.cuda.set_device(local_rank)
   dev = torch.device('cuda', local_rank)
   dist = None
   if world > 1:
     import torch.distributed as dist
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    dist.init_process_group('nccl', device_id=dev)   # "nccl" is RCCL on ROCm
+    if args.dist_backend == 'nccl':
+      dist.init_process_group('nccl', device_id=dev)   # "nccl" is RCCL on ROCm
+    else:
+      dist.init_process_group(args.dist_backend)
 
   import tensorflow_nufft as tfft
   m = args.points
@@ -132,7 +154,7 @@ def main():
   elapsed = time.perf_counter() - t0
   stages = plan.get_timing()
   if dist is not None:
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == 'nccl' else 'cpu')
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -168,9 +190,12 @@ def main():
         'roofline': {
             'bound': 'hbm', 'kernel': 'spread_2d_w8_wave_kernel', 'achieved': round(achieved, 1),
             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
-            'traffic': None, 'algorithmic_bytes': algo, 'kernel_ms': round(spread_ms, 4),
+            'traffic': pmc_traffic('spread_2d_w8_wave_kernel', m), 'algorithmic_bytes': algo,
+            'kernel_ms': round(spread_ms, 4),
             'note': 'the kernel is bound by the LDS atomic pipe (2 ds_add_f64 + 2 broadcast reads per '
-                    'point-pass per CU), not by HBM: DESIGN.md section 5',
+                    'point-pass per CU), not by HBM: DESIGN.md section 4. traffic = offline PMC pass '
+                    '(profiles/r01_pmc_traffic.txt); the excess over algorithmic_bytes is the 8-byte strength '
+                    'gather through the sort permutation (one 64-B sector per random point)',
         },
     }
     if world == 1 and not args.no_cpu_baseline:
