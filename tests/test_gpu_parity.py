@@ -5,6 +5,7 @@ per test; `tol` is the transform's requested precision (north star: rel-l2
 import numpy as np
 import pytest
 
+
 from conftest import rel_l2
 
 pytestmark = pytest.mark.gpu
@@ -400,3 +401,57 @@ def test_concurrent_calls_are_reentrant(tfft):
   assert not errors, errors
   for i in range(8):
     assert rel_l2(results[i], items[i][2]) < 1e-6
+
+
+def test_config4_full_size_properties(tfft):
+  # BASELINE config 4 at full size: 3D type 1, 256^3 modes, M = 1e8, tol = 1e-4 (w = 6).
+  # Size-independent checks: adjointness against the type-2 transform on the same
+  # points, and a 12^3 low-frequency block against a dense float64 NUDFT of all points.
+  import torch
+  M = 100_000_000
+  grid = [256, 256, 256]
+  g = torch.Generator(device='cuda').manual_seed(4)
+  pts = (torch.rand((M, 3), generator=g, device='cuda') * 2 - 1) * np.pi
+  c = torch.complex(torch.rand(M, generator=g, device='cuda') - .5, torch.rand(M, generator=g, device='cuda') - .5)
+  Ac = tfft.nufft(c, pts, grid_shape=grid, transform_type='type_1', fft_direction='forward', tol=1e-4)
+  k = torch.arange(-6, 6, device='cuda', dtype=torch.float64)
+  sub = torch.zeros((12, 12, 12), dtype=torch.complex128, device='cuda')
+  for s in range(0, M, 2_000_000):
+    p = pts[s:s + 2_000_000].to(torch.float64)
+    e0 = torch.exp(-1j * p[:, 0:1] * k)
+    e1 = torch.exp(-1j * p[:, 1:2] * k)
+    e2 = torch.exp(-1j * p[:, 2:3] * k)
+    t = torch.einsum('j,ja->ja', c[s:s + 2_000_000].to(torch.complex128), e0)
+    sub += torch.einsum('ja,jb,jc->abc', t, e1, e2)
+  got = Ac[128 - 6:128 + 6, 128 - 6:128 + 6, 128 - 6:128 + 6].to(torch.complex128)
+  err = float(torch.linalg.norm(got - sub) / torch.linalg.norm(sub))
+  assert err < 1e-4, err
+  f = torch.complex(torch.rand(grid, generator=g, device='cuda') - .5, torch.rand(grid, generator=g, device='cuda') - .5)
+  lhs = torch.vdot(f.reshape(-1).to(torch.complex128), Ac.reshape(-1).to(torch.complex128))
+  del Ac, sub
+  AHf = tfft.nufft(f, pts, transform_type='type_2', fft_direction='backward', tol=1e-4)
+  rhs = torch.vdot(AHf.to(torch.complex128), c.to(torch.complex128))
+  assert abs(lhs - rhs) / abs(lhs) < 2e-4, (lhs, rhs)
+  tfft._lib.lib().nufft_hip_op_clear_cache()
+
+
+def test_config5_batched_items(tfft):
+  # BASELINE config 5 flavour: batched 2D type 1, 512^2, M = 1e6 per item; a
+  # GPU's share of per-item points (calls) and of shared points (transforms)
+  import torch
+  from oracle import oracle
+  B, M, grid = 4, 1_000_000, [512, 512]
+  g = torch.Generator(device='cuda').manual_seed(5)
+  pts = (torch.rand((B, M, 2), generator=g, device='cuda') * 2 - 1) * np.pi
+  c = torch.complex(torch.rand((B, M), generator=g, device='cuda') - .5, torch.rand((B, M), generator=g, device='cuda') - .5)
+  out = tfft.nufft(c, pts, grid_shape=grid, transform_type='type_1')
+  assert out.shape == (B, 512, 512)
+  shared = tfft.nufft(c, pts[1], grid_shape=grid, transform_type='type_1')
+  for b in (1, 3):
+    ref = oracle.nufft(c[b].cpu().numpy().astype(np.complex128), pts[b].cpu().numpy(), grid, 'type_1', 'forward',
+                       tol=1e-12, sigma=2.0)
+    assert rel_l2(out[b].cpu().numpy(), ref) < 1e-6
+  ref = oracle.nufft(c[2].cpu().numpy().astype(np.complex128), pts[1].cpu().numpy(), grid, 'type_1', 'forward',
+                     tol=1e-12, sigma=2.0)
+  assert rel_l2(shared[2].cpu().numpy(), ref) < 1e-6
+  assert rel_l2(shared[1].cpu().numpy(), out[1].cpu().numpy()) < 1e-6
