@@ -34,6 +34,31 @@ __device__ __forceinline__ T horner_cell(const T* __restrict__ tab, int nc, int 
   return acc;
 }
 
+// Piecewise-polynomial kernel values for the first 8 stencil cells of up to
+// three dimensions at once. The coefficient loop is OUTER, so each step is one
+// wave-uniform 8-wide row load (s_load_dwordx8) feeding 8 x NDIM independent
+// FMAs; with the cell loop outer the compiler emits one scalar load per FMA and
+// waits for each (measured: 150 us of a 365 us interp kernel). Rows are zero
+// beyond the kernel width, so cells q >= w come out exactly 0.
+template <typename T, int NDIM>
+__device__ __forceinline__ void horner8(const T* __restrict__ tab, int nc, T z0, T z1, T z2,
+                                        T (&k0)[8], T (&k1)[8], T (&k2)[8]) {
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const T t = tab[(nc - 1) * kMaxW + q];
+    k0[q] = t; k1[q] = t; k2[q] = t;
+  }
+  for (int k = nc - 2; k >= 0; --k) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const T t = tab[k * kMaxW + q];
+      k0[q] = fma(k0[q], z0, t);
+      if (NDIM > 1) k1[q] = fma(k1[q], z1, t);
+      if (NDIM > 2) k2[q] = fma(k2[q], z2, t);
+    }
+  }
+}
+
 __device__ __forceinline__ void lds_add(double* p, double v) { unsafeAtomicAdd(p, v); }
 __device__ __forceinline__ void glb_add(float* p, float v) { unsafeAtomicAdd(p, v); }
 __device__ __forceinline__ void glb_add(double* p, double v) { unsafeAtomicAdd(p, v); }
@@ -50,6 +75,49 @@ __device__ __forceinline__ int rec_idx<double>(const SortedPoints<double>& sp, i
                                                const Rec<double>& r) {
   (void)sp; (void)rank; (void)j;
   return r.idx;
+}
+
+// Rows (a1, a2) of an LDS tile are dealt to waves; lanes run along x. No
+// integer division or 64-bit modulo per cell (a generic `i % L0`, `% nf` walk
+// cost ~20 us per 16x16x4 tile, i.e. 10 ms of the 3-D spread at 131072 tiles):
+// the row counters advance incrementally and periodic wrap is one conditional
+// subtract (o + a < 2 nf always, since tile <= nf and w <= nf / 2).
+struct RowWalk {
+  int a1, a2;
+  __device__ __forceinline__ RowWalk(int first, int L1) : a1(first), a2(0) {
+    while (a1 >= L1) { a1 -= L1; ++a2; }
+  }
+  __device__ __forceinline__ void advance(int step, int L1) {
+    a1 += step;
+    while (a1 >= L1) { a1 -= L1; ++a2; }
+  }
+};
+__device__ __forceinline__ int wrap1(int v, int n) { return v >= n ? v - n : v; }
+
+// Adds a finished LDS tile (planar double re/im) to the periodic fine grid.
+// Consecutive lanes take (re, im) of consecutive cells of one row, so a
+// global_atomic_add_f32 wave-instruction covers contiguous bytes.
+template <typename T, int RANK>
+__device__ __forceinline__ void tile_to_grid(const Geom& g, const double* plane_re, const double* plane_im,
+                                             int LS, int PS, int tb, T* __restrict__ out, int wave,
+                                             int nwaves, int lane) {
+  const int L0 = g.ldim[0], L1 = g.ldim[1];
+  const int L2 = RANK > 2 ? g.ldim[2] : 1;
+  const int t0 = tb % g.ntile[0];
+  const int t1 = (tb / g.ntile[0]) % g.ntile[1];
+  const int t2 = tb / (g.ntile[0] * g.ntile[1]);
+  const int o0 = t0 * g.tile[0], o1 = t1 * g.tile[1], o2 = t2 * g.tile[2];
+  for (RowWalk r(wave, L1); r.a2 < L2; r.advance(nwaves, L1)) {
+    const int g1 = wrap1(o1 + r.a1, g.nf[1]);
+    const int g2 = RANK > 2 ? wrap1(o2 + r.a2, g.nf[2]) : 0;
+    const int64_t rowbase = (int64_t)g.nf[0] * (g1 + (int64_t)g.nf[1] * g2);
+    const int lrow = r.a2 * PS + r.a1 * LS;
+    for (int e = lane; e < 2 * L0; e += 64) {
+      const int a0 = e >> 1, comp = e & 1;
+      const T v = (T)(comp ? plane_im : plane_re)[lrow + a0];
+      if (v != (T)0) glb_add(&out[2 * (rowbase + wrap1(o0 + a0, g.nf[0])) + comp], v);
+    }
+  }
 }
 
 // Which subproblem does workgroup `s` own? sub_start is the exclusive scan of
@@ -550,6 +618,9 @@ __device__ __forceinline__ double bcast_lane(double v, int lane) {
 template <typename T> struct Pair;
 template <> struct Pair<float> { using type = float2; };
 template <> struct Pair<double> { using type = double2; };
+template <typename T> struct Quad;
+template <> struct Quad<float> { using type = float4; };
+template <> struct Quad<double> { using type = double4; };
 
 template <typename T, int RANK, int NW, int CH>
 __global__ __launch_bounds__(NW * 64) void spread_wave_kernel(
@@ -599,23 +670,11 @@ __global__ __launch_bounds__(NW * 64) void spread_wave_kernel(
         const int idx = rec_idx<T>(sp, RANK, j, rec);
         const T re = cc[2 * (int64_t)idx] * scale, im = cc[2 * (int64_t)idx + 1] * scale;
         off = (int)(loc & 1023) + (int)((loc >> 10) & 1023) * LS + (RANK > 2 ? (int)((loc >> 20) & 1023) * PS : 0);
-        const T zl = RANK == 2 ? rec.z1 : rec.z2;
+        T kl[8];
+        if (RANK == 2) horner8<T, 2>(horner, nc, rec.z0, rec.z1, (T)0, kx, kl, k2);
+        else horner8<T, 3>(horner, nc, rec.z0, rec.z1, rec.z2, kx, k2, kl);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          T a0 = (T)0, a1 = (T)0, al = (T)0;
-          if (q < w) {
-            a0 = horner[(nc - 1) * kMaxW + q];
-            a1 = a0;
-            al = a0;
-            for (int k = nc - 2; k >= 0; --k) {
-              const T t = horner[k * kMaxW + q];
-              a0 = fma(a0, rec.z0, t);
-              if (RANK > 2) a1 = fma(a1, rec.z1, t);
-              al = fma(al, zl, t);
-            }
-          }
-          kx[q] = a0; k2[q] = a1; klr[q] = al * re; kli[q] = al * im;
-        }
+        for (int q = 0; q < 8; ++q) { klr[q] = kl[q] * re; kli[q] = kl[q] * im; }
       } else {
 #pragma unroll
         for (int q = 0; q < 8; ++q) { kx[q] = (T)0; k2[q] = (T)0; }
@@ -677,24 +736,8 @@ __global__ __launch_bounds__(NW * 64) void spread_wave_kernel(
   }
   __syncthreads();
 
-  const int t0 = tb % g.ntile[0];
-  const int t1 = (tb / g.ntile[0]) % g.ntile[1];
-  const int t2 = tb / (g.ntile[0] * g.ntile[1]);
-  const int o0 = t0 * g.tile[0], o1 = t1 * g.tile[1], o2 = t2 * g.tile[2];
-  T* out = fw + 2 * (int64_t)blockIdx.y * fw_stride;
-  const int ncomp = 2 * L0 * L1 * L2;   // (re, im) of consecutive cells on consecutive lanes
-  for (int i = tid; i < ncomp; i += NW * 64) {
-    const int comp = i & 1;
-    const int cellid = i >> 1;
-    const int a0 = cellid % L0, a1 = (cellid / L0) % L1, a2 = cellid / (L0 * L1);
-    const T v = (T)(comp ? plane_im : plane_re)[a2 * PS + a1 * LS + a0];
-    if (v != (T)0) {
-      const int64_t g0 = (o0 + a0) % g.nf[0];
-      const int64_t g1 = (o1 + a1) % g.nf[1];
-      const int64_t g2 = RANK > 2 ? (o2 + a2) % g.nf[2] : 0;
-      glb_add(&out[2 * (g0 + (int64_t)g.nf[0] * (g1 + (int64_t)g.nf[1] * g2)) + comp], v);
-    }
-  }
+  (void)L0;
+  tile_to_grid<T, RANK>(g, plane_re, plane_im, LS, PS, tb, fw + 2 * (int64_t)blockIdx.y * fw_stride, wave, NW, lane);
 }
 
 // ------------------------- spread: 3-D wavefront path with compile-time width
@@ -750,18 +793,10 @@ __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
         const int idx = rec_idx<T>(sp, 3, j, rec);
         const T re = cc[2 * (int64_t)idx] * scale, im = cc[2 * (int64_t)idx + 1] * scale;
         off = (int)(loc & 1023) + (int)((loc >> 10) & 1023) * LS + (int)((loc >> 20) & 1023) * PS;
+        T h0[8], h1[8], h2[8];
+        horner8<T, 3>(horner, nc, rec.z0, rec.z1, rec.z2, h0, h1, h2);
 #pragma unroll
-        for (int q = 0; q < W; ++q) {
-          T a0 = horner[(nc - 1) * kMaxW + q];
-          T a1 = a0, a2 = a0;
-          for (int k = nc - 2; k >= 0; --k) {
-            const T t = horner[k * kMaxW + q];
-            a0 = fma(a0, rec.z0, t);
-            a1 = fma(a1, rec.z1, t);
-            a2 = fma(a2, rec.z2, t);
-          }
-          kx[q] = a0; ky[q] = a1; klr[q] = a2 * re; kli[q] = a2 * im;
-        }
+        for (int q = 0; q < W; ++q) { kx[q] = h0[q]; ky[q] = h1[q]; klr[q] = h2[q] * re; kli[q] = h2[q] * im; }
       }
 #pragma unroll
       for (int q = 0; q < W; ++q) {
@@ -798,24 +833,8 @@ __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
   }
   __syncthreads();
 
-  const int t0 = tb % g.ntile[0];
-  const int t1 = (tb / g.ntile[0]) % g.ntile[1];
-  const int t2 = tb / (g.ntile[0] * g.ntile[1]);
-  const int o0 = t0 * g.tile[0], o1 = t1 * g.tile[1], o2 = t2 * g.tile[2];
-  T* out = fw + 2 * (int64_t)blockIdx.y * fw_stride;
-  const int ncomp = 2 * L0 * L1 * L2;
-  for (int i = tid; i < ncomp; i += NW * 64) {
-    const int comp = i & 1;
-    const int cellid = i >> 1;
-    const int a0 = cellid % L0, a1 = (cellid / L0) % L1, a2 = cellid / (L0 * L1);
-    const T v = (T)(comp ? plane_im : plane_re)[a2 * PS + a1 * LS + a0];
-    if (v != (T)0) {
-      const int64_t g0 = (o0 + a0) % g.nf[0];
-      const int64_t g1 = (o1 + a1) % g.nf[1];
-      const int64_t g2 = (o2 + a2) % g.nf[2];
-      glb_add(&out[2 * (g0 + (int64_t)g.nf[0] * (g1 + (int64_t)g.nf[1] * g2)) + comp], v);
-    }
-  }
+  (void)L0; (void)L2;
+  tile_to_grid<T, 3>(g, plane_re, plane_im, LS, PS, tb, fw + 2 * (int64_t)blockIdx.y * fw_stride, wave, NW, lane);
 }
 
 // ------------------- interp: LDS-tiled path, any w <= 8, rank 2 or 3 (type 2)
@@ -866,16 +885,18 @@ __global__ __launch_bounds__(256) void interp_wave_kernel(
   const int t2 = tb / (g.ntile[0] * g.ntile[1]);
   const int o0 = t0 * g.tile[0], o1 = t1 * g.tile[1], o2 = t2 * g.tile[2];
   const T2* in = reinterpret_cast<const T2*>(fw) + (int64_t)blockIdx.y * fw_stride;
-  for (int i = tid; i < ncell; i += 256) {
-    const int a0 = i % LS, a1 = (i / LS) % L1, a2 = i / PS;
-    T2 v; v.x = (T)0; v.y = (T)0;
-    if (a0 < L0) {
-      const int64_t g0 = (o0 + a0) % g.nf[0];
-      const int64_t g1 = (o1 + a1) % g.nf[1];
-      const int64_t g2 = RANK > 2 ? (o2 + a2) % g.nf[2] : 0;
-      v = in[g0 + (int64_t)g.nf[0] * (g1 + (int64_t)g.nf[1] * g2)];
+  (void)ncell;
+  for (RowWalk r(wave, L1); r.a2 < L2; r.advance(4, L1)) {
+    const int g1 = wrap1(o1 + r.a1, g.nf[1]);
+    const int g2 = RANK > 2 ? wrap1(o2 + r.a2, g.nf[2]) : 0;
+    const int64_t rowbase = (int64_t)g.nf[0] * (g1 + (int64_t)g.nf[1] * g2);
+    T2* lrow = tile + r.a2 * PS + r.a1 * LS;
+    // pad columns [L0, LS) are read by lanes dx >= w (their weight is 0): keep them finite
+    for (int a0 = lane; a0 < LS; a0 += 64) {
+      T2 v; v.x = (T)0; v.y = (T)0;
+      if (a0 < L0) v = in[rowbase + wrap1(o0 + a0, g.nf[0])];
+      lrow[a0] = v;
     }
-    tile[i] = v;
   }
   __syncthreads();
 
@@ -898,22 +919,8 @@ __global__ __launch_bounds__(256) void interp_wave_kernel(
         const uint32_t loc = rec.loc;
         idx = rec_idx<T>(sp, RANK, j, rec);
         off = (int)(loc & 1023) + (int)((loc >> 10) & 1023) * LS + (RANK > 2 ? (int)((loc >> 20) & 1023) * PS : 0);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          T a0 = (T)0, a1 = (T)0, a2 = (T)0;
-          if (q < w) {
-            a0 = horner[(nc - 1) * kMaxW + q];
-            a1 = a0;
-            a2 = a0;
-            for (int k = nc - 2; k >= 0; --k) {
-              const T t = horner[k * kMaxW + q];
-              a0 = fma(a0, rec.z0, t);
-              a1 = fma(a1, rec.z1, t);
-              if (RANK > 2) a2 = fma(a2, rec.z2, t);
-            }
-          }
-          kx[q] = a0; ky[q] = a1; kz[q] = a2;
-        }
+        if (RANK == 2) horner8<T, 2>(horner, nc, rec.z0, rec.z1, (T)0, kx, ky, kz);
+        else horner8<T, 3>(horner, nc, rec.z0, rec.z1, rec.z2, kx, ky, kz);
       } else {
 #pragma unroll
         for (int q = 0; q < 8; ++q) { kx[q] = (T)0; ky[q] = (T)0; kz[q] = (T)0; }
@@ -932,16 +939,24 @@ __global__ __launch_bounds__(256) void interp_wave_kernel(
       const int q = q0 + pg;                 // this lane group's point
       const int2 m = meta[q];
       const T kxv = kxs[q * 8 + dx];
+      // this lane group's ky[0..7]: two wide LDS reads instead of eight scalar ones
+      T kyr[8];
+      {
+        using T4 = typename Quad<T>::type;
+        const T4 lo = *reinterpret_cast<const T4*>(kys + q * 8);
+        const T4 hi = *reinterpret_cast<const T4*>(kys + q * 8 + 4);
+        kyr[0] = lo.x; kyr[1] = lo.y; kyr[2] = lo.z; kyr[3] = lo.w;
+        kyr[4] = hi.x; kyr[5] = hi.y; kyr[6] = hi.z; kyr[7] = hi.w;
+      }
       T sre = (T)0, sim = (T)0;
       const T2* tp = tile + m.x + dx;
       if (RANK == 2) {
 #pragma unroll
         for (int dy = 0; dy < 8; ++dy) {
           if (dy < w) {
-            const T kyv = kys[q * 8 + dy];
             const T2 v = tp[dy * LS];
-            sre = fma(kyv, v.x, sre);
-            sim = fma(kyv, v.y, sim);
+            sre = fma(kyr[dy], v.x, sre);
+            sim = fma(kyr[dy], v.y, sim);
           }
         }
       } else {
@@ -951,10 +966,9 @@ __global__ __launch_bounds__(256) void interp_wave_kernel(
 #pragma unroll
           for (int dy = 0; dy < 8; ++dy) {
             if (dy < w) {
-              const T kyv = kys[q * 8 + dy];
               const T2 v = tp[dz * PS + dy * LS];
-              lre = fma(kyv, v.x, lre);
-              lim = fma(kyv, v.y, lim);
+              lre = fma(kyr[dy], v.x, lre);
+              lim = fma(kyr[dy], v.y, lim);
             }
           }
           sre = fma(kzv, lre, sre);
