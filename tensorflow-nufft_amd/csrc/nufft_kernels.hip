@@ -127,7 +127,24 @@ __device__ __forceinline__ bool locate_subproblem(const Geom& g, const int32_t* 
                                                   int* tile, int* p0, int* p1) {
   const int nt = g.ntiles;
   if (s >= sub_start[nt]) return false;
-  int lo = 0, hi = nt;
+  // Invariant: sub_start[lo] <= s < sub_start[hi]. Most tiles own exactly one
+  // subproblem, so the answer is near s: gallop outwards from that guess
+  // before bisecting (2-4 dependent loads instead of log2(ntiles) = 12-18).
+  int lo, hi;
+  const int guess = s < nt ? s : nt - 1;
+  if (sub_start[guess] <= s) {
+    lo = guess;
+    int step = 1;
+    hi = lo + 1;
+    while (hi < nt && sub_start[hi] <= s) { lo = hi; step <<= 1; hi = lo + step; }
+    if (hi > nt) hi = nt;
+  } else {
+    hi = guess;
+    int step = 1;
+    lo = hi - 1;
+    while (lo > 0 && sub_start[lo] > s) { hi = lo; step <<= 1; lo = hi - step; }
+    if (lo < 0) lo = 0;
+  }
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
     if (sub_start[mid] <= s) lo = mid; else hi = mid;
@@ -777,7 +794,11 @@ __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
   const int cell = dy * LS + dx;
   const T* cc = c + 2 * (int64_t)blockIdx.y * c_stride;
 
-  for (int base = p0 + wave * CH; base < p1; base += NW * CH) {
+  // each wave takes an equal contiguous share of the subproblem's points
+  const int share = (p1 - p0 + NW - 1) / NW;
+  const int wbeg = p0 + wave * share;
+  const int wend = (wbeg + share < p1) ? wbeg + share : p1;
+  for (int base = wbeg; base < wend; base += CH) {
     const int j = base + lane;
     int off = 0;
     T klr[W], kli[W];
@@ -787,7 +808,7 @@ __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
       T kx[W], ky[W];
 #pragma unroll
       for (int q = 0; q < W; ++q) { kx[q] = (T)0; ky[q] = (T)0; }
-      if (j < p1) {
+      if (j < wend) {
         const Rec<T> rec = sp.rec[j];
         const uint32_t loc = rec.loc;
         const int idx = rec_idx<T>(sp, 3, j, rec);
@@ -804,7 +825,7 @@ __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
         kys[lane * 8 + q] = ky[q];
       }
     }
-    int npts = p1 - base;
+    int npts = wend - base;
     if (npts > CH) npts = CH;
     // z factor x strength: same for every lane of a pass -> v_readlane from the
     // owning lane's registers (all lanes execute the readlanes; only the w x w
@@ -1241,7 +1262,7 @@ bool wave_method_supported(const Geom& g, int precision) {
   (void)precision;
   if (g.w > 8) return false;
   if (g.rank == 2) return g.tile[0] == 32 && g.tile[1] == 32;
-  if (g.rank == 3) return g.tile[0] == 16 && g.tile[1] == 16 && g.tile[2] == 4;
+  if (g.rank == 3) return g.tile[0] == 16 && g.tile[1] == 16 && (g.tile[2] == 4 || g.tile[2] == 8 || g.tile[2] == 2);
   return false;
 }
 int wave_lstride(int rank) { return rank == 2 ? 40 : 24; }

@@ -32,11 +32,12 @@ def run(name, ttype, grid, M, tol, ntransf=1, per_item_points=False, steps=10, *
   print('    stage us/call:', ' '.join(f'{k}={v[0]/max(v[1],1)*1e3:.0f}(x{v[1]//steps})' for k, v in tm.items() if v[1]))
   plan.close(); del pts, srcs; torch.cuda.empty_cache()
 
+S = int(os.environ.get('BENCH_S', '0'))
 which = sys.argv[1:] or ['2', '3', '4', '5', '5s']
 if '2' in which: run('cfg2 2D t1 1024^2 M=1e7', 'type_1', [1024, 1024], 10_000_000, 1e-6)
 if '3' in which: run('cfg3 2D t2 1024^2 M=1e7', 'type_2', [1024, 1024], 10_000_000, 1e-6)
-if '4' in which: run('cfg4 3D t1 256^3 M=1e8 tol1e-4', 'type_1', [256, 256, 256], 100_000_000, 1e-4, steps=3)
-if '4s' in which: run('cfg4-small 3D t1 256^3 M=1e7 tol1e-4', 'type_1', [256, 256, 256], 10_000_000, 1e-4, steps=3)
+if '4' in which: run('cfg4 3D t1 256^3 M=1e8 tol1e-4', 'type_1', [256, 256, 256], 100_000_000, 1e-4, steps=3, max_subproblem_size=S)
+if '4s' in which: run('cfg4-small 3D t1 256^3 M=1e7 tol1e-4', 'type_1', [256, 256, 256], 10_000_000, 1e-4, steps=3, max_subproblem_size=S)
 if '5' in which: run('cfg5 per-item pts: 32 x (2D t1 512^2 M=1e6)', 'type_1', [512, 512], 1_000_000, 1e-6, ntransf=32, per_item_points=True, steps=3)
 if '5s' in which: run('cfg5 shared pts: 32 transforms (2D t1 512^2 M=1e6)', 'type_1', [512, 512], 1_000_000, 1e-6, ntransf=32, steps=3)
 if '1' in which: run('cfg1 1D t1 N=4096 M=1e5 f64', 'type_1', [4096], 100_000, 1e-6, dtype=torch.complex128)
