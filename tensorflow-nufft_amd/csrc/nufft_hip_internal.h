@@ -25,6 +25,7 @@ struct Geom {
   int ncoef;        // polynomial terms
   int nf[3];        // fine grid, x fastest
   int tile[3];      // tile size in fine cells
+  int tile_shift[3];  // log2(tile) when tile is a power of two, else -1
   int ntile[3];     // tiles per dimension
   int ldim[3];      // LDS tile extent = tile + w - 1
   int lstride;      // padded LDS row length (>= ldim[0])

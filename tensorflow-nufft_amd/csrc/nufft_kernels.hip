@@ -186,15 +186,32 @@ __device__ __forceinline__ int fold_point(const Geom& g, const PointsIn& in, int
       s = fmod(x + kPiD, 2.0 * kPiD);
       if (s < 0.0) s += 2.0 * kPiD;
     }
-    double xs = s * ((double)g.nf[d] * (1.0 / (2.0 * kPiD)));
+    const int nf = g.nf[d];
+    double xs = s * ((double)nf * (1.0 / (2.0 * kPiD)));
     if (!(xs > -1.0e15 && xs < 1.0e15)) xs = 0.0;   // NaN / inf / absurd: keep memory safe
     const double i0f = ceil(xs - 0.5 * (double)g.w);
     double zz = 2.0 * (i0f - xs) + (double)(g.w - 1);
     zz = fmin(1.0, fmax(-1.0, zz));
-    long long i0 = (long long)i0f % g.nf[d];
-    if (i0 < 0) i0 += g.nf[d];
-    const int t = (int)i0 / g.tile[d];
-    const int l = (int)i0 - t * g.tile[d];
+    // periodic wrap of the stencil start: in-range points need at most one
+    // add/subtract; the 64-bit modulo is kept for out-of-range garbage only
+    int i0;
+    if (i0f >= -(double)nf && i0f < 2.0 * (double)nf) {
+      i0 = (int)i0f;
+      if (i0 < 0) i0 += nf;
+      else if (i0 >= nf) i0 -= nf;
+    } else {
+      long long m = (long long)i0f % nf;
+      if (m < 0) m += nf;
+      i0 = (int)m;
+    }
+    int t, l;
+    if (g.tile_shift[d] >= 0) {           // power-of-two tile: shift / mask
+      t = i0 >> g.tile_shift[d];
+      l = i0 & (g.tile[d] - 1);
+    } else {
+      t = i0 / g.tile[d];
+      l = i0 - t * g.tile[d];
+    }
     tc[d] = t;
     loc |= (uint32_t)l << (10 * d);
     zz3[d] = (T)zz;

@@ -681,6 +681,11 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
       g.ntiles *= g.ntile[d];
     }
     g.lstride = g.ldim[0];
+    for (int d = 0; d < 3; ++d) {
+      g.tile_shift[d] = -1;
+      for (int b = 0; b <= 10; ++b)
+        if (g.tile[d] == (1 << b)) g.tile_shift[d] = b;
+    }
     if (spread_lds_bytes(g, NUFFT_HIP_METHOD_TILE_GENERIC, precision) <= lds_limit) break;
     int big = 0;
     for (int d = 1; d < rank; ++d)
