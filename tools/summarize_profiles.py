@@ -3,7 +3,7 @@ profiles/ (kernel stats + PMC traffic of the spread kernel)."""
 import collections, csv, glob, json, re, sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
-stats = glob.glob('gpurun_out/prof_bench2/runc/*_kernel_stats.csv')[0]
+stats = sorted(glob.glob('gpurun_out/prof_bench2/runc/*_kernel_stats.csv'), key=lambda f: __import__('os').path.getmtime(f))[-1]
 rows = list(csv.DictReader(open(stats)))
 lines = [f'# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline   (MI355X, {tag})',
          '# kernel | calls | avg_us | total_ms | pct']
@@ -13,7 +13,7 @@ open(f'profiles/{tag}_bench_kernel_stats.txt', 'w').write('\n'.join(lines) + '\n
 print('\n'.join(lines[:9]))
 
 def counters(d):
-  f = glob.glob(f'gpurun_out/{d}/runc/*_counter_collection.csv')[0]
+  f = sorted(glob.glob(f'gpurun_out/{d}/runc/*_counter_collection.csv'), key=lambda f: __import__('os').path.getmtime(f))[-1]
   agg = collections.defaultdict(lambda: collections.defaultdict(list))
   for r in csv.DictReader(open(f)):
     name = re.split(r'[(<]', r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', ''))[0]
