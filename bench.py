@@ -73,22 +73,28 @@ def cpu_baseline(args):
   c = (rng.uniform(-.5, .5, m) + 1j * rng.uniform(-.5, .5, m)).astype(np.complex64)
   # reference CPU rule for this config: sigma = 1.25, w = 10,
   # float arithmetic, own piecewise-polynomial kernel (kerevalmeth 1), all cores
-  best = float('inf')
-  total = 0.0
-  runs = 0
-  while runs < 3 and total < 30.0:
-    t0 = time.perf_counter()
-    oracle.nufft(c, pts, GRID, 'type_1', 'forward', tol=TOL, kerevalmeth=1, nthreads=cores)
-    dt = time.perf_counter() - t0
-    best = min(best, dt)
-    total += dt
-    runs += 1
+  # OpenMP thread counts to try: all hardware threads, the physical cores of a
+  # 2-way SMT part, and a NUMA-friendly 64 / 32; the best one is reported.
+  cand = sorted({cores, max(1, cores // 2), min(cores, 64), min(cores, 32)}, reverse=True)
+  best, best_threads, total, runs = float('inf'), cores, 0.0, 0
+  for nt in cand:
+    for _ in range(2):
+      if total > 30.0:
+        break
+      t0 = time.perf_counter()
+      oracle.nufft(c, pts, GRID, 'type_1', 'forward', tol=TOL, kerevalmeth=1, nthreads=nt)
+      dt = time.perf_counter() - t0
+      total += dt
+      runs += 1
+      if dt < best:
+        best, best_threads = dt, nt
+  cores = best_threads
   sigma, w, _, nf = oracle.query(2, GRID, float(np.float32(TOL)), 'f32')
   return {
       'value': round(m / best / 1e6, 3), 'unit': 'Mpts/s', 'cores': cores, 'kind': 'port',
       'sample': f'full type-1 transform (sort+spread+FFT+deconvolve) of {m} of the {M} points on the '
                 f'same 1024x1024 grid, reference CPU rule sigma={sigma} w={w} fine grid {nf[0]}x{nf[1]}, '
-                f'fp32, {cores} OpenMP threads, best of {runs} runs, {best:.2f} s each',
+                f'fp32, best of {runs} runs over thread counts {cand}: {cores} OpenMP threads, {best:.2f} s',
   }
 
 

@@ -80,7 +80,8 @@ struct SortWork {
   int32_t* bad_count;
 };
 
-constexpr int kMaxLdsTiles = 16384;   // 64 KiB of LDS counters
+constexpr int kMaxLdsTiles = 16384;     // 64 KiB of 32-bit LDS counters
+constexpr int kMaxLds16Tiles = 73728;   // 144 KiB of packed 16-bit LDS counters
 
 enum Stage {
   STAGE_SORT_COUNT = 0, STAGE_SORT_SCAN, STAGE_SORT_SCATTER, STAGE_ZERO, STAGE_SPREAD,
@@ -97,6 +98,8 @@ struct StageHook {
 
 // Launchers (nufft_kernels.hip). All enqueue on `stream` and return hipGetLastError().
 int sort_blocks(const Geom& g, int64_t M, int64_t* per_block);
+int sort_blocks16(int64_t M, int64_t* per_block);
+int sort_mode(const Geom& g, int64_t M);
 bool sort_uses_lds(const Geom& g);
 template <typename T>
 hipError_t launch_sort(const Geom& g, const PointsIn& in, const SortWork& w, const SortedOut<T>& out,

@@ -63,19 +63,34 @@ __device__ __forceinline__ void lds_add(double* p, double v) { unsafeAtomicAdd(p
 __device__ __forceinline__ void glb_add(float* p, float v) { unsafeAtomicAdd(p, v); }
 __device__ __forceinline__ void glb_add(double* p, double v) { unsafeAtomicAdd(p, v); }
 
+// Decoded view of a sorted record.
 template <typename T>
-__device__ __forceinline__ int rec_idx(const SortedPoints<T>& sp, int rank, int j, const Rec<T>& r);
+struct PointView { uint32_t loc; T z0, z1, z2; int idx; };
+
+template <typename T, int RANK>
+__device__ __forceinline__ PointView<T> unpack_rec(const Rec<T>& r);
 template <>
-__device__ __forceinline__ int rec_idx<float>(const SortedPoints<float>& sp, int rank, int j,
-                                              const Rec<float>& r) {
-  return rank < 3 ? r.idx : sp.idx3[j];
+__device__ __forceinline__ PointView<float> unpack_rec<float, 1>(const Rec<float>& r) {
+  return {r.loc, r.z0, r.z1, 0.f, r.idx};
 }
 template <>
-__device__ __forceinline__ int rec_idx<double>(const SortedPoints<double>& sp, int rank, int j,
-                                               const Rec<double>& r) {
-  (void)sp; (void)rank; (void)j;
-  return r.idx;
+__device__ __forceinline__ PointView<float> unpack_rec<float, 2>(const Rec<float>& r) {
+  return {r.loc, r.z0, r.z1, 0.f, r.idx};
 }
+template <>
+__device__ __forceinline__ PointView<float> unpack_rec<float, 3>(const Rec<float>& r) {
+  const uint32_t w0 = r.loc, w1 = __float_as_uint(r.z0), w2 = __float_as_uint(r.z1);
+  PointView<float> v;
+  v.loc = (w0 >> 28) | ((w1 >> 28) << 10) | ((w2 >> 28) << 20);
+  v.z0 = (float)(w0 & 0x0fffffffu) * 7.450580596923828e-09f - 1.0f;   // 2^-27
+  v.z1 = (float)(w1 & 0x0fffffffu) * 7.450580596923828e-09f - 1.0f;
+  v.z2 = (float)(w2 & 0x0fffffffu) * 7.450580596923828e-09f - 1.0f;
+  v.idx = r.idx;
+  return v;
+}
+template <> __device__ __forceinline__ PointView<double> unpack_rec<double, 1>(const Rec<double>& r) { return {r.loc, r.z0, r.z1, r.z2, r.idx}; }
+template <> __device__ __forceinline__ PointView<double> unpack_rec<double, 2>(const Rec<double>& r) { return {r.loc, r.z0, r.z1, r.z2, r.idx}; }
+template <> __device__ __forceinline__ PointView<double> unpack_rec<double, 3>(const Rec<double>& r) { return {r.loc, r.z0, r.z1, r.z2, r.idx}; }
 
 // Rows (a1, a2) of an LDS tile are dealt to waves; lanes run along x. No
 // integer division or 64-bit modulo per cell (a generic `i % L0`, `% nf` walk
@@ -229,7 +244,29 @@ __device__ __forceinline__ void store_record(const SortedOut<T>& out, int rank, 
 template <>
 __device__ __forceinline__ void store_record<float>(const SortedOut<float>& out, int rank, int pos,
                                                     Rec<float> r, int32_t idx) {
-  if (rank < 3) r.idx = idx; else out.idx3[pos] = idx;
+  if (rank < 3) {
+    r.idx = idx;
+  } else {
+    // 3-D float: 28-bit fixed-point Horner arguments + 4-bit tile-local starts per
+    // dimension + the point index, so the record stays ONE 16-byte store (a
+    // separate 4-byte index array doubled the scattered write transactions)
+    const uint32_t l0 = r.loc & 1023u, l1 = (r.loc >> 10) & 1023u, l2 = (r.loc >> 20) & 1023u;
+    uint32_t w[3];
+    const float z[3] = {r.z0, r.z1, r.z2};
+    const uint32_t l[3] = {l0, l1, l2};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      float q = (z[d] + 1.0f) * 134217728.0f;   // 2^27
+      q = fminf(fmaxf(q, 0.0f), 268435455.0f);
+      w[d] = (uint32_t)__float2uint_rn(q);
+      if (w[d] > 268435455u) w[d] = 268435455u;
+      w[d] |= l[d] << 28;
+    }
+    r.loc = w[0];
+    r.z0 = __uint_as_float(w[1]);
+    r.z1 = __uint_as_float(w[2]);
+    r.idx = idx;
+  }
   out.rec[pos] = r;   // one 16-byte store
 }
 template <>
@@ -318,6 +355,88 @@ __global__ __launch_bounds__(kSortBlock) void scatter_lds_kernel(Geom g, PointsI
     const int pos = atomicAdd(&cur[tile], 1);
     store_record<T>(out, g.rank, pos, r, (int32_t)i);
   }
+}
+
+// --- path A16 (16384 < ntiles <= kMaxLds16Tiles): same scheme with 16-bit
+// counters packed two per LDS word, so that 65536 tiles (3-D 512^3 at 16x16x8)
+// fit in 128 KiB of LDS. A workgroup never takes more than 65535 points, so a
+// packed counter cannot carry into its neighbour. The per-(workgroup, tile)
+// prefix is 32-bit and lives in HBM; the scatter keeps only RELATIVE 16-bit
+// cursors in LDS and adds tile_start + prefix read from L2.
+template <typename T>
+__global__ __launch_bounds__(kSortBlock) void hist16_lds_kernel(Geom g, PointsIn in, int64_t per_block,
+                                                                uint32_t* __restrict__ hist16,
+                                                                int32_t* __restrict__ tile_of,
+                                                                uint16_t* __restrict__ rank16,
+                                                                int32_t* __restrict__ bad_count) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned* h2 = reinterpret_cast<unsigned*>(smem_raw);
+  const int nw = (g.ntiles + 1) >> 1;
+  for (int t = threadIdx.x; t < nw; t += kSortBlock) h2[t] = 0u;
+  __syncthreads();
+  const int64_t lo = (int64_t)blockIdx.x * per_block;
+  const int64_t hi = (lo + per_block < in.M) ? lo + per_block : in.M;
+  bool bad = false;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += kSortBlock) {
+    Rec<T> r;
+    const int tile = fold_point<T>(g, in, i, &r, &bad);
+    const int sh = 16 * (tile & 1);
+    const unsigned old = atomicAdd(&h2[tile >> 1], 1u << sh);
+    tile_of[i] = tile;
+    rank16[i] = (uint16_t)((old >> sh) & 0xffffu);   // rank inside (workgroup, tile)
+  }
+  if (bad && in.check_range) atomicAdd(bad_count, 1);
+  __syncthreads();
+  uint32_t* out = hist16 + (int64_t)blockIdx.x * nw;
+  for (int t = threadIdx.x; t < nw; t += kSortBlock) out[t] = h2[t];
+}
+
+// hist16[b][t] (uint16) -> pref[b][t] (int32 exclusive prefix over b), totals -> tile_count
+__global__ __launch_bounds__(1024) void colscan16_kernel(int nt, int nblk, const uint16_t* __restrict__ hist16,
+                                                         int32_t* __restrict__ pref,
+                                                         int32_t* __restrict__ tile_count) {
+  __shared__ int part[16][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int t = blockIdx.x * 64 + tx;
+  const int nt2 = ((nt + 1) >> 1) << 1;   // row pitch of hist16 in uint16
+  const int rpg = (nblk + 15) / 16;
+  const int r0 = ty * rpg;
+  const int r1 = (r0 + rpg < nblk) ? r0 + rpg : nblk;
+  int sum = 0;
+  if (t < nt)
+    for (int r = r0; r < r1; ++r) sum += hist16[(int64_t)r * nt2 + t];
+  part[ty][tx] = sum;
+  __syncthreads();
+  int run = 0;
+  for (int k = 0; k < ty; ++k) run += part[k][tx];
+  if (t < nt) {
+    for (int r = r0; r < r1; ++r) {
+      const int v = hist16[(int64_t)r * nt2 + t];
+      pref[(int64_t)r * nt + t] = run;
+      run += v;
+    }
+    if (ty == 15) tile_count[t] = run;
+  }
+}
+
+// Streaming scatter for path A16: position = tile_start + prefix of the point's
+// workgroup + its 16-bit rank; no LDS, full occupancy.
+template <typename T>
+__global__ __launch_bounds__(256) void scatter_ranked_kernel(Geom g, PointsIn in, int64_t per_block,
+                                                             const int32_t* __restrict__ tile_of,
+                                                             const uint16_t* __restrict__ rank16,
+                                                             const int32_t* __restrict__ pref,
+                                                             const int32_t* __restrict__ tile_start,
+                                                             SortedOut<T> out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= in.M) return;
+  Rec<T> r;
+  bool bad = false;
+  fold_point<T>(g, in, i, &r, &bad);
+  const int tile = tile_of[i];
+  const int64_t blk = i / per_block;
+  const int pos = tile_start[tile] + pref[blk * g.ntiles + tile] + (int)rank16[i];
+  store_record<T>(out, g.rank, pos, r, (int32_t)i);
 }
 
 // --- path B (many tiles): per-point rank from a global counter (the
@@ -427,9 +546,9 @@ __global__ __launch_bounds__(kBlock) void spread_tile_generic_kernel(
 
   const T* cc = c + 2 * (int64_t)blockIdx.y * c_stride;
   for (int j = p0 + tid; j < p1; j += kBlock) {
-    const Rec<T> rec = sp.rec[j];
+    const PointView<T> rec = unpack_rec<T, RANK>(sp.rec[j]);
     const uint32_t loc = rec.loc;
-    const int idx = rec_idx<T>(sp, RANK, j, rec);
+    const int idx = rec.idx;
     const T re = cc[2 * (int64_t)idx] * scale;
     const T im = cc[2 * (int64_t)idx + 1] * scale;
     T kx[kMaxW];
@@ -699,9 +818,9 @@ __global__ __launch_bounds__(NW * 64) void spread_wave_kernel(
     if (lane < CH) {
       T kx[8], k2[8];
       if (valid) {
-        const Rec<T> rec = sp.rec[j];
+        const PointView<T> rec = unpack_rec<T, RANK>(sp.rec[j]);
         const uint32_t loc = rec.loc;
-        const int idx = rec_idx<T>(sp, RANK, j, rec);
+        const int idx = rec.idx;
         const T re = cc[2 * (int64_t)idx] * scale, im = cc[2 * (int64_t)idx + 1] * scale;
         off = (int)(loc & 1023) + (int)((loc >> 10) & 1023) * LS + (RANK > 2 ? (int)((loc >> 20) & 1023) * PS : 0);
         T kl[8];
@@ -826,9 +945,9 @@ __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
 #pragma unroll
       for (int q = 0; q < W; ++q) { kx[q] = (T)0; ky[q] = (T)0; }
       if (j < wend) {
-        const Rec<T> rec = sp.rec[j];
+        const PointView<T> rec = unpack_rec<T, 3>(sp.rec[j]);
         const uint32_t loc = rec.loc;
-        const int idx = rec_idx<T>(sp, 3, j, rec);
+        const int idx = rec.idx;
         const T re = cc[2 * (int64_t)idx] * scale, im = cc[2 * (int64_t)idx + 1] * scale;
         off = (int)(loc & 1023) + (int)((loc >> 10) & 1023) * LS + (int)((loc >> 20) & 1023) * PS;
         T h0[8], h1[8], h2[8];
@@ -953,9 +1072,9 @@ __global__ __launch_bounds__(256) void interp_wave_kernel(
       T kx[8], ky[8], kz[8];
       int off = 0, idx = -1;
       if (j < p1) {
-        const Rec<T> rec = sp.rec[j];
+        const PointView<T> rec = unpack_rec<T, RANK>(sp.rec[j]);
         const uint32_t loc = rec.loc;
-        idx = rec_idx<T>(sp, RANK, j, rec);
+        idx = rec.idx;
         off = (int)(loc & 1023) + (int)((loc >> 10) & 1023) * LS + (RANK > 2 ? (int)((loc >> 20) & 1023) * PS : 0);
         if (RANK == 2) horner8<T, 2>(horner, nc, rec.z0, rec.z1, (T)0, kx, ky, kz);
         else horner8<T, 3>(horner, nc, rec.z0, rec.z1, rec.z2, kx, ky, kz);
@@ -1042,9 +1161,9 @@ __global__ __launch_bounds__(kBlock) void interp_tile_generic_kernel(
   const T* in = fw + 2 * (int64_t)blockIdx.y * fw_stride;
   T* cc = c + 2 * (int64_t)blockIdx.y * c_stride;
   for (int j = p0 + (int)threadIdx.x; j < p1; j += kBlock) {
-    const Rec<T> rec = sp.rec[j];
+    const PointView<T> rec = unpack_rec<T, RANK>(sp.rec[j]);
     const uint32_t loc = rec.loc;
-    const int idx = rec_idx<T>(sp, RANK, j, rec);
+    const int idx = rec.idx;
     T kx[kMaxW];
     int gx[kMaxW];
     const T z0 = rec.z0;
@@ -1192,6 +1311,14 @@ __global__ __launch_bounds__(256) void permute_kernel(const V* __restrict__ src,
 
 static inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
 
+template <typename K>
+static hipError_t ensure_lds(K kernel, size_t bytes) {
+  if (bytes > 64 * 1024)
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  return hipSuccess;
+}
+
 int sort_blocks(const Geom& g, int64_t M, int64_t* per_block) {
   // at most 512 workgroups (longer per-tile runs per workgroup => better write
   // combining in the scatter; measured r01), at least 4096 points each
@@ -1207,7 +1334,26 @@ int sort_blocks(const Geom& g, int64_t M, int64_t* per_block) {
   return (int)((M + pb - 1) / pb);
 }
 
+// 0: LDS histogram, 32-bit counters; 1: LDS histogram, packed 16-bit counters
+// (workgroups capped at 65535 points); 2: global counters.
+int sort_mode(const Geom& g, int64_t M) {
+  if (g.ntiles <= kMaxLdsTiles) return 0;
+  if (g.ntiles <= kMaxLds16Tiles) {
+    int64_t pb;
+    const int64_t nblk = sort_blocks16(M, &pb);
+    if (nblk * (int64_t)g.ntiles * 6 <= ((int64_t)2 << 30)) return 1;   // hist16 + pref <= 2 GiB
+  }
+  return 2;
+}
 bool sort_uses_lds(const Geom& g) { return g.ntiles <= kMaxLdsTiles; }
+
+int sort_blocks16(int64_t M, int64_t* per_block) {
+  int64_t pb = (M + 511) / 512;
+  if (pb < 4096) pb = 4096;
+  if (pb > 65535) pb = 65535;
+  *per_block = pb;
+  return (int)((M + pb - 1) / pb);
+}
 
 template <typename T>
 hipError_t launch_sort(const Geom& g, const PointsIn& in, const SortWork& w, const SortedOut<T>& out,
@@ -1219,10 +1365,15 @@ hipError_t launch_sort(const Geom& g, const PointsIn& in, const SortWork& w, con
     scan_tiles_kernel<<<1, 1024, 0, stream>>>(w.tile_count, g.ntiles, g.max_sub, w.tile_start, w.sub_start);
     return hipGetLastError();
   }
-  if (sort_uses_lds(g)) {
+  const int mode = sort_mode(g, in.M);
+  if (mode == 0) {
     int64_t per_block;
     const int nblk = sort_blocks(g, in.M, &per_block);
     const size_t lds = sizeof(int) * (size_t)g.ntiles;
+    e = ensure_lds(hist_lds_kernel<T>, lds);
+    if (e != hipSuccess) return e;
+    e = ensure_lds(scatter_lds_kernel<T>, lds);
+    if (e != hipSuccess) return e;
     hook.begin(STAGE_SORT_COUNT);
     hist_lds_kernel<T><<<nblk, kSortBlock, lds, stream>>>(g, in, per_block, w.hist, w.bad_count);
     hook.end(STAGE_SORT_COUNT);
@@ -1232,6 +1383,31 @@ hipError_t launch_sort(const Geom& g, const PointsIn& in, const SortWork& w, con
     hook.end(STAGE_SORT_SCAN);
     hook.begin(STAGE_SORT_SCATTER);
     scatter_lds_kernel<T><<<nblk, kSortBlock, lds, stream>>>(g, in, per_block, w.hist, w.tile_start, out);
+    hook.end(STAGE_SORT_SCATTER);
+    return hipGetLastError();
+  }
+  if (mode == 1) {
+    int64_t per_block;
+    const int nblk = sort_blocks16(in.M, &per_block);
+    const int nw = (g.ntiles + 1) >> 1;
+    const size_t lds = sizeof(unsigned) * (size_t)nw;
+    uint32_t* hist16 = reinterpret_cast<uint32_t*>(w.hist);                 // [nblk][nw] words
+    int32_t* pref = w.hist + (int64_t)nblk * nw;                            // [nblk][ntiles]
+    e = ensure_lds(hist16_lds_kernel<T>, lds);
+    if (e != hipSuccess) return e;
+    uint16_t* rank16 = reinterpret_cast<uint16_t*>(w.rank_of);
+    hook.begin(STAGE_SORT_COUNT);
+    hist16_lds_kernel<T><<<nblk, kSortBlock, lds, stream>>>(g, in, per_block, hist16, w.tile_of, rank16,
+                                                            w.bad_count);
+    hook.end(STAGE_SORT_COUNT);
+    hook.begin(STAGE_SORT_SCAN);
+    colscan16_kernel<<<(g.ntiles + 63) / 64, 1024, 0, stream>>>(
+        g.ntiles, nblk, reinterpret_cast<const uint16_t*>(hist16), pref, w.tile_count);
+    scan_tiles_kernel<<<1, 1024, 0, stream>>>(w.tile_count, g.ntiles, g.max_sub, w.tile_start, w.sub_start);
+    hook.end(STAGE_SORT_SCAN);
+    hook.begin(STAGE_SORT_SCATTER);
+    scatter_ranked_kernel<T><<<blocks_for(in.M, 256), 256, 0, stream>>>(g, in, per_block, w.tile_of, rank16,
+                                                                        pref, w.tile_start, out);
     hook.end(STAGE_SORT_SCATTER);
     return hipGetLastError();
   }
@@ -1311,14 +1487,6 @@ size_t interp_lds_bytes(const Geom& g, int method, int precision) {
 // sum_b ceil(n_b / S) <= ntiles + M / S.
 static inline unsigned subproblem_grid(const Geom& g, int64_t M) {
   return (unsigned)((int64_t)g.ntiles + M / g.max_sub);
-}
-
-template <typename K>
-static hipError_t ensure_lds(K kernel, size_t bytes) {
-  if (bytes > 64 * 1024)
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  return hipSuccess;
 }
 
 template <typename T>

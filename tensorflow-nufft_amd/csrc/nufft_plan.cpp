@@ -219,7 +219,7 @@ struct nufft_hip_plan_s {
   void* fft_work = nullptr;
   size_t fft_work_bytes = 0;
 
-  int64_t M = 0, cap = 0;
+  int64_t M = 0, cap = 0, cap_global = 0;
   void* rec = nullptr;           // Rec<T>[cap], tile-sorted
   int32_t* idx3 = nullptr;       // float rank-3 only
   int32_t *hist = nullptr;       // LDS-histogram sort: [nblk][ntiles]
@@ -364,31 +364,37 @@ StageHook make_hook(nufft_hip_plan p) {
 
 int ensure_point_capacity(nufft_hip_plan p, int64_t M) {
   int rc;
-  if (sort_uses_lds(p->g)) {
-    int64_t per_block;
-    const int64_t need = (int64_t)sort_blocks(p->g, M, &per_block) * p->g.ntiles;
-    if (need > p->hist_elems) {
-      HIP_TRY(p, hipStreamSynchronize(p->stream));
-      dev_free(p->hist);
-      p->hist = nullptr;
-      p->hist_elems = 0;
-      if ((rc = dev_alloc(p, (void**)&p->hist, sizeof(int32_t) * (size_t)need))) return rc;
-      p->hist_elems = need;
-    }
+  const int mode = sort_mode(p->g, M);
+  int64_t need = 0, per_block;
+  if (mode == 0) need = (int64_t)sort_blocks(p->g, M, &per_block) * p->g.ntiles;
+  if (mode == 1) {
+    const int64_t nblk = sort_blocks16(M, &per_block);
+    need = nblk * ((p->g.ntiles + 1) / 2) + nblk * (int64_t)p->g.ntiles;   // hist16 words + 32-bit prefix
+  }
+  if (need > p->hist_elems) {
+    HIP_TRY(p, hipStreamSynchronize(p->stream));
+    dev_free(p->hist);
+    p->hist = nullptr;
+    p->hist_elems = 0;
+    if ((rc = dev_alloc(p, (void**)&p->hist, sizeof(int32_t) * (size_t)need))) return rc;
+    p->hist_elems = need;
+  }
+  if (mode != 0 && M > p->cap_global) {   // per-point tile / rank arrays (modes 1 and 2)
+    HIP_TRY(p, hipStreamSynchronize(p->stream));
+    dev_free(p->tile_of); dev_free(p->rank_of);
+    p->tile_of = p->rank_of = nullptr;
+    p->cap_global = 0;
+    if ((rc = dev_alloc(p, (void**)&p->tile_of, (size_t)M * 4))) return rc;
+    if ((rc = dev_alloc(p, (void**)&p->rank_of, (size_t)M * 4))) return rc;
+    p->cap_global = M;
   }
   if (M <= p->cap) return NUFFT_HIP_OK;
   HIP_TRY(p, hipStreamSynchronize(p->stream));
-  dev_free(p->rec); dev_free(p->idx3); dev_free(p->tile_of); dev_free(p->rank_of);
-  p->rec = nullptr; p->idx3 = nullptr; p->tile_of = p->rank_of = nullptr;
+  dev_free(p->rec); dev_free(p->idx3);
+  p->rec = nullptr; p->idx3 = nullptr;
   p->cap = 0;
   const size_t rec_bytes = p->precision == NUFFT_HIP_F32 ? sizeof(Rec<float>) : sizeof(Rec<double>);
   if ((rc = dev_alloc(p, &p->rec, (size_t)M * rec_bytes))) return rc;
-  if (p->precision == NUFFT_HIP_F32 && p->rank == 3)
-    if ((rc = dev_alloc(p, (void**)&p->idx3, (size_t)M * 4))) return rc;
-  if (!sort_uses_lds(p->g)) {
-    if ((rc = dev_alloc(p, (void**)&p->tile_of, (size_t)M * 4))) return rc;
-    if ((rc = dev_alloc(p, (void**)&p->rank_of, (size_t)M * 4))) return rc;
-  }
   p->cap = M;
   return NUFFT_HIP_OK;
 }
@@ -670,6 +676,7 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
     int t = d < rank ? (p->opts.tile_dims[d] > 0 ? p->opts.tile_dims[d] : def_tile[rank - 1][d]) : 1;
     t = std::max(1, std::min(t, 1024));
     if (d < rank) t = std::min(t, g.nf[d]);
+    if (rank == 3 && precision == NUFFT_HIP_F32) t = std::min(t, 16);   // packed 3-D float records: 4-bit tile-local starts
     g.tile[d] = t;
   }
   const size_t lds_limit = 96 * 1024;

@@ -455,3 +455,34 @@ def test_config5_batched_items(tfft):
                      tol=1e-12, sigma=2.0)
   assert rel_l2(shared[2].cpu().numpy(), ref) < 1e-6
   assert rel_l2(shared[1].cpu().numpy(), out[1].cpu().numpy()) < 1e-6
+
+
+@pytest.mark.parametrize('tile,mode', [((16, 16, 8), 'lds32'), ((4, 8, 4), 'lds16'), ((4, 4, 4), 'global')])
+def test_all_three_sort_paths_give_the_same_transform(tfft, tile, mode):
+  # tile counts 3456 / 55296 / 110592 select the 32-bit LDS histogram sort, the packed
+  # 16-bit LDS histogram sort and the global-counter sort (nufft_kernels.hip, sort_mode)
+  import torch
+  from oracle import oracle
+  rng = np.random.default_rng(41)
+  grid = [96, 96, 96]
+  M = 300000
+  pts = rng.uniform(-np.pi, np.pi, (M, 3)).astype(np.float32)
+  pts[:50000] = (0.05 * rng.standard_normal((50000, 3)) + 1.0).astype(np.float32)   # a cluster
+  c = (rng.uniform(-.5, .5, M) + 1j * rng.uniform(-.5, .5, M)).astype(np.complex64)
+  truth = oracle.nufft(c.astype(np.complex128), pts, grid, 'type_1', 'forward', tol=1e-10)
+  plan = tfft.Plan('type_1', grid, 'forward', tol=1e-4, tile_dims=tile)
+  i = plan.info()
+  assert tuple(i.tile_dims) == tile
+  ntiles = i.num_tiles[0] * i.num_tiles[1] * i.num_tiles[2]
+  assert {'lds32': ntiles <= 16384, 'lds16': 16384 < ntiles <= 73728, 'global': ntiles > 73728}[mode]
+  plan.set_points(_dev(pts))
+  out = plan.execute(_dev(c)).cpu().numpy()
+  assert rel_l2(out, truth) < 1e-4, rel_l2(out, truth)
+  # type 2 on the same sorted points
+  plan2 = tfft.Plan('type_2', grid, 'backward', tol=1e-4, tile_dims=tile)
+  plan2.set_points(_dev(pts))
+  f = (rng.uniform(-.5, .5, grid) + 1j * rng.uniform(-.5, .5, grid)).astype(np.complex64)
+  out2 = plan2.execute(_dev(f)).cpu().numpy()
+  truth2 = oracle.nufft(f.astype(np.complex128), pts, None, 'type_2', 'backward', tol=1e-10)
+  assert rel_l2(out2, truth2) < 1e-4
+  plan.close(); plan2.close()

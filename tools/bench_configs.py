@@ -40,4 +40,7 @@ if '4' in which: run('cfg4 3D t1 256^3 M=1e8 tol1e-4', 'type_1', [256, 256, 256]
 if '4s' in which: run('cfg4-small 3D t1 256^3 M=1e7 tol1e-4', 'type_1', [256, 256, 256], 10_000_000, 1e-4, steps=3, max_subproblem_size=S)
 if '5' in which: run('cfg5 per-item pts: 32 x (2D t1 512^2 M=1e6)', 'type_1', [512, 512], 1_000_000, 1e-6, ntransf=32, per_item_points=True, steps=3)
 if '5s' in which: run('cfg5 shared pts: 32 transforms (2D t1 512^2 M=1e6)', 'type_1', [512, 512], 1_000_000, 1e-6, ntransf=32, steps=3)
+if '4t2' in which: run('cfg4-type2 3D t2 256^3 M=1e8 tol1e-4', 'type_2', [256, 256, 256], 100_000_000, 1e-4, steps=3)
+if '2d' in which: run('2D t1 1024^2 M=1e7 f64 tol1e-9', 'type_1', [1024, 1024], 10_000_000, 1e-9, dtype=torch.complex128, steps=3)
+if '2d6' in which: run('2D t1 1024^2 M=1e7 f64 tol1e-6', 'type_1', [1024, 1024], 10_000_000, 1e-6, dtype=torch.complex128, steps=3)
 if '1' in which: run('cfg1 1D t1 N=4096 M=1e5 f64', 'type_1', [4096], 100_000, 1e-6, dtype=torch.complex128)
