@@ -108,6 +108,7 @@ def main():
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--dist-backend', default='nccl', help='nccl (= RCCL, default) | gloo (testing)')
   ap.add_argument('--device', type=int, default=None, help='force a device index (testing)')
+  ap.add_argument('--force-dist', action='store_true', help='initialise torch.distributed even at world size 1 (testing)')
   args = ap.parse_args()
 
   world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -120,9 +121,12 @@ def main():
   torch.cuda.set_device(local_rank)
   dev = torch.device('cuda', local_rank)
   dist = None
-  if world > 1:
+  if world > 1 or args.force_dist:
     import torch.distributed as dist
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
+    os.environ.setdefault('RANK', '0')
+    os.environ.setdefault('WORLD_SIZE', '1')
     if args.dist_backend == 'nccl':
       dist.init_process_group('nccl', device_id=dev)   # "nccl" is RCCL on ROCm
     else:

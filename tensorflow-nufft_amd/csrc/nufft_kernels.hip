@@ -41,14 +41,43 @@ __device__ __forceinline__ T horner_cell(const T* __restrict__ tab, int nc, int 
 // waits for each (measured: 150 us of a 365 us interp kernel). Rows are zero
 // beyond the kernel width, so cells q >= w come out exactly 0.
 template <typename T, int NDIM>
-__device__ __forceinline__ void horner8(const T* __restrict__ tab, int nc, T z0, T z1, T z2,
-                                        T (&k0)[8], T (&k1)[8], T (&k2)[8]) {
+__device__ __forceinline__ void horner8_rt(const T* __restrict__ tab, int nc, T z0, T z1, T z2,
+                                           T (&k0)[8], T (&k1)[8], T (&k2)[8]) {
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     const T t = tab[(nc - 1) * kMaxW + q];
     k0[q] = t; k1[q] = t; k2[q] = t;
   }
   for (int k = nc - 2; k >= 0; --k) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const T t = tab[k * kMaxW + q];
+      k0[q] = fma(k0[q], z0, t);
+      if (NDIM > 1) k1[q] = fma(k1[q], z1, t);
+      if (NDIM > 2) k2[q] = fma(k2[q], z2, t);
+    }
+  }
+}
+
+// Every width <= 8 needs at most kFixedCoef terms in either precision (rows
+// above the fitted count are zero), so the common case is a fully unrolled
+// evaluation whose row loads have no loop-carried wait: they are issued together
+// (or hoisted out of the point loop when the scalar registers allow).
+constexpr int kFixedCoef = 10;
+template <typename T, int NDIM>
+__device__ __forceinline__ void horner8(const T* __restrict__ tab, int nc, T z0, T z1, T z2,
+                                        T (&k0)[8], T (&k1)[8], T (&k2)[8]) {
+  if (nc > kFixedCoef) {
+    horner8_rt<T, NDIM>(tab, nc, z0, z1, z2, k0, k1, k2);
+    return;
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const T t = tab[(kFixedCoef - 1) * kMaxW + q];
+    k0[q] = t; k1[q] = t; k2[q] = t;
+  }
+#pragma unroll
+  for (int k = kFixedCoef - 2; k >= 0; --k) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const T t = tab[k * kMaxW + q];
@@ -1066,13 +1095,19 @@ __global__ __launch_bounds__(256) void interp_wave_kernel(
   const int dx = lane & 7, pg = lane >> 3;
   T* cc = c + 2 * (int64_t)blockIdx.y * c_stride;
 
+  // the next chunk's records are requested before this chunk is processed, so
+  // their HBM latency overlaps the gather below
+  Rec<T> rec_next;
+  if (p0 + wave * 64 + lane < p1) rec_next = sp.rec[p0 + wave * 64 + lane];
   for (int base = p0 + wave * 64; base < p1; base += 4 * 64) {
     const int j = base + lane;
+    const Rec<T> rec_cur = rec_next;
+    if (j + 4 * 64 < p1) rec_next = sp.rec[j + 4 * 64];
     {
       T kx[8], ky[8], kz[8];
       int off = 0, idx = -1;
       if (j < p1) {
-        const PointView<T> rec = unpack_rec<T, RANK>(sp.rec[j]);
+        const PointView<T> rec = unpack_rec<T, RANK>(rec_cur);
         const uint32_t loc = rec.loc;
         idx = rec.idx;
         off = (int)(loc & 1023) + (int)((loc >> 10) & 1023) * LS + (RANK > 2 ? (int)((loc >> 20) & 1023) * PS : 0);
