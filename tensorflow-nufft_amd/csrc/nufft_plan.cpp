@@ -539,7 +539,7 @@ int spread_interp_impl(nufft_hip_plan p, int dir, void* c, void* f) {
 
 void destroy(nufft_hip_plan p) {
   if (!p) return;
-  if (p->stream || true) (void)hipStreamSynchronize(p->stream);
+  (void)hipStreamSynchronize(p->stream);
   for (auto& kv : p->fft_plans) rocfft_plan_destroy(kv.second);
   if (p->fft_info) rocfft_execution_info_destroy(p->fft_info);
   dev_free(p->fft_work);

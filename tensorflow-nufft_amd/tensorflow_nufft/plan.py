@@ -107,20 +107,6 @@ class Plan:
       self._check(self.lib.nufft_hip_interp(self._handle, out.data_ptr(), f.data_ptr()))
     return out
 
-  def fine_grid(self):
-    """Copy of the fine (oversampled) grid of the last batch, array order."""
-    ptr = ctypes.c_void_p()
-    n = ctypes.c_int64()
-    self._check(self.lib.nufft_hip_debug_fine_grid(self._handle, ctypes.byref(ptr), ctypes.byref(n)))
-    i = self.info()
-    shape = [i.batch_size] + [int(i.fine_dims[self.rank - 1 - d]) for d in range(self.rank)]
-    out = torch.empty(shape, dtype=self.cdtype, device=self.device)
-    torch.cuda.current_stream(self.device).synchronize()
-    import ctypes as _c
-    hip = _c.CDLL('libamdhip64.so')
-    hip.hipMemcpy(_c.c_void_p(out.data_ptr()), ptr, _c.c_size_t(out.numel() * out.element_size()), 3)
-    return out
-
   def set_timing(self, enable=True):
     self._check(self.lib.nufft_hip_plan_set_timing(self._handle, int(enable)))
 

@@ -174,8 +174,10 @@ def test_batch_broadcasting(tfft):
   rng = np.random.default_rng(6)
   grid = [24, 24]
   M = 576
+  # the last three interleave 'transform' dims (points batch 1) before 'call' dims,
+  # which takes the permute path of nufft_kernels.cc:241-345
   for sb, pb in ([[2, 4], [1]], [[1], [2, 4]], [[3], [3]], [[2, 1, 3], [2, 4, 1]], [[4], []], [[], [4]],
-                 [[2, 3], [3]], [[3, 1], [3, 2]]):
+                 [[2, 3], [3]], [[3, 1], [3, 2]], [[3, 2], [1, 2]], [[2, 3, 4], [1, 3, 1]], [[2, 1, 2], [1, 3, 2]]):
     pts = rng.uniform(-np.pi, np.pi, pb + [M, 2]).astype(np.float32)
     src = (rng.uniform(-.5, .5, sb + [M]) + 1j * rng.uniform(-.5, .5, sb + [M])).astype(np.complex64)
     out = tfft.nufft(_dev(src), _dev(pts), grid_shape=grid, transform_type='type_1', fft_direction='backward')
