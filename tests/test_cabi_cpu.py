@@ -51,7 +51,7 @@ def test_default_options_and_struct_layout():
 
 @pytest.mark.parametrize('rank,dims,tol,prec,w,nf,method', [
     (2, [1024, 1024], float(np.float32(1e-6)), 4, 8, [2048, 2048, 1], 2),   # BASELINE config 2/3
-    (3, [256, 256, 256], float(np.float32(1e-4)), 4, 6, [512, 512, 512], 1),  # config 4
+    (3, [256, 256, 256], float(np.float32(1e-4)), 4, 6, [512, 512, 512], 2),  # config 4
     (2, [512, 512], float(np.float32(1e-6)), 4, 8, [1024, 1024, 1], 2),     # config 5
     (1, [4096], float(np.float32(1e-6)), 8, 8, [8192, 1, 1], 1),            # config 1 (fp64)
     (2, [6, 8], 1e-6, 4, 8, [16, 16, 1], 1),                                # fine grid >= 2 w
