@@ -231,7 +231,7 @@ struct nufft_hip_plan_s {
   std::string err;
 
   // optional per-stage timing with HIP events on the plan's stream
-  bool timing = false;
+  int timing = 0;   // 0 off, 1 every stage, 2 only the spread / interp kernel
   struct Pending { int stage; hipEvent_t e0, e1; };
   std::vector<Pending> pending;
   std::vector<hipEvent_t> free_events;
@@ -342,12 +342,14 @@ hipEvent_t take_event(nufft_hip_plan p) {
 }
 void stage_begin(void* ctx, int stage) {
   nufft_hip_plan p = (nufft_hip_plan)ctx;
+  if (p->timing == 2 && stage != STAGE_SPREAD && stage != STAGE_INTERP) return;
   hipEvent_t e = take_event(p);
   (void)hipEventRecord(e, p->stream);
   p->open_event[stage] = e;
 }
 void stage_end(void* ctx, int stage) {
   nufft_hip_plan p = (nufft_hip_plan)ctx;
+  if (p->timing == 2 && stage != STAGE_SPREAD && stage != STAGE_INTERP) return;
   hipEvent_t e = take_event(p);
   (void)hipEventRecord(e, p->stream);
   p->pending.push_back({stage, p->open_event[stage], e});
@@ -874,7 +876,7 @@ int nufft_hip_plan_set_stream(nufft_hip_plan p, void* stream) {
 
 int nufft_hip_plan_set_timing(nufft_hip_plan p, int enable) {
   if (!p) return NUFFT_HIP_INVALID_ARGUMENT;
-  p->timing = enable != 0;
+  p->timing = enable;
   return NUFFT_HIP_OK;
 }
 

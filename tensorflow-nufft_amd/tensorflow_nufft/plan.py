@@ -108,6 +108,7 @@ class Plan:
     return out
 
   def set_timing(self, enable=True):
+    """0/False off, 1/True every stage, 2 only the spread / interp kernel."""
     self._check(self.lib.nufft_hip_plan_set_timing(self._handle, int(enable)))
 
   def get_timing(self):

