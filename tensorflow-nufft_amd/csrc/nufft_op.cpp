@@ -146,6 +146,7 @@ int analyze(const nufft_hip_op_desc* d, Analysis* a, std::string* err) {
 struct CachedPlan {
   std::string key;
   nufft_hip_plan plan;
+  hipStream_t own_stream;   // private stream of a pipelining lane (nullptr: caller's stream)
 };
 std::mutex g_cache_mu;
 std::list<CachedPlan> g_cache;    // most recently returned at the front
@@ -163,28 +164,34 @@ std::string plan_key(const nufft_hip_op_desc* d, const Analysis& a, int type, in
   return k;
 }
 
-nufft_hip_plan cache_take(const std::string& key) {
+nufft_hip_plan cache_take(const std::string& key, hipStream_t* own_stream) {
   std::lock_guard<std::mutex> lk(g_cache_mu);
   for (auto it = g_cache.begin(); it != g_cache.end(); ++it)
     if (it->key == key) {
       nufft_hip_plan p = it->plan;
+      *own_stream = it->own_stream;
       g_cache.erase(it);
       return p;
     }
   return nullptr;
 }
 
-void cache_give(const std::string& key, nufft_hip_plan p) {
-  nufft_hip_plan evict = nullptr;
+void release_entry(nufft_hip_plan p, hipStream_t own_stream) {
+  nufft_hip_plan_destroy(p);   // synchronises the plan's stream
+  if (own_stream) (void)hipStreamDestroy(own_stream);
+}
+
+void cache_give(const std::string& key, nufft_hip_plan p, hipStream_t own_stream) {
+  CachedPlan evict{std::string(), nullptr, nullptr};
   {
     std::lock_guard<std::mutex> lk(g_cache_mu);
-    g_cache.push_front({key, p});
+    g_cache.push_front({key, p, own_stream});
     if (g_cache.size() > kMaxCached) {
-      evict = g_cache.back().plan;
+      evict = g_cache.back();
       g_cache.pop_back();
     }
   }
-  if (evict) nufft_hip_plan_destroy(evict);
+  if (evict.plan) release_entry(evict.plan, evict.own_stream);
 }
 
 }  // namespace
@@ -240,14 +247,38 @@ int nufft_hip_op_compute(const nufft_hip_op_desc* desc, const void* source, cons
     return fail(errbuf, errbuf_len, NUFFT_HIP_INTERNAL,
                 "no HIP device available (this library has no CPU fallback)");
   }
-  const std::string key = plan_key(desc, a, desc->transform_type, (int)a.num_transforms, tol, stream_v, device);
-  nufft_hip_plan plan = cache_take(key);
-  if (!plan) {
-    char pe[512] = {0};
-    rc = nufft_hip_plan_create(&plan, desc->transform_type, rank, dims, desc->fft_direction,
-                               (int)a.num_transforms, tol, desc->precision, &opts, stream_v, pe, sizeof(pe));
-    if (rc) return fail(errbuf, errbuf_len, rc, pe);
+  // One plan on the caller's stream, or -- when the batch needs several
+  // sequential set_points + execute calls -- two plans on private streams that
+  // alternate calls: the memory-bound sort of one call overlaps the LDS-bound
+  // spread of the other (measured r01: 0.126 -> 0.092 ms per 512^2, M = 1e6 item).
+  const int nlanes = a.num_calls >= 2 ? 2 : 1;
+  nufft_hip_plan plans[2] = {nullptr, nullptr};
+  hipStream_t lane_stream[2] = {nullptr, nullptr};
+  std::string keys[2];
+  for (int l = 0; l < nlanes; ++l) {
+    void* key_stream = nlanes == 1 ? stream_v : reinterpret_cast<void*>((intptr_t)(l + 1));
+    keys[l] = plan_key(desc, a, desc->transform_type, (int)a.num_transforms, tol, key_stream, device);
+    plans[l] = cache_take(keys[l], &lane_stream[l]);
+    if (!plans[l]) {
+      if (nlanes > 1 && hipStreamCreateWithFlags(&lane_stream[l], hipStreamNonBlocking) != hipSuccess) {
+        for (int k = 0; k < l; ++k) release_entry(plans[k], lane_stream[k]);
+        return fail(errbuf, errbuf_len, NUFFT_HIP_INTERNAL, "hipStreamCreate failed");
+      }
+      char pe[512] = {0};
+      rc = nufft_hip_plan_create(&plans[l], desc->transform_type, rank, dims, desc->fft_direction,
+                                 (int)a.num_transforms, tol, desc->precision, &opts,
+                                 nlanes == 1 ? stream_v : (void*)lane_stream[l], pe, sizeof(pe));
+      if (rc) {
+        if (lane_stream[l]) (void)hipStreamDestroy(lane_stream[l]);
+        for (int k = 0; k < l; ++k) release_entry(plans[k], lane_stream[k]);
+        return fail(errbuf, errbuf_len, rc, pe);
+      }
+    }
   }
+  nufft_hip_plan plan = plans[0];
+  auto release_all = [&]() {
+    for (int l = 0; l < nlanes; ++l) release_entry(plans[l], lane_stream[l]);
+  };
 
   // Source / target with batch dims permuted to [outer..., inner..., element...]
   // when the original order interleaves them (nufft_kernels.cc:241-345,372-378).
@@ -271,7 +302,7 @@ int nufft_hip_op_compute(const nufft_hip_op_desc* desc, const void* source, cons
   };
   auto hip_fail = [&](hipError_t e) {
     cleanup();
-    nufft_hip_plan_destroy(plan);
+    release_all();
     return fail(errbuf, errbuf_len, NUFFT_HIP_INTERNAL, std::string("HIP error: ") + hipGetErrorString(e));
   };
   std::vector<int64_t> tperm_shape, tt_strides_for_back;
@@ -305,7 +336,15 @@ int nufft_hip_op_compute(const nufft_hip_op_desc* desc, const void* source, cons
     pfac[d2] = pfac[d2 + 1] * pts_outer[d2 + 1];
   }
   const size_t rsize = (size_t)desc->precision;
+  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+  if (nlanes > 1) {
+    hipError_t e = hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(ev_fork, stream);
+    for (int l = 0; l < nlanes && e == hipSuccess; ++l) e = hipStreamWaitEvent(lane_stream[l], ev_fork, 0);
+    if (e != hipSuccess) return hip_fail(e);
+  }
   for (int64_t call = 0; call < a.num_calls; ++call) {
+    plan = plans[call % nlanes];
     const char* pb = (const char*)points + (size_t)call * (size_t)a.num_points * rank * rsize;
     // x = LAST coordinate of each point (reverse of the last axis, :282-286)
     const void* px = pb + (size_t)(rank - 1) * rsize;
@@ -337,9 +376,22 @@ int nufft_hip_op_compute(const nufft_hip_op_desc* desc, const void* source, cons
   }
   if (rc) {
     const std::string msg = nufft_hip_last_error(plan);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
     cleanup();
-    nufft_hip_plan_destroy(plan);
+    release_all();
     return fail(errbuf, errbuf_len, rc, msg);
+  }
+  if (nlanes > 1) {   // join: the caller's stream continues after both lanes
+    hipError_t e = hipSuccess;
+    for (int l = 0; l < nlanes && e == hipSuccess; ++l) {
+      e = hipEventCreateWithFlags(&ev_join[l], hipEventDisableTiming);
+      if (e == hipSuccess) e = hipEventRecord(ev_join[l], lane_stream[l]);
+      if (e == hipSuccess) e = hipStreamWaitEvent(stream, ev_join[l], 0);
+    }
+    (void)hipEventDestroy(ev_fork);
+    for (int l = 0; l < nlanes; ++l)
+      if (ev_join[l]) (void)hipEventDestroy(ev_join[l]);
+    if (e != hipSuccess) return hip_fail(e);
   }
   if (a.transpose) {
     // target[original order] = ttarget[outer.., inner.., elem..]: for output dim j
@@ -356,7 +408,7 @@ int nufft_hip_op_compute(const nufft_hip_op_desc* desc, const void* source, cons
     if (e != hipSuccess) return hip_fail(e);
   }
   cleanup();
-  cache_give(key, plan);
+  for (int l = 0; l < nlanes; ++l) cache_give(keys[l], plans[l], lane_stream[l]);
   return NUFFT_HIP_OK;
 }
 
@@ -366,7 +418,7 @@ void nufft_hip_op_clear_cache(void) {
     std::lock_guard<std::mutex> lk(g_cache_mu);
     tmp.swap(g_cache);
   }
-  for (auto& c : tmp) nufft_hip_plan_destroy(c.plan);
+  for (auto& c : tmp) release_entry(c.plan, c.own_stream);
 }
 
 }  // extern "C"

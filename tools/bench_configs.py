@@ -46,4 +46,14 @@ if '2d6' in which: run('2D t1 1024^2 M=1e7 f64 tol1e-6', 'type_1', [1024, 1024],
 for t in ('1e-5', '1e-4', '1e-3', '1e-2'):
   if ('2t' + t) in which: run(f'2D t1 1024^2 M=1e7 f32 tol{t}', 'type_1', [1024, 1024], 10_000_000, float(t), steps=5)
   if ('3t' + t) in which: run(f'2D t2 1024^2 M=1e7 f32 tol{t}', 'type_2', [1024, 1024], 10_000_000, float(t), steps=5)
+if '5op' in which:
+  g = torch.Generator(device='cuda').manual_seed(5)
+  B, M = 32, 1_000_000
+  pts = (torch.rand((B, M, 2), generator=g, device='cuda') * 2 - 1) * np.pi
+  c = rnd_c([B, M], g)
+  for _ in range(3): out = tfft.nufft(c, pts, grid_shape=[512, 512], transform_type='type_1')
+  torch.cuda.synchronize(); t0 = time.perf_counter()
+  for _ in range(5): out = tfft.nufft(c, pts, grid_shape=[512, 512], transform_type='type_1')
+  torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
+  print(f'cfg5 via tfft.nufft (op level, per-item points, 32 items): {dt*1e3:.3f} ms  {B*M/dt/1e6:.1f} Mpts/s')
 if '1' in which: run('cfg1 1D t1 N=4096 M=1e5 f64', 'type_1', [4096], 100_000, 1e-6, dtype=torch.complex128)

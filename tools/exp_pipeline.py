@@ -5,7 +5,8 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tensorflow-nufft_amd'))
 import numpy as np, torch
 import tensorflow_nufft as tfft
-M = 10_000_000
+M = int(float(os.environ.get('EXP_M', '1e7')))
+GRID = [int(os.environ.get('EXP_N', '1024'))] * 2
 g = torch.Generator(device='cuda').manual_seed(2)
 NP = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 pts = [(torch.rand((M, 2), generator=g, device='cuda') * 2 - 1) * np.pi for _ in range(NP)]
@@ -14,8 +15,8 @@ streams = [torch.cuda.Stream() for _ in range(NP)]
 plans, outs = [], []
 for i in range(NP):
   with torch.cuda.stream(streams[i]):
-    plans.append(tfft.Plan('type_1', [1024, 1024], 'forward', tol=1e-6))
-    outs.append(torch.empty((1024, 1024), dtype=torch.complex64, device='cuda'))
+    plans.append(tfft.Plan('type_1', GRID, 'forward', tol=1e-6))
+    outs.append(torch.empty(GRID, dtype=torch.complex64, device='cuda'))
 def run(steps):
   for s in range(steps):
     i = s % NP
