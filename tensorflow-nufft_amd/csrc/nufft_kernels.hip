@@ -136,7 +136,12 @@ struct RowWalk {
     while (a1 >= L1) { a1 -= L1; ++a2; }
   }
 };
-__device__ __forceinline__ int wrap1(int v, int n) { return v >= n ? v - n : v; }
+// o + a < 3 n always (tile <= n, w <= n / 2), and < 2 n except for tiny grids
+// such as n = 18 with 16-wide tiles: two conditional subtracts cover every case.
+__device__ __forceinline__ int wrap1(int v, int n) {
+  v = v >= n ? v - n : v;
+  return v >= n ? v - n : v;
+}
 
 // Adds a finished LDS tile (planar double re/im) to the periodic fine grid.
 // Consecutive lanes take (re, im) of consecutive cells of one row, so a

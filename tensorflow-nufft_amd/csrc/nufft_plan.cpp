@@ -663,6 +663,7 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
   // batch size: reference nufft_plan.cu.cc:1923-1928 (min(ntransf, 8) unless set)
   p->batch_size = p->opts.max_batch_size > 0 ? std::min(p->opts.max_batch_size, ntransf)
                                              : std::min(ntransf, 8);
+  p->batch_size = std::min(p->batch_size, 32768);   // grid.y limit of the batched launches
   if (p->fine_elems * p->batch_size > kMaxArraySize) {
     const long long sz = (long long)(p->fine_elems * p->batch_size);
     delete p;

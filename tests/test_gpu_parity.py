@@ -488,3 +488,24 @@ def test_all_three_sort_paths_give_the_same_transform(tfft, tile, mode):
   truth2 = oracle.nufft(f.astype(np.complex128), pts, None, 'type_2', 'backward', tol=1e-10)
   assert rel_l2(out2, truth2) < 1e-4
   plan.close(); plan2.close()
+
+
+@pytest.mark.parametrize('grid', [[9, 9, 9], [9, 10], [8, 9, 12], [10, 9], [33]])
+@pytest.mark.parametrize('ttype', ['type_1', 'type_2'])
+def test_tiny_and_odd_grids(tfft, grid, ttype):
+  # fine grids barely larger than a tile (nf = 18 with 16-wide tiles wraps twice)
+  # and odd mode counts (integer modes -(N//2).., as the reference C++ does)
+  rng = np.random.default_rng(51)
+  M = 2000
+  rank = len(grid)
+  pts = rng.uniform(-np.pi, np.pi, (M, rank)).astype(np.float32)
+  for tol in (1e-4, 1e-6):
+    if ttype == 'type_1':
+      src = (rng.standard_normal(M) + 1j * rng.standard_normal(M)).astype(np.complex64)
+    else:
+      src = (rng.standard_normal(grid) + 1j * rng.standard_normal(grid)).astype(np.complex64)
+    out = tfft.nufft(_dev(src), _dev(pts), grid_shape=grid if ttype == 'type_1' else None,
+                     transform_type=ttype, tol=tol).cpu().numpy()
+    ref = tfft.nudft(src.astype(np.complex128), pts.astype(np.float64), grid_shape=grid if ttype == 'type_1' else None,
+                     transform_type=ttype)
+    assert rel_l2(out, ref) < tol, (grid, ttype, tol, rel_l2(out, ref))
