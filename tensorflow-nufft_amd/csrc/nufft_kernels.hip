@@ -805,9 +805,6 @@ __device__ __forceinline__ double bcast_lane(double v, int lane) {
 template <typename T> struct Pair;
 template <> struct Pair<float> { using type = float2; };
 template <> struct Pair<double> { using type = double2; };
-template <typename T> struct Quad;
-template <> struct Quad<float> { using type = float4; };
-template <> struct Quad<double> { using type = double4; };
 
 template <typename T, int RANK, int NW, int CH>
 __global__ __launch_bounds__(NW * 64) void spread_wave_kernel(
@@ -1028,31 +1025,57 @@ __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
   tile_to_grid<T, 3>(g, plane_re, plane_im, LS, PS, tb, fw + 2 * (int64_t)blockIdx.y * fw_stride, wave, NW, lane);
 }
 
-// ------------------- interp: LDS-tiled path, any w <= 8, rank 2 or 3 (type 2)
+// ---------------- interp: LDS tile, one thread per point, compile-time width
 
-// Sum over an aligned group of 8 lanes, result valid in the group's first lane.
-__device__ __forceinline__ float red8(float v) {
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x104, 0xf, 0xf, true));  // row_shl:4
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x102, 0xf, 0xf, true));  // row_shl:2
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, true));  // row_shl:1
-  return v;
-}
-__device__ __forceinline__ double red8(double v) {
-  v += __shfl_down(v, 4, 8);
-  v += __shfl_down(v, 2, 8);
-  v += __shfl_down(v, 1, 8);
-  return v;
+// A first version gathered 8 points per wavefront pass (lane = (point, dx),
+// kernel values staged in LDS, 8-lane DPP reductions); PMC showed it
+// instruction-issue bound (14 issue slots per point: staging, meta reads, DPP,
+// scalar loop control; 2-D 309 us, 3-D 17.2 ms at M = 1e8). Replaces the
+// reference's InterpSubproblem* kernels (nufft_plan.cu.cc:1041-1187, 1608-1804).
+// Here a thread keeps its point's kernel values in registers and walks the
+// W^RANK stencil with immediate LDS offsets: one ds_read_b64 + one packed FMA
+// per cell, ~4.5 issue slots per point (2-D, W = 8). Bank conflicts between
+// the 64 unrelated points of a wavefront remain (random cells), but the LDS
+// pipe then does ~7 cycles per point against ~14 issue-cycles before.
+template <typename T, int NDIM, int W>
+__device__ __forceinline__ void hornerW(const T* __restrict__ tab, int nc, T z0, T z1, T z2,
+                                        T (&k0)[W], T (&k1)[W], T (&k2)[W]) {
+  if (nc <= kFixedCoef) {
+#pragma unroll
+    for (int q = 0; q < W; ++q) {
+      const T t = tab[(kFixedCoef - 1) * kMaxW + q];
+      k0[q] = t; k1[q] = t; k2[q] = t;
+    }
+#pragma unroll
+    for (int k = kFixedCoef - 2; k >= 0; --k) {
+#pragma unroll
+      for (int q = 0; q < W; ++q) {
+        const T t = tab[k * kMaxW + q];
+        k0[q] = fma(k0[q], z0, t);
+        if (NDIM > 1) k1[q] = fma(k1[q], z1, t);
+        if (NDIM > 2) k2[q] = fma(k2[q], z2, t);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < W; ++q) {
+      const T t = tab[(nc - 1) * kMaxW + q];
+      k0[q] = t; k1[q] = t; k2[q] = t;
+    }
+    for (int k = nc - 2; k >= 0; --k) {
+#pragma unroll
+      for (int q = 0; q < W; ++q) {
+        const T t = tab[k * kMaxW + q];
+        k0[q] = fma(k0[q], z0, t);
+        if (NDIM > 1) k1[q] = fma(k1[q], z1, t);
+        if (NDIM > 2) k2[q] = fma(k2[q], z2, t);
+      }
+    }
+  }
 }
 
-// One workgroup per subproblem: the fine-grid tile (+ one-sided halo) is staged
-// in LDS as interleaved complex; kernel values are produced one point per lane
-// and staged; then 8 points are gathered per wavefront pass, lane (p, dx)
-// accumulating column dx of point p over dy (and dz), followed by an 8-lane
-// DPP reduction. Replaces the reference's InterpSubproblem* kernels
-// (nufft_plan.cu.cc:1041-1187, 1608-1804); its default is the untiled
-// InterpNuptsDriven* (:963-1038), kept here as the generic kernel below.
-template <typename T, int RANK>
-__global__ __launch_bounds__(256) void interp_wave_kernel(
+template <typename T, int RANK, int W>
+__global__ __launch_bounds__(256) void interp_point_kernel(
     Geom g, SortedPoints<T> sp, const T* __restrict__ horner, T* __restrict__ c,
     const T* __restrict__ fw, int64_t c_stride, int64_t fw_stride, T scale) {
   using T2 = typename Pair<T>::type;
@@ -1061,11 +1084,7 @@ __global__ __launch_bounds__(256) void interp_wave_kernel(
   const int L0 = g.ldim[0], L1 = g.ldim[1];
   const int L2 = RANK > 2 ? g.ldim[2] : 1;
   const int PS = LS * L1;
-  const int ncell = PS * L2;
   T2* tile = reinterpret_cast<T2*>(smem_raw);
-  constexpr int kPer = (RANK == 2) ? 16 : 24;
-  T* stage_all = reinterpret_cast<T*>(tile + ncell);
-  int2* meta_all = reinterpret_cast<int2*>(stage_all + 4 * 64 * kPer);   // (off, idx) per staged point
   int tb, p0, p1;
   if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1)) return;
   const int tid = threadIdx.x;
@@ -1076,109 +1095,52 @@ __global__ __launch_bounds__(256) void interp_wave_kernel(
   const int t2 = tb / (g.ntile[0] * g.ntile[1]);
   const int o0 = t0 * g.tile[0], o1 = t1 * g.tile[1], o2 = t2 * g.tile[2];
   const T2* in = reinterpret_cast<const T2*>(fw) + (int64_t)blockIdx.y * fw_stride;
-  (void)ncell;
   for (RowWalk r(wave, L1); r.a2 < L2; r.advance(4, L1)) {
     const int g1 = wrap1(o1 + r.a1, g.nf[1]);
     const int g2 = RANK > 2 ? wrap1(o2 + r.a2, g.nf[2]) : 0;
     const int64_t rowbase = (int64_t)g.nf[0] * (g1 + (int64_t)g.nf[1] * g2);
     T2* lrow = tile + r.a2 * PS + r.a1 * LS;
-    // pad columns [L0, LS) are read by lanes dx >= w (their weight is 0): keep them finite
-    for (int a0 = lane; a0 < LS; a0 += 64) {
-      T2 v; v.x = (T)0; v.y = (T)0;
-      if (a0 < L0) v = in[rowbase + wrap1(o0 + a0, g.nf[0])];
-      lrow[a0] = v;
-    }
+    for (int a0 = lane; a0 < L0; a0 += 64) lrow[a0] = in[rowbase + wrap1(o0 + a0, g.nf[0])];
   }
   __syncthreads();
 
-  const int w = g.w, nc = g.ncoef;
-  T* st = stage_all + wave * (64 * kPer);
-  T* kxs = st;                 // [64][8]
-  T* kys = st + 64 * 8;        // [64][8]
-  T* kzs = st + 64 * 16;       // [64][8] (rank 3)
-  int2* meta = meta_all + wave * 64;
-  const int dx = lane & 7, pg = lane >> 3;
-  T* cc = c + 2 * (int64_t)blockIdx.y * c_stride;
-
-  // the next chunk's records are requested before this chunk is processed, so
-  // their HBM latency overlaps the gather below
-  Rec<T> rec_next;
-  if (p0 + wave * 64 + lane < p1) rec_next = sp.rec[p0 + wave * 64 + lane];
-  for (int base = p0 + wave * 64; base < p1; base += 4 * 64) {
-    const int j = base + lane;
-    const Rec<T> rec_cur = rec_next;
-    if (j + 4 * 64 < p1) rec_next = sp.rec[j + 4 * 64];
-    {
-      T kx[8], ky[8], kz[8];
-      int off = 0, idx = -1;
-      if (j < p1) {
-        const PointView<T> rec = unpack_rec<T, RANK>(rec_cur);
-        const uint32_t loc = rec.loc;
-        idx = rec.idx;
-        off = (int)(loc & 1023) + (int)((loc >> 10) & 1023) * LS + (RANK > 2 ? (int)((loc >> 20) & 1023) * PS : 0);
-        if (RANK == 2) horner8<T, 2>(horner, nc, rec.z0, rec.z1, (T)0, kx, ky, kz);
-        else horner8<T, 3>(horner, nc, rec.z0, rec.z1, rec.z2, kx, ky, kz);
-      } else {
+  const int nc = g.ncoef;
+  T2* cc = reinterpret_cast<T2*>(c) + (int64_t)blockIdx.y * c_stride;
+  for (int j = p0 + tid; j < p1; j += 256) {
+    const PointView<T> rec = unpack_rec<T, RANK>(sp.rec[j]);
+    T kx[W], ky[W], kz[W];
+    hornerW<T, RANK, W>(horner, nc, rec.z0, rec.z1, rec.z2, kx, ky, kz);
+    const T2* tp = tile + (int)(rec.loc & 1023) + (int)((rec.loc >> 10) & 1023) * LS +
+                   (RANK > 2 ? (int)((rec.loc >> 20) & 1023) * PS : 0);
+    T sre = (T)0, sim = (T)0;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { kx[q] = (T)0; ky[q] = (T)0; kz[q] = (T)0; }
-      }
+    for (int dz = 0; dz < (RANK > 2 ? W : 1); ++dz) {
+      T pre = (T)0, pim = (T)0;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        kxs[lane * 8 + q] = kx[q];
-        kys[lane * 8 + q] = ky[q];
-        if (RANK > 2) kzs[lane * 8 + q] = kz[q];
-      }
-      meta[lane] = make_int2(off, idx);
-    }
-    int npts = p1 - base;
-    if (npts > 64) npts = 64;
-    for (int q0 = 0; q0 < npts; q0 += 8) {
-      const int q = q0 + pg;                 // this lane group's point
-      const int2 m = meta[q];
-      const T kxv = kxs[q * 8 + dx];
-      // this lane group's ky[0..7]: two wide LDS reads instead of eight scalar ones
-      T kyr[8];
-      {
-        using T4 = typename Quad<T>::type;
-        const T4 lo = *reinterpret_cast<const T4*>(kys + q * 8);
-        const T4 hi = *reinterpret_cast<const T4*>(kys + q * 8 + 4);
-        kyr[0] = lo.x; kyr[1] = lo.y; kyr[2] = lo.z; kyr[3] = lo.w;
-        kyr[4] = hi.x; kyr[5] = hi.y; kyr[6] = hi.z; kyr[7] = hi.w;
-      }
-      T sre = (T)0, sim = (T)0;
-      const T2* tp = tile + m.x + dx;
-      if (RANK == 2) {
+      for (int dy = 0; dy < W; ++dy) {
+        const T2* row = tp + dz * PS + dy * LS;
+        T rre = (T)0, rim = (T)0;
 #pragma unroll
-        for (int dy = 0; dy < 8; ++dy) {
-          if (dy < w) {
-            const T2 v = tp[dy * LS];
-            sre = fma(kyr[dy], v.x, sre);
-            sim = fma(kyr[dy], v.y, sim);
-          }
+        for (int dx = 0; dx < W; ++dx) {
+          const T2 v = row[dx];
+          rre = fma(kx[dx], v.x, rre);
+          rim = fma(kx[dx], v.y, rim);
         }
-      } else {
-        for (int dz = 0; dz < w; ++dz) {
-          const T kzv = kzs[q * 8 + dz];
-          T lre = (T)0, lim = (T)0;
-#pragma unroll
-          for (int dy = 0; dy < 8; ++dy) {
-            if (dy < w) {
-              const T2 v = tp[dz * PS + dy * LS];
-              lre = fma(kyr[dy], v.x, lre);
-              lim = fma(kyr[dy], v.y, lim);
-            }
-          }
-          sre = fma(kzv, lre, sre);
-          sim = fma(kzv, lim, sim);
-        }
+        pre = fma(ky[dy], rre, pre);
+        pim = fma(ky[dy], rim, pim);
       }
-      sre = red8(sre * kxv);
-      sim = red8(sim * kxv);
-      if (dx == 0 && m.y >= 0) {
-        T2 r; r.x = sre * scale; r.y = sim * scale;
-        reinterpret_cast<T2*>(cc)[m.y] = r;
+      if (RANK > 2) {
+        sre = fma(kz[dz], pre, sre);
+        sim = fma(kz[dz], pim, sim);
+      } else {
+        sre = pre;
+        sim = pim;
       }
     }
+    T2 out;
+    out.x = sre * scale;
+    out.y = sim * scale;
+    cc[rec.idx] = out;
   }
 }
 
@@ -1520,7 +1482,7 @@ size_t interp_lds_bytes(const Geom& g, int method, int precision) {
   if (method != NUFFT_HIP_METHOD_TILE_WAVE) return 0;
   size_t cells = (size_t)g.lstride;
   for (int d = 1; d < g.rank; ++d) cells *= (size_t)g.ldim[d];
-  return cells * 2 * (size_t)precision + (size_t)precision * 4 * 64 * (g.rank == 2 ? 16 : 24) + 4 * 64 * 8;
+  return cells * 2 * (size_t)precision;
 }
 
 // Upper bound on the number of subproblems, known without reading the device:
@@ -1617,16 +1579,22 @@ hipError_t launch_interp(const Geom& g, int method, const SortedPoints<T>& sp, i
   dim3 grid(subproblem_grid(g, M), (unsigned)batch);
   if (method == NUFFT_HIP_METHOD_TILE_WAVE) {
     const size_t lds = interp_lds_bytes(g, method, (int)sizeof(T));
-    hipError_t e;
-    if (g.rank == 2) {
-      e = ensure_lds(interp_wave_kernel<T, 2>, lds);
-      if (e != hipSuccess) return e;
-      interp_wave_kernel<T, 2><<<grid, 256, lds, stream>>>(g, sp, horner, c, fw, c_stride, fw_stride, scale);
-    } else {
-      e = ensure_lds(interp_wave_kernel<T, 3>, lds);
-      if (e != hipSuccess) return e;
-      interp_wave_kernel<T, 3><<<grid, 256, lds, stream>>>(g, sp, horner, c, fw, c_stride, fw_stride, scale);
+    hipError_t e = hipSuccess;
+#define NUFFT_LAUNCH_IP(RR, WW)                                                                       \
+  case RR * 100 + WW:                                                                                 \
+    e = ensure_lds(interp_point_kernel<T, RR, WW>, lds);                                              \
+    if (e != hipSuccess) return e;                                                                    \
+    interp_point_kernel<T, RR, WW><<<grid, 256, lds, stream>>>(g, sp, horner, c, fw, c_stride, fw_stride, \
+                                                               scale);                                \
+    break;
+    switch (g.rank * 100 + g.w) {
+      NUFFT_LAUNCH_IP(2, 2) NUFFT_LAUNCH_IP(2, 3) NUFFT_LAUNCH_IP(2, 4) NUFFT_LAUNCH_IP(2, 5)
+      NUFFT_LAUNCH_IP(2, 6) NUFFT_LAUNCH_IP(2, 7) NUFFT_LAUNCH_IP(2, 8)
+      NUFFT_LAUNCH_IP(3, 2) NUFFT_LAUNCH_IP(3, 3) NUFFT_LAUNCH_IP(3, 4) NUFFT_LAUNCH_IP(3, 5)
+      NUFFT_LAUNCH_IP(3, 6) NUFFT_LAUNCH_IP(3, 7) NUFFT_LAUNCH_IP(3, 8)
+      default: return hipErrorInvalidValue;
     }
+#undef NUFFT_LAUNCH_IP
     return hipGetLastError();
   }
   switch (g.rank) {

@@ -56,4 +56,7 @@ if '5op' in which:
   for _ in range(5): out = tfft.nufft(c, pts, grid_shape=[512, 512], transform_type='type_1')
   torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
   print(f'cfg5 via tfft.nufft (op level, per-item points, 32 items): {dt*1e3:.3f} ms  {B*M/dt/1e6:.1f} Mpts/s')
+if '1dbig' in which:
+  run('1D t1 N=2^20 M=1e7 f32', 'type_1', [1 << 20], 10_000_000, 1e-6, steps=5)
+  run('1D t2 N=2^20 M=1e7 f32', 'type_2', [1 << 20], 10_000_000, 1e-6, steps=5)
 if '1' in which: run('cfg1 1D t1 N=4096 M=1e5 f64', 'type_1', [4096], 100_000, 1e-6, dtype=torch.complex128)
