@@ -14,6 +14,7 @@
 // stencil start, so the halo is one sided), the subproblem lookup (binary
 // search in a scanned array, no host sync) and the wavefront-per-point
 // scatter are specific to this build. Wavefront = 64 lanes throughout.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 
@@ -805,6 +806,7 @@ __device__ __forceinline__ double bcast_lane(double v, int lane) {
 template <typename T> struct Pair;
 template <> struct Pair<float> { using type = float2; };
 template <> struct Pair<double> { using type = double2; };
+template <typename T> using T2_t = typename Pair<T>::type;
 
 template <typename T, int RANK, int NW, int CH>
 __global__ __launch_bounds__(NW * 64) void spread_wave_kernel(
@@ -1243,44 +1245,51 @@ __global__ __launch_bounds__(256) void deconvolve_kernel(Geom g, int dir, T* __r
                                                          T* __restrict__ fw, const T* __restrict__ rf0,
                                                          const T* __restrict__ rf1,
                                                          const T* __restrict__ rf2) {
-  const int64_t N0 = g.nmodes[0], N1 = g.nmodes[1], N2 = g.nmodes[2];
-  const int64_t nf0 = g.nf[0], nf1 = g.nf[1], nf2 = g.nf[2];
-  const int64_t ntot = N0 * N1 * N2, nftot = nf0 * nf1 * nf2;
-  T* fb = f + 2 * (int64_t)blockIdx.y * ntot;
-  T* fwb = fw + 2 * (int64_t)blockIdx.y * nftot;
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // grid: x over the fastest dimension, y = row (second dimension), z = slab * batch;
+  // no per-element division
+  const int N0 = g.nmodes[0], N1 = g.nmodes[1], N2 = g.nmodes[2];
+  const int nf0 = g.nf[0], nf1 = g.nf[1], nf2 = g.nf[2];
+  const int64_t ntot = (int64_t)N0 * N1 * N2, nftot = (int64_t)nf0 * nf1 * nf2;
+  const int d2 = dir == 1 ? N2 : nf2;
+  const int b = blockIdx.z / d2;
+  const int i2 = blockIdx.z - b * d2;
+  const int i1 = blockIdx.y;
+  const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
+  T2_t<T>* fb = reinterpret_cast<T2_t<T>*>(f) + (int64_t)b * ntot;
+  T2_t<T>* fwb = reinterpret_cast<T2_t<T>*>(fw) + (int64_t)b * nftot;
   if (dir == 1) {
-    if (i >= ntot) return;
-    const int64_t a0 = i % N0, a1 = (i / N0) % N1, a2 = i / (N0 * N1);
-    const int64_t k0 = a0 - N0 / 2, k1 = a1 - N1 / 2, k2 = a2 - N2 / 2;
-    const int64_t w0 = k0 >= 0 ? k0 : nf0 + k0;
-    const int64_t w1 = k1 >= 0 ? k1 : nf1 + k1;
-    const int64_t w2 = k2 >= 0 ? k2 : nf2 + k2;
+    if (i0 >= N0) return;
+    const int k0 = i0 - N0 / 2, k1 = i1 - N1 / 2, k2 = i2 - N2 / 2;
+    const int w0 = k0 >= 0 ? k0 : nf0 + k0;
+    const int w1 = k1 >= 0 ? k1 : nf1 + k1;
+    const int w2 = k2 >= 0 ? k2 : nf2 + k2;
     T r = rf0[k0 < 0 ? -k0 : k0];
     if (g.rank > 1) r *= rf1[k1 < 0 ? -k1 : k1];
     if (g.rank > 2) r *= rf2[k2 < 0 ? -k2 : k2];
-    const int64_t wi = w0 + nf0 * (w1 + nf1 * w2);
-    fb[2 * i] = fwb[2 * wi] * r;
-    fb[2 * i + 1] = fwb[2 * wi + 1] * r;
+    const T2_t<T> v = fwb[w0 + (int64_t)nf0 * (w1 + (int64_t)nf1 * w2)];
+    T2_t<T> o;
+    o.x = v.x * r;
+    o.y = v.y * r;
+    fb[i0 + (int64_t)N0 * (i1 + (int64_t)N1 * i2)] = o;
   } else {
-    if (i >= nftot) return;
-    const int64_t w0 = i % nf0, w1 = (i / nf0) % nf1, w2 = i / (nf0 * nf1);
+    if (i0 >= nf0) return;
     // kept modes: k in [-(N/2), (N-1)/2]
-    int64_t k0 = w0 <= (N0 - 1) / 2 ? w0 : w0 - nf0;
-    int64_t k1 = w1 <= (N1 - 1) / 2 ? w1 : w1 - nf1;
-    int64_t k2 = w2 <= (N2 - 1) / 2 ? w2 : w2 - nf2;
+    const int k0 = i0 <= (N0 - 1) / 2 ? i0 : i0 - nf0;
+    const int k1 = i1 <= (N1 - 1) / 2 ? i1 : i1 - nf1;
+    const int k2 = i2 <= (N2 - 1) / 2 ? i2 : i2 - nf2;
     const bool keep = k0 >= -(N0 / 2) && k1 >= -(N1 / 2) && k2 >= -(N2 / 2);
-    T vre = 0, vim = 0;
+    T2_t<T> o;
+    o.x = (T)0;
+    o.y = (T)0;
     if (keep) {
       T r = rf0[k0 < 0 ? -k0 : k0];
       if (g.rank > 1) r *= rf1[k1 < 0 ? -k1 : k1];
       if (g.rank > 2) r *= rf2[k2 < 0 ? -k2 : k2];
-      const int64_t fi = (k0 + N0 / 2) + N0 * ((k1 + N1 / 2) + N1 * (k2 + N2 / 2));
-      vre = fb[2 * fi] * r;
-      vim = fb[2 * fi + 1] * r;
+      const T2_t<T> v = fb[(k0 + N0 / 2) + (int64_t)N0 * ((k1 + N1 / 2) + (int64_t)N1 * (k2 + N2 / 2))];
+      o.x = v.x * r;
+      o.y = v.y * r;
     }
-    fwb[2 * i] = vre;
-    fwb[2 * i + 1] = vim;
+    fwb[i0 + (int64_t)nf0 * (i1 + (int64_t)nf1 * i2)] = o;
   }
 }
 
@@ -1623,11 +1632,21 @@ template hipError_t launch_interp<double>(const Geom&, int, const SortedPoints<d
 template <typename T>
 hipError_t launch_deconvolve(const Geom& g, int dir, T* f, T* fw, const T* const rfser[3],
                              int batch, hipStream_t stream) {
-  int64_t n = 1;
-  for (int d = 0; d < 3; ++d) n *= (dir == 1) ? g.nmodes[d] : g.nf[d];
-  if (n == 0 || batch == 0) return hipSuccess;
-  dim3 grid(blocks_for(n, 256), (unsigned)batch);
-  deconvolve_kernel<T><<<grid, 256, 0, stream>>>(g, dir, f, fw, rfser[0], rfser[1], rfser[2]);
+  const int d0 = dir == 1 ? g.nmodes[0] : g.nf[0];
+  const int d1 = dir == 1 ? g.nmodes[1] : g.nf[1];
+  const int d2 = dir == 1 ? g.nmodes[2] : g.nf[2];
+  if (d0 == 0 || d1 == 0 || d2 == 0 || batch == 0) return hipSuccess;
+  // gridDim.y / .z are limited to 65535: fall back to looping the batch
+  if (d1 > 65535) return hipErrorInvalidValue;
+  const int per_launch = std::max(1, 65535 / d2);
+  for (int b0 = 0; b0 < batch; b0 += per_launch) {
+    const int nb = std::min(per_launch, batch - b0);
+    int64_t nel = (int64_t)g.nmodes[0] * g.nmodes[1] * g.nmodes[2];
+    int64_t nfel = (int64_t)g.nf[0] * g.nf[1] * g.nf[2];
+    dim3 grid(blocks_for(d0, 256), (unsigned)d1, (unsigned)(d2 * nb));
+    deconvolve_kernel<T><<<grid, 256, 0, stream>>>(g, dir, f + 2 * b0 * nel, fw + 2 * b0 * nfel, rfser[0],
+                                                   rfser[1], rfser[2]);
+  }
   return hipGetLastError();
 }
 template hipError_t launch_deconvolve<float>(const Geom&, int, float*, float*, const float* const[3],

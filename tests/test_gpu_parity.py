@@ -509,3 +509,32 @@ def test_tiny_and_odd_grids(tfft, grid, ttype):
     ref = tfft.nudft(src.astype(np.complex128), pts.astype(np.float64), grid_shape=grid if ttype == 'type_1' else None,
                      transform_type=ttype)
     assert rel_l2(out, ref) < tol, (grid, ttype, tol, rel_l2(out, ref))
+
+
+def test_set_points_and_execute_capture_into_a_hip_graph(tfft):
+  # after warm-up neither call allocates or synchronises, so the whole transform
+  # (sort, spread, rocFFT, deconvolve) can be captured once and replayed
+  import torch
+  rng = np.random.default_rng(61)
+  M, grid = 200000, [256, 256]
+  pts = _dev(rng.uniform(-np.pi, np.pi, (M, 2)).astype(np.float32))
+  c1 = _dev((rng.standard_normal(M) + 1j * rng.standard_normal(M)).astype(np.complex64))
+  s = torch.cuda.Stream()
+  with torch.cuda.stream(s):
+    plan = tfft.Plan('type_1', grid, 'forward', tol=1e-6)
+    out = torch.empty(grid, dtype=torch.complex64, device='cuda')
+    cbuf = c1.clone()
+    for _ in range(2):
+      plan.set_points(pts); plan.execute(cbuf, out=out)
+    s.synchronize()
+    ref1 = out.clone()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+      plan.set_points(pts); plan.execute(cbuf, out=out)
+    out.zero_()
+    graph.replay(); s.synchronize()
+    assert rel_l2(out.cpu().numpy(), ref1.cpu().numpy()) < 1e-6
+    cbuf.copy_(2.0 * c1)          # new strengths in the captured buffer
+    graph.replay(); s.synchronize()
+    assert rel_l2(out.cpu().numpy(), 2.0 * ref1.cpu().numpy()) < 1e-6
+    plan.close()
