@@ -305,7 +305,6 @@ int nufft_hip_op_compute(const nufft_hip_op_desc* desc, const void* source, cons
     release_all();
     return fail(errbuf, errbuf_len, NUFFT_HIP_INTERNAL, std::string("HIP error: ") + hipGetErrorString(e));
   };
-  std::vector<int64_t> tperm_shape, tt_strides_for_back;
   if (a.transpose) {
     // tsource[outer.., inner.., elem..] = source[perm]
     std::vector<int64_t> sst = contiguous_strides(sshape), oshape(s_nd), ostr(s_nd);

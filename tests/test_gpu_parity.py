@@ -278,6 +278,16 @@ def test_error_messages(tfft):
   with pytest.raises(tfft.InvalidArgumentError, match='Dimension must be 1, 2 or 3'):
     tfft.nufft(_dev(src), _dev(np.zeros((10, 4), np.float32)), grid_shape=[8, 8, 8, 8], transform_type='type_1')
   tfft.nufft(_dev(np.zeros((8, 8), np.complex64)), _dev(pts), transform_type='type_2')   # no grid_shape needed
+  # spread / interp-only ops need an even, 2-3-5-smooth grid >= 2 w (nufft_plan.h:829-837)
+  with pytest.raises(tfft.InvalidArgumentError, match='Invalid grid dimension size: 14'):
+    tfft.spread(_dev(src), _dev(pts), [14, 64])
+  with pytest.raises(tfft.InvalidArgumentError, match='Invalid grid dimension size: 66'):
+    tfft.interp(_dev(np.zeros((64, 66), np.complex64)), _dev(pts))
+  with pytest.raises(tfft.InvalidArgumentError, match='Incompatible shapes'):
+    tfft.nufft(_dev(np.zeros((3, 10), np.complex64)), _dev(np.zeros((2, 10, 2), np.float32)), grid_shape=[8, 8],
+               transform_type='type_1')
+  with pytest.raises(tfft.InvalidArgumentError, match='must have type'):
+    tfft.nufft(_dev(src), _dev(pts.astype(np.float64)), grid_shape=[8, 8], transform_type='type_1')
 
 
 def test_empty_and_tiny_inputs(tfft):
