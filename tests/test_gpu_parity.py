@@ -548,3 +548,30 @@ def test_set_points_and_execute_capture_into_a_hip_graph(tfft):
     graph.replay(); s.synchronize()
     assert rel_l2(out.cpu().numpy(), 2.0 * ref1.cpu().numpy()) < 1e-6
     plan.close()
+
+
+def test_partial_last_batch_and_plan_lifecycle(tfft):
+  # 11 transforms with the default batch of 8 => one full batch + a batch of 3 (second rocFFT plan);
+  # then create/destroy many plans to catch leaks or stale state
+  import torch
+  rng = np.random.default_rng(71)
+  M, grid = 5000, [40, 48]
+  pts = rng.uniform(-np.pi, np.pi, (M, 2)).astype(np.float32)
+  c = (rng.standard_normal((11, M)) + 1j * rng.standard_normal((11, M))).astype(np.complex64)
+  out = tfft.nufft(_dev(c), _dev(pts), grid_shape=grid, transform_type='type_1').cpu().numpy()
+  for t in (0, 7, 8, 10):
+    one = tfft.nufft(_dev(c[t]), _dev(pts), grid_shape=grid, transform_type='type_1').cpu().numpy()
+    assert rel_l2(out[t], one) < 1e-6, t
+  f = (rng.standard_normal([11] + grid) + 1j * rng.standard_normal([11] + grid)).astype(np.complex64)
+  out2 = tfft.nufft(_dev(f), _dev(pts), transform_type='type_2').cpu().numpy()
+  for t in (0, 8, 10):
+    one = tfft.nufft(_dev(f[t]), _dev(pts), transform_type='type_2').cpu().numpy()
+    assert rel_l2(out2[t], one) < 1e-6, t
+  free0 = torch.cuda.mem_get_info()[0]
+  for i in range(30):
+    p = tfft.Plan('type_1', [64 + 2 * i, 64], 'forward', tol=1e-5)
+    p.set_points(_dev(pts))
+    p.execute(_dev(c[0]))
+    p.close()
+  torch.cuda.synchronize()
+  assert torch.cuda.mem_get_info()[0] > free0 - (64 << 20)   # nothing substantial leaked
