@@ -575,3 +575,24 @@ def test_partial_last_batch_and_plan_lifecycle(tfft):
     p.close()
   torch.cuda.synchronize()
   assert torch.cuda.mem_get_info()[0] > free0 - (64 << 20)   # nothing substantial leaked
+
+
+@pytest.mark.parametrize('sigma', [1.25, 1.5, 2.0])
+def test_other_upsampling_factors(tfft, sigma):
+  # InternalOptions::upsampling_factor (cc/kernels/nufft_options.h:117-120): the kernel fit
+  # and the width rule work for any sigma > 1 (the reference GPU path has sigma = 2 tables only).
+  # With sigma = 1.25 the width rule itself misses tol by a small factor.
+  import torch
+  from oracle import oracle
+  rng = np.random.default_rng(81)
+  grid, M = [60, 72], 20000
+  pts = rng.uniform(-np.pi, np.pi, (M, 2))
+  c = rng.standard_normal(M) + 1j * rng.standard_normal(M)
+  truth = oracle.nudft(c, pts, grid, 'type_1', 'forward')
+  for tol in (1e-4, 1e-8):
+    plan = tfft.Plan('type_1', grid, 'forward', tol=tol, dtype=torch.complex128, upsampling_factor=sigma)
+    assert abs(plan.info().upsampling_factor - sigma) < 1e-12
+    plan.set_points(_dev(pts))
+    out = plan.execute(_dev(c)).cpu().numpy()
+    plan.close()
+    assert rel_l2(out, truth) < (tol if sigma == 2.0 else 6 * tol), (sigma, tol, rel_l2(out, truth))
