@@ -32,6 +32,7 @@ struct Geom {
   int ntiles;       // product of ntile
   int max_sub;      // points per subproblem
   int nmodes[3];    // N, x fastest
+  int fixed_point;  // 3-D float spread accumulates packed 32+32-bit fixed point in LDS
 };
 
 // Per-point record in tile-sorted order. float: 16 bytes, one dwordx4 access;

@@ -928,31 +928,69 @@ __global__ __launch_bounds__(NW * 64) void spread_wave_kernel(
 
 // ------------------------- spread: 3-D wavefront path with compile-time width
 
-// Same scheme as spread_wave_kernel<T, 3, ...> with the kernel width W as a
-// template parameter: the per-point body is straight-line code (2 v_readlane,
-// 2 multiplies, 2 conversions, 2 ds_add_f64 per z-plane), so the only LDS wait
-// in the loop is a counted one on the prefetched kx/ky reads and the atomics
-// of consecutive points stream back to back. (With a run-time width the
-// compiler drains the LDS queue, lgkmcnt(0), after every point: measured 45 %
-// LDS-array activity against 82 % for the 2-D kernel, profiles/r01_pmc_*.)
-template <typename T, int W, int NW, int CH>
+// Same scheme as spread_wave_kernel<T, 3, ...> with the kernel width W and the
+// tile depth TZ as template parameters (tile 16 x 16 x TZ, row stride 24): every
+// LDS offset of the per-point body is an immediate and the body is straight-line
+// code -- no exec-masked branch (lanes outside the W x W patch add 0 at their
+// natural patch address), so the only LDS wait in the loop is a COUNTED one on the
+// prefetched kx/ky reads and the atomics of consecutive points stream back to
+// back. History (r01, config 4): run-time width, LDS reads for the z factors,
+// lgkmcnt(0) after every point: 35 ms, 45 % LDS-array activity; W-templated
+// with v_readlane broadcasts: 24 ms; this form: see DESIGN.md.
+//
+// FX = false: two fp64 planes, 2 W ds_add_f64 per point.
+// FX = true (float, W <= 6, i.e. tol >= ~1e-4): ONE 64-bit integer per cell
+// holding (re, im) as two signed 32-bit fixed-point fields, W ds_add_u64 per
+// point. X = re_i 2^32 + im_i is added exactly (the sign extension of im_i is
+// folded into the upper half), so the fields cannot interfere while each sum
+// fits in 32 bits. The scale is per subproblem: 2^31 / sum_j max(|re c_j|,
+// |im c_j|), the true worst-case bound of any cell (kernel values <= 1), from
+// a first pass over the subproblem's strengths -- one huge strength only
+// coarsens its own subproblem. Quantisation <= 0.5 LSB per contribution; worst
+// case 2^-32 n w^1.5 ||c_sub|| (n <= 4096: 1.4e-5), typically ~1e-6 relative.
+template <typename T, int W, int TZ, int NW, int CH, bool FX>
 __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
     Geom g, SortedPoints<T> sp, const T* __restrict__ horner, const T* __restrict__ c,
     T* __restrict__ fw, int64_t c_stride, int64_t fw_stride, T scale) {
+  using T2 = typename Pair<T>::type;
+  constexpr int LS = 24, L0 = 16 + W - 1, L1 = 16 + W - 1, L2 = TZ + W - 1;
+  constexpr int PS = LS * L1;
+  constexpr int plane = PS * L2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int LS = g.lstride;
-  const int L0 = g.ldim[0], L1 = g.ldim[1], L2 = g.ldim[2];
-  const int PS = LS * L1;
-  const int plane = PS * L2;
-  double* plane_re = reinterpret_cast<double*>(smem_raw);
-  double* plane_im = plane_re + plane;
-  T* stage_all = reinterpret_cast<T*>(plane_im + plane);
+  double* plane_re = reinterpret_cast<double*>(smem_raw);             // FX: the packed plane
+  double* plane_im = plane_re + (FX ? 0 : plane);
+  double* pad = plane_re + (FX ? 1 : 2) * plane;                      // 64 elements of spill room
+  T* stage_all = reinterpret_cast<T*>(pad + 64);
+  float* red = reinterpret_cast<float*>(stage_all + NW * CH * 16);    // [NW] (FX bound reduction)
   int tb, p0, p1;
   if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1)) return;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  for (int i = tid; i < 2 * plane; i += NW * 64) plane_re[i] = 0.0;
+  for (int i = tid; i < (FX ? 1 : 2) * plane + 64; i += NW * 64) plane_re[i] = 0.0;
+  const T2* cc = reinterpret_cast<const T2*>(c) + (int64_t)blockIdx.y * c_stride;
+  const int npt = p1 - p0;
+
+  T pre = scale;     // multiplies the strengths (FX: also converts to LSB units)
+  T lsb = (T)1;
+  if (FX) {
+    float part = 0.f;
+    for (int j = p0 + tid; j < p1; j += NW * 64) {
+      const T2 cv = cc[unpack_rec<T, 3>(sp.rec[j]).idx];
+      part += fmaxf(fabsf((float)cv.x), fabsf((float)cv.y));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o);
+    if (lane == 0) red[wave] = part;
+    __syncthreads();
+    float bound = 0.f;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) bound += red[k];
+    bound *= fabsf((float)scale);
+    const float room = 2147483000.f - (float)npt;   // 2^31 minus the rounding of every contribution
+    pre = bound > 0.f ? (T)((float)scale * (room / bound)) : (T)0;
+    lsb = bound > 0.f ? (T)(bound / room) : (T)0;
+  }
   __syncthreads();
 
   const int nc = g.ncoef;
@@ -961,32 +999,31 @@ __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
   const int dx = lane & 7, dy = lane >> 3;
   const bool active = dx < W && dy < W;
   const int cell = dy * LS + dx;
-  const T* cc = c + 2 * (int64_t)blockIdx.y * c_stride;
-
-  // each wave takes an equal contiguous share of the subproblem's points
-  const int share = (p1 - p0 + NW - 1) / NW;
+  const int share = (npt + NW - 1) / NW;
   const int wbeg = p0 + wave * share;
   const int wend = (wbeg + share < p1) ? wbeg + share : p1;
+
   for (int base = wbeg; base < wend; base += CH) {
     const int j = base + lane;
     int off = 0;
-    T klr[W], kli[W];
+    T kz[W];
+    T cre = (T)0, cim = (T)0;
 #pragma unroll
-    for (int q = 0; q < W; ++q) { klr[q] = (T)0; kli[q] = (T)0; }
+    for (int q = 0; q < W; ++q) kz[q] = (T)0;
     if (lane < CH) {
       T kx[W], ky[W];
 #pragma unroll
       for (int q = 0; q < W; ++q) { kx[q] = (T)0; ky[q] = (T)0; }
       if (j < wend) {
         const PointView<T> rec = unpack_rec<T, 3>(sp.rec[j]);
-        const uint32_t loc = rec.loc;
-        const int idx = rec.idx;
-        const T re = cc[2 * (int64_t)idx] * scale, im = cc[2 * (int64_t)idx + 1] * scale;
-        off = (int)(loc & 1023) + (int)((loc >> 10) & 1023) * LS + (int)((loc >> 20) & 1023) * PS;
+        const T2 cv = cc[rec.idx];
+        cre = cv.x * pre;
+        cim = cv.y * pre;
+        off = (int)(rec.loc & 1023) + (int)((rec.loc >> 10) & 1023) * LS + (int)((rec.loc >> 20) & 1023) * PS;
         T h0[8], h1[8], h2[8];
         horner8<T, 3>(horner, nc, rec.z0, rec.z1, rec.z2, h0, h1, h2);
 #pragma unroll
-        for (int q = 0; q < W; ++q) { kx[q] = h0[q]; ky[q] = h1[q]; klr[q] = h2[q] * re; kli[q] = h2[q] * im; }
+        for (int q = 0; q < W; ++q) { kx[q] = h0[q]; ky[q] = h1[q]; kz[q] = h2[q]; }
       }
 #pragma unroll
       for (int q = 0; q < W; ++q) {
@@ -996,35 +1033,67 @@ __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
     }
     int npts = wend - base;
     if (npts > CH) npts = CH;
-    // z factor x strength: same for every lane of a pass -> v_readlane from the
-    // owning lane's registers (all lanes execute the readlanes; only the w x w
-    // patch issues atomics)
-    T a_n = (T)0;
-    if (active) a_n = kxs[dx] * kys[dy];
+    // raw staging values of the NEXT point are requested before this point's atomics
+    T kx_n = kxs[dx], ky_n = kys[dy];
     for (int q = 0; q < npts; ++q) {
-      const T a = a_n;
+      // lanes outside the patch read unwritten staging slots: force their weight to 0
+      const T a = active ? kx_n * ky_n : (T)0;
       const int qn = (q + 1 < npts) ? q + 1 : q;
-      if (active) a_n = kxs[qn * 8 + dx] * kys[qn * 8 + dy];
+      kx_n = kxs[qn * 8 + dx];
+      ky_n = kys[qn * 8 + dy];
       const int o = __builtin_amdgcn_readlane(off, q) + cell;
-      T br[W], bi[W];
+      const T ar = a * bcast_lane(cre, q);
+      const T ai = a * bcast_lane(cim, q);
+      // Lanes outside the W x W patch add 0 at their natural 8 x 8 patch address
+      // (keeps the body branch-free, the offsets immediate and the bank pattern
+      // conflict free). Those addresses stay inside LDS: columns < 24 = LS, and
+      // rows >= L1 fall into the first rows of the next z-plane / the next
+      // component plane / the 64-element pad behind the planes.
+      double* pr = plane_re + o;
+      double* pi = plane_im + o;
 #pragma unroll
       for (int dz = 0; dz < W; ++dz) {
-        br[dz] = bcast_lane(klr[dz], q);
-        bi[dz] = bcast_lane(kli[dz], q);
-      }
-      if (active) {
-#pragma unroll
-        for (int dz = 0; dz < W; ++dz) {
-          lds_add(&plane_re[o + dz * PS], (double)(a * br[dz]));
-          lds_add(&plane_im[o + dz * PS], (double)(a * bi[dz]));
+        const T kzq = bcast_lane(kz[dz], q);
+        if (FX) {
+          const int ir = __float2int_rn((float)(ar * kzq));
+          const int ii = __float2int_rn((float)(ai * kzq));
+          const unsigned hi = (unsigned)(ir + (ii >> 31));   // + sign extension of the low field
+          const unsigned long long x = ((unsigned long long)hi << 32) | (unsigned)ii;
+          atomicAdd(reinterpret_cast<unsigned long long*>(pr) + dz * PS, x);
+        } else {
+          lds_add(pr + dz * PS, (double)(ar * kzq));
+          lds_add(pi + dz * PS, (double)(ai * kzq));
         }
       }
     }
   }
   __syncthreads();
 
-  (void)L0; (void)L2;
-  tile_to_grid<T, 3>(g, plane_re, plane_im, LS, PS, tb, fw + 2 * (int64_t)blockIdx.y * fw_stride, wave, NW, lane);
+  // write-out: (FX: unpack, scale back,) add to the periodic fine grid
+  const int t0 = tb % g.ntile[0];
+  const int t1 = (tb / g.ntile[0]) % g.ntile[1];
+  const int t2 = tb / (g.ntile[0] * g.ntile[1]);
+  const int o0 = t0 * 16, o1 = t1 * 16, o2 = t2 * TZ;
+  T* out = fw + 2 * (int64_t)blockIdx.y * fw_stride;
+  for (RowWalk r(wave, L1); r.a2 < L2; r.advance(NW, L1)) {
+    const int g1 = wrap1(o1 + r.a1, g.nf[1]);
+    const int g2 = wrap1(o2 + r.a2, g.nf[2]);
+    const int64_t rowbase = (int64_t)g.nf[0] * (g1 + (int64_t)g.nf[1] * g2);
+    const int lrow = r.a2 * PS + r.a1 * LS;
+    for (int e = lane; e < 2 * L0; e += 64) {
+      const int a0 = e >> 1, comp = e & 1;
+      T v;
+      if (FX) {
+        const long long t = (long long)reinterpret_cast<const unsigned long long*>(plane_re)[lrow + a0];
+        const int im_sum = (int)(unsigned)(t & 0xffffffffll);
+        const int re_sum = (int)((t - (long long)im_sum) >> 32);
+        v = (T)(comp ? im_sum : re_sum) * lsb;
+      } else {
+        v = (T)(comp ? plane_im : plane_re)[lrow + a0];
+      }
+      if (v != (T)0) glb_add(&out[2 * (rowbase + wrap1(o0 + a0, g.nf[0])) + comp], v);
+    }
+  }
 }
 
 // ---------------- interp: LDS tile, one thread per point, compile-time width
@@ -1466,7 +1535,7 @@ bool wave_method_supported(const Geom& g, int precision) {
   (void)precision;
   if (g.w > 8) return false;
   if (g.rank == 2) return g.tile[0] == 32 && g.tile[1] == 32;
-  if (g.rank == 3) return g.tile[0] == 16 && g.tile[1] == 16 && (g.tile[2] == 4 || g.tile[2] == 8 || g.tile[2] == 2);
+  if (g.rank == 3) return g.tile[0] == 16 && g.tile[1] == 16 && (g.tile[2] == 4 || (g.tile[2] == 8 && g.w <= 6));
   return false;
 }
 int wave_lstride(int rank) { return rank == 2 ? 40 : 24; }
@@ -1482,7 +1551,8 @@ size_t spread_lds_bytes(const Geom& g, int method, int precision) {
       return sizeof(double) * 2 * kWPlane + sizeof(float) * wave8_nw() * wave8_ch() * kWW * 3;
     if (g.rank == 2) return cells * 2 * sizeof(double) + (size_t)precision * 4 * 64 * 24;
     const int nw = precision == NUFFT_HIP_F32 ? 16 : 8;
-    return cells * 2 * sizeof(double) + (size_t)precision * nw * 32 * 16;
+    return cells * (g.fixed_point ? 1 : 2) * sizeof(double) + 64 * sizeof(double) +
+           (size_t)precision * nw * 32 * 16 + 256;
   }
   return cells * 2 * sizeof(double);
 }
@@ -1535,18 +1605,31 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
                                                                         fw_stride, scale);
     } else {
       constexpr int nw = wave3d_nw<T>();
-#define NUFFT_LAUNCH_W3(WW)                                                                      \
+#define NUFFT_LAUNCH_W3(WW, TZV, FXV)                                                            \
+  e = ensure_lds(spread_wave3_kernel<T, WW, TZV, nw, 32, FXV>, lds_bytes);                        \
+  if (e != hipSuccess) return e;                                                                 \
+  spread_wave3_kernel<T, WW, TZV, nw, 32, FXV><<<grid, nw * 64, lds_bytes, stream>>>(            \
+      g, sp, horner, c, fw, c_stride, fw_stride, scale);
+#define NUFFT_CASE_W3(WW)                                                                        \
   case WW:                                                                                       \
-    e = ensure_lds(spread_wave3_kernel<T, WW, nw, 32>, lds_bytes);                               \
-    if (e != hipSuccess) return e;                                                               \
-    spread_wave3_kernel<T, WW, nw, 32><<<grid, nw * 64, lds_bytes, stream>>>(g, sp, horner, c, fw, \
-                                                                           c_stride, fw_stride, scale); \
+    if (g.tile[2] == 8) {                                                                        \
+      if constexpr (WW <= 6) {                                                                   \
+        if (g.fixed_point) {                                                                     \
+          if constexpr (sizeof(T) == 4) { NUFFT_LAUNCH_W3(WW, 8, true) } else { return hipErrorInvalidValue; } \
+        } else { NUFFT_LAUNCH_W3(WW, 8, false) }                                                 \
+      } else { return hipErrorInvalidValue; }                                                    \
+    } else if (g.tile[2] == 4) {                                                                 \
+      if (g.fixed_point) {                                                                       \
+        if constexpr (sizeof(T) == 4 && WW <= 6) { NUFFT_LAUNCH_W3(WW, 4, true) } else { return hipErrorInvalidValue; } \
+      } else { NUFFT_LAUNCH_W3(WW, 4, false) }                                                   \
+    } else { return hipErrorInvalidValue; }                                                      \
     break;
       switch (g.w) {
-        NUFFT_LAUNCH_W3(2) NUFFT_LAUNCH_W3(3) NUFFT_LAUNCH_W3(4) NUFFT_LAUNCH_W3(5)
-        NUFFT_LAUNCH_W3(6) NUFFT_LAUNCH_W3(7) NUFFT_LAUNCH_W3(8)
+        NUFFT_CASE_W3(2) NUFFT_CASE_W3(3) NUFFT_CASE_W3(4) NUFFT_CASE_W3(5)
+        NUFFT_CASE_W3(6) NUFFT_CASE_W3(7) NUFFT_CASE_W3(8)
         default: return hipErrorInvalidValue;
       }
+#undef NUFFT_CASE_W3
 #undef NUFFT_LAUNCH_W3
     }
     return hipGetLastError();

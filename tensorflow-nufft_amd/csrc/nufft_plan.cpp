@@ -734,6 +734,16 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
                 "spread_method TILE_WAVE needs rank 2 or 3, kernel width <= 8 and the default tile sizes");
   }
   p->method = method;
+  // packed fixed-point accumulation: 3-D float wavefront kernel at w <= 6 (tol >= ~1e-4)
+  g.fixed_point = 0;
+  if (method == NUFFT_HIP_METHOD_TILE_WAVE && rank == 3 && precision == NUFFT_HIP_F32 && w <= 6 &&
+      p->opts.lds_accumulate != 1)
+    g.fixed_point = 1;
+  if (p->opts.lds_accumulate == 2 && !g.fixed_point) {
+    delete p;
+    return fail(NUFFT_HIP_INVALID_ARGUMENT,
+                "lds_accumulate = 2 (fixed point) needs the 3-D float wavefront method with kernel width <= 6");
+  }
   if (method == NUFFT_HIP_METHOD_TILE_WAVE) g.lstride = wave_lstride(rank);
   // wavefront kernels: one subproblem per typical tile measured fastest (r01 sweeps);
   // every extra subproblem of a tile repeats its zero-fill and write-out

@@ -50,7 +50,8 @@ class OptionsStruct(ctypes.Structure):
               ('spread_method', ctypes.c_int32),
               ('max_subproblem_size', ctypes.c_int32),
               ('tile_dims', ctypes.c_int32 * 3),
-              ('reserved', ctypes.c_int32 * 8)]
+              ('lds_accumulate', ctypes.c_int32),
+              ('reserved', ctypes.c_int32 * 7)]
 
 
 class PlanInfo(ctypes.Structure):

@@ -596,3 +596,34 @@ def test_other_upsampling_factors(tfft, sigma):
     out = plan.execute(_dev(c)).cpu().numpy()
     plan.close()
     assert rel_l2(out, truth) < (tol if sigma == 2.0 else 6 * tol), (sigma, tol, rel_l2(out, truth))
+
+
+@pytest.mark.parametrize('tol', [1e-2, 1e-3, 1e-4])
+def test_fixed_point_lds_accumulation_3d(tfft, tol):
+  # 3-D float, w <= 6: packed 32+32-bit fixed-point LDS accumulation (lds_accumulate = 2, the
+  # default there) against double accumulation (= 1) and the fp64 oracle; including strengths
+  # with a 1e6 dynamic range and a dense cluster (per-subproblem scaling)
+  import torch
+  from oracle import oracle
+  rng = np.random.default_rng(91)
+  grid, M = [40, 48, 36], 60000
+  pts = rng.uniform(-np.pi, np.pi, (M, 3)).astype(np.float32)
+  pts[:20000] = (0.03 * rng.standard_normal((20000, 3)) - 0.7).astype(np.float32)
+  for name, c in (('uniform', rng.uniform(-.5, .5, M) + 1j * rng.uniform(-.5, .5, M)),
+                  ('dynamic-range', (rng.standard_normal(M) + 1j * rng.standard_normal(M)) *
+                   10.0 ** rng.uniform(-3, 3, M)),
+                  ('one-huge', np.where(np.arange(M) == 777, 1e6, 1.0) * (rng.standard_normal(M) + 0.3j))):
+    c = c.astype(np.complex64)
+    truth = oracle.nufft(c.astype(np.complex128), pts, grid, 'type_1', 'forward', tol=1e-12)
+    errs = {}
+    for mode in (1, 2, 0):
+      plan = tfft.Plan('type_1', grid, 'forward', tol=tol, lds_accumulate=mode)
+      assert plan.info().kernel_width <= 6 and plan.info().spread_method == 2
+      plan.set_points(_dev(pts))
+      errs[mode] = rel_l2(plan.execute(_dev(c)).cpu().numpy(), truth)
+      plan.close()
+      assert errs[mode] < tol, (name, mode, errs)
+    assert errs[0] == pytest.approx(errs[2], rel=0.5) or errs[0] < 0.1 * tol   # auto = fixed point here
+    assert errs[2] < errs[1] + 0.05 * tol, (name, errs)
+  with pytest.raises(tfft.InvalidArgumentError, match='fixed point'):
+    tfft.Plan('type_1', grid, 'forward', tol=1e-6, lds_accumulate=2)
