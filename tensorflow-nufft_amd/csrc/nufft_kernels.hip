@@ -784,15 +784,6 @@ __global__ __launch_bounds__(NW * 64) void spread_2d_w8_wave_kernel(
   }
 }
 
-// ----------------- spread: wavefront-per-point path, any w <= 8, rank 2 or 3
-
-// Generalisation of the kernel above. Lanes are laid out as an 8 x 8 (dy, dx)
-// patch of which the w x w sub-patch is active; rank 3 loops over dz with the
-// same patch (2 ds_add_f64 per point and z-plane). The LDS row stride must be
-// 8 or 24 (mod 32) fp64 elements so that the four rows of a half-wave land in
-// disjoint bank groups (2-D: tile 32x32, stride 40; 3-D: tile 16x16x4, stride
-// 24). Staging per point: kx[8], ky[8] (rank 3), and the last dimension's
-// kernel values multiplied by the strength, (k*re, k*im)[8].
 __device__ __forceinline__ float bcast_lane(float v, int lane) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
@@ -808,127 +799,90 @@ template <> struct Pair<float> { using type = float2; };
 template <> struct Pair<double> { using type = double2; };
 template <typename T> using T2_t = typename Pair<T>::type;
 
-template <typename T, int RANK, int NW, int CH>
-__global__ __launch_bounds__(NW * 64) void spread_wave_kernel(
+// --------------------- spread: 2-D wavefront path with compile-time width
+
+// The 2-D kernel for every width <= 8 and both precisions, in the branch-free
+// form of the 3-D kernel below: tile 32 x 32, row stride 40, lanes outside the
+// W x W patch add 0 at their natural 8 x 8 patch address (rows beyond the tile
+// fall into the next component plane or the 256-element pad behind the planes).
+template <typename T, int W, int NW, int CH>
+__global__ __launch_bounds__(NW * 64) void spread_wave2_kernel(
     Geom g, SortedPoints<T> sp, const T* __restrict__ horner, const T* __restrict__ c,
     T* __restrict__ fw, int64_t c_stride, int64_t fw_stride, T scale) {
   using T2 = typename Pair<T>::type;
+  constexpr int LS = 40, L0 = 32 + W - 1, L1 = 32 + W - 1;
+  constexpr int plane = LS * L1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int LS = g.lstride;
-  const int L0 = g.ldim[0], L1 = g.ldim[1];
-  const int L2 = RANK > 2 ? g.ldim[2] : 1;
-  const int PS = LS * L1;              // z-plane stride (elements)
-  const int plane = PS * L2;           // elements per component plane
   double* plane_re = reinterpret_cast<double*>(smem_raw);
   double* plane_im = plane_re + plane;
-  constexpr int kPer = (RANK == 2) ? (8 + 16) : (8 + 8 + 16);   // T words per staged point
-  T* stage_all = reinterpret_cast<T*>(plane_im + plane);
+  T* stage_all = reinterpret_cast<T*>(plane_im + plane + 256);
   int tb, p0, p1;
   if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1)) return;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  for (int i = tid; i < 2 * plane; i += NW * 64) plane_re[i] = 0.0;
+  for (int i = tid; i < 2 * plane + 256; i += NW * 64) plane_re[i] = 0.0;
   __syncthreads();
 
-  const int w = g.w, nc = g.ncoef;
-  T* st = stage_all + wave * (CH * kPer);
-  T* kxs = st;                                   // [CH][8]
-  T* kys = st + CH * 8;                          // [CH][8]   (rank 3 only)
-  T2* klc = reinterpret_cast<T2*>(st + CH * (RANK == 2 ? 8 : 16));   // [CH][8] (k_last*re, k_last*im)
+  const int nc = g.ncoef;
+  T* kxs = stage_all + wave * (CH * 24);                     // [CH][8]
+  T2* kyc = reinterpret_cast<T2*>(kxs + CH * 8);             // [CH][8] (ky*re, ky*im)
   const int dx = lane & 7, dy = lane >> 3;
-  const bool active = dx < w && dy < w;
+  const bool active = dx < W && dy < W;
   const int cell = dy * LS + dx;
-  const T* cc = c + 2 * (int64_t)blockIdx.y * c_stride;
+  const T2* cc = reinterpret_cast<const T2*>(c) + (int64_t)blockIdx.y * c_stride;
 
   for (int base = p0 + wave * CH; base < p1; base += NW * CH) {
     const int j = base + lane;
-    const bool valid = lane < CH && j < p1;
     int off = 0;
-    T klr[8], kli[8];   // (k_last * re, k_last * im) of this lane's point
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { klr[q] = (T)0; kli[q] = (T)0; }
     if (lane < CH) {
-      T kx[8], k2[8];
-      if (valid) {
-        const PointView<T> rec = unpack_rec<T, RANK>(sp.rec[j]);
-        const uint32_t loc = rec.loc;
-        const int idx = rec.idx;
-        const T re = cc[2 * (int64_t)idx] * scale, im = cc[2 * (int64_t)idx + 1] * scale;
-        off = (int)(loc & 1023) + (int)((loc >> 10) & 1023) * LS + (RANK > 2 ? (int)((loc >> 20) & 1023) * PS : 0);
-        T kl[8];
-        if (RANK == 2) horner8<T, 2>(horner, nc, rec.z0, rec.z1, (T)0, kx, kl, k2);
-        else horner8<T, 3>(horner, nc, rec.z0, rec.z1, rec.z2, kx, k2, kl);
+      T kx[8], ky[8], kdummy[8];
+      T re = (T)0, im = (T)0;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { klr[q] = kl[q] * re; kli[q] = kl[q] * im; }
-      } else {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) { kx[q] = (T)0; k2[q] = (T)0; }
+      for (int q = 0; q < 8; ++q) { kx[q] = (T)0; ky[q] = (T)0; }
+      if (j < p1) {
+        const PointView<T> rec = unpack_rec<T, 2>(sp.rec[j]);
+        const T2 cv = cc[rec.idx];
+        re = cv.x * scale;
+        im = cv.y * scale;
+        off = (int)(rec.loc & 1023) + (int)((rec.loc >> 10) & 1023) * LS;
+        horner8<T, 2>(horner, nc, rec.z0, rec.z1, (T)0, kx, ky, kdummy);
       }
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         kxs[lane * 8 + q] = kx[q];
-        if (RANK > 2) kys[lane * 8 + q] = k2[q];
-        if (RANK == 2) {
-          T2 v; v.x = klr[q]; v.y = kli[q];
-          klc[lane * 8 + q] = v;
-        }
+        T2 v; v.x = ky[q] * re; v.y = ky[q] * im;
+        kyc[lane * 8 + q] = v;
       }
     }
     int npts = p1 - base;
     if (npts > CH) npts = CH;
-    if (RANK == 2) {
-      const int nround = (npts + 3) & ~3;
-      for (int q = 0; q < nround; q += 4) {
-        T a[4]; T2 b[4]; int o[4];
+    const int nround = (npts + 3) & ~3;   // padded slots hold zeros and off = 0
+    for (int q = 0; q < nround; q += 4) {
+      T a[4]; T2 b[4]; int o[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          a[u] = kxs[(q + u) * 8 + dx];
-          b[u] = klc[(q + u) * 8 + dy];
-          o[u] = __builtin_amdgcn_readlane(off, q + u) + cell;
-        }
-        if (active) {
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            lds_add(&plane_re[o[u]], (double)(a[u] * b[u].x));
-            lds_add(&plane_im[o[u]], (double)(a[u] * b[u].y));
-          }
-        }
+      for (int u = 0; u < 4; ++u) {
+        a[u] = kxs[(q + u) * 8 + dx];
+        b[u] = kyc[(q + u) * 8 + dy];
+        o[u] = __builtin_amdgcn_readlane(off, q + u) + cell;
       }
-    } else {
-      // kx*ky is lane dependent (two staging reads, next point's prefetched);
-      // the z factor times the strength is the same for all lanes of a pass, so
-      // it comes straight from the owning lane's registers through v_readlane
-      // (scalar broadcast) instead of LDS.
-      T a_n = kxs[dx] * kys[dy];
-      for (int q = 0; q < npts; ++q) {
-        const T a = a_n;
-        const int qn = (q + 1 < npts) ? q + 1 : q;
-        a_n = kxs[qn * 8 + dx] * kys[qn * 8 + dy];
-        const int o = __builtin_amdgcn_readlane(off, q) + cell;
 #pragma unroll
-        for (int dz = 0; dz < 8; ++dz) {
-          if (dz < w) {
-            const T br = bcast_lane(klr[dz], q);
-            const T bi = bcast_lane(kli[dz], q);
-            if (active) {
-              lds_add(&plane_re[o + dz * PS], (double)(a * br));
-              lds_add(&plane_im[o + dz * PS], (double)(a * bi));
-            }
-          }
-        }
+      for (int u = 0; u < 4; ++u) {
+        const T wa = active ? a[u] : (T)0;   // (all 8 staged values are written, but keep the patch exact)
+        lds_add(&plane_re[o[u]], (double)(wa * b[u].x));
+        lds_add(&plane_im[o[u]], (double)(wa * b[u].y));
       }
     }
   }
   __syncthreads();
-
+  Geom gl = g;   // tile_to_grid reads the extents from the geometry
   (void)L0;
-  tile_to_grid<T, RANK>(g, plane_re, plane_im, LS, PS, tb, fw + 2 * (int64_t)blockIdx.y * fw_stride, wave, NW, lane);
+  tile_to_grid<T, 2>(gl, plane_re, plane_im, LS, plane, tb, fw + 2 * (int64_t)blockIdx.y * fw_stride, wave, NW, lane);
 }
 
 // ------------------------- spread: 3-D wavefront path with compile-time width
 
-// Same scheme as spread_wave_kernel<T, 3, ...> with the kernel width W and the
+// The 3-D counterpart of spread_wave2_kernel, with the kernel width W and the
 // tile depth TZ as template parameters (tile 16 x 16 x TZ, row stride 24): every
 // LDS offset of the per-point body is an immediate and the body is straight-line
 // code -- no exec-masked branch (lanes outside the W x W patch add 0 at their
@@ -1525,6 +1479,8 @@ static int wave8_ch() { wave8_shape_init(); return g_w8_ch; }
 
 // Specialised 2-D w = 8 float kernel applicable?
 static bool wave8_supported(const Geom& g, int precision) {
+  static const bool off = getenv("NUFFT_HIP_NO_W8") != nullptr;   // A/B against spread_wave2_kernel<float, 8>
+  if (off) return false;
   return precision == NUFFT_HIP_F32 && g.rank == 2 && g.w == kWW && g.ncoef <= kWaveCoef &&
          g.tile[0] == kWT && g.tile[1] == kWT && g.lstride == kWS;
 }
@@ -1549,7 +1505,7 @@ size_t spread_lds_bytes(const Geom& g, int method, int precision) {
   if (method == NUFFT_HIP_METHOD_TILE_WAVE) {
     if (wave8_supported(g, precision))
       return sizeof(double) * 2 * kWPlane + sizeof(float) * wave8_nw() * wave8_ch() * kWW * 3;
-    if (g.rank == 2) return cells * 2 * sizeof(double) + (size_t)precision * 4 * 64 * 24;
+    if (g.rank == 2) return (cells * 2 + 256) * sizeof(double) + (size_t)precision * 4 * 64 * 24;
     const int nw = precision == NUFFT_HIP_F32 ? 16 : 8;
     return cells * (g.fixed_point ? 1 : 2) * sizeof(double) + 64 * sizeof(double) +
            (size_t)precision * nw * 32 * 16 + 256;
@@ -1599,10 +1555,19 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
       }
     }
     if (g.rank == 2) {
-      e = ensure_lds(spread_wave_kernel<T, 2, 4, 64>, lds_bytes);
-      if (e != hipSuccess) return e;
-      spread_wave_kernel<T, 2, 4, 64><<<grid, 256, lds_bytes, stream>>>(g, sp, horner, c, fw, c_stride,
-                                                                        fw_stride, scale);
+#define NUFFT_CASE_W2(WW)                                                                    \
+  case WW:                                                                                   \
+    e = ensure_lds(spread_wave2_kernel<T, WW, 4, 64>, lds_bytes);                            \
+    if (e != hipSuccess) return e;                                                           \
+    spread_wave2_kernel<T, WW, 4, 64><<<grid, 256, lds_bytes, stream>>>(g, sp, horner, c, fw, \
+                                                                        c_stride, fw_stride, scale); \
+    break;
+      switch (g.w) {
+        NUFFT_CASE_W2(2) NUFFT_CASE_W2(3) NUFFT_CASE_W2(4) NUFFT_CASE_W2(5)
+        NUFFT_CASE_W2(6) NUFFT_CASE_W2(7) NUFFT_CASE_W2(8)
+        default: return hipErrorInvalidValue;
+      }
+#undef NUFFT_CASE_W2
     } else {
       constexpr int nw = wave3d_nw<T>();
 #define NUFFT_LAUNCH_W3(WW, TZV, FXV)                                                            \
