@@ -153,3 +153,41 @@ def test_python_surface_fails_loudly_without_gpu():
     tfft.nufft(np.zeros(4, np.complex64), np.zeros((4, 1), np.float32), grid_shape=[8], transform_type='type_1')
   with pytest.raises(ValueError, match='grid_shape must be provided for type-1 transforms'):
     tfft.nufft(np.zeros(4, np.complex64), np.zeros((4, 1), np.float32), transform_type='type_1')
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+  # include/nufft_hip.h must be usable from C (the reference-side binding could be cgo/JNI/ctypes):
+  # compile a C program against it with gcc -std=c99 -pedantic, link libnufft_hip.so, run a host-only call
+  import shutil
+  import subprocess
+  if shutil.which('gcc') is None:
+    pytest.skip('gcc not available')
+  src = tmp_path / 'use_abi.c'
+  src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "nufft_hip.h"
+int main(void) {
+  nufft_hip_options o;
+  nufft_hip_plan_info info;
+  char err[256];
+  int64_t dims[3] = {1024, 1024, 1};
+  int rc;
+  nufft_hip_default_options(&o);
+  if (nufft_hip_abi_version() != NUFFT_HIP_ABI_VERSION) return 2;
+  rc = nufft_hip_plan_describe(NUFFT_HIP_TYPE_1, 2, dims, NUFFT_HIP_FORWARD, 1, 1e-6, NUFFT_HIP_F32, &o, &info,
+                               err, sizeof err);
+  if (rc != NUFFT_HIP_OK) { printf("%s\n", err); return 3; }
+  printf("%d %d %d\n", (int)info.kernel_width, (int)info.fine_dims[0], (int)info.spread_method);
+  return 0;
+}
+''')
+  exe = tmp_path / 'use_abi'
+  libdir = os.path.dirname(_lib.LIB_PATH)
+  cmd = ['gcc', '-std=c99', '-pedantic', '-Wall', '-Werror', '-I', os.path.join(ROOT, 'include'), str(src),
+         '-o', str(exe), '-L', libdir, '-lnufft_hip', '-Wl,-rpath,' + libdir, '-Wl,-rpath,/opt/rocm/lib']
+  r = subprocess.run(cmd, capture_output=True, text=True)
+  assert r.returncode == 0, r.stderr
+  r = subprocess.run([str(exe)], capture_output=True, text=True)
+  assert r.returncode == 0, (r.stdout, r.stderr)
+  assert r.stdout.split() == ['8', '2048', '2']
