@@ -649,3 +649,17 @@ def test_radial_mri_example_shape(tfft):
   # and it is a recognisable image: correlation with the input
   a, b = np.abs(recon.cpu().numpy()).ravel(), np.abs(image).ravel()
   assert np.corrcoef(a, b)[0, 1] > 0.95
+
+
+def test_native_cpp_client_of_the_c_abi():
+  # a C++ program that uses only the HIP runtime and include/nufft_hip.h (no Python, no torch)
+  import os
+  import subprocess
+  from conftest import PKG
+  exe = os.path.join(PKG, 'csrc', 'examples', 'abi_client')
+  if not os.path.exists(exe):
+    r = subprocess.run(['make', '-C', os.path.join(PKG, 'csrc'), 'examples'], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+  r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+  assert r.returncode == 0, (r.stdout, r.stderr)
+  assert 'type-1 rel-l2' in r.stdout
