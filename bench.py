@@ -48,6 +48,10 @@ def algorithmic_spread_bytes(m, nf, rank):
   return m * (4 * rank + 8) + 8 * cells
 
 
+# dominant kernel of the headline config (2-D, w = 8, float, >= 0.5 points per fine cell)
+SPREAD_KERNEL = 'spread_2d_w8_group_kernel'
+
+
 def pmc_traffic(kernel_name, m):
   """HBM-side bytes per launch of the spread kernel from the PMC passes committed
   under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs,
@@ -106,6 +110,9 @@ def main():
   ap.add_argument('--points', type=int, default=M)
   ap.add_argument('--cpu-points', type=int, default=M)
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--no-extras', action='store_true',
+                  help='skip the informational two-stream leg (used under rocprofv3 so that its per-kernel '
+                       'average covers single-stream launches only)')
   ap.add_argument('--dist-backend', default='nccl', help='nccl (= RCCL, default) | gloo (testing)')
   ap.add_argument('--device', type=int, default=None, help='force a device index (testing)')
   ap.add_argument('--force-dist', action='store_true', help='initialise torch.distributed even at world size 1 (testing)')
@@ -188,7 +195,7 @@ def main():
   # informational: two independent transforms in flight on two streams (the sort is
   # memory-bound, the spread LDS-bound, so they overlap); NOT the headline value
   two_stream = None
-  if world == 1:
+  if world == 1 and not args.no_extras:
     s2 = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
     lanes = []
     for st in s2:
@@ -231,12 +238,13 @@ def main():
             'stage_us': {k: round(v[0] / max(v[1], 1) * 1e3, 1) for k, v in stage_all.items() if v[1]},
         },
         'roofline': {
-            'bound': 'hbm', 'kernel': 'spread_2d_w8_wave_kernel', 'achieved': round(achieved, 1),
+            'bound': 'hbm', 'kernel': SPREAD_KERNEL, 'achieved': round(achieved, 1),
             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
-            'traffic': pmc_traffic('spread_2d_w8_wave_kernel', m), 'algorithmic_bytes': algo,
+            'traffic': pmc_traffic(SPREAD_KERNEL, m), 'algorithmic_bytes': algo,
             'kernel_ms': round(spread_ms, 4),
-            'note': 'the kernel is bound by the LDS atomic pipe (2 ds_add_f64 + 2 broadcast reads per '
-                    'point-pass per CU), not by HBM: DESIGN.md section 4. traffic = offline PMC pass '
+            'note': 'the kernel is bound by the LDS pipe (per point 3/4 ds_read_b128 + ~0.8 ds_add_f64 after '
+                    'grouping points by start cell) plus its per-tile LDS sort, not by HBM: DESIGN.md section 4. '
+                    'traffic = offline PMC pass '
                     '(profiles/r01_pmc_traffic.txt); the excess over algorithmic_bytes is the 8-byte strength '
                     'gather through the sort permutation (one 64-B sector per random point)',
         },

@@ -671,6 +671,9 @@ __global__ __launch_bounds__(kBlock) void spread_tile_generic_kernel(
 // once: conflict free by construction, for every point position. Kernel values are produced 64 points at a time (one point
 // per lane, Horner in registers) and handed to the per-point passes through
 // a small LDS staging area read with broadcast loads.
+__device__ __forceinline__ float bcast_lane(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
 constexpr int kWT = 32;              // tile edge
 constexpr int kWW = 8;               // kernel width
 constexpr int kWL = kWT + kWW - 1;   // 39 rows/cols used
@@ -784,9 +787,215 @@ __global__ __launch_bounds__(NW * 64) void spread_2d_w8_wave_kernel(
   }
 }
 
-__device__ __forceinline__ float bcast_lane(float v, int lane) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+// Cell-grouped variant of the kernel above for dense point sets (>~ 1 point per
+// fine cell). The subproblem's <= 4096 points are first counting-sorted IN LDS
+// by stencil start cell (1024 keys; 32-bit LDS integer atomics run 64 points per
+// wave-instruction, so this costs ~1 % of the kernel). Consecutive passes of a
+// wave that share a start cell then accumulate their 8x8 products in registers
+// and issue ONE pair of ds_add_f64 per group instead of one per point: at
+// config 2's density (2.4 points per cell) that removes ~60 % of the LDS atomics
+// that bound the ungrouped kernel.
+constexpr int kGroupMaxSub = 4096;
+constexpr double kGroupMinDensity = 0.5;   // points per fine cell
+constexpr int kGroupStage = 32; // points whose kernel values are in LDS at a time (per wave)
+constexpr int kGroupBlk = 36;   // staging words per block of 4 points (8 x 4 + 4 pad)
+template <int CH> constexpr int kGroupStageWave = 3 * (CH / 4) * kGroupBlk;   // words per wave (kx, ky re, ky im)
+template <int NW, int CH>
+__global__ __launch_bounds__(NW * 64) void spread_2d_w8_group_kernel(
+    Geom g, SortedPoints<float> sp, const float* __restrict__ horner, const float* __restrict__ c,
+    float* __restrict__ fw, int64_t c_stride, int64_t fw_stride, float scale) {
+  constexpr int NT = NW * 64;
+  constexpr int IT = kGroupMaxSub / NT;     // records per thread in the LDS sort
+  constexpr int PER = 1024 / NT;            // counters per thread in the scan
+  constexpr int SC = CH < kGroupStage ? CH : kGroupStage;   // points staged through LDS at a time
+  static_assert(PER >= 1, "at most 16 waves");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* plane_re = reinterpret_cast<double*>(smem_raw);
+  double* plane_im = plane_re + kWPlane;
+  float* stage_all = reinterpret_cast<float*>(plane_im + kWPlane);
+  uint32_t* cnt = reinterpret_cast<uint32_t*>(stage_all + NW * kGroupStageWave<SC>);   // [1024]
+  uint16_t* perm = reinterpret_cast<uint16_t*>(cnt + 1024);                     // [4096]
+  uint32_t* wsum = reinterpret_cast<uint32_t*>(perm + kGroupMaxSub);            // [16]
+  int tb, p0, p1;
+  if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1)) return;
+  const int n = p1 - p0;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  for (int i = tid; i < 2 * kWPlane; i += NT) plane_re[i] = 0.0;
+  for (int i = tid; i < 1024; i += NT) cnt[i] = 0u;
+  __syncthreads();
+
+  // ---- LDS counting sort of the subproblem by start cell
+  // (all loads are unconditional on clamped indices: a load under a divergent
+  // branch makes the compiler wait for it before the next one is issued)
+  uint32_t kr[IT];   // key | rank-in-cell << 10
+#pragma unroll
+  for (int u = 0; u < IT; ++u) {
+    const int i = tid + u * NT;
+    kr[u] = 0u;
+    if (u * NT < n) kr[u] = sp.rec[p0 + (i < n ? i : n - 1)].loc;
+  }
+#pragma unroll
+  for (int u = 0; u < IT; ++u) {
+    const int i = tid + u * NT;
+    const uint32_t key = (((kr[u] >> 10) & 31u) << 5) | (kr[u] & 31u);
+    if (i < n) kr[u] = key | (atomicAdd(&cnt[key], 1u) << 10);
+  }
+  __syncthreads();
+  {
+    uint32_t v[PER], tot = 0u;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) { v[u] = cnt[tid * PER + u]; tot += v[u]; }
+    uint32_t incl = tot;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t t = __shfl_up(incl, d);
+      if (lane >= d) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t run = incl - tot;
+    for (int w2 = 0; w2 < wave; ++w2) run += wsum[w2];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) { cnt[tid * PER + u] = run; run += v[u]; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < IT; ++u) {
+    const int i = tid + u * NT;
+    if (i < n) perm[cnt[kr[u] & 1023u] + (kr[u] >> 10)] = (uint16_t)i;
+  }
+  __syncthreads();
+
+  // Staging holds kernel values of 4 consecutive points side by side, so one
+  // ds_read_b128 fetches a lane's kx (or ky) for 4 passes (6 cycles instead of
+  // 4 x 3.4, tools/ubench/lds_read_bench.hip). Block stride 36 words: the
+  // lane-per-point b32 writes of one q then hit 64 distinct banks.
+  float* kxs = stage_all + wave * kGroupStageWave<SC>;   // [CH/4][8][4] (+4 pad per block)
+  float* kyr = kxs + kGroupStageWave<SC> / 3;            // ky * re(c)
+  float* kyi = kyr + kGroupStageWave<SC> / 3;            // ky * im(c)
+  const int dx = lane & 7, dy = lane >> 3;
+  const int cell = (dy * kWS + dx) * (int)sizeof(double);
+  const float* cc = c + 2 * (int64_t)blockIdx.y * c_stride;
+
+  // Two-deep software pipeline over the wave's chunks: the record gather of chunk
+  // i+2 and the strength gather of chunk i+1 (which needs record i+1's index)
+  // are in flight while chunk i is spread, so neither HBM latency is exposed.
+  const float2* c2 = reinterpret_cast<const float2*>(cc);
+  auto load_rec = [&](int b) {   // lanes past the end re-read the last point; masked below
+    const int li = b + lane;
+    return sp.rec[p0 + perm[li < n ? li : n - 1]];
+  };
+  auto load_c = [&](const Rec<float>& r) { return c2[r.idx]; };
+  constexpr int STEP = NW * CH;
+  Rec<float> r_cur = load_rec(wave * CH);
+  Rec<float> r_nxt = load_rec(wave * CH + STEP);
+  float2 c_cur = load_c(r_cur);
+  for (int base = wave * CH; base < n; base += STEP) {
+    const float2 c_nxt = load_c(r_nxt);
+    const Rec<float> r_nn = load_rec(base + 2 * STEP);
+    const uint32_t loc = r_cur.loc;
+    const float zx = r_cur.z0, zy = r_cur.z1;
+    const bool valid = lane < CH && base + lane < n;
+    const float re = valid ? c_cur.x * scale : 0.f, im = valid ? c_cur.y * scale : 0.f;
+    const uint32_t key = valid ? (loc & 0xfffffu) : 0xffffffffu;
+    const int off = (((loc >> 10) & 1023) * kWS + (loc & 1023)) * (int)sizeof(double);
+    float kx[kWW], ky[kWW];
+    // The ES kernel is even, so cell 7-q's polynomial is cell q's at -z: evaluate the
+    // even and odd parts in z^2 once per pair (12 instead of 22 FMAs for two cells,
+    // and only 48 coefficients, which stay in SGPRs). x and y share coefficients:
+    // each term is one v_pk_fma_f32.
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const v2f zz = {zx, zy};
+    const v2f z2 = zz * zz;
+#pragma unroll
+    for (int q = 0; q < kWW / 2; ++q) {
+      const float te = horner[(kWaveCoef - 2) * kMaxW + q], to = horner[(kWaveCoef - 1) * kMaxW + q];
+      v2f e = {te, te}, o = {to, to};
+#pragma unroll
+      for (int m = kWaveCoef / 2 - 2; m >= 0; --m) {
+        const float ce = horner[(2 * m) * kMaxW + q], co = horner[(2 * m + 1) * kMaxW + q];
+        const v2f cce = {ce, ce}, cco = {co, co};
+        e = __builtin_elementwise_fma(e, z2, cce);
+        o = __builtin_elementwise_fma(o, z2, cco);
+      }
+      const v2f lo = __builtin_elementwise_fma(zz, o, e), hi = __builtin_elementwise_fma(-zz, o, e);
+      kx[q] = lo.x; ky[q] = lo.y;
+      kx[kWW - 1 - q] = hi.x; ky[kWW - 1 - q] = hi.y;
+    }
+    r_cur = r_nxt;
+    c_cur = c_nxt;
+    r_nxt = r_nn;
+    int npts = n - base;
+    if (npts > CH) npts = CH;
+    // a pass ends a group when the next point starts in a different cell (or the staged half ends)
+    const uint32_t nxt = __shfl_down(key, 1);
+    const unsigned long long tailm =
+        __ballot(lane < npts && (lane == npts - 1 || (lane & (SC - 1)) == SC - 1 || nxt != key));
+    // Kernel values of the chunk stay in registers; they go through LDS SC points
+    // at a time so that the staging area stays small (LDS bytes decide how many
+    // workgroups share a CU).
+#pragma unroll 1
+    for (int h = 0; h < CH; h += SC) {
+      if (h >= npts) break;
+      if (lane >= h && lane < h + SC) {
+        const int sl = lane - h;
+        const int sb = (sl >> 2) * kGroupBlk + (sl & 3);
+#pragma unroll
+        for (int q = 0; q < kWW; ++q) {
+          kxs[sb + 4 * q] = kx[q];
+          kyr[sb + 4 * q] = ky[q] * re;
+          kyi[sb + 4 * q] = ky[q] * im;
+        }
+      }
+      int nh = npts - h;
+      if (nh > SC) nh = SC;
+      const unsigned tails = (unsigned)(tailm >> h);
+      const int nround = (nh + 3) & ~3;   // padded lanes hold zeros and are never tails
+      float ar = 0.f, ai = 0.f;
+      for (int q = 0; q < nround; q += 4) {
+        const float4 ax4 = *reinterpret_cast<const float4*>(kxs + (q >> 2) * kGroupBlk + 4 * dx);
+        const float4 br4 = *reinterpret_cast<const float4*>(kyr + (q >> 2) * kGroupBlk + 4 * dy);
+        const float4 bi4 = *reinterpret_cast<const float4*>(kyi + (q >> 2) * kGroupBlk + 4 * dy);
+        const float a[4] = {ax4.x, ax4.y, ax4.z, ax4.w};
+        const float br[4] = {br4.x, br4.y, br4.z, br4.w};
+        const float bi[4] = {bi4.x, bi4.y, bi4.z, bi4.w};
+        const unsigned t4 = (tails >> q) & 15u;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          ar = fmaf(a[u], br[u], ar);
+          ai = fmaf(a[u], bi[u], ai);
+          if (t4 & (1u << u)) {
+            const int o = __builtin_amdgcn_readlane(off, h + q + u) + cell;   // byte offset into the re plane
+            lds_add(reinterpret_cast<double*>(smem_raw + o), (double)ar);
+            lds_add(reinterpret_cast<double*>(smem_raw + o) + kWPlane, (double)ai);
+            ar = 0.f;
+            ai = 0.f;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  const int t0 = tb % g.ntile[0];
+  const int t1 = tb / g.ntile[0];
+  const int o0 = t0 * kWT, o1 = t1 * kWT;
+  float* out = fw + 2 * (int64_t)blockIdx.y * fw_stride;
+  for (int i = tid; i < 2 * kWL * kWL; i += NT) {
+    const int comp = i & 1;
+    const int cellid = i >> 1;
+    const int a0 = cellid % kWL, a1 = cellid / kWL;
+    const float v = (float)(comp ? plane_im : plane_re)[a1 * kWS + a0];
+    if (v != 0.f) {
+      int g0 = o0 + a0; if (g0 >= g.nf[0]) g0 -= g.nf[0];
+      int g1 = o1 + a1; if (g1 >= g.nf[1]) g1 -= g.nf[1];
+      glb_add(&out[2 * (g0 + (int64_t)g.nf[0] * g1) + comp], v);
+    }
+  }
 }
+
 __device__ __forceinline__ double bcast_lane(double v, int lane) {
   const long long b = __builtin_bit_cast(long long, v);
   const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), lane);
@@ -1467,15 +1676,33 @@ template hipError_t launch_sort<double>(const Geom&, const PointsIn&, const Sort
 
 // Launch shape of the specialised kernel (waves per workgroup, points per
 // staging chunk); NUFFT_HIP_W8_SHAPE = "NWxCH" overrides for experiments.
+// Cell-grouped kernel: NUFFT_HIP_W8_GROUP = 0 never, 1 always; unset: by point density
+// (the in-LDS sort only pays when start cells are shared often enough).
+static bool wave8_use_group(const Geom& g, int64_t M) {
+  static const int mode = [] { const char* e = getenv("NUFFT_HIP_W8_GROUP"); return e ? atoi(e) : -1; }();
+  if (g.max_sub > kGroupMaxSub) return false;
+  if (mode >= 0) return mode != 0;
+  return (double)M >= kGroupMinDensity * (double)g.nf[0] * (double)g.nf[1];
+}
+
+// Defaults from the r01 sweeps (tools/sweep_w8.py, tools/sweep_w8_group.py): 4 x 64
+// for the per-point kernel, 8 x 64 for the cell-grouped one.
 static int g_w8_nw = 0, g_w8_ch = 0;
 static void wave8_shape_init() {
   if (g_w8_nw) return;
-  int nw = 4, ch = 64;
+  int nw = -1, ch = -1;
   if (const char* e = getenv("NUFFT_HIP_W8_SHAPE")) sscanf(e, "%dx%d", &nw, &ch);
   g_w8_nw = nw; g_w8_ch = ch;
 }
-static int wave8_nw() { wave8_shape_init(); return g_w8_nw; }
-static int wave8_ch() { wave8_shape_init(); return g_w8_ch; }
+static int wave8_nw(bool grouped) { wave8_shape_init(); return g_w8_nw > 0 ? g_w8_nw : (grouped ? 8 : 4); }
+static int wave8_ch(bool grouped) { wave8_shape_init(); return g_w8_ch > 0 ? g_w8_ch : (grouped ? 64 : 64); }
+static size_t wave8_lds(bool grouped) {
+  const size_t planes = sizeof(double) * 2 * kWPlane;
+  const int nw = wave8_nw(grouped), ch = wave8_ch(grouped);
+  if (!grouped) return planes + sizeof(float) * nw * ch * kWW * 3;
+  return planes + sizeof(float) * nw * 3 * ((ch < kGroupStage ? ch : kGroupStage) / 4) * kGroupBlk +
+         1024 * 4 + kGroupMaxSub * 2 + 64;   // + counters, permutation, wave sums
+}
 
 // Specialised 2-D w = 8 float kernel applicable?
 static bool wave8_supported(const Geom& g, int precision) {
@@ -1503,8 +1730,7 @@ size_t spread_lds_bytes(const Geom& g, int method, int precision) {
   size_t cells = (size_t)g.lstride;
   for (int d = 1; d < g.rank; ++d) cells *= (size_t)g.ldim[d];
   if (method == NUFFT_HIP_METHOD_TILE_WAVE) {
-    if (wave8_supported(g, precision))
-      return sizeof(double) * 2 * kWPlane + sizeof(float) * wave8_nw() * wave8_ch() * kWW * 3;
+    if (wave8_supported(g, precision)) return std::max(wave8_lds(false), wave8_lds(true));
     if (g.rank == 2) return (cells * 2 + 256) * sizeof(double) + (size_t)precision * 4 * 64 * 24;
     const int nw = precision == NUFFT_HIP_F32 ? 16 : 8;
     return cells * (g.fixed_point ? 1 : 2) * sizeof(double) + 64 * sizeof(double) +
@@ -1536,7 +1762,26 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
   if (method == NUFFT_HIP_METHOD_TILE_WAVE) {
     if constexpr (sizeof(T) == 4) {
       if (wave8_supported(g, 4)) {
-        const int shape = wave8_nw() * 100 + wave8_ch();
+        const bool grouped = wave8_use_group(g, M);
+        const int shape = wave8_nw(grouped) * 100 + wave8_ch(grouped);
+        lds_bytes = wave8_lds(grouped);   // the plan's figure is the maximum of the two variants
+        if (grouped) {
+#define NUFFT_LAUNCH_W8G(NWV, CHV)                                                             \
+  case NWV * 100 + CHV:                                                                        \
+    e = ensure_lds(spread_2d_w8_group_kernel<NWV, CHV>, lds_bytes);                            \
+    if (e != hipSuccess) return e;                                                             \
+    spread_2d_w8_group_kernel<NWV, CHV><<<grid, NWV * 64, lds_bytes, stream>>>(                \
+        g, sp, horner, c, fw, c_stride, fw_stride, scale);                                     \
+    break;
+          switch (shape) {
+            NUFFT_LAUNCH_W8G(4, 64) NUFFT_LAUNCH_W8G(4, 32) NUFFT_LAUNCH_W8G(8, 64) NUFFT_LAUNCH_W8G(8, 32)
+            NUFFT_LAUNCH_W8G(2, 64) NUFFT_LAUNCH_W8G(2, 32) NUFFT_LAUNCH_W8G(16, 32) NUFFT_LAUNCH_W8G(4, 16)
+            NUFFT_LAUNCH_W8G(8, 16)
+            default: return hipErrorInvalidValue;
+          }
+#undef NUFFT_LAUNCH_W8G
+          return hipGetLastError();
+        }
 #define NUFFT_LAUNCH_W8(NWV, CHV)                                                              \
   case NWV * 100 + CHV:                                                                        \
     e = ensure_lds(spread_2d_w8_wave_kernel<NWV, CHV>, lds_bytes);                             \

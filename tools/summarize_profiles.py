@@ -3,9 +3,9 @@ profiles/ (kernel stats + PMC traffic of the spread kernel)."""
 import collections, csv, glob, json, re, sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
-stats = sorted(glob.glob('gpurun_out/prof_bench2/runc/*_kernel_stats.csv'), key=lambda f: __import__('os').path.getmtime(f))[-1]
+stats = sorted(glob.glob('gpurun_out/prof_bench2/**/*kernel_stats.csv', recursive=True), key=lambda f: __import__('os').path.getmtime(f))[-1]
 rows = list(csv.DictReader(open(stats)))
-lines = [f'# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline   (MI355X, {tag})',
+lines = [f'# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras   (MI355X, {tag})',
          '# kernel | calls | avg_us | total_ms | pct']
 for r in rows[:14]:
   lines.append(f"{r['Name'][:90]} | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {float(r['TotalDurationNs'])/1e6:.3f} | {r['Percentage']}")
@@ -13,7 +13,7 @@ open(f'profiles/{tag}_bench_kernel_stats.txt', 'w').write('\n'.join(lines) + '\n
 print('\n'.join(lines[:9]))
 
 def counters(d):
-  f = sorted(glob.glob(f'gpurun_out/{d}/runc/*_counter_collection.csv'), key=lambda f: __import__('os').path.getmtime(f))[-1]
+  f = sorted(glob.glob(f'gpurun_out/{d}/**/*counter_collection.csv', recursive=True), key=lambda f: __import__('os').path.getmtime(f))[-1]
   agg = collections.defaultdict(lambda: collections.defaultdict(list))
   for r in csv.DictReader(open(f)):
     name = re.split(r'[(<]', r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', ''))[0]
