@@ -691,3 +691,41 @@ def test_distance_to_the_reference_cpu_rule_output(tfft, ttype):
   print(f'{ttype}: ours-truth {e_ours:.2e}  cpu_rule-truth {e_rule:.2e}  ours-cpu_rule {d:.2e}')
   assert e_ours <= tol, e_ours
   assert d <= tol + e_rule, (d, e_rule)
+
+
+_W8_CHILD = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+import tensorflow_nufft as tfft
+from oracle import oracle
+rng = np.random.default_rng(5)
+worst = 0.0
+for name, grid, M in (('uniform', [96, 80], 120000), ('one_cell', [64, 64], 5000), ('ragged', [40, 136], 64 * 37 + 1)):
+  pts = rng.uniform(-np.pi, np.pi, (M, 2)).astype(np.float32)
+  if name == 'one_cell':   # every point inside one fine cell: a single group per 64-point chunk
+    pts = (0.3 + 1e-3 * rng.uniform(0, 1, (M, 2))).astype(np.float32)
+  c = (rng.uniform(-.5, .5, M) + 1j * rng.uniform(-.5, .5, M)).astype(np.complex64)
+  truth = oracle.nufft(c.astype(np.complex128), pts, grid, 'type_1', 'backward', tol=1e-12, sigma=2.0)
+  out = tfft.nufft(torch.from_numpy(c).cuda(), torch.from_numpy(pts).cuda(), grid_shape=grid,
+                   transform_type='type_1', fft_direction='backward', tol=1e-6).cpu().numpy()
+  err = np.linalg.norm(out - truth) / np.linalg.norm(truth)
+  worst = max(worst, err)
+  print(name, err)
+print('WORST', worst)
+'''
+
+
+@pytest.mark.parametrize('group', ['0', '1'])
+def test_w8_spread_variants_forced(group):
+  # The 2-D w = 8 float spreader has a per-point and a cell-grouped kernel, picked by point
+  # density; NUFFT_HIP_W8_GROUP forces one (read once per process, hence the child process).
+  # Both must meet tol = 1e-6 against the fp64 oracle on dense, degenerate and ragged inputs.
+  import os
+  import subprocess
+  import sys
+  from conftest import PKG, ROOT
+  env = dict(os.environ, NUFFT_HIP_W8_GROUP=group)
+  r = subprocess.run([sys.executable, '-c', _W8_CHILD, ROOT, PKG], env=env, capture_output=True, text=True, timeout=600)
+  assert r.returncode == 0, r.stderr[-2000:]
+  worst = float(r.stdout.strip().splitlines()[-1].split()[1])
+  assert worst < 1e-6, r.stdout
