@@ -136,9 +136,10 @@ int nufft_hip_plan_set_stream(nufft_hip_plan plan, void* stream);
  * stage (no synchronisation while enabled). get_timing synchronises the
  * stream, returns accumulated milliseconds and call counts per stage since the
  * last get, and resets them. Stage order: sort-count, sort-scan, sort-scatter,
- * zero, spread, fft, deconvolve, interp. enable: 0 off, 1 every stage, 2 only
+ * zero, spread, fft, deconvolve, interp, sort-cell (the per-subproblem ordering
+ * by stencil start cell, when the plan uses it). enable: 0 off, 1 every stage, 2 only
  * the dominant kernel (spread / interp; two events per execute). */
-#define NUFFT_HIP_NUM_STAGES 8
+#define NUFFT_HIP_NUM_STAGES 9
 int nufft_hip_plan_set_timing(nufft_hip_plan plan, int enable);
 int nufft_hip_plan_get_timing(nufft_hip_plan plan, double* ms, int32_t* calls, int n);
 const char* nufft_hip_last_error(nufft_hip_plan plan);

@@ -33,6 +33,7 @@ struct Geom {
   int max_sub;      // points per subproblem
   int nmodes[3];    // N, x fastest
   int fixed_point;  // 3-D float spread accumulates packed 32+32-bit fixed point in LDS
+  int cell_sorted;  // records of each subproblem are ordered by stencil start cell (set per set_points)
 };
 
 // Per-point record in tile-sorted order. float: 16 bytes, one dwordx4 access;
@@ -86,7 +87,7 @@ constexpr int kMaxLds16Tiles = 73728;   // 144 KiB of packed 16-bit LDS counters
 
 enum Stage {
   STAGE_SORT_COUNT = 0, STAGE_SORT_SCAN, STAGE_SORT_SCATTER, STAGE_ZERO, STAGE_SPREAD,
-  STAGE_FFT, STAGE_DECONVOLVE, STAGE_INTERP, STAGE_COUNT
+  STAGE_FFT, STAGE_DECONVOLVE, STAGE_INTERP, STAGE_SORT_CELL, STAGE_COUNT
 };
 // Optional per-stage HIP-event timing (bench / profiling); no-ops when disabled.
 struct StageHook {
@@ -105,6 +106,14 @@ bool sort_uses_lds(const Geom& g);
 template <typename T>
 hipError_t launch_sort(const Geom& g, const PointsIn& in, const SortWork& w, const SortedOut<T>& out,
                        hipStream_t stream, const StageHook& hook);
+// Second sort level: reorders the records of every subproblem by stencil start cell,
+// `in` -> `out` (distinct buffers). cellsort_wanted: the plan's spread kernel exploits the
+// order (2-D, w = 8, float) and the point density makes it pay; the host applies it lazily
+// (nufft_plan.cpp, maybe_cellsort).
+bool cellsort_wanted(const Geom& g, int method, int precision, int64_t M);
+template <typename T>
+hipError_t launch_cellsort(const Geom& g, int64_t M, const int32_t* tile_start, const int32_t* sub_start,
+                           const Rec<T>* in, Rec<T>* out, hipStream_t stream);
 template <typename T>
 hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, int64_t M,
                          const T* horner, const T* c, T* fw, int batch, int64_t c_stride,

@@ -787,28 +787,99 @@ __global__ __launch_bounds__(NW * 64) void spread_2d_w8_wave_kernel(
   }
 }
 
-// Cell-grouped variant of the kernel above for dense point sets (>~ 1 point per
-// fine cell). The subproblem's <= 4096 points are first counting-sorted IN LDS
-// by stencil start cell (1024 keys; 32-bit LDS integer atomics run 64 points per
-// wave-instruction, so this costs ~1 % of the kernel). Consecutive passes of a
-// wave that share a start cell then accumulate their 8x8 products in registers
-// and issue ONE pair of ds_add_f64 per group instead of one per point: at
-// config 2's density (2.4 points per cell) that removes ~60 % of the LDS atomics
-// that bound the ungrouped kernel.
+// Exclusive scan of cnt[1024] in place by a workgroup of NT threads (NT | 1024);
+// wsum: >= NT/64 words of LDS scratch. Ends with a barrier.
+template <int NT>
+__device__ __forceinline__ void scan1024(uint32_t* cnt, uint32_t* wsum, int tid) {
+  constexpr int PER = 1024 / NT;
+  const int lane = tid & 63, wave = tid >> 6;
+  uint32_t v[PER], tot = 0u;
+#pragma unroll
+  for (int u = 0; u < PER; ++u) { v[u] = cnt[tid * PER + u]; tot += v[u]; }
+  uint32_t incl = tot;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t t = __shfl_up(incl, d);
+    if (lane >= d) incl += t;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  uint32_t run = incl - tot;
+  for (int w2 = 0; w2 < wave; ++w2) run += wsum[w2];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) { cnt[tid * PER + u] = run; run += v[u]; }
+  __syncthreads();
+}
+
+// Second sort level, run once per set_points for dense 2-D point sets: every
+// subproblem (<= 4096 points of one 32 x 32 tile) is counting-sorted by stencil
+// start cell (1024 keys) with LDS integer atomics; records move from `in` to
+// `out`. Points that share a start cell share the 8 x 8 patch address, which
+// lets the spread kernel accumulate them in registers before one LDS atomic,
+// and gives neighbouring interp threads neighbouring LDS addresses.
+constexpr int kCellSortMaxSub = 4096;
+constexpr int kCellSortThreads = 512;
+template <typename T>
+__global__ __launch_bounds__(kCellSortThreads) void cellsort2d_kernel(
+    Geom g, const int32_t* __restrict__ tile_start, const int32_t* __restrict__ sub_start,
+    const Rec<T>* __restrict__ in, Rec<T>* __restrict__ out) {
+  constexpr int NT = kCellSortThreads;
+  constexpr int IT = kCellSortMaxSub / NT;
+  __shared__ uint32_t cnt[1024];
+  __shared__ uint32_t wsum[16];
+  int tb, p0, p1;
+  if (!locate_subproblem(g, tile_start, sub_start, blockIdx.x, &tb, &p0, &p1)) return;
+  const int n = p1 - p0;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 1024; i += NT) cnt[i] = 0u;
+  // loads are unconditional on clamped indices so that all of them are in flight together
+  Rec<T> r[IT];
+#pragma unroll
+  for (int u = 0; u < IT; ++u) {
+    const int i = tid + u * NT;
+    if (u * NT < n) r[u] = in[p0 + (i < n ? i : n - 1)];
+  }
+  __syncthreads();
+  uint32_t kr[IT];   // key | rank-in-cell << 10
+#pragma unroll
+  for (int u = 0; u < IT; ++u) {
+    const int i = tid + u * NT;
+    kr[u] = 0u;
+    if (u * NT < n) {
+      const uint32_t key = (((r[u].loc >> 10) & 31u) << 5) | (r[u].loc & 31u);
+      if (i < n) kr[u] = key | (atomicAdd(&cnt[key], 1u) << 10);
+    }
+  }
+  __syncthreads();
+  scan1024<NT>(cnt, wsum, tid);
+#pragma unroll
+  for (int u = 0; u < IT; ++u) {
+    const int i = tid + u * NT;
+    if (u * NT < n && i < n) out[p0 + cnt[kr[u] & 1023u] + (kr[u] >> 10)] = r[u];
+  }
+}
+
+// Cell-grouped variant of the kernel above for dense point sets (>~ 0.5 points per
+// fine cell). The subproblem's points are ordered by stencil start cell, either
+// already in HBM (PRE: cellsort2d_kernel ran at set_points) or by the same
+// counting sort done here in LDS. Consecutive passes of a wave that share a
+// start cell then accumulate their 8x8 products in registers and issue ONE pair
+// of ds_add_f64 per group instead of one per point: at config 2's density (2.4
+// points per cell) that removes ~60 % of the LDS atomics that bound the
+// ungrouped kernel.
 constexpr int kGroupMaxSub = 4096;
 constexpr double kGroupMinDensity = 0.5;   // points per fine cell
 constexpr int kGroupStage = 32; // points whose kernel values are in LDS at a time (per wave)
 constexpr int kGroupBlk = 36;   // staging words per block of 4 points (8 x 4 + 4 pad)
 template <int CH> constexpr int kGroupStageWave = 3 * (CH / 4) * kGroupBlk;   // words per wave (kx, ky re, ky im)
-template <int NW, int CH>
+template <int NW, int CH, bool PRE>
 __global__ __launch_bounds__(NW * 64) void spread_2d_w8_group_kernel(
     Geom g, SortedPoints<float> sp, const float* __restrict__ horner, const float* __restrict__ c,
     float* __restrict__ fw, int64_t c_stride, int64_t fw_stride, float scale) {
   constexpr int NT = NW * 64;
   constexpr int IT = kGroupMaxSub / NT;     // records per thread in the LDS sort
-  constexpr int PER = 1024 / NT;            // counters per thread in the scan
   constexpr int SC = CH < kGroupStage ? CH : kGroupStage;   // points staged through LDS at a time
-  static_assert(PER >= 1, "at most 16 waves");
+  static_assert(1024 % NT == 0, "at most 16 waves");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* plane_re = reinterpret_cast<double*>(smem_raw);
   double* plane_im = plane_re + kWPlane;
@@ -823,48 +894,34 @@ __global__ __launch_bounds__(NW * 64) void spread_2d_w8_group_kernel(
   const int lane = tid & 63;
   const int wave = tid >> 6;
   for (int i = tid; i < 2 * kWPlane; i += NT) plane_re[i] = 0.0;
-  for (int i = tid; i < 1024; i += NT) cnt[i] = 0u;
-  __syncthreads();
-
-  // ---- LDS counting sort of the subproblem by start cell
-  // (all loads are unconditional on clamped indices: a load under a divergent
-  // branch makes the compiler wait for it before the next one is issued)
-  uint32_t kr[IT];   // key | rank-in-cell << 10
-#pragma unroll
-  for (int u = 0; u < IT; ++u) {
-    const int i = tid + u * NT;
-    kr[u] = 0u;
-    if (u * NT < n) kr[u] = sp.rec[p0 + (i < n ? i : n - 1)].loc;
-  }
-#pragma unroll
-  for (int u = 0; u < IT; ++u) {
-    const int i = tid + u * NT;
-    const uint32_t key = (((kr[u] >> 10) & 31u) << 5) | (kr[u] & 31u);
-    if (i < n) kr[u] = key | (atomicAdd(&cnt[key], 1u) << 10);
-  }
-  __syncthreads();
-  {
-    uint32_t v[PER], tot = 0u;
-#pragma unroll
-    for (int u = 0; u < PER; ++u) { v[u] = cnt[tid * PER + u]; tot += v[u]; }
-    uint32_t incl = tot;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t t = __shfl_up(incl, d);
-      if (lane >= d) incl += t;
-    }
-    if (lane == 63) wsum[wave] = incl;
+  if constexpr (!PRE) {
+    for (int i = tid; i < 1024; i += NT) cnt[i] = 0u;
     __syncthreads();
-    uint32_t run = incl - tot;
-    for (int w2 = 0; w2 < wave; ++w2) run += wsum[w2];
+
+    // ---- LDS counting sort of the subproblem by start cell (plans whose records are
+    // not already cell-ordered by cellsort2d_kernel)
+    // (all loads are unconditional on clamped indices: a load under a divergent
+    // branch makes the compiler wait for it before the next one is issued)
+    uint32_t kr[IT];   // key | rank-in-cell << 10
 #pragma unroll
-    for (int u = 0; u < PER; ++u) { cnt[tid * PER + u] = run; run += v[u]; }
-  }
-  __syncthreads();
+    for (int u = 0; u < IT; ++u) {
+      const int i = tid + u * NT;
+      kr[u] = 0u;
+      if (u * NT < n) kr[u] = sp.rec[p0 + (i < n ? i : n - 1)].loc;
+    }
 #pragma unroll
-  for (int u = 0; u < IT; ++u) {
-    const int i = tid + u * NT;
-    if (i < n) perm[cnt[kr[u] & 1023u] + (kr[u] >> 10)] = (uint16_t)i;
+    for (int u = 0; u < IT; ++u) {
+      const int i = tid + u * NT;
+      const uint32_t key = (((kr[u] >> 10) & 31u) << 5) | (kr[u] & 31u);
+      if (i < n) kr[u] = key | (atomicAdd(&cnt[key], 1u) << 10);
+    }
+    __syncthreads();
+    scan1024<NT>(cnt, wsum, tid);
+#pragma unroll
+    for (int u = 0; u < IT; ++u) {
+      const int i = tid + u * NT;
+      if (i < n) perm[cnt[kr[u] & 1023u] + (kr[u] >> 10)] = (uint16_t)i;
+    }
   }
   __syncthreads();
 
@@ -885,7 +942,9 @@ __global__ __launch_bounds__(NW * 64) void spread_2d_w8_group_kernel(
   const float2* c2 = reinterpret_cast<const float2*>(cc);
   auto load_rec = [&](int b) {   // lanes past the end re-read the last point; masked below
     const int li = b + lane;
-    return sp.rec[p0 + perm[li < n ? li : n - 1]];
+    const int lc = li < n ? li : n - 1;
+    if constexpr (PRE) return sp.rec[p0 + lc];
+    else return sp.rec[p0 + perm[lc]];
   };
   auto load_c = [&](const Rec<float>& r) { return c2[r.idx]; };
   constexpr int STEP = NW * CH;
@@ -1696,12 +1755,12 @@ static void wave8_shape_init() {
 }
 static int wave8_nw(bool grouped) { wave8_shape_init(); return g_w8_nw > 0 ? g_w8_nw : (grouped ? 8 : 4); }
 static int wave8_ch(bool grouped) { wave8_shape_init(); return g_w8_ch > 0 ? g_w8_ch : (grouped ? 64 : 64); }
-static size_t wave8_lds(bool grouped) {
+static size_t wave8_lds(bool grouped, bool presorted = false) {
   const size_t planes = sizeof(double) * 2 * kWPlane;
   const int nw = wave8_nw(grouped), ch = wave8_ch(grouped);
   if (!grouped) return planes + sizeof(float) * nw * ch * kWW * 3;
   return planes + sizeof(float) * nw * 3 * ((ch < kGroupStage ? ch : kGroupStage) / 4) * kGroupBlk +
-         1024 * 4 + kGroupMaxSub * 2 + 64;   // + counters, permutation, wave sums
+         (presorted ? 0 : 1024 * 4 + kGroupMaxSub * 2 + 64);   // + counters, permutation, wave sums
 }
 
 // Specialised 2-D w = 8 float kernel applicable?
@@ -1725,6 +1784,34 @@ int wave_lstride(int rank) { return rank == 2 ? 40 : 24; }
 
 template <typename T> static constexpr int wave3d_nw() { return sizeof(T) == 4 ? 16 : 8; }
 
+// Upper bound on the number of subproblems, known without reading the device:
+// sum_b ceil(n_b / S) <= ntiles + M / S.
+static inline unsigned subproblem_grid(const Geom& g, int64_t M) {
+  return (unsigned)((int64_t)g.ntiles + M / g.max_sub);
+}
+
+// NUFFT_HIP_CELLSORT = 0 never, 1 whenever the geometry allows; unset: by point density.
+bool cellsort_wanted(const Geom& g, int method, int precision, int64_t M) {
+  static const int mode = [] { const char* e = getenv("NUFFT_HIP_CELLSORT"); return e ? atoi(e) : -1; }();
+  // only the 2-D w = 8 float spreader has a kernel that exploits the order
+  if (method != NUFFT_HIP_METHOD_TILE_WAVE || !wave8_supported(g, precision)) return false;
+  if (g.max_sub > kCellSortMaxSub || M == 0 || mode == 0) return false;
+  if (mode > 0) return true;
+  return wave8_use_group(g, M);
+}
+
+template <typename T>
+hipError_t launch_cellsort(const Geom& g, int64_t M, const int32_t* tile_start, const int32_t* sub_start,
+                           const Rec<T>* in, Rec<T>* out, hipStream_t stream) {
+  if (M == 0) return hipSuccess;
+  cellsort2d_kernel<T><<<subproblem_grid(g, M), kCellSortThreads, 0, stream>>>(g, tile_start, sub_start, in, out);
+  return hipGetLastError();
+}
+template hipError_t launch_cellsort<float>(const Geom&, int64_t, const int32_t*, const int32_t*,
+                                           const Rec<float>*, Rec<float>*, hipStream_t);
+template hipError_t launch_cellsort<double>(const Geom&, int64_t, const int32_t*, const int32_t*,
+                                            const Rec<double>*, Rec<double>*, hipStream_t);
+
 size_t spread_lds_bytes(const Geom& g, int method, int precision) {
   // LDS tiles are double for both precisions
   size_t cells = (size_t)g.lstride;
@@ -1746,11 +1833,6 @@ size_t interp_lds_bytes(const Geom& g, int method, int precision) {
   return cells * 2 * (size_t)precision;
 }
 
-// Upper bound on the number of subproblems, known without reading the device:
-// sum_b ceil(n_b / S) <= ntiles + M / S.
-static inline unsigned subproblem_grid(const Geom& g, int64_t M) {
-  return (unsigned)((int64_t)g.ntiles + M / g.max_sub);
-}
 
 template <typename T>
 hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, int64_t M,
@@ -1762,21 +1844,27 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
   if (method == NUFFT_HIP_METHOD_TILE_WAVE) {
     if constexpr (sizeof(T) == 4) {
       if (wave8_supported(g, 4)) {
-        const bool grouped = wave8_use_group(g, M);
+        const bool grouped = g.cell_sorted || wave8_use_group(g, M);
         const int shape = wave8_nw(grouped) * 100 + wave8_ch(grouped);
-        lds_bytes = wave8_lds(grouped);   // the plan's figure is the maximum of the two variants
+        lds_bytes = wave8_lds(grouped, g.cell_sorted);   // the plan's figure is the maximum over the variants
         if (grouped) {
 #define NUFFT_LAUNCH_W8G(NWV, CHV)                                                             \
   case NWV * 100 + CHV:                                                                        \
-    e = ensure_lds(spread_2d_w8_group_kernel<NWV, CHV>, lds_bytes);                            \
-    if (e != hipSuccess) return e;                                                             \
-    spread_2d_w8_group_kernel<NWV, CHV><<<grid, NWV * 64, lds_bytes, stream>>>(                \
-        g, sp, horner, c, fw, c_stride, fw_stride, scale);                                     \
+    if (g.cell_sorted) {                                                                       \
+      e = ensure_lds(spread_2d_w8_group_kernel<NWV, CHV, true>, lds_bytes);                    \
+      if (e != hipSuccess) return e;                                                           \
+      spread_2d_w8_group_kernel<NWV, CHV, true><<<grid, NWV * 64, lds_bytes, stream>>>(        \
+          g, sp, horner, c, fw, c_stride, fw_stride, scale);                                   \
+    } else {                                                                                   \
+      e = ensure_lds(spread_2d_w8_group_kernel<NWV, CHV, false>, lds_bytes);                   \
+      if (e != hipSuccess) return e;                                                           \
+      spread_2d_w8_group_kernel<NWV, CHV, false><<<grid, NWV * 64, lds_bytes, stream>>>(       \
+          g, sp, horner, c, fw, c_stride, fw_stride, scale);                                   \
+    }                                                                                          \
     break;
           switch (shape) {
             NUFFT_LAUNCH_W8G(4, 64) NUFFT_LAUNCH_W8G(4, 32) NUFFT_LAUNCH_W8G(8, 64) NUFFT_LAUNCH_W8G(8, 32)
-            NUFFT_LAUNCH_W8G(2, 64) NUFFT_LAUNCH_W8G(2, 32) NUFFT_LAUNCH_W8G(16, 32) NUFFT_LAUNCH_W8G(4, 16)
-            NUFFT_LAUNCH_W8G(8, 16)
+            NUFFT_LAUNCH_W8G(16, 32) NUFFT_LAUNCH_W8G(8, 16) NUFFT_LAUNCH_W8G(16, 64)
             default: return hipErrorInvalidValue;
           }
 #undef NUFFT_LAUNCH_W8G

@@ -221,6 +221,9 @@ struct nufft_hip_plan_s {
 
   int64_t M = 0, cap = 0, cap_global = 0;
   void* rec = nullptr;           // Rec<T>[cap], tile-sorted
+  void* rec2 = nullptr;          // Rec<T>[cap2]: target of the lazy cell-sort pass (then swapped with rec)
+  int64_t cap2 = 0;
+  int64_t spread_uses = 0;       // spread launches fed by the current sorted points
   int32_t* idx3 = nullptr;       // float rank-3 only
   int32_t *hist = nullptr;       // LDS-histogram sort: [nblk][ntiles]
   int64_t hist_elems = 0;
@@ -419,6 +422,8 @@ int set_points_impl(nufft_hip_plan p, int64_t M, const void* x, const void* y, c
   w.hist = p->hist; w.tile_of = p->tile_of; w.rank_of = p->rank_of;
   w.tile_count = p->tile_count; w.tile_start = p->tile_start; w.sub_start = p->sub_start;
   w.bad_count = p->bad_count;
+  p->g.cell_sorted = 0;   // the second sort level, if any, runs lazily (maybe_cellsort)
+  p->spread_uses = 0;
   SortedOut<T> out;
   out.rec = (Rec<T>*)p->rec;
   out.idx3 = p->idx3;
@@ -454,11 +459,51 @@ SortedPoints<T> sorted_view(nufft_hip_plan p) {
 // type 2: f -> amplify into fine grid -> FFT -> interpolate -> c
 // batched over min(ntransf, batch_size) transforms per pass (one launch per
 // stage and pass; the reference launches per transform, nufft_plan.cu.cc:2469-2571).
+
+// Second sort level, applied lazily. Ordering every subproblem by stencil start
+// cell costs about a third of a spread launch and saves about a sixth of each one
+// (the cell-grouped kernel then skips its in-LDS sort), so it only pays when the
+// same points feed several launches: a plan reused across executes, or many
+// transforms per execute. It therefore runs inside the execute that brings the
+// count to three, never in set_points, and never while the stream is being
+// captured into a graph (it may allocate).
+template <typename T>
+int maybe_cellsort(nufft_hip_plan p, int launches) {
+  const int64_t before = p->spread_uses;
+  p->spread_uses += launches;
+  if (p->g.cell_sorted || before + launches < 3) return NUFFT_HIP_OK;
+  if (!cellsort_wanted(p->g, p->method, p->precision, p->M)) return NUFFT_HIP_OK;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(p->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return NUFFT_HIP_OK;
+  if (p->M > p->cap2) {
+    HIP_TRY(p, hipStreamSynchronize(p->stream));
+    dev_free(p->rec2);
+    p->rec2 = nullptr;
+    p->cap2 = 0;
+    int rc;
+    if ((rc = dev_alloc(p, &p->rec2, (size_t)p->M * sizeof(Rec<T>)))) return rc;
+    p->cap2 = p->M;
+  }
+  const StageHook hook = make_hook(p);
+  hook.begin(STAGE_SORT_CELL);
+  HIP_TRY(p, launch_cellsort<T>(p->g, p->M, p->tile_start, p->sub_start, (const Rec<T>*)p->rec,
+                                (Rec<T>*)p->rec2, p->stream));
+  hook.end(STAGE_SORT_CELL);
+  std::swap(p->rec, p->rec2);
+  std::swap(p->cap, p->cap2);
+  p->g.cell_sorted = 1;
+  return NUFFT_HIP_OK;
+}
+
 template <typename T>
 int execute_impl(nufft_hip_plan p, void* c, void* f) {
   if (!p->points_set) {
     p->err = "set_points must be called before execute";
     return NUFFT_HIP_INVALID_ARGUMENT;
+  }
+  if (p->type == NUFFT_HIP_TYPE_1) {
+    const int rc = maybe_cellsort<T>(p, p->ntransf);
+    if (rc) return rc;
   }
   const SortedPoints<T> sp = sorted_view<T>(p);
   const T* rf[3] = {(const T*)p->d_rfser[0], (const T*)p->d_rfser[1], (const T*)p->d_rfser[2]};
@@ -512,6 +557,10 @@ int spread_interp_impl(nufft_hip_plan p, int dir, void* c, void* f) {
     p->err = "set_points must be called before spread/interp";
     return NUFFT_HIP_INVALID_ARGUMENT;
   }
+  if (dir == 1) {
+    const int rc = maybe_cellsort<T>(p, p->ntransf);
+    if (rc) return rc;
+  }
   const SortedPoints<T> sp = sorted_view<T>(p);
   const T scale = (T)p->spread_scale;
   // The op output IS the grid here; batch over all transforms in one launch
@@ -548,7 +597,7 @@ void destroy(nufft_hip_plan p) {
   dev_free(p->d_horner);
   for (int d = 0; d < 3; ++d) dev_free(p->d_rfser[d]);
   dev_free(p->d_fine);
-  dev_free(p->rec); dev_free(p->idx3); dev_free(p->hist); dev_free(p->tile_of); dev_free(p->rank_of);
+  dev_free(p->rec); dev_free(p->rec2); dev_free(p->idx3); dev_free(p->hist); dev_free(p->tile_of); dev_free(p->rank_of);
   for (auto& pe : p->pending) { (void)hipEventDestroy(pe.e0); (void)hipEventDestroy(pe.e1); }
   for (auto e : p->free_events) (void)hipEventDestroy(e);
   dev_free(p->tile_count); dev_free(p->tile_start); dev_free(p->sub_start); dev_free(p->bad_count);
@@ -736,6 +785,7 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
   p->method = method;
   // packed fixed-point accumulation: 3-D float wavefront kernel at w <= 6 (tol >= ~1e-4)
   g.fixed_point = 0;
+  g.cell_sorted = 0;
   if (method == NUFFT_HIP_METHOD_TILE_WAVE && rank == 3 && precision == NUFFT_HIP_F32 && w <= 6 &&
       p->opts.lds_accumulate != 1)
     g.fixed_point = 1;

@@ -20,7 +20,7 @@ FORWARD, BACKWARD = -1, 1
 F32, F64 = 4, 8
 OP_NUFFT, OP_INTERP, OP_SPREAD = 0, 1, 2
 METHOD_AUTO, METHOD_TILE_GENERIC, METHOD_TILE_WAVE = 0, 1, 2
-STAGES = ('sort_count', 'sort_scan', 'sort_scatter', 'zero', 'spread', 'fft', 'deconvolve', 'interp')
+STAGES = ('sort_count', 'sort_scan', 'sort_scatter', 'zero', 'spread', 'fft', 'deconvolve', 'interp', 'sort_cell')
 
 
 class InvalidArgumentError(ValueError):
