@@ -217,14 +217,25 @@ __device__ __forceinline__ bool locate_subproblem(const Geom& g, const int32_t* 
 // and the Horner argument z = 2(i0 - x') + w - 1 in [-1, 1]. Points are binned
 // by the WRAPPED STENCIL START, so a tile's halo is one sided (w - 1 cells).
 // Returns the tile index; fills the record (without idx).
+// Coordinates of point i. All three loads are unconditional (the host points unused
+// dimensions at the x array): loads under a branch are waited for one by one, which
+// defeats the batching in the count / scatter loops below.
 template <typename T>
-__device__ __forceinline__ int fold_point(const Geom& g, const PointsIn& in, int64_t i, Rec<T>* r,
-                                          bool* bad) {
+__device__ __forceinline__ void load_coords(const PointsIn& in, int64_t i, T x[3]) {
+#pragma unroll
+  for (int d = 0; d < 3; ++d) x[d] = ((const T*)in.pts[d])[i * in.stride];
+}
+
+template <typename T>
+__device__ __forceinline__ int fold_coords(const Geom& g, const PointsIn& in, const T xin[3], Rec<T>* r,
+                                           bool* bad) {
   uint32_t loc = 0;
   int tc[3] = {0, 0, 0};
   T zz3[3] = {(T)0, (T)0, (T)0};
-  for (int d = 0; d < g.rank; ++d) {
-    const double x = (double)((const T*)in.pts[d])[i * in.stride];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    if (d >= g.rank) break;
+    const double x = (double)xin[d];
     double s;
     if (in.range_mode == NUFFT_HIP_RANGE_STRICT) {
       *bad |= !(x > -kPiD && x < kPiD);   // IsWithinRange, nufft_plan.h:866-898 (strict inequalities)
@@ -274,6 +285,14 @@ __device__ __forceinline__ int fold_point(const Geom& g, const PointsIn& in, int
 }
 
 template <typename T>
+__device__ __forceinline__ int fold_point(const Geom& g, const PointsIn& in, int64_t i, Rec<T>* r,
+                                          bool* bad) {
+  T x[3];
+  load_coords<T>(in, i, x);
+  return fold_coords<T>(g, in, x, r, bad);
+}
+
+template <typename T>
 __device__ __forceinline__ void store_record(const SortedOut<T>& out, int rank, int pos, Rec<T> r,
                                              int32_t idx);
 template <>
@@ -316,6 +335,7 @@ __device__ __forceinline__ void store_record<double>(const SortedOut<double>& ou
 // histograms. No global atomics, deterministic tile order. Three passes over
 // the raw points (hist, scatter) + two tiny scans.
 constexpr int kSortBlock = 1024;
+constexpr int kSortBatch = 4;    // points in flight per thread in the count / scatter loops
 
 template <typename T>
 __global__ __launch_bounds__(kSortBlock) void hist_lds_kernel(Geom g, PointsIn in, int64_t per_block,
@@ -329,10 +349,22 @@ __global__ __launch_bounds__(kSortBlock) void hist_lds_kernel(Geom g, PointsIn i
   const int64_t lo = (int64_t)blockIdx.x * per_block;
   const int64_t hi = (lo + per_block < in.M) ? lo + per_block : in.M;
   bool bad = false;
-  for (int64_t i = lo + threadIdx.x; i < hi; i += kSortBlock) {
-    Rec<T> r;
-    const int tile = fold_point<T>(g, in, i, &r, &bad);
-    atomicAdd(&h[tile], 1);
+  // kSortBatch points per thread per pass, their loads issued back to back on clamped
+  // indices: with one load in flight per thread the kernel ran at the latency bound
+  // (32 waves x 512 B per CU / ~2 us = 1.7 TB/s)
+  for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += kSortBatch * kSortBlock) {
+    T x[kSortBatch][3];
+#pragma unroll
+    for (int u = 0; u < kSortBatch; ++u) {
+      const int64_t i = i0 + u * kSortBlock;
+      load_coords<T>(in, i < hi ? i : hi - 1, x[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < kSortBatch; ++u) {
+      Rec<T> r;
+      const int tile = fold_coords<T>(g, in, x[u], &r, &bad);
+      if (i0 + u * kSortBlock < hi) atomicAdd(&h[tile], 1);
+    }
   }
   if (bad && in.check_range) atomicAdd(bad_count, 1);
   __syncthreads();
@@ -384,11 +416,23 @@ __global__ __launch_bounds__(kSortBlock) void scatter_lds_kernel(Geom g, PointsI
   const int64_t lo = (int64_t)blockIdx.x * per_block;
   const int64_t hi = (lo + per_block < in.M) ? lo + per_block : in.M;
   bool bad = false;
-  for (int64_t i = lo + threadIdx.x; i < hi; i += kSortBlock) {
-    Rec<T> r;
-    const int tile = fold_point<T>(g, in, i, &r, &bad);
-    const int pos = atomicAdd(&cur[tile], 1);
-    store_record<T>(out, g.rank, pos, r, (int32_t)i);
+  for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += kSortBatch * kSortBlock) {
+    T x[kSortBatch][3];
+#pragma unroll
+    for (int u = 0; u < kSortBatch; ++u) {
+      const int64_t i = i0 + u * kSortBlock;
+      load_coords<T>(in, i < hi ? i : hi - 1, x[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < kSortBatch; ++u) {
+      const int64_t i = i0 + u * kSortBlock;
+      Rec<T> r;
+      const int tile = fold_coords<T>(g, in, x[u], &r, &bad);
+      if (i < hi) {
+        const int pos = atomicAdd(&cur[tile], 1);
+        store_record<T>(out, g.rank, pos, r, (int32_t)i);
+      }
+    }
   }
 }
 
@@ -412,13 +456,25 @@ __global__ __launch_bounds__(kSortBlock) void hist16_lds_kernel(Geom g, PointsIn
   const int64_t lo = (int64_t)blockIdx.x * per_block;
   const int64_t hi = (lo + per_block < in.M) ? lo + per_block : in.M;
   bool bad = false;
-  for (int64_t i = lo + threadIdx.x; i < hi; i += kSortBlock) {
-    Rec<T> r;
-    const int tile = fold_point<T>(g, in, i, &r, &bad);
-    const int sh = 16 * (tile & 1);
-    const unsigned old = atomicAdd(&h2[tile >> 1], 1u << sh);
-    tile_of[i] = tile;
-    rank16[i] = (uint16_t)((old >> sh) & 0xffffu);   // rank inside (workgroup, tile)
+  for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += kSortBatch * kSortBlock) {
+    T x[kSortBatch][3];
+#pragma unroll
+    for (int u = 0; u < kSortBatch; ++u) {
+      const int64_t i = i0 + u * kSortBlock;
+      load_coords<T>(in, i < hi ? i : hi - 1, x[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < kSortBatch; ++u) {
+      const int64_t i = i0 + u * kSortBlock;
+      Rec<T> r;
+      const int tile = fold_coords<T>(g, in, x[u], &r, &bad);
+      if (i < hi) {
+        const int sh = 16 * (tile & 1);
+        const unsigned old = atomicAdd(&h2[tile >> 1], 1u << sh);
+        tile_of[i] = tile;
+        rank16[i] = (uint16_t)((old >> sh) & 0xffffu);   // rank inside (workgroup, tile)
+      }
+    }
   }
   if (bad && in.check_range) atomicAdd(bad_count, 1);
   __syncthreads();

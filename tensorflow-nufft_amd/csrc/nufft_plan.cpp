@@ -413,7 +413,8 @@ int set_points_impl(nufft_hip_plan p, int64_t M, const void* x, const void* y, c
   const bool check = p->opts.check_points_range && p->opts.points_range != NUFFT_HIP_RANGE_INFINITE;
   if (check) HIP_TRY(p, hipMemsetAsync(p->bad_count, 0, sizeof(int32_t) * 4, p->stream));
   PointsIn in;
-  in.pts[0] = x; in.pts[1] = y; in.pts[2] = z;
+  // unused dimensions alias x so that the kernels can load all three unconditionally
+  in.pts[0] = x; in.pts[1] = p->rank > 1 ? y : x; in.pts[2] = p->rank > 2 ? z : x;
   in.stride = stride;
   in.M = M;
   in.range_mode = p->opts.points_range;
