@@ -90,6 +90,12 @@ __device__ __forceinline__ void horner8(const T* __restrict__ tab, int nc, T z0,
 }
 
 __device__ __forceinline__ void lds_add(double* p, double v) { unsafeAtomicAdd(p, v); }
+// float -> int, rounding half up, as one VALU instruction
+__device__ __forceinline__ int cvt_rpi(float x) {
+  int r;
+  asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
 __device__ __forceinline__ void glb_add(float* p, float v) { unsafeAtomicAdd(p, v); }
 __device__ __forceinline__ void glb_add(double* p, double v) { unsafeAtomicAdd(p, v); }
 
@@ -1239,7 +1245,8 @@ __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
   double* plane_im = plane_re + (FX ? 0 : plane);
   double* pad = plane_re + (FX ? 1 : 2) * plane;                      // 64 elements of spill room
   T* stage_all = reinterpret_cast<T*>(pad + 64);
-  float* red = reinterpret_cast<float*>(stage_all + NW * CH * 16);    // [NW] (FX bound reduction)
+  constexpr int SW = W <= 6 ? 6 : 8;                                  // staging row length
+  float* red = reinterpret_cast<float*>(stage_all + NW * CH * 2 * SW);   // [NW] (FX bound reduction)
   int tb, p0, p1;
   if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1)) return;
   const int tid = threadIdx.x;
@@ -1272,8 +1279,8 @@ __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
   __syncthreads();
 
   const int nc = g.ncoef;
-  T* kxs = stage_all + wave * (CH * 16);   // [CH][8]
-  T* kys = kxs + CH * 8;                   // [CH][8]
+  T* kxs = stage_all + wave * (CH * 2 * SW);   // [CH][SW]
+  T* kys = kxs + CH * SW;                      // [CH][SW]
   const int dx = lane & 7, dy = lane >> 3;
   const bool active = dx < W && dy < W;
   const int cell = dy * LS + dx;
@@ -1305,8 +1312,8 @@ __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
       }
 #pragma unroll
       for (int q = 0; q < W; ++q) {
-        kxs[lane * 8 + q] = kx[q];
-        kys[lane * 8 + q] = ky[q];
+        kxs[lane * SW + q] = kx[q];
+        kys[lane * SW + q] = ky[q];
       }
     }
     int npts = wend - base;
@@ -1317,8 +1324,8 @@ __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
       // lanes outside the patch read unwritten staging slots: force their weight to 0
       const T a = active ? kx_n * ky_n : (T)0;
       const int qn = (q + 1 < npts) ? q + 1 : q;
-      kx_n = kxs[qn * 8 + dx];
-      ky_n = kys[qn * 8 + dy];
+      kx_n = kxs[qn * SW + dx];   // lanes outside the patch read a neighbour's slot; masked above
+      ky_n = kys[qn * SW + dy];
       const int o = __builtin_amdgcn_readlane(off, q) + cell;
       const T ar = a * bcast_lane(cre, q);
       const T ai = a * bcast_lane(cim, q);
@@ -1333,8 +1340,12 @@ __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
       for (int dz = 0; dz < W; ++dz) {
         const T kzq = bcast_lane(kz[dz], q);
         if (FX) {
-          const int ir = __float2int_rn((float)(ar * kzq));
-          const int ii = __float2int_rn((float)(ai * kzq));
+          // v_cvt_rpi_i32_f32 = floor(x + 0.5) in ONE instruction (__float2int_rn is
+          // v_rndne + v_cvt); the loop is VALU-issue bound, every instruction counts
+          typedef float v2f __attribute__((ext_vector_type(2)));
+          const v2f pr2 = (v2f){(float)ar, (float)ai} * (v2f){(float)kzq, (float)kzq};   // one v_pk_mul_f32
+          const int ir = cvt_rpi(pr2.x);
+          const int ii = cvt_rpi(pr2.y);
           const unsigned hi = (unsigned)(ir + (ii >> 31));   // + sign extension of the low field
           const unsigned long long x = ((unsigned long long)hi << 32) | (unsigned)ii;
           atomicAdd(reinterpret_cast<unsigned long long*>(pr) + dz * PS, x);
@@ -1423,8 +1434,11 @@ __device__ __forceinline__ void hornerW(const T* __restrict__ tab, int nc, T z0,
   }
 }
 
+// Threads per workgroup: 256 in 2-D (12.5 KB tiles, the thread limit of the CU binds), 512
+// in 3-D, where a 46 KB tile lets only three workgroups share a CU.
+template <int RANK> constexpr int kInterpThreads = RANK > 2 ? 512 : 256;
 template <typename T, int RANK, int W>
-__global__ __launch_bounds__(256) void interp_point_kernel(
+__global__ __launch_bounds__(kInterpThreads<RANK>) void interp_point_kernel(
     Geom g, SortedPoints<T> sp, const T* __restrict__ horner, T* __restrict__ c,
     const T* __restrict__ fw, int64_t c_stride, int64_t fw_stride, T scale) {
   using T2 = typename Pair<T>::type;
@@ -1444,7 +1458,8 @@ __global__ __launch_bounds__(256) void interp_point_kernel(
   const int t2 = tb / (g.ntile[0] * g.ntile[1]);
   const int o0 = t0 * g.tile[0], o1 = t1 * g.tile[1], o2 = t2 * g.tile[2];
   const T2* in = reinterpret_cast<const T2*>(fw) + (int64_t)blockIdx.y * fw_stride;
-  for (RowWalk r(wave, L1); r.a2 < L2; r.advance(4, L1)) {
+  constexpr int NT = kInterpThreads<RANK>;
+  for (RowWalk r(wave, L1); r.a2 < L2; r.advance(NT / 64, L1)) {
     const int g1 = wrap1(o1 + r.a1, g.nf[1]);
     const int g2 = RANK > 2 ? wrap1(o2 + r.a2, g.nf[2]) : 0;
     const int64_t rowbase = (int64_t)g.nf[0] * (g1 + (int64_t)g.nf[1] * g2);
@@ -1455,7 +1470,7 @@ __global__ __launch_bounds__(256) void interp_point_kernel(
 
   const int nc = g.ncoef;
   T2* cc = reinterpret_cast<T2*>(c) + (int64_t)blockIdx.y * c_stride;
-  for (int j = p0 + tid; j < p1; j += 256) {
+  for (int j = p0 + tid; j < p1; j += NT) {
     const PointView<T> rec = unpack_rec<T, RANK>(sp.rec[j]);
     T kx[W], ky[W], kz[W];
     hornerW<T, RANK, W>(horner, nc, rec.z0, rec.z1, rec.z2, kx, ky, kz);
@@ -1838,7 +1853,13 @@ bool wave_method_supported(const Geom& g, int precision) {
 }
 int wave_lstride(int rank) { return rank == 2 ? 40 : 24; }
 
-template <typename T> static constexpr int wave3d_nw() { return sizeof(T) == 4 ? 16 : 8; }
+// Waves per workgroup of the 3-D kernel. LDS decides how many workgroups share a CU and
+// 69 VGPRs allow 7 waves per SIMD: the float fixed-point form (one 52 KB plane) runs two
+// workgroups of 12 waves (3 per SIMD each; config 4: 11.8 ms against 15.6 ms with 16 waves
+// in ONE workgroup; 2 x 14 does not co-reside: 4+4+3+3 waves per SIMD twice exceeds the
+// register file of SIMD 0); two fp64 planes leave room for one workgroup only.
+template <typename T, bool FX> static constexpr int wave3d_nw() { return sizeof(T) == 4 ? (FX ? 12 : 16) : 8; }
+static int wave3d_nw_rt(int precision, bool fx) { return precision == NUFFT_HIP_F32 ? (fx ? 12 : 16) : 8; }
 
 // Upper bound on the number of subproblems, known without reading the device:
 // sum_b ceil(n_b / S) <= ntiles + M / S.
@@ -1875,9 +1896,9 @@ size_t spread_lds_bytes(const Geom& g, int method, int precision) {
   if (method == NUFFT_HIP_METHOD_TILE_WAVE) {
     if (wave8_supported(g, precision)) return std::max(wave8_lds(false), wave8_lds(true));
     if (g.rank == 2) return (cells * 2 + 256) * sizeof(double) + (size_t)precision * 4 * 64 * 24;
-    const int nw = precision == NUFFT_HIP_F32 ? 16 : 8;
+    const int nw = wave3d_nw_rt(precision, g.fixed_point != 0);
     return cells * (g.fixed_point ? 1 : 2) * sizeof(double) + 64 * sizeof(double) +
-           (size_t)precision * nw * 32 * 16 + 256;
+           (size_t)precision * nw * 32 * 2 * (g.w <= 6 ? 6 : 8) + 256;
   }
   return cells * 2 * sizeof(double);
 }
@@ -1958,12 +1979,11 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
       }
 #undef NUFFT_CASE_W2
     } else {
-      constexpr int nw = wave3d_nw<T>();
 #define NUFFT_LAUNCH_W3(WW, TZV, FXV)                                                            \
-  e = ensure_lds(spread_wave3_kernel<T, WW, TZV, nw, 32, FXV>, lds_bytes);                        \
+  e = ensure_lds(spread_wave3_kernel<T, WW, TZV, wave3d_nw<T, FXV>(), 32, FXV>, lds_bytes);       \
   if (e != hipSuccess) return e;                                                                 \
-  spread_wave3_kernel<T, WW, TZV, nw, 32, FXV><<<grid, nw * 64, lds_bytes, stream>>>(            \
-      g, sp, horner, c, fw, c_stride, fw_stride, scale);
+  spread_wave3_kernel<T, WW, TZV, wave3d_nw<T, FXV>(), 32, FXV>                                   \
+      <<<grid, wave3d_nw<T, FXV>() * 64, lds_bytes, stream>>>(g, sp, horner, c, fw, c_stride, fw_stride, scale);
 #define NUFFT_CASE_W3(WW)                                                                        \
   case WW:                                                                                       \
     if (g.tile[2] == 8) {                                                                        \
@@ -2030,8 +2050,8 @@ hipError_t launch_interp(const Geom& g, int method, const SortedPoints<T>& sp, i
   case RR * 100 + WW:                                                                                 \
     e = ensure_lds(interp_point_kernel<T, RR, WW>, lds);                                              \
     if (e != hipSuccess) return e;                                                                    \
-    interp_point_kernel<T, RR, WW><<<grid, 256, lds, stream>>>(g, sp, horner, c, fw, c_stride, fw_stride, \
-                                                               scale);                                \
+    interp_point_kernel<T, RR, WW><<<grid, kInterpThreads<RR>, lds, stream>>>(g, sp, horner, c, fw,   \
+                                                                              c_stride, fw_stride, scale); \
     break;
     switch (g.rank * 100 + g.w) {
       NUFFT_LAUNCH_IP(2, 2) NUFFT_LAUNCH_IP(2, 3) NUFFT_LAUNCH_IP(2, 4) NUFFT_LAUNCH_IP(2, 5)
