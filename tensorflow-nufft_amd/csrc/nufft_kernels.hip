@@ -849,27 +849,32 @@ __global__ __launch_bounds__(NW * 64) void spread_2d_w8_wave_kernel(
   }
 }
 
-// Exclusive scan of cnt[1024] in place by a workgroup of NT threads (NT | 1024);
-// wsum: >= NT/64 words of LDS scratch. Ends with a barrier.
+// Exclusive scan of cnt[1024] in place by a workgroup of NT threads; the first NS = largest
+// power of two <= NT threads do the work. wsum: >= NS/64 words of LDS scratch. Ends with a
+// barrier.
 template <int NT>
 __device__ __forceinline__ void scan1024(uint32_t* cnt, uint32_t* wsum, int tid) {
-  constexpr int PER = 1024 / NT;
+  constexpr int NS = NT >= 1024 ? 1024 : NT >= 512 ? 512 : NT >= 256 ? 256 : NT >= 128 ? 128 : 64;
+  constexpr int PER = 1024 / NS;
   const int lane = tid & 63, wave = tid >> 6;
+  const bool on = tid < NS;
   uint32_t v[PER], tot = 0u;
 #pragma unroll
-  for (int u = 0; u < PER; ++u) { v[u] = cnt[tid * PER + u]; tot += v[u]; }
+  for (int u = 0; u < PER; ++u) { v[u] = on ? cnt[tid * PER + u] : 0u; tot += v[u]; }
   uint32_t incl = tot;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
     const uint32_t t = __shfl_up(incl, d);
     if (lane >= d) incl += t;
   }
-  if (lane == 63) wsum[wave] = incl;
+  if (on && lane == 63) wsum[wave] = incl;
   __syncthreads();
-  uint32_t run = incl - tot;
-  for (int w2 = 0; w2 < wave; ++w2) run += wsum[w2];
+  if (on) {
+    uint32_t run = incl - tot;
+    for (int w2 = 0; w2 < wave; ++w2) run += wsum[w2];
 #pragma unroll
-  for (int u = 0; u < PER; ++u) { cnt[tid * PER + u] = run; run += v[u]; }
+    for (int u = 0; u < PER; ++u) { cnt[tid * PER + u] = run; run += v[u]; }
+  }
   __syncthreads();
 }
 
@@ -939,9 +944,9 @@ __global__ __launch_bounds__(NW * 64) void spread_2d_w8_group_kernel(
     Geom g, SortedPoints<float> sp, const float* __restrict__ horner, const float* __restrict__ c,
     float* __restrict__ fw, int64_t c_stride, int64_t fw_stride, float scale) {
   constexpr int NT = NW * 64;
-  constexpr int IT = kGroupMaxSub / NT;     // records per thread in the LDS sort
+  constexpr int IT = (kGroupMaxSub + NT - 1) / NT;   // records per thread in the LDS sort
   constexpr int SC = CH < kGroupStage ? CH : kGroupStage;   // points staged through LDS at a time
-  static_assert(1024 % NT == 0, "at most 16 waves");
+  static_assert(NT <= 1024, "at most 16 waves");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* plane_re = reinterpret_cast<double*>(smem_raw);
   double* plane_im = plane_re + kWPlane;
@@ -1816,7 +1821,8 @@ static bool wave8_use_group(const Geom& g, int64_t M) {
 }
 
 // Defaults from the r01 sweeps (tools/sweep_w8.py, tools/sweep_w8_group.py): 4 x 64
-// for the per-point kernel, 8 x 64 for the cell-grouped one.
+// for the per-point kernel, 12 x 64 for the cell-grouped one (79 KB of LDS: two
+// workgroups = 24 waves per CU, 3 per SIMD each; 8 x 64 = 16 waves per CU was 8 % slower).
 static int g_w8_nw = 0, g_w8_ch = 0;
 static void wave8_shape_init() {
   if (g_w8_nw) return;
@@ -1824,7 +1830,7 @@ static void wave8_shape_init() {
   if (const char* e = getenv("NUFFT_HIP_W8_SHAPE")) sscanf(e, "%dx%d", &nw, &ch);
   g_w8_nw = nw; g_w8_ch = ch;
 }
-static int wave8_nw(bool grouped) { wave8_shape_init(); return g_w8_nw > 0 ? g_w8_nw : (grouped ? 8 : 4); }
+static int wave8_nw(bool grouped) { wave8_shape_init(); return g_w8_nw > 0 ? g_w8_nw : (grouped ? 12 : 4); }
 static int wave8_ch(bool grouped) { wave8_shape_init(); return g_w8_ch > 0 ? g_w8_ch : (grouped ? 64 : 64); }
 static size_t wave8_lds(bool grouped, bool presorted = false) {
   const size_t planes = sizeof(double) * 2 * kWPlane;
@@ -1941,7 +1947,8 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
     break;
           switch (shape) {
             NUFFT_LAUNCH_W8G(4, 64) NUFFT_LAUNCH_W8G(4, 32) NUFFT_LAUNCH_W8G(8, 64) NUFFT_LAUNCH_W8G(8, 32)
-            NUFFT_LAUNCH_W8G(16, 32) NUFFT_LAUNCH_W8G(8, 16) NUFFT_LAUNCH_W8G(16, 64)
+            NUFFT_LAUNCH_W8G(16, 32) NUFFT_LAUNCH_W8G(8, 16) NUFFT_LAUNCH_W8G(16, 64) NUFFT_LAUNCH_W8G(12, 64)
+            NUFFT_LAUNCH_W8G(12, 32) NUFFT_LAUNCH_W8G(10, 64) NUFFT_LAUNCH_W8G(6, 64)
             default: return hipErrorInvalidValue;
           }
 #undef NUFFT_LAUNCH_W8G
