@@ -1475,8 +1475,12 @@ __global__ __launch_bounds__(kInterpThreads<RANK>) void interp_point_kernel(
 
   const int nc = g.ncoef;
   T2* cc = reinterpret_cast<T2*>(c) + (int64_t)blockIdx.y * c_stride;
+  // the next record is requested (on a clamped index, outside any branch) before this
+  // point's ~300 dependent instructions, so its HBM latency is off the critical path
+  Rec<T> raw = sp.rec[p0 + tid < p1 ? p0 + tid : p1 - 1];
   for (int j = p0 + tid; j < p1; j += NT) {
-    const PointView<T> rec = unpack_rec<T, RANK>(sp.rec[j]);
+    const PointView<T> rec = unpack_rec<T, RANK>(raw);
+    raw = sp.rec[j + NT < p1 ? j + NT : p1 - 1];
     T kx[W], ky[W], kz[W];
     hornerW<T, RANK, W>(horner, nc, rec.z0, rec.z1, rec.z2, kx, ky, kz);
     const T2* tp = tile + (int)(rec.loc & 1023) + (int)((rec.loc >> 10) & 1023) * LS +
@@ -1865,6 +1869,11 @@ int wave_lstride(int rank) { return rank == 2 ? 40 : 24; }
 // in ONE workgroup; 2 x 14 does not co-reside: 4+4+3+3 waves per SIMD twice exceeds the
 // register file of SIMD 0); two fp64 planes leave room for one workgroup only.
 template <typename T, bool FX> static constexpr int wave3d_nw() { return sizeof(T) == 4 ? (FX ? 12 : 16) : 8; }
+#ifndef NUFFT_W2NW
+#define NUFFT_W2NW 4
+#define NUFFT_W2CH 64
+#endif
+constexpr int kW2NW = NUFFT_W2NW, kW2CH = NUFFT_W2CH;   // launch shape of spread_wave2_kernel
 static int wave3d_nw_rt(int precision, bool fx) { return precision == NUFFT_HIP_F32 ? (fx ? 12 : 16) : 8; }
 
 // Upper bound on the number of subproblems, known without reading the device:
@@ -1901,7 +1910,7 @@ size_t spread_lds_bytes(const Geom& g, int method, int precision) {
   for (int d = 1; d < g.rank; ++d) cells *= (size_t)g.ldim[d];
   if (method == NUFFT_HIP_METHOD_TILE_WAVE) {
     if (wave8_supported(g, precision)) return std::max(wave8_lds(false), wave8_lds(true));
-    if (g.rank == 2) return (cells * 2 + 256) * sizeof(double) + (size_t)precision * 4 * 64 * 24;
+    if (g.rank == 2) return (cells * 2 + 256) * sizeof(double) + (size_t)precision * kW2NW * kW2CH * 24;
     const int nw = wave3d_nw_rt(precision, g.fixed_point != 0);
     return cells * (g.fixed_point ? 1 : 2) * sizeof(double) + 64 * sizeof(double) +
            (size_t)precision * nw * 32 * 2 * (g.w <= 6 ? 6 : 8) + 256;
@@ -1974,9 +1983,9 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
     if (g.rank == 2) {
 #define NUFFT_CASE_W2(WW)                                                                    \
   case WW:                                                                                   \
-    e = ensure_lds(spread_wave2_kernel<T, WW, 4, 64>, lds_bytes);                            \
+    e = ensure_lds(spread_wave2_kernel<T, WW, kW2NW, kW2CH>, lds_bytes);                            \
     if (e != hipSuccess) return e;                                                           \
-    spread_wave2_kernel<T, WW, 4, 64><<<grid, 256, lds_bytes, stream>>>(g, sp, horner, c, fw, \
+    spread_wave2_kernel<T, WW, kW2NW, kW2CH><<<grid, kW2NW * 64, lds_bytes, stream>>>(g, sp, horner, c, fw, \
                                                                         c_stride, fw_stride, scale); \
     break;
       switch (g.w) {
