@@ -939,7 +939,7 @@ constexpr double kGroupMinDensity = 0.5;   // points per fine cell
 constexpr int kGroupStage = 32; // points whose kernel values are in LDS at a time (per wave)
 constexpr int kGroupBlk = 36;   // staging words per block of 4 points (8 x 4 + 4 pad)
 template <int CH> constexpr int kGroupStageWave = 3 * (CH / 4) * kGroupBlk;   // words per wave (kx, ky re, ky im)
-template <int NW, int CH, bool PRE>
+template <int W, int NW, int CH, bool PRE>
 __global__ __launch_bounds__(NW * 64) void spread_2d_w8_group_kernel(
     Geom g, SortedPoints<float> sp, const float* __restrict__ horner, const float* __restrict__ c,
     float* __restrict__ fw, int64_t c_stride, int64_t fw_stride, float scale) {
@@ -1028,15 +1028,17 @@ __global__ __launch_bounds__(NW * 64) void spread_2d_w8_group_kernel(
     const uint32_t key = valid ? (loc & 0xfffffu) : 0xffffffffu;
     const int off = (((loc >> 10) & 1023) * kWS + (loc & 1023)) * (int)sizeof(double);
     float kx[kWW], ky[kWW];
-    // The ES kernel is even, so cell 7-q's polynomial is cell q's at -z: evaluate the
+    // The ES kernel is even, so cell W-1-q's polynomial is cell q's at -z: evaluate the
     // even and odd parts in z^2 once per pair (12 instead of 22 FMAs for two cells,
-    // and only 48 coefficients, which stay in SGPRs). x and y share coefficients:
+    // and at most 48 coefficients, which stay in SGPRs). x and y share coefficients:
     // each term is one v_pk_fma_f32.
     typedef float v2f __attribute__((ext_vector_type(2)));
     const v2f zz = {zx, zy};
     const v2f z2 = zz * zz;
 #pragma unroll
-    for (int q = 0; q < kWW / 2; ++q) {
+    for (int q = 0; q < kWW; ++q) { kx[q] = 0.f; ky[q] = 0.f; }   // cells >= W stay 0 (narrower kernels)
+#pragma unroll
+    for (int q = 0; q < (W + 1) / 2; ++q) {
       const float te = horner[(kWaveCoef - 2) * kMaxW + q], to = horner[(kWaveCoef - 1) * kMaxW + q];
       v2f e = {te, te}, o = {to, to};
 #pragma unroll
@@ -1048,7 +1050,7 @@ __global__ __launch_bounds__(NW * 64) void spread_2d_w8_group_kernel(
       }
       const v2f lo = __builtin_elementwise_fma(zz, o, e), hi = __builtin_elementwise_fma(-zz, o, e);
       kx[q] = lo.x; ky[q] = lo.y;
-      kx[kWW - 1 - q] = hi.x; ky[kWW - 1 - q] = hi.y;
+      if (W - 1 - q != q) { kx[W - 1 - q] = hi.x; ky[W - 1 - q] = hi.y; }
     }
     r_cur = r_nxt;
     c_cur = c_nxt;
@@ -1836,19 +1838,27 @@ static void wave8_shape_init() {
 }
 static int wave8_nw(bool grouped) { wave8_shape_init(); return g_w8_nw > 0 ? g_w8_nw : (grouped ? 12 : 4); }
 static int wave8_ch(bool grouped) { wave8_shape_init(); return g_w8_ch > 0 ? g_w8_ch : (grouped ? 64 : 64); }
-static size_t wave8_lds(bool grouped, bool presorted = false) {
-  const size_t planes = sizeof(double) * 2 * kWPlane;
-  const int nw = wave8_nw(grouped), ch = wave8_ch(grouped);
-  if (!grouped) return planes + sizeof(float) * nw * ch * kWW * 3;
-  return planes + sizeof(float) * nw * 3 * ((ch < kGroupStage ? ch : kGroupStage) / 4) * kGroupBlk +
+constexpr int kW2NW = 4, kW2CH = 64;   // launch shape of spread_wave2_kernel (others measured no better)
+static size_t group_lds(int nw, int ch, bool presorted) {
+  return sizeof(double) * 2 * kWPlane + sizeof(float) * nw * 3 * ((ch < kGroupStage ? ch : kGroupStage) / 4) * kGroupBlk +
          (presorted ? 0 : 1024 * 4 + kGroupMaxSub * 2 + 64);   // + counters, permutation, wave sums
+}
+static size_t wave8_lds(bool grouped, bool presorted = false) {
+  const int nw = wave8_nw(grouped), ch = wave8_ch(grouped);
+  if (!grouped) return sizeof(double) * 2 * kWPlane + sizeof(float) * nw * ch * kWW * 3;
+  return group_lds(nw, ch, presorted);
+}
+static size_t wave2_lds(const Geom& g, int precision) {
+  size_t cells = (size_t)g.lstride;
+  for (int d = 1; d < g.rank; ++d) cells *= (size_t)g.ldim[d];
+  return (cells * 2 + 256) * sizeof(double) + (size_t)precision * kW2NW * kW2CH * 24;
 }
 
 // Specialised 2-D w = 8 float kernel applicable?
 static bool wave8_supported(const Geom& g, int precision) {
   static const bool off = getenv("NUFFT_HIP_NO_W8") != nullptr;   // A/B against spread_wave2_kernel<float, 8>
   if (off) return false;
-  return precision == NUFFT_HIP_F32 && g.rank == 2 && g.w == kWW && g.ncoef <= kWaveCoef &&
+  return precision == NUFFT_HIP_F32 && g.rank == 2 && g.w <= kWW && g.ncoef <= kWaveCoef &&
          g.tile[0] == kWT && g.tile[1] == kWT && g.lstride == kWS;
 }
 
@@ -1869,11 +1879,6 @@ int wave_lstride(int rank) { return rank == 2 ? 40 : 24; }
 // in ONE workgroup; 2 x 14 does not co-reside: 4+4+3+3 waves per SIMD twice exceeds the
 // register file of SIMD 0); two fp64 planes leave room for one workgroup only.
 template <typename T, bool FX> static constexpr int wave3d_nw() { return sizeof(T) == 4 ? (FX ? 12 : 16) : 8; }
-#ifndef NUFFT_W2NW
-#define NUFFT_W2NW 4
-#define NUFFT_W2CH 64
-#endif
-constexpr int kW2NW = NUFFT_W2NW, kW2CH = NUFFT_W2CH;   // launch shape of spread_wave2_kernel
 static int wave3d_nw_rt(int precision, bool fx) { return precision == NUFFT_HIP_F32 ? (fx ? 12 : 16) : 8; }
 
 // Upper bound on the number of subproblems, known without reading the device:
@@ -1909,8 +1914,10 @@ size_t spread_lds_bytes(const Geom& g, int method, int precision) {
   size_t cells = (size_t)g.lstride;
   for (int d = 1; d < g.rank; ++d) cells *= (size_t)g.ldim[d];
   if (method == NUFFT_HIP_METHOD_TILE_WAVE) {
-    if (wave8_supported(g, precision)) return std::max(wave8_lds(false), wave8_lds(true));
-    if (g.rank == 2) return (cells * 2 + 256) * sizeof(double) + (size_t)precision * kW2NW * kW2CH * 24;
+    if (wave8_supported(g, precision))   // maximum over the kernels launch_spread may pick
+      return std::max(std::max(wave8_lds(true), group_lds(12, 64, false)),
+                      g.w == kWW ? wave8_lds(false) : wave2_lds(g, precision));
+    if (g.rank == 2) return wave2_lds(g, precision);
     const int nw = wave3d_nw_rt(precision, g.fixed_point != 0);
     return cells * (g.fixed_point ? 1 : 2) * sizeof(double) + 64 * sizeof(double) +
            (size_t)precision * nw * 32 * 2 * (g.w <= 6 ? 6 : 8) + 256;
@@ -1940,29 +1947,44 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
         const int shape = wave8_nw(grouped) * 100 + wave8_ch(grouped);
         lds_bytes = wave8_lds(grouped, g.cell_sorted);   // the plan's figure is the maximum over the variants
         if (grouped) {
-#define NUFFT_LAUNCH_W8G(NWV, CHV)                                                             \
+#define NUFFT_LAUNCH_W8G(WV, NWV, CHV)                                                         \
   case NWV * 100 + CHV:                                                                        \
     if (g.cell_sorted) {                                                                       \
-      e = ensure_lds(spread_2d_w8_group_kernel<NWV, CHV, true>, lds_bytes);                    \
+      e = ensure_lds(spread_2d_w8_group_kernel<WV, NWV, CHV, true>, lds_bytes);                \
       if (e != hipSuccess) return e;                                                           \
-      spread_2d_w8_group_kernel<NWV, CHV, true><<<grid, NWV * 64, lds_bytes, stream>>>(        \
+      spread_2d_w8_group_kernel<WV, NWV, CHV, true><<<grid, NWV * 64, lds_bytes, stream>>>(    \
           g, sp, horner, c, fw, c_stride, fw_stride, scale);                                   \
     } else {                                                                                   \
-      e = ensure_lds(spread_2d_w8_group_kernel<NWV, CHV, false>, lds_bytes);                   \
+      e = ensure_lds(spread_2d_w8_group_kernel<WV, NWV, CHV, false>, lds_bytes);               \
       if (e != hipSuccess) return e;                                                           \
-      spread_2d_w8_group_kernel<NWV, CHV, false><<<grid, NWV * 64, lds_bytes, stream>>>(       \
+      spread_2d_w8_group_kernel<WV, NWV, CHV, false><<<grid, NWV * 64, lds_bytes, stream>>>(   \
           g, sp, horner, c, fw, c_stride, fw_stride, scale);                                   \
     }                                                                                          \
     break;
-          switch (shape) {
-            NUFFT_LAUNCH_W8G(4, 64) NUFFT_LAUNCH_W8G(4, 32) NUFFT_LAUNCH_W8G(8, 64) NUFFT_LAUNCH_W8G(8, 32)
-            NUFFT_LAUNCH_W8G(16, 32) NUFFT_LAUNCH_W8G(8, 16) NUFFT_LAUNCH_W8G(16, 64) NUFFT_LAUNCH_W8G(12, 64)
-            NUFFT_LAUNCH_W8G(12, 32) NUFFT_LAUNCH_W8G(10, 64) NUFFT_LAUNCH_W8G(6, 64)
+#define NUFFT_CASE_W8G(WV)   /* narrower kernels: default shape only */                       \
+  case WV:                                                                                     \
+    lds_bytes = group_lds(12, 64, g.cell_sorted);                                              \
+    switch (1264) {                                                                            \
+      NUFFT_LAUNCH_W8G(WV, 12, 64)                                                             \
+    }                                                                                          \
+    break;
+          switch (g.w) {
+            NUFFT_CASE_W8G(2) NUFFT_CASE_W8G(3) NUFFT_CASE_W8G(4) NUFFT_CASE_W8G(5)
+            NUFFT_CASE_W8G(6) NUFFT_CASE_W8G(7)
+            case 8:
+              switch (shape) {
+                NUFFT_LAUNCH_W8G(8, 4, 64) NUFFT_LAUNCH_W8G(8, 8, 64) NUFFT_LAUNCH_W8G(8, 8, 32)
+                NUFFT_LAUNCH_W8G(8, 16, 32) NUFFT_LAUNCH_W8G(8, 12, 64) NUFFT_LAUNCH_W8G(8, 12, 32)
+                default: return hipErrorInvalidValue;
+              }
+              break;
             default: return hipErrorInvalidValue;
           }
+#undef NUFFT_CASE_W8G
 #undef NUFFT_LAUNCH_W8G
           return hipGetLastError();
         }
+        if (g.w == kWW) {
 #define NUFFT_LAUNCH_W8(NWV, CHV)                                                              \
   case NWV * 100 + CHV:                                                                        \
     e = ensure_lds(spread_2d_w8_wave_kernel<NWV, CHV>, lds_bytes);                             \
@@ -1978,9 +2000,11 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
         }
 #undef NUFFT_LAUNCH_W8
         return hipGetLastError();
+        }   // narrower kernels at low density: spread_wave2_kernel below
       }
     }
     if (g.rank == 2) {
+      lds_bytes = wave2_lds(g, (int)sizeof(T));
 #define NUFFT_CASE_W2(WW)                                                                    \
   case WW:                                                                                   \
     e = ensure_lds(spread_wave2_kernel<T, WW, kW2NW, kW2CH>, lds_bytes);                            \

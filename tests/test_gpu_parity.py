@@ -711,6 +711,17 @@ for name, grid, M in (('uniform', [96, 80], 120000), ('one_cell', [64, 64], 5000
   err = np.linalg.norm(out - truth) / np.linalg.norm(truth)
   worst = max(worst, err)
   print(name, err)
+# narrower kernels (odd and even widths) through the same two spreaders: w = 7, 6, 5, 4, 3
+grid, M = [96, 80], 120000
+pts = rng.uniform(-np.pi, np.pi, (M, 2)).astype(np.float32)
+c = (rng.uniform(-.5, .5, M) + 1j * rng.uniform(-.5, .5, M)).astype(np.complex64)
+truth = oracle.nufft(c.astype(np.complex128), pts, grid, 'type_1', 'forward', tol=1e-12, sigma=2.0)
+for tol in (1e-5, 1e-4, 1e-3, 1e-2, 1e-1):
+  out = tfft.nufft(torch.from_numpy(c).cuda(), torch.from_numpy(pts).cuda(), grid_shape=grid,
+                   transform_type='type_1', tol=tol).cpu().numpy()
+  err = np.linalg.norm(out - truth) / np.linalg.norm(truth)
+  worst = max(worst, err / tol * 1e-6)    # normalised so that the 1e-6 threshold below means err <= tol
+  print('tol', tol, err)
 print('WORST', worst)
 '''
 
