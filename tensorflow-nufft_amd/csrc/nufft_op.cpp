@@ -150,7 +150,8 @@ struct CachedPlan {
 };
 std::mutex g_cache_mu;
 std::list<CachedPlan> g_cache;    // most recently returned at the front
-constexpr size_t kMaxCached = 8;
+constexpr size_t kMaxCached = 16;
+constexpr int kMaxLanes = 4;   // pipelined plans per op call (nufft_hip_op_compute)
 
 std::string plan_key(const nufft_hip_op_desc* d, const Analysis& a, int type, int ntransf,
                      double tol, void* stream, int device) {
@@ -251,10 +252,16 @@ int nufft_hip_op_compute(const nufft_hip_op_desc* desc, const void* source, cons
   // sequential set_points + execute calls -- two plans on private streams that
   // alternate calls: the memory-bound sort of one call overlaps the LDS-bound
   // spread of the other (measured r01: 0.126 -> 0.092 ms per 512^2, M = 1e6 item).
-  const int nlanes = a.num_calls >= 2 ? 2 : 1;
-  nufft_hip_plan plans[2] = {nullptr, nullptr};
-  hipStream_t lane_stream[2] = {nullptr, nullptr};
-  std::string keys[2];
+  // NUFFT_HIP_OP_LANES overrides the lane count (1..kMaxLanes); three or four lanes measured
+  // no better than two on config 5 (32 items of M = 1e6: 3.6 / 2.9 / 3.2 / 3.1 ms for 1-4
+  // lanes): ~14 launches per item keep the host and the whole-GPU kernels equally busy.
+  static const int lanes_env = [] { const char* e = getenv("NUFFT_HIP_OP_LANES"); return e ? atoi(e) : 0; }();
+  int want_lanes = 2;
+  if (lanes_env > 0) want_lanes = lanes_env < kMaxLanes ? lanes_env : kMaxLanes;
+  const int nlanes = (int)std::min<int64_t>(a.num_calls, want_lanes);
+  nufft_hip_plan plans[kMaxLanes] = {};
+  hipStream_t lane_stream[kMaxLanes] = {};
+  std::string keys[kMaxLanes];
   for (int l = 0; l < nlanes; ++l) {
     void* key_stream = nlanes == 1 ? stream_v : reinterpret_cast<void*>((intptr_t)(l + 1));
     keys[l] = plan_key(desc, a, desc->transform_type, (int)a.num_transforms, tol, key_stream, device);
@@ -335,7 +342,7 @@ int nufft_hip_op_compute(const nufft_hip_op_desc* desc, const void* source, cons
     pfac[d2] = pfac[d2 + 1] * pts_outer[d2 + 1];
   }
   const size_t rsize = (size_t)desc->precision;
-  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[kMaxLanes] = {};
   if (nlanes > 1) {
     hipError_t e = hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventRecord(ev_fork, stream);

@@ -742,7 +742,8 @@ def test_w8_spread_variants_forced(group):
   assert worst < 1e-6, r.stdout
 
 
-def test_plan_reuse_switches_to_cell_sorted_records(tfft):
+@pytest.mark.parametrize('tol', [1e-6, 1e-3])
+def test_plan_reuse_switches_to_cell_sorted_records(tfft, tol):
   # A dense 2-D w = 8 float plan reorders its records by stencil start cell lazily, inside
   # the execute that brings the number of spread launches on the same points to three
   # (DESIGN.md section 4). Results before and after the switch must agree with the oracle,
@@ -752,14 +753,14 @@ def test_plan_reuse_switches_to_cell_sorted_records(tfft):
   grid = [72, 96]
   M = 90000            # 3.3 points per fine cell
   pts = rng.uniform(-np.pi, np.pi, (M, 2)).astype(np.float32)
-  plan = tfft.Plan('type_1', grid, 'forward', tol=1e-6)
+  plan = tfft.Plan('type_1', grid, 'forward', tol=tol)
   plan.set_points(_dev(pts))
   plan.set_timing(True)
   for it in range(5):
     c = (rng.uniform(-.5, .5, M) + 1j * rng.uniform(-.5, .5, M)).astype(np.complex64)
     truth = oracle.nufft(c.astype(np.complex128), pts, grid, 'type_1', 'forward', tol=1e-12, sigma=2.0)
     out = plan.execute(_dev(c)).cpu().numpy()
-    assert rel_l2(out, truth) < 1e-6, (it, rel_l2(out, truth))
+    assert rel_l2(out, truth) < tol, (it, rel_l2(out, truth))
   tm = plan.get_timing()
   assert tm['sort_cell'][1] == 1, tm       # ran exactly once, in the third execute
   # new points reset it
@@ -767,11 +768,11 @@ def test_plan_reuse_switches_to_cell_sorted_records(tfft):
   plan.set_points(_dev(pts2))
   c = (rng.uniform(-.5, .5, M) + 1j * rng.uniform(-.5, .5, M)).astype(np.complex64)
   truth = oracle.nufft(c.astype(np.complex128), pts2, grid, 'type_1', 'forward', tol=1e-12, sigma=2.0)
-  assert rel_l2(plan.execute(_dev(c)).cpu().numpy(), truth) < 1e-6
+  assert rel_l2(plan.execute(_dev(c)).cpu().numpy(), truth) < tol
   assert plan.get_timing()['sort_cell'][1] == 0
   plan.close()
   # batch of 4 transforms on shared points: the switch happens in the first execute
-  plan = tfft.Plan('type_1', grid, 'forward', num_transforms=4, tol=1e-6)
+  plan = tfft.Plan('type_1', grid, 'forward', num_transforms=4, tol=tol)
   plan.set_points(_dev(pts))
   plan.set_timing(True)
   cb = (rng.uniform(-.5, .5, (4, M)) + 1j * rng.uniform(-.5, .5, (4, M))).astype(np.complex64)
@@ -779,5 +780,5 @@ def test_plan_reuse_switches_to_cell_sorted_records(tfft):
   assert plan.get_timing()['sort_cell'][1] == 1
   for t in range(4):
     truth = oracle.nufft(cb[t].astype(np.complex128), pts, grid, 'type_1', 'forward', tol=1e-12, sigma=2.0)
-    assert rel_l2(out[t], truth) < 1e-6
+    assert rel_l2(out[t], truth) < tol
   plan.close()
