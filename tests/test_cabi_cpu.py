@@ -191,3 +191,14 @@ int main(void) {
   r = subprocess.run([str(exe)], capture_output=True, text=True)
   assert r.returncode == 0, (r.stdout, r.stderr)
   assert r.stdout.split() == ['8', '2048', '2']
+
+
+def test_stage_list_matches_the_header():
+  # the Python stage names index the arrays nufft_hip_plan_get_timing fills
+  import re
+  from conftest import ROOT
+  from tensorflow_nufft import _lib
+  hdr = open(os.path.join(ROOT, 'include', 'nufft_hip.h')).read()
+  n = int(re.search(r'#define NUFFT_HIP_NUM_STAGES (\d+)', hdr).group(1))
+  assert n == len(_lib.STAGES)
+  assert _lib.STAGES[-1] == 'sort_cell' and _lib.STAGES[4] == 'spread'
