@@ -782,3 +782,49 @@ def test_plan_reuse_switches_to_cell_sorted_records(tfft, tol):
     truth = oracle.nufft(cb[t].astype(np.complex128), pts, grid, 'type_1', 'forward', tol=1e-12, sigma=2.0)
     assert rel_l2(out[t], truth) < tol
   plan.close()
+
+
+def test_randomised_geometry_sweep_vs_oracle(tfft):
+  # 48 seeded random cases over rank, grid (odd / even / tiny), M, tol, precision, type,
+  # direction and point distribution (uniform, clustered in one tile, on the period
+  # boundary, exactly on fine-grid nodes); each must meet its own tol against the fp64
+  # oracle (sigma 2, tol 1e-12). Catches geometry-dependent kernel selection mistakes
+  # (grouped / per-point / generic spreaders, three sort paths, tile wrap-around).
+  from oracle import oracle
+  import torch
+  rng = np.random.default_rng(20261003)
+  worst = []
+  for case in range(48):
+    rank = int(rng.integers(1, 4))
+    hi = {1: 300, 2: 70, 3: 22}[rank]
+    grid = [int(rng.integers(3, hi)) for _ in range(rank)]
+    f64 = bool(rng.integers(0, 4) == 0)
+    tol = float(rng.choice([1e-9, 1e-7, 1e-5]) if f64 else rng.choice([1e-6, 1e-5, 1e-4, 1e-3, 1e-2]))
+    M = int(rng.choice([1, 7, 64, 65, 1000, 20000, 60000]))
+    ttype = 'type_1' if rng.integers(0, 2) else 'type_2'
+    fd = 'forward' if rng.integers(0, 2) else 'backward'
+    dist = int(rng.integers(0, 4))
+    rdt, cdt = (np.float64, np.complex128) if f64 else (np.float32, np.complex64)
+    if dist == 0:
+      pts = rng.uniform(-np.pi, np.pi, (M, rank))
+    elif dist == 1:      # clustered: every point within ~two fine cells of one spot
+      pts = rng.uniform(-np.pi, np.pi, (1, rank)) + rng.uniform(-1, 1, (M, rank)) * (4 * np.pi / (2 * np.array(grid)))
+      pts = np.clip(pts, -np.pi, np.pi)
+    elif dist == 2:      # hugging the period boundary from both sides (folded range is [-3pi, 3pi])
+      pts = np.where(rng.integers(0, 2, (M, rank)) == 1, np.pi, -np.pi) + rng.uniform(-1e-3, 1e-3, (M, rank))
+    else:                # exactly on fine-grid nodes of the sigma = 2 grid (kernel argument = +-1 edge cases)
+      pts = np.stack([(rng.integers(0, 2 * g, M) / (2 * g) - 0.5) * 2 * np.pi for g in grid], axis=-1)
+    pts = pts.astype(rdt)
+    if ttype == 'type_1':
+      src = (rng.uniform(-.5, .5, M) + 1j * rng.uniform(-.5, .5, M)).astype(cdt)
+      gs = grid
+    else:
+      src = (rng.uniform(-.5, .5, grid) + 1j * rng.uniform(-.5, .5, grid)).astype(cdt)
+      gs = None
+    truth = oracle.nufft(src.astype(np.complex128), pts, gs, ttype, fd, tol=1e-12, sigma=2.0)
+    out = tfft.nufft(_dev(src), _dev(pts), grid_shape=gs, transform_type=ttype, fft_direction=fd, tol=tol).cpu().numpy()
+    nrm = np.linalg.norm(truth)
+    err = np.linalg.norm(out - truth) / nrm if nrm > 0 else np.linalg.norm(out)
+    worst.append((err / tol, case, rank, grid, M, tol, ttype, fd, dist, 'f64' if f64 else 'f32', err))
+    assert err <= tol, worst[-1]
+  print('worst err/tol:', max(worst)[:2])
