@@ -1466,12 +1466,31 @@ __global__ __launch_bounds__(kInterpThreads<RANK>) void interp_point_kernel(
   const int o0 = t0 * g.tile[0], o1 = t1 * g.tile[1], o2 = t2 * g.tile[2];
   const T2* in = reinterpret_cast<const T2*>(fw) + (int64_t)blockIdx.y * fw_stride;
   constexpr int NT = kInterpThreads<RANK>;
-  for (RowWalk r(wave, L1); r.a2 < L2; r.advance(NT / 64, L1)) {
-    const int g1 = wrap1(o1 + r.a1, g.nf[1]);
-    const int g2 = RANK > 2 ? wrap1(o2 + r.a2, g.nf[2]) : 0;
-    const int64_t rowbase = (int64_t)g.nf[0] * (g1 + (int64_t)g.nf[1] * g2);
-    T2* lrow = tile + r.a2 * PS + r.a1 * LS;
-    for (int a0 = lane; a0 < L0; a0 += 64) lrow[a0] = in[rowbase + wrap1(o0 + a0, g.nf[0])];
+  // Tile rows (L0 <= 39 cells: one lane per cell) are fetched kRowBatch at a time: the
+  // loads of a batch are issued back to back on clamped addresses and only then stored
+  // to LDS. One load - wait - store per row exposed an L2 latency per row (10 rows per
+  // wave in 2-D, 35 in 3-D) at the head of every workgroup.
+  constexpr int kRowBatch = 8;
+  const int nrows = L1 * L2;
+  const int a0c = lane < L0 ? lane : L0 - 1;
+  const int64_t gx = wrap1(o0 + a0c, g.nf[0]);
+  for (int rb = wave; rb < nrows; rb += kRowBatch * (NT / 64)) {
+    T2 v[kRowBatch];
+    int lofs[kRowBatch];
+#pragma unroll
+    for (int u = 0; u < kRowBatch; ++u) {
+      const int row = rb + u * (NT / 64);
+      const int rc = row < nrows ? row : nrows - 1;
+      const int a2 = RANK > 2 ? rc / L1 : 0;
+      const int a1 = rc - a2 * L1;
+      const int g1 = wrap1(o1 + a1, g.nf[1]);
+      const int g2 = RANK > 2 ? wrap1(o2 + a2, g.nf[2]) : 0;
+      v[u] = in[(int64_t)g.nf[0] * (g1 + (int64_t)g.nf[1] * g2) + gx];
+      lofs[u] = row < nrows ? a2 * PS + a1 * LS + lane : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < kRowBatch; ++u)
+      if (lofs[u] >= 0 && lane < L0) tile[lofs[u]] = v[u];
   }
   __syncthreads();
 
