@@ -1725,11 +1725,10 @@ static hipError_t ensure_lds(K kernel, size_t bytes) {
 int sort_blocks(const Geom& g, int64_t M, int64_t* per_block) {
   // at most 512 workgroups (longer per-tile runs per workgroup => better write
   // combining in the scatter; measured r01), at least 4096 points each
-  static int maxblk = 0;
-  if (!maxblk) {
-    maxblk = 512;
-    if (const char* e = getenv("NUFFT_HIP_SORT_BLOCKS")) maxblk = atoi(e) > 0 ? atoi(e) : 512;
-  }
+  static const int maxblk = [] {
+    const char* e = getenv("NUFFT_HIP_SORT_BLOCKS");   // tuning knob (tools/sweep_sort.py)
+    return e && atoi(e) > 0 ? atoi(e) : 512;
+  }();
   int64_t pb = (M + maxblk - 1) / maxblk;
   if (pb < 4096) pb = 4096;
   *per_block = pb;
@@ -1848,15 +1847,17 @@ static bool wave8_use_group(const Geom& g, int64_t M) {
 // Defaults from the r01 sweeps (tools/sweep_w8.py, tools/sweep_w8_group.py): 4 x 64
 // for the per-point kernel, 12 x 64 for the cell-grouped one (79 KB of LDS: two
 // workgroups = 24 waves per CU, 3 per SIMD each; 8 x 64 = 16 waves per CU was 8 % slower).
-static int g_w8_nw = 0, g_w8_ch = 0;
-static void wave8_shape_init() {
-  if (g_w8_nw) return;
-  int nw = -1, ch = -1;
-  if (const char* e = getenv("NUFFT_HIP_W8_SHAPE")) sscanf(e, "%dx%d", &nw, &ch);
-  g_w8_nw = nw; g_w8_ch = ch;
+struct W8Shape { int nw = -1, ch = -1; };
+static const W8Shape& wave8_shape_env() {   // NUFFT_HIP_W8_SHAPE = "NWxCH" (tuning knob), read once
+  static const W8Shape s = [] {
+    W8Shape v;
+    if (const char* e = getenv("NUFFT_HIP_W8_SHAPE")) sscanf(e, "%dx%d", &v.nw, &v.ch);
+    return v;
+  }();
+  return s;
 }
-static int wave8_nw(bool grouped) { wave8_shape_init(); return g_w8_nw > 0 ? g_w8_nw : (grouped ? 12 : 4); }
-static int wave8_ch(bool grouped) { wave8_shape_init(); return g_w8_ch > 0 ? g_w8_ch : (grouped ? 64 : 64); }
+static int wave8_nw(bool grouped) { const int v = wave8_shape_env().nw; return v > 0 ? v : (grouped ? 12 : 4); }
+static int wave8_ch(bool grouped) { const int v = wave8_shape_env().ch; return v > 0 ? v : 64; }
 constexpr int kW2NW = 4, kW2CH = 64;   // launch shape of spread_wave2_kernel (others measured no better)
 static size_t group_lds(int nw, int ch, bool presorted) {
   return sizeof(double) * 2 * kWPlane + sizeof(float) * nw * 3 * ((ch < kGroupStage ? ch : kGroupStage) / 4) * kGroupBlk +
