@@ -111,6 +111,7 @@ hipError_t launch_sort(const Geom& g, const PointsIn& in, const SortWork& w, con
 // order (2-D, w = 8, float) and the point density makes it pay; the host applies it lazily
 // (nufft_plan.cpp, maybe_cellsort).
 bool cellsort_wanted(const Geom& g, int method, int precision, int64_t M);
+bool cellsort_wanted_interp(const Geom& g, int method, int precision, int64_t M);
 template <typename T>
 hipError_t launch_cellsort(const Geom& g, int64_t M, const int32_t* tile_start, const int32_t* sub_start,
                            const Rec<T>* in, Rec<T>* out, hipStream_t stream);

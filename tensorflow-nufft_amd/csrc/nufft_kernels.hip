@@ -860,13 +860,13 @@ __global__ __launch_bounds__(NW * 64) void spread_2d_w8_wave_kernel(
   }
 }
 
-// Exclusive scan of cnt[1024] in place by a workgroup of NT threads; the first NS = largest
-// power of two <= NT threads do the work. wsum: >= NS/64 words of LDS scratch. Ends with a
-// barrier.
-template <int NT>
-__device__ __forceinline__ void scan1024(uint32_t* cnt, uint32_t* wsum, int tid) {
+// Exclusive scan of cnt[NK] (NK = 1024 or 2048) in place by a workgroup of NT threads; the
+// first NS = largest power of two <= NT threads do the work. wsum: >= NS/64 words of LDS
+// scratch. Ends with a barrier.
+template <int NT, int NK>
+__device__ __forceinline__ void scan_counts(uint32_t* cnt, uint32_t* wsum, int tid) {
   constexpr int NS = NT >= 1024 ? 1024 : NT >= 512 ? 512 : NT >= 256 ? 256 : NT >= 128 ? 128 : 64;
-  constexpr int PER = 1024 / NS;
+  constexpr int PER = NK / NS;
   const int lane = tid & 63, wave = tid >> 6;
   const bool on = tid < NS;
   uint32_t v[PER], tot = 0u;
@@ -888,6 +888,8 @@ __device__ __forceinline__ void scan1024(uint32_t* cnt, uint32_t* wsum, int tid)
   }
   __syncthreads();
 }
+template <int NT>
+__device__ __forceinline__ void scan1024(uint32_t* cnt, uint32_t* wsum, int tid) { scan_counts<NT, 1024>(cnt, wsum, tid); }
 
 // Second sort level, run once per set_points for dense 2-D point sets: every
 // subproblem (<= 4096 points of one 32 x 32 tile) is counting-sorted by stencil
@@ -937,6 +939,49 @@ __global__ __launch_bounds__(kCellSortThreads) void cellsort2d_kernel(
   }
 }
 
+// The 3-D counterpart (tile 16 x 16 x 4|8: 2048 keys, x fastest). Its consumer is the
+// thread-per-point interp kernel: neighbouring threads then read neighbouring (or the
+// same) LDS cells, which removes the bank conflicts that bound its stencil loop.
+template <typename T>
+__global__ __launch_bounds__(kCellSortThreads) void cellsort3d_kernel(
+    Geom g, const int32_t* __restrict__ tile_start, const int32_t* __restrict__ sub_start,
+    const Rec<T>* __restrict__ in, Rec<T>* __restrict__ out) {
+  constexpr int NT = kCellSortThreads;
+  constexpr int IT = kCellSortMaxSub / NT;
+  __shared__ uint32_t cnt[2048];
+  __shared__ uint32_t wsum[16];
+  int tb, p0, p1;
+  if (!locate_subproblem(g, tile_start, sub_start, blockIdx.x, &tb, &p0, &p1)) return;
+  const int n = p1 - p0;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 2048; i += NT) cnt[i] = 0u;
+  Rec<T> r[IT];
+#pragma unroll
+  for (int u = 0; u < IT; ++u) {
+    const int i = tid + u * NT;
+    if (u * NT < n) r[u] = in[p0 + (i < n ? i : n - 1)];
+  }
+  __syncthreads();
+  uint32_t kr[IT];   // key | rank-in-cell << 11
+#pragma unroll
+  for (int u = 0; u < IT; ++u) {
+    const int i = tid + u * NT;
+    kr[u] = 0u;
+    if (u * NT < n) {
+      const uint32_t loc = unpack_rec<T, 3>(r[u]).loc;
+      const uint32_t key = (loc & 15u) | (((loc >> 10) & 15u) << 4) | (((loc >> 20) & 7u) << 8);
+      if (i < n) kr[u] = key | (atomicAdd(&cnt[key], 1u) << 11);
+    }
+  }
+  __syncthreads();
+  scan_counts<NT, 2048>(cnt, wsum, tid);
+#pragma unroll
+  for (int u = 0; u < IT; ++u) {
+    const int i = tid + u * NT;
+    if (u * NT < n && i < n) out[p0 + cnt[kr[u] & 2047u] + (kr[u] >> 11)] = r[u];
+  }
+}
+
 // Cell-grouped variant of the kernel above for dense point sets (>~ 0.5 points per
 // fine cell). The subproblem's points are ordered by stencil start cell, either
 // already in HBM (PRE: cellsort2d_kernel ran at set_points) or by the same
@@ -947,6 +992,7 @@ __global__ __launch_bounds__(kCellSortThreads) void cellsort2d_kernel(
 // ungrouped kernel.
 constexpr int kGroupMaxSub = 4096;
 constexpr double kGroupMinDensity = 0.5;   // points per fine cell
+constexpr double kInterpSortMinDensity = 0.3;   // 3-D interp cell sort pays from here (r01: 0.075 loses, 0.75 and 1.8 win)
 constexpr int kGroupStage = 32; // points whose kernel values are in LDS at a time (per wave)
 constexpr int kGroupBlk = 36;   // staging words per block of 4 points (8 x 4 + 4 pad)
 template <int CH> constexpr int kGroupStageWave = 3 * (CH / 4) * kGroupBlk;   // words per wave (kx, ky re, ky im)
@@ -1929,11 +1975,26 @@ bool cellsort_wanted(const Geom& g, int method, int precision, int64_t M) {
   return wave8_use_group(g, M);
 }
 
+// The same ordering for the 3-D interp kernel (type 2 / interp op), applied eagerly in
+// set_points: it costs ~1 ms per 1e8 points and removes the LDS bank conflicts of the
+// stencil loop. NUFFT_HIP_CELLSORT3D = 0 / 1 forces it off / on.
+bool cellsort_wanted_interp(const Geom& g, int method, int precision, int64_t M) {
+  (void)precision;
+  static const int mode = [] { const char* e = getenv("NUFFT_HIP_CELLSORT3D"); return e ? atoi(e) : -1; }();
+  if (method != NUFFT_HIP_METHOD_TILE_WAVE || g.rank != 3 || g.tile[0] != 16 || g.tile[1] != 16 || g.tile[2] > 8) return false;
+  if (g.max_sub > kCellSortMaxSub || M == 0 || mode == 0) return false;
+  if (mode > 0) return true;
+  return (double)M >= kInterpSortMinDensity * (double)g.nf[0] * (double)g.nf[1] * (double)g.nf[2];
+}
+
 template <typename T>
 hipError_t launch_cellsort(const Geom& g, int64_t M, const int32_t* tile_start, const int32_t* sub_start,
                            const Rec<T>* in, Rec<T>* out, hipStream_t stream) {
   if (M == 0) return hipSuccess;
-  cellsort2d_kernel<T><<<subproblem_grid(g, M), kCellSortThreads, 0, stream>>>(g, tile_start, sub_start, in, out);
+  if (g.rank == 3)
+    cellsort3d_kernel<T><<<subproblem_grid(g, M), kCellSortThreads, 0, stream>>>(g, tile_start, sub_start, in, out);
+  else
+    cellsort2d_kernel<T><<<subproblem_grid(g, M), kCellSortThreads, 0, stream>>>(g, tile_start, sub_start, in, out);
   return hipGetLastError();
 }
 template hipError_t launch_cellsort<float>(const Geom&, int64_t, const int32_t*, const int32_t*,

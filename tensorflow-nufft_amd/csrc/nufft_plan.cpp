@@ -423,12 +423,30 @@ int set_points_impl(nufft_hip_plan p, int64_t M, const void* x, const void* y, c
   w.hist = p->hist; w.tile_of = p->tile_of; w.rank_of = p->rank_of;
   w.tile_count = p->tile_count; w.tile_start = p->tile_start; w.sub_start = p->sub_start;
   w.bad_count = p->bad_count;
-  p->g.cell_sorted = 0;   // the second sort level, if any, runs lazily (maybe_cellsort)
+  p->g.cell_sorted = 0;   // the 2-D spread's second sort level runs lazily (maybe_cellsort)
   p->spread_uses = 0;
+  // 3-D interp plans order every subproblem by start cell right away (rec2 -> rec)
+  const bool cells = (p->type == NUFFT_HIP_TYPE_2 || p->opts.spread_only) &&
+                     cellsort_wanted_interp(p->g, p->method, p->precision, M);
+  if (cells && M > p->cap2) {
+    HIP_TRY(p, hipStreamSynchronize(p->stream));
+    dev_free(p->rec2);
+    p->rec2 = nullptr;
+    p->cap2 = 0;
+    if ((rc = dev_alloc(p, &p->rec2, (size_t)M * sizeof(Rec<T>)))) return rc;
+    p->cap2 = M;
+  }
   SortedOut<T> out;
-  out.rec = (Rec<T>*)p->rec;
+  out.rec = (Rec<T>*)(cells ? p->rec2 : p->rec);
   out.idx3 = p->idx3;
-  HIP_TRY(p, launch_sort<T>(p->g, in, w, out, p->stream, make_hook(p)));
+  const StageHook hook = make_hook(p);
+  HIP_TRY(p, launch_sort<T>(p->g, in, w, out, p->stream, hook));
+  if (cells) {
+    hook.begin(STAGE_SORT_CELL);
+    HIP_TRY(p, launch_cellsort<T>(p->g, M, p->tile_start, p->sub_start, (const Rec<T>*)p->rec2,
+                                  (Rec<T>*)p->rec, p->stream));
+    hook.end(STAGE_SORT_CELL);
+  }
   if (check) {
     int32_t bad = 0;
     HIP_TRY(p, hipMemcpyAsync(&bad, p->bad_count, sizeof(int32_t), hipMemcpyDeviceToHost, p->stream));
