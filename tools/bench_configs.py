@@ -62,3 +62,5 @@ if '1dbig' in which:
 if '1' in which: run('cfg1 1D t1 N=4096 M=1e5 f64', 'type_1', [4096], 100_000, 1e-6, dtype=torch.complex128)
 if '4t2s' in which: run('3D t2 256^3 M=1e7 tol1e-4 (sparse)', 'type_2', [256, 256, 256], 10_000_000, 1e-4, steps=3)
 if '4t2d' in which: run('3D t2 128^3 M=3e7 tol1e-4 (dense)', 'type_2', [128, 128, 128], 30_000_000, 1e-4, steps=3)
+if '3d6' in which: run('3D t1 256^3 M=3e7 tol1e-6 f32', 'type_1', [256, 256, 256], 30_000_000, 1e-6, steps=3)
+if '3d6t2' in which: run('3D t2 256^3 M=3e7 tol1e-6 f32', 'type_2', [256, 256, 256], 30_000_000, 1e-6, steps=3)
