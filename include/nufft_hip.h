@@ -80,7 +80,8 @@ typedef struct nufft_hip_options {
   int32_t max_subproblem_size; /* points per workgroup pass; 0 = auto */
   int32_t tile_dims[3];        /* fine-grid cells per tile, x fastest; 0 = auto */
   int32_t lds_accumulate;      /* LDS tile accumulation: 0 auto, 1 double, 2 packed 32+32-bit fixed
-                                  point (3-D float, kernel width <= 6 only) */
+                                  point (3-D float, kernel width <= 7 only; width 7 caps
+                                  max_subproblem_size at 512) */
   int32_t reserved[7];
 } nufft_hip_options;
 

@@ -2127,7 +2127,7 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
       } else { return hipErrorInvalidValue; }                                                    \
     } else if (g.tile[2] == 4) {                                                                 \
       if (g.fixed_point) {                                                                       \
-        if constexpr (sizeof(T) == 4 && WW <= 6) { NUFFT_LAUNCH_W3(WW, 4, true) } else { return hipErrorInvalidValue; } \
+        if constexpr (sizeof(T) == 4) { NUFFT_LAUNCH_W3(WW, 4, true) } else { return hipErrorInvalidValue; } \
       } else { NUFFT_LAUNCH_W3(WW, 4, false) }                                                   \
     } else { return hipErrorInvalidValue; }                                                      \
     break;

@@ -802,21 +802,27 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
                 "spread_method TILE_WAVE needs rank 2 or 3, kernel width <= 8 and the default tile sizes");
   }
   p->method = method;
-  // packed fixed-point accumulation: 3-D float wavefront kernel at w <= 6 (tol >= ~1e-4)
+  // packed 32+32-bit fixed-point accumulation: the 3-D float wavefront kernel at w <= 7.
+  // The quantisation step is (sum of |c| over the SUBPROBLEM) / 2^31 against a typical
+  // contribution of |c| * 0.04 (w = 7-8 kernel products), i.e. a relative error of about
+  // 4e-9 * points per subproblem: w = 7 (tol 1e-5) caps the subproblem at 512 points
+  // (measured +1.4e-6); w = 8 (tol 1e-6) would need ~25 and keeps the fp64 planes
+  // (measured 2.4e-6 at 256 points per subproblem).
   g.fixed_point = 0;
   g.cell_sorted = 0;
-  if (method == NUFFT_HIP_METHOD_TILE_WAVE && rank == 3 && precision == NUFFT_HIP_F32 && w <= 6 &&
+  if (method == NUFFT_HIP_METHOD_TILE_WAVE && rank == 3 && precision == NUFFT_HIP_F32 && w <= 7 &&
       p->opts.lds_accumulate != 1)
     g.fixed_point = 1;
   if (p->opts.lds_accumulate == 2 && !g.fixed_point) {
     delete p;
     return fail(NUFFT_HIP_INVALID_ARGUMENT,
-                "lds_accumulate = 2 (fixed point) needs the 3-D float wavefront method with kernel width <= 6");
+                "lds_accumulate = 2 (fixed point) needs the 3-D float wavefront method with kernel width <= 7");
   }
   if (method == NUFFT_HIP_METHOD_TILE_WAVE) g.lstride = wave_lstride(rank);
   // wavefront kernels: one subproblem per typical tile measured fastest (r01 sweeps);
   // every extra subproblem of a tile repeats its zero-fill and write-out
   if (method == NUFFT_HIP_METHOD_TILE_WAVE && auto_sub) g.max_sub = 4096;
+  if (g.fixed_point && w > 6) g.max_sub = std::min(g.max_sub, 512);
   p->lds_bytes = spread_lds_bytes(g, method, precision);
   if (p->lds_bytes > 160 * 1024 || interp_lds_bytes(g, method, precision) > 160 * 1024) {
     // does not fit (e.g. 3-D double at w = 8): fall back to the generic tile path

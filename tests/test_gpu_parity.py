@@ -598,11 +598,13 @@ def test_other_upsampling_factors(tfft, sigma):
     assert rel_l2(out, truth) < (tol if sigma == 2.0 else 6 * tol), (sigma, tol, rel_l2(out, truth))
 
 
-@pytest.mark.parametrize('tol', [1e-2, 1e-3, 1e-4])
+@pytest.mark.parametrize('tol', [1e-2, 1e-3, 1e-4, 1e-5])
 def test_fixed_point_lds_accumulation_3d(tfft, tol):
-  # 3-D float, w <= 6: packed 32+32-bit fixed-point LDS accumulation (lds_accumulate = 2, the
-  # default there) against double accumulation (= 1) and the fp64 oracle; including strengths
-  # with a 1e6 dynamic range and a dense cluster (per-subproblem scaling)
+  # 3-D float: packed 32+32-bit fixed-point LDS accumulation (lds_accumulate = 2, the default)
+  # against double accumulation (= 1) and the fp64 oracle; including strengths with a 1e6
+  # dynamic range and a dense cluster (per-subproblem scaling; width 7 caps the subproblem
+  # at 512 points so that the quantisation step stays well below tol = 1e-5; width 8 keeps
+  # the fp64 planes)
   import torch
   from oracle import oracle
   rng = np.random.default_rng(91)
@@ -618,15 +620,15 @@ def test_fixed_point_lds_accumulation_3d(tfft, tol):
     errs = {}
     for mode in (1, 2, 0):
       plan = tfft.Plan('type_1', grid, 'forward', tol=tol, lds_accumulate=mode)
-      assert plan.info().kernel_width <= 6 and plan.info().spread_method == 2
+      assert plan.info().kernel_width <= 7 and plan.info().spread_method == 2
       plan.set_points(_dev(pts))
       errs[mode] = rel_l2(plan.execute(_dev(c)).cpu().numpy(), truth)
       plan.close()
       assert errs[mode] < tol, (name, mode, errs)
     assert errs[0] == pytest.approx(errs[2], rel=0.5) or errs[0] < 0.1 * tol   # auto = fixed point here
-    assert errs[2] < errs[1] + 0.05 * tol, (name, errs)
+    assert errs[2] < errs[1] + 0.2 * tol, (name, errs)
   with pytest.raises(tfft.InvalidArgumentError, match='fixed point'):
-    tfft.Plan('type_1', grid, 'forward', tol=1e-6, lds_accumulate=2)
+    tfft.Plan('type_1', grid, 'forward', tol=1e-6, lds_accumulate=2)   # w = 8: not accurate enough
 
 
 def test_radial_mri_example_shape(tfft):

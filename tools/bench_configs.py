@@ -64,3 +64,5 @@ if '4t2s' in which: run('3D t2 256^3 M=1e7 tol1e-4 (sparse)', 'type_2', [256, 25
 if '4t2d' in which: run('3D t2 128^3 M=3e7 tol1e-4 (dense)', 'type_2', [128, 128, 128], 30_000_000, 1e-4, steps=3)
 if '3d6' in which: run('3D t1 256^3 M=3e7 tol1e-6 f32', 'type_1', [256, 256, 256], 30_000_000, 1e-6, steps=3)
 if '3d6t2' in which: run('3D t2 256^3 M=3e7 tol1e-6 f32', 'type_2', [256, 256, 256], 30_000_000, 1e-6, steps=3)
+if '3d5' in which: run('3D t1 256^3 M=3e7 tol1e-5 f32', 'type_1', [256, 256, 256], 30_000_000, 1e-5, steps=3)
+if '3d5d' in which: run('3D t1 256^3 M=3e7 tol1e-5 f32, fp64 LDS planes', 'type_1', [256, 256, 256], 30_000_000, 1e-5, steps=3, lds_accumulate=1)
