@@ -98,6 +98,8 @@ struct StageHook {
   void end(int s) const { if (end_fn) end_fn(ctx, s); }
 };
 
+// Forces the (otherwise lazy) load of this library's device code and waits for it.
+hipError_t preload_device_code();
 // Launchers (nufft_kernels.hip). All enqueue on `stream` and return hipGetLastError().
 int sort_blocks(const Geom& g, int64_t M, int64_t* per_block);
 int sort_blocks16(int64_t M, int64_t* per_block);

@@ -15,6 +15,7 @@
 // search in a scanned array, no host sync) and the wavefront-per-point
 // scatter are specific to this build. Wavefront = 64 lanes throughout.
 #include <algorithm>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 
@@ -1776,6 +1777,32 @@ static hipError_t ensure_lds(K kernel, size_t bytes) {
   if (bytes > 64 * 1024)
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  return hipSuccess;
+}
+
+// The HIP runtime loads this library's device code lazily, at the first kernel launch
+// (deferred loading). With that default the FIRST launch of a fresh process faulted in
+// 5-15 % of runs on ROCm 7.2 / gfx950 ("Memory access fault ... write access to a
+// read-only page", at addresses unrelated to any buffer of ours), as soon as the code
+// object grew past ~1.25 MB; never with HIP_ENABLE_DEFERRED_LOADING=0, never on a later
+// launch (r01: 5/40 against 0/40 runs; serialised launches put the fault inside the very
+// first kernel). So the plan forces the load here -- a function-attribute query makes the
+// runtime build the module for the device -- and waits for the device before anything of
+// ours is launched.
+hipError_t preload_device_code() {
+  static std::mutex mu;
+  static bool done[64] = {};
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lk(mu);
+  if (dev >= 0 && dev < 64 && done[dev]) return hipSuccess;
+  hipFuncAttributes attr;
+  e = hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(scan_tiles_kernel));
+  if (e != hipSuccess) return e;
+  e = hipDeviceSynchronize();
+  if (e != hipSuccess) return e;
+  if (dev >= 0 && dev < 64) done[dev] = true;
   return hipSuccess;
 }
 

@@ -862,7 +862,13 @@ int nufft_hip_plan_create(nufft_hip_plan* out, int type, int rank, const int64_t
     return fail(NUFFT_HIP_INTERNAL, "no HIP device available (this library has no CPU fallback)");
   }
   Geom& g = p->g;
-  // device state
+  // device code first (see preload_device_code), then device state
+  if (const hipError_t pe = preload_device_code(); pe != hipSuccess) {
+    const std::string m = format("loading the device code failed: %s", hipGetErrorString(pe));
+    (void)hipGetLastError();
+    delete p;
+    return fail(NUFFT_HIP_INTERNAL, m);
+  }
   int rc = precision == NUFFT_HIP_F32 ? upload_tables<float>(p) : upload_tables<double>(p);
   if (!rc) rc = dev_alloc(p, (void**)&p->tile_count, sizeof(int32_t) * (size_t)g.ntiles);
   if (!rc) rc = dev_alloc(p, (void**)&p->tile_start, sizeof(int32_t) * ((size_t)g.ntiles + 1));
