@@ -2093,8 +2093,7 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
             NUFFT_CASE_W8G(6) NUFFT_CASE_W8G(7)
             case 8:
               switch (shape) {
-                NUFFT_LAUNCH_W8G(8, 4, 64) NUFFT_LAUNCH_W8G(8, 8, 64) NUFFT_LAUNCH_W8G(8, 8, 32)
-                NUFFT_LAUNCH_W8G(8, 16, 32) NUFFT_LAUNCH_W8G(8, 12, 64) NUFFT_LAUNCH_W8G(8, 12, 32)
+                NUFFT_LAUNCH_W8G(8, 8, 64) NUFFT_LAUNCH_W8G(8, 12, 64) NUFFT_LAUNCH_W8G(8, 12, 32)   // r01 sweep kept these
                 default: return hipErrorInvalidValue;
               }
               break;
@@ -2114,8 +2113,6 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
     break;
         switch (shape) {
           NUFFT_LAUNCH_W8(4, 64) NUFFT_LAUNCH_W8(4, 32) NUFFT_LAUNCH_W8(8, 64) NUFFT_LAUNCH_W8(8, 32)
-          NUFFT_LAUNCH_W8(2, 64) NUFFT_LAUNCH_W8(2, 32) NUFFT_LAUNCH_W8(16, 32) NUFFT_LAUNCH_W8(4, 16)
-          NUFFT_LAUNCH_W8(8, 16)
           default: return hipErrorInvalidValue;
         }
 #undef NUFFT_LAUNCH_W8
