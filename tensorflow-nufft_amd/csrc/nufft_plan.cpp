@@ -264,10 +264,67 @@ namespace {
     }                                                                         \
   } while (0)
 
+// Debug allocator ("electric fence", NUFFT_HIP_DEBUG_EFENCE=1): every plan buffer gets its
+// own mapping inside a larger reserved address range and ENDS within 15 bytes of the end of
+// that mapping, so the first access past its end (and any access before its first page)
+// faults instead of silently touching a neighbour. GPU AddressSanitizer is not available
+// on this stack; tests/test_gpu_parity.py::test_plan_buffers_under_electric_fence runs a
+// mix of plans this way.
+struct FenceRec { void* va; size_t reserved; void* mapped_at; size_t mapped; hipMemGenericAllocationHandle_t handle; };
+static std::map<void*, FenceRec> g_fence;
+static std::mutex g_fence_mu;
+static bool fence_enabled() {
+  static const bool on = getenv("NUFFT_HIP_DEBUG_EFENCE") != nullptr;
+  return on;
+}
+static hipError_t fence_alloc(void** ptr, size_t bytes) {
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  prop.location.id = dev;
+  size_t gran = 0;
+  e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum);
+  if (e != hipSuccess) return e;
+  if (!gran) return hipErrorInvalidValue;
+  FenceRec r = {};
+  r.mapped = (bytes + gran - 1) / gran * gran;
+  r.reserved = r.mapped + 2 * gran;            // one unmapped granule on either side
+  if ((e = hipMemAddressReserve(&r.va, r.reserved, gran, nullptr, 0)) != hipSuccess) return e;
+  if ((e = hipMemCreate(&r.handle, r.mapped, &prop, 0)) != hipSuccess) return e;
+  r.mapped_at = (char*)r.va + gran;
+  if ((e = hipMemMap(r.mapped_at, r.mapped, 0, r.handle, 0)) != hipSuccess) return e;
+  hipMemAccessDesc acc = {};
+  acc.location = prop.location;
+  acc.flags = hipMemAccessFlagsProtReadWrite;
+  if ((e = hipMemSetAccess(r.mapped_at, r.mapped, &acc, 1)) != hipSuccess) return e;
+  *ptr = (char*)r.mapped_at + ((r.mapped - bytes) & ~(size_t)15);
+  std::lock_guard<std::mutex> lk(g_fence_mu);
+  g_fence[*ptr] = r;
+  return hipSuccess;
+}
+static bool fence_free(void* p) {
+  FenceRec r;
+  {
+    std::lock_guard<std::mutex> lk(g_fence_mu);
+    auto it = g_fence.find(p);
+    if (it == g_fence.end()) return false;
+    r = it->second;
+    g_fence.erase(it);
+  }
+  (void)hipDeviceSynchronize();
+  (void)hipMemUnmap(r.mapped_at, r.mapped);
+  (void)hipMemRelease(r.handle);
+  (void)hipMemAddressFree(r.va, r.reserved);
+  return true;
+}
+
 int dev_alloc(nufft_hip_plan p, void** ptr, size_t bytes) {
   *ptr = nullptr;
   if (bytes == 0) bytes = 16;
-  hipError_t e = hipMalloc(ptr, bytes);
+  hipError_t e = fence_enabled() ? fence_alloc(ptr, bytes) : hipMalloc(ptr, bytes);
   if (e != hipSuccess) {
     p->err = format("out of device memory allocating %zu bytes (%s)", bytes, hipGetErrorString(e));
     (void)hipGetLastError();
@@ -278,7 +335,9 @@ int dev_alloc(nufft_hip_plan p, void** ptr, size_t bytes) {
 }
 
 void dev_free(void* p) {
-  if (p) (void)hipFree(p);
+  if (!p) return;
+  if (fence_enabled() && fence_free(p)) return;
+  (void)hipFree(p);
 }
 
 int get_fft_plan(nufft_hip_plan p, int batch, rocfft_plan* out) {

@@ -885,3 +885,42 @@ def test_first_launch_in_fresh_processes():
     assert r.returncode == 0, (k, r.stderr[-1500:])
     sums.append(float(r.stdout.strip().splitlines()[-1].split()[1]))
   assert max(sums) - min(sums) <= 1e-4 * abs(sums[0]), sums
+
+
+_EFENCE_CHILD = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+import tensorflow_nufft as tfft
+rng = np.random.default_rng(3)
+n = 0
+for rank, grid, M in ((1, [300], 5000), (2, [96, 80], 120000), (2, [33, 47], 900), (3, [20, 24, 18], 60000), (3, [9, 31, 12], 4000)):
+  for cdt, rdt, tols in ((torch.complex64, np.float32, (1e-6, 1e-4, 1e-2)), (torch.complex128, np.float64, (1e-9, 1e-5))):
+    pts = torch.from_numpy(rng.uniform(-np.pi, np.pi, (M, rank)).astype(rdt)).cuda()
+    for tol in tols:
+      for ttype in ('type_1', 'type_2'):
+        shape = [M] if ttype == 'type_1' else grid
+        src = torch.complex(torch.rand(shape, dtype=torch.float64), torch.rand(shape, dtype=torch.float64)).to(cdt).cuda()
+        plan = tfft.Plan(ttype, grid, 'forward', tol=tol, dtype=cdt)
+        plan.set_points(pts)
+        for _ in range(4):          # the fourth execute runs on cell-sorted records where that applies
+          out = plan.execute(src)
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(torch.view_as_real(out)).all())
+        plan.close()
+        n += 1
+print('PLANS', n)
+'''
+
+
+def test_plan_buffers_under_electric_fence():
+  # Every plan buffer allocated so that it ends at an unmapped page (NUFFT_HIP_DEBUG_EFENCE,
+  # nufft_plan.cpp): any kernel reading or writing past the end of a plan buffer faults.
+  # 50 plans: rank 1-3, both precisions, widths 2-12, both types, repeated executes.
+  import os
+  import subprocess
+  import sys
+  from conftest import PKG, ROOT
+  env = dict(os.environ, NUFFT_HIP_DEBUG_EFENCE='1')
+  r = subprocess.run([sys.executable, '-c', _EFENCE_CHILD, ROOT, PKG], env=env, capture_output=True, text=True, timeout=900)
+  assert r.returncode == 0, r.stderr[-2000:]
+  assert r.stdout.strip().splitlines()[-1] == 'PLANS 50', r.stdout[-500:]
