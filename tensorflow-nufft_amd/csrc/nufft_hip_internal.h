@@ -33,6 +33,7 @@ struct Geom {
   int max_sub;      // points per subproblem
   int nmodes[3];    // N, x fastest
   int fixed_point;  // 3-D float spread accumulates packed 32+32-bit fixed point in LDS
+  int split_reim;   // 3-D float fp64-plane spread: real and imaginary parts in separate launches
   int cell_sorted;  // records of each subproblem are ordered by stencil start cell (set per set_points)
 };
 

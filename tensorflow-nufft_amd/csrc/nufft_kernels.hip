@@ -1297,7 +1297,9 @@ __global__ __launch_bounds__(NW * 64) void spread_wave2_kernel(
 // a first pass over the subproblem's strengths -- one huge strength only
 // coarsens its own subproblem. Quantisation <= 0.5 LSB per contribution; worst
 // case 2^-32 n w^1.5 ||c_sub|| (n <= 4096: 1.4e-5), typically ~1e-6 relative.
-template <typename T, int W, int TZ, int NW, int CH, bool FX>
+// COMP (fp64 planes only): 0 = both components in one launch (two planes); 1 / 2 = only
+// the real / imaginary part (ONE plane, so two workgroups fit a CU; the host launches both).
+template <typename T, int W, int TZ, int NW, int CH, bool FX, int COMP = 0>
 __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
     Geom g, SortedPoints<T> sp, const T* __restrict__ horner, const T* __restrict__ c,
     T* __restrict__ fw, int64_t c_stride, int64_t fw_stride, T scale) {
@@ -1307,8 +1309,9 @@ __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
   constexpr int plane = PS * L2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* plane_re = reinterpret_cast<double*>(smem_raw);             // FX: the packed plane
-  double* plane_im = plane_re + (FX ? 0 : plane);
-  double* pad = plane_re + (FX ? 1 : 2) * plane;                      // 64 elements of spill room
+  constexpr int NPL = (FX || COMP != 0) ? 1 : 2;
+  double* plane_im = plane_re + (NPL == 1 ? 0 : plane);
+  double* pad = plane_re + NPL * plane;                               // 64 elements of spill room
   T* stage_all = reinterpret_cast<T*>(pad + 64);
   constexpr int SW = W <= 6 ? 6 : 8;                                  // staging row length
   float* red = reinterpret_cast<float*>(stage_all + NW * CH * 2 * SW);   // [NW] (FX bound reduction)
@@ -1317,7 +1320,7 @@ __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  for (int i = tid; i < (FX ? 1 : 2) * plane + 64; i += NW * 64) plane_re[i] = 0.0;
+  for (int i = tid; i < NPL * plane + 64; i += NW * 64) plane_re[i] = 0.0;
   const T2* cc = reinterpret_cast<const T2*>(c) + (int64_t)blockIdx.y * c_stride;
   const int npt = p1 - p0;
 
@@ -1415,8 +1418,8 @@ __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
           const unsigned long long x = ((unsigned long long)hi << 32) | (unsigned)ii;
           atomicAdd(reinterpret_cast<unsigned long long*>(pr) + dz * PS, x);
         } else {
-          lds_add(pr + dz * PS, (double)(ar * kzq));
-          lds_add(pi + dz * PS, (double)(ai * kzq));
+          if (COMP != 2) lds_add(pr + dz * PS, (double)(ar * kzq));
+          if (COMP != 1) lds_add(pi + dz * PS, (double)(ai * kzq));
         }
       }
     }
@@ -1443,6 +1446,7 @@ __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
         const int re_sum = (int)((t - (long long)im_sum) >> 32);
         v = (T)(comp ? im_sum : re_sum) * lsb;
       } else {
+        if (COMP != 0 && comp != COMP - 1) continue;
         v = (T)(comp ? plane_im : plane_re)[lrow + a0];
       }
       if (v != (T)0) glb_add(&out[2 * (rowbase + wrap1(o0 + a0, g.nf[0])) + comp], v);
@@ -2038,8 +2042,8 @@ size_t spread_lds_bytes(const Geom& g, int method, int precision) {
       return std::max(std::max(wave8_lds(true), group_lds(12, 64, false)),
                       g.w == kWW ? wave8_lds(false) : wave2_lds(g, precision));
     if (g.rank == 2) return wave2_lds(g, precision);
-    const int nw = wave3d_nw_rt(precision, g.fixed_point != 0);
-    return cells * (g.fixed_point ? 1 : 2) * sizeof(double) + 64 * sizeof(double) +
+    const int nw = g.split_reim ? 12 : wave3d_nw_rt(precision, g.fixed_point != 0);
+    return cells * ((g.fixed_point || g.split_reim) ? 1 : 2) * sizeof(double) + 64 * sizeof(double) +
            (size_t)precision * nw * 32 * 2 * (g.w <= 6 ? 6 : 8) + 256;
   }
   return cells * 2 * sizeof(double);
@@ -2141,6 +2145,11 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
   if (e != hipSuccess) return e;                                                                 \
   spread_wave3_kernel<T, WW, TZV, wave3d_nw<T, FXV>(), 32, FXV>                                   \
       <<<grid, wave3d_nw<T, FXV>() * 64, lds_bytes, stream>>>(g, sp, horner, c, fw, c_stride, fw_stride, scale);
+#define NUFFT_LAUNCH_W3S(WW, TZV, CV)                                                            \
+  e = ensure_lds(spread_wave3_kernel<T, WW, TZV, 12, 32, false, CV>, lds_bytes);                  \
+  if (e != hipSuccess) return e;                                                                 \
+  spread_wave3_kernel<T, WW, TZV, 12, 32, false, CV>                                              \
+      <<<grid, 12 * 64, lds_bytes, stream>>>(g, sp, horner, c, fw, c_stride, fw_stride, scale);
 #define NUFFT_CASE_W3(WW)                                                                        \
   case WW:                                                                                       \
     if (g.tile[2] == 8) {                                                                        \
@@ -2152,6 +2161,9 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
     } else if (g.tile[2] == 4) {                                                                 \
       if (g.fixed_point) {                                                                       \
         if constexpr (sizeof(T) == 4) { NUFFT_LAUNCH_W3(WW, 4, true) } else { return hipErrorInvalidValue; } \
+      } else if (g.split_reim) {                                                                 \
+        if constexpr (sizeof(T) == 4) { NUFFT_LAUNCH_W3S(WW, 4, 1) NUFFT_LAUNCH_W3S(WW, 4, 2) }   \
+        else { return hipErrorInvalidValue; }                                                    \
       } else { NUFFT_LAUNCH_W3(WW, 4, false) }                                                   \
     } else { return hipErrorInvalidValue; }                                                      \
     break;
@@ -2161,6 +2173,7 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
         default: return hipErrorInvalidValue;
       }
 #undef NUFFT_CASE_W3
+#undef NUFFT_LAUNCH_W3S
 #undef NUFFT_LAUNCH_W3
     }
     return hipGetLastError();

@@ -868,6 +868,7 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
   // (measured +1.4e-6); w = 8 (tol 1e-6) would need ~25 and keeps the fp64 planes
   // (measured 2.4e-6 at 256 points per subproblem).
   g.fixed_point = 0;
+  g.split_reim = 0;
   g.cell_sorted = 0;
   if (method == NUFFT_HIP_METHOD_TILE_WAVE && rank == 3 && precision == NUFFT_HIP_F32 && w <= 7 &&
       p->opts.lds_accumulate != 1)
@@ -877,6 +878,10 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
     return fail(NUFFT_HIP_INVALID_ARGUMENT,
                 "lds_accumulate = 2 (fixed point) needs the 3-D float wavefront method with kernel width <= 7");
   }
+  // fp64 planes in 3-D float at tile depth 4 (w = 8, or w <= 7 with lds_accumulate = 1):
+  // one plane per launch, so that two workgroups share a CU
+  g.split_reim = (method == NUFFT_HIP_METHOD_TILE_WAVE && rank == 3 && precision == NUFFT_HIP_F32 &&
+                  !g.fixed_point && g.tile[2] == 4 && getenv("NUFFT_HIP_NO_SPLIT") == nullptr) ? 1 : 0;
   if (method == NUFFT_HIP_METHOD_TILE_WAVE) g.lstride = wave_lstride(rank);
   // wavefront kernels: one subproblem per typical tile measured fastest (r01 sweeps);
   // every extra subproblem of a tile repeats its zero-fill and write-out
