@@ -995,20 +995,23 @@ constexpr int kGroupMaxSub = 4096;
 constexpr double kGroupMinDensity = 0.5;   // points per fine cell
 constexpr double kInterpSortMinDensity = 0.3;   // 3-D interp cell sort pays from here (r01: 0.075 loses, 0.75 and 1.8 win)
 constexpr int kGroupStage = 32; // points whose kernel values are in LDS at a time (per wave)
+template <typename T> constexpr int kGroupStageOf = sizeof(T) == 8 ? 16 : kGroupStage;   // double: half, same bytes
 constexpr int kGroupBlk = 36;   // staging words per block of 4 points (8 x 4 + 4 pad)
 template <int CH> constexpr int kGroupStageWave = 3 * (CH / 4) * kGroupBlk;   // words per wave (kx, ky re, ky im)
-template <int W, int NW, int CH, bool PRE>
+template <typename T, int W, int NW, int CH, bool PRE>
 __global__ __launch_bounds__(NW * 64) void spread_2d_w8_group_kernel(
-    Geom g, SortedPoints<float> sp, const float* __restrict__ horner, const float* __restrict__ c,
-    float* __restrict__ fw, int64_t c_stride, int64_t fw_stride, float scale) {
+    Geom g, SortedPoints<T> sp, const T* __restrict__ horner, const T* __restrict__ c,
+    T* __restrict__ fw, int64_t c_stride, int64_t fw_stride, T scale) {
+  typedef T v2 __attribute__((ext_vector_type(2)));
+  typedef T v4 __attribute__((ext_vector_type(4)));
   constexpr int NT = NW * 64;
   constexpr int IT = (kGroupMaxSub + NT - 1) / NT;   // records per thread in the LDS sort
-  constexpr int SC = CH < kGroupStage ? CH : kGroupStage;   // points staged through LDS at a time
+  constexpr int SC = CH < kGroupStageOf<T> ? CH : kGroupStageOf<T>;   // points staged through LDS at a time
   static_assert(NT <= 1024, "at most 16 waves");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* plane_re = reinterpret_cast<double*>(smem_raw);
   double* plane_im = plane_re + kWPlane;
-  float* stage_all = reinterpret_cast<float*>(plane_im + kWPlane);
+  T* stage_all = reinterpret_cast<T*>(plane_im + kWPlane);
   uint32_t* cnt = reinterpret_cast<uint32_t*>(stage_all + NW * kGroupStageWave<SC>);   // [1024]
   uint16_t* perm = reinterpret_cast<uint16_t*>(cnt + 1024);                     // [4096]
   uint32_t* wsum = reinterpret_cast<uint32_t*>(perm + kGroupMaxSub);            // [16]
@@ -1054,59 +1057,58 @@ __global__ __launch_bounds__(NW * 64) void spread_2d_w8_group_kernel(
   // ds_read_b128 fetches a lane's kx (or ky) for 4 passes (6 cycles instead of
   // 4 x 3.4, tools/ubench/lds_read_bench.hip). Block stride 36 words: the
   // lane-per-point b32 writes of one q then hit 64 distinct banks.
-  float* kxs = stage_all + wave * kGroupStageWave<SC>;   // [CH/4][8][4] (+4 pad per block)
-  float* kyr = kxs + kGroupStageWave<SC> / 3;            // ky * re(c)
-  float* kyi = kyr + kGroupStageWave<SC> / 3;            // ky * im(c)
+  T* kxs = stage_all + wave * kGroupStageWave<SC>;   // [CH/4][8][4] (+4 pad per block)
+  T* kyr = kxs + kGroupStageWave<SC> / 3;            // ky * re(c)
+  T* kyi = kyr + kGroupStageWave<SC> / 3;            // ky * im(c)
   const int dx = lane & 7, dy = lane >> 3;
   const int cell = (dy * kWS + dx) * (int)sizeof(double);
-  const float* cc = c + 2 * (int64_t)blockIdx.y * c_stride;
+  const T* cc = c + 2 * (int64_t)blockIdx.y * c_stride;
 
   // Two-deep software pipeline over the wave's chunks: the record gather of chunk
   // i+2 and the strength gather of chunk i+1 (which needs record i+1's index)
   // are in flight while chunk i is spread, so neither HBM latency is exposed.
-  const float2* c2 = reinterpret_cast<const float2*>(cc);
+  const v2* c2 = reinterpret_cast<const v2*>(cc);
   auto load_rec = [&](int b) {   // lanes past the end re-read the last point; masked below
     const int li = b + lane;
     const int lc = li < n ? li : n - 1;
     if constexpr (PRE) return sp.rec[p0 + lc];
     else return sp.rec[p0 + perm[lc]];
   };
-  auto load_c = [&](const Rec<float>& r) { return c2[r.idx]; };
+  auto load_c = [&](const Rec<T>& r) { return c2[r.idx]; };
   constexpr int STEP = NW * CH;
-  Rec<float> r_cur = load_rec(wave * CH);
-  Rec<float> r_nxt = load_rec(wave * CH + STEP);
-  float2 c_cur = load_c(r_cur);
+  Rec<T> r_cur = load_rec(wave * CH);
+  Rec<T> r_nxt = load_rec(wave * CH + STEP);
+  v2 c_cur = load_c(r_cur);
   for (int base = wave * CH; base < n; base += STEP) {
-    const float2 c_nxt = load_c(r_nxt);
-    const Rec<float> r_nn = load_rec(base + 2 * STEP);
+    const v2 c_nxt = load_c(r_nxt);
+    const Rec<T> r_nn = load_rec(base + 2 * STEP);
     const uint32_t loc = r_cur.loc;
-    const float zx = r_cur.z0, zy = r_cur.z1;
+    const T zx = r_cur.z0, zy = r_cur.z1;
     const bool valid = lane < CH && base + lane < n;
-    const float re = valid ? c_cur.x * scale : 0.f, im = valid ? c_cur.y * scale : 0.f;
+    const T re = valid ? c_cur.x * scale : (T)0, im = valid ? c_cur.y * scale : (T)0;
     const uint32_t key = valid ? (loc & 0xfffffu) : 0xffffffffu;
     const int off = (((loc >> 10) & 1023) * kWS + (loc & 1023)) * (int)sizeof(double);
-    float kx[kWW], ky[kWW];
+    T kx[kWW], ky[kWW];
     // The ES kernel is even, so cell W-1-q's polynomial is cell q's at -z: evaluate the
     // even and odd parts in z^2 once per pair (12 instead of 22 FMAs for two cells,
     // and at most 48 coefficients, which stay in SGPRs). x and y share coefficients:
-    // each term is one v_pk_fma_f32.
-    typedef float v2f __attribute__((ext_vector_type(2)));
-    const v2f zz = {zx, zy};
-    const v2f z2 = zz * zz;
+    // each term is one v_pk_fma_f32 (two v_fma_f64 in double).
+    const v2 zz = {zx, zy};
+    const v2 z2 = zz * zz;
 #pragma unroll
-    for (int q = 0; q < kWW; ++q) { kx[q] = 0.f; ky[q] = 0.f; }   // cells >= W stay 0 (narrower kernels)
+    for (int q = 0; q < kWW; ++q) { kx[q] = (T)0; ky[q] = (T)0; }   // cells >= W stay 0 (narrower kernels)
 #pragma unroll
     for (int q = 0; q < (W + 1) / 2; ++q) {
-      const float te = horner[(kWaveCoef - 2) * kMaxW + q], to = horner[(kWaveCoef - 1) * kMaxW + q];
-      v2f e = {te, te}, o = {to, to};
+      const T te = horner[(kWaveCoef - 2) * kMaxW + q], to = horner[(kWaveCoef - 1) * kMaxW + q];
+      v2 e = {te, te}, o = {to, to};
 #pragma unroll
       for (int m = kWaveCoef / 2 - 2; m >= 0; --m) {
-        const float ce = horner[(2 * m) * kMaxW + q], co = horner[(2 * m + 1) * kMaxW + q];
-        const v2f cce = {ce, ce}, cco = {co, co};
+        const T ce = horner[(2 * m) * kMaxW + q], co = horner[(2 * m + 1) * kMaxW + q];
+        const v2 cce = {ce, ce}, cco = {co, co};
         e = __builtin_elementwise_fma(e, z2, cce);
         o = __builtin_elementwise_fma(o, z2, cco);
       }
-      const v2f lo = __builtin_elementwise_fma(zz, o, e), hi = __builtin_elementwise_fma(-zz, o, e);
+      const v2 lo = __builtin_elementwise_fma(zz, o, e), hi = __builtin_elementwise_fma(-zz, o, e);
       kx[q] = lo.x; ky[q] = lo.y;
       if (W - 1 - q != q) { kx[W - 1 - q] = hi.x; ky[W - 1 - q] = hi.y; }
     }
@@ -1139,25 +1141,25 @@ __global__ __launch_bounds__(NW * 64) void spread_2d_w8_group_kernel(
       if (nh > SC) nh = SC;
       const unsigned tails = (unsigned)(tailm >> h);
       const int nround = (nh + 3) & ~3;   // padded lanes hold zeros and are never tails
-      float ar = 0.f, ai = 0.f;
+      T ar = (T)0, ai = (T)0;
       for (int q = 0; q < nround; q += 4) {
-        const float4 ax4 = *reinterpret_cast<const float4*>(kxs + (q >> 2) * kGroupBlk + 4 * dx);
-        const float4 br4 = *reinterpret_cast<const float4*>(kyr + (q >> 2) * kGroupBlk + 4 * dy);
-        const float4 bi4 = *reinterpret_cast<const float4*>(kyi + (q >> 2) * kGroupBlk + 4 * dy);
-        const float a[4] = {ax4.x, ax4.y, ax4.z, ax4.w};
-        const float br[4] = {br4.x, br4.y, br4.z, br4.w};
-        const float bi[4] = {bi4.x, bi4.y, bi4.z, bi4.w};
+        const v4 ax4 = *reinterpret_cast<const v4*>(kxs + (q >> 2) * kGroupBlk + 4 * dx);
+        const v4 br4 = *reinterpret_cast<const v4*>(kyr + (q >> 2) * kGroupBlk + 4 * dy);
+        const v4 bi4 = *reinterpret_cast<const v4*>(kyi + (q >> 2) * kGroupBlk + 4 * dy);
+        const T a[4] = {ax4.x, ax4.y, ax4.z, ax4.w};
+        const T br[4] = {br4.x, br4.y, br4.z, br4.w};
+        const T bi[4] = {bi4.x, bi4.y, bi4.z, bi4.w};
         const unsigned t4 = (tails >> q) & 15u;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          ar = fmaf(a[u], br[u], ar);
-          ai = fmaf(a[u], bi[u], ai);
+          ar = fma(a[u], br[u], ar);
+          ai = fma(a[u], bi[u], ai);
           if (t4 & (1u << u)) {
             const int o = __builtin_amdgcn_readlane(off, h + q + u) + cell;   // byte offset into the re plane
             lds_add(reinterpret_cast<double*>(smem_raw + o), (double)ar);
             lds_add(reinterpret_cast<double*>(smem_raw + o) + kWPlane, (double)ai);
-            ar = 0.f;
-            ai = 0.f;
+            ar = (T)0;
+            ai = (T)0;
           }
         }
       }
@@ -1168,13 +1170,13 @@ __global__ __launch_bounds__(NW * 64) void spread_2d_w8_group_kernel(
   const int t0 = tb % g.ntile[0];
   const int t1 = tb / g.ntile[0];
   const int o0 = t0 * kWT, o1 = t1 * kWT;
-  float* out = fw + 2 * (int64_t)blockIdx.y * fw_stride;
+  T* out = fw + 2 * (int64_t)blockIdx.y * fw_stride;
   for (int i = tid; i < 2 * kWL * kWL; i += NT) {
     const int comp = i & 1;
     const int cellid = i >> 1;
     const int a0 = cellid % kWL, a1 = cellid / kWL;
-    const float v = (float)(comp ? plane_im : plane_re)[a1 * kWS + a0];
-    if (v != 0.f) {
+    const T v = (T)(comp ? plane_im : plane_re)[a1 * kWS + a0];
+    if (v != (T)0) {
       int g0 = o0 + a0; if (g0 >= g.nf[0]) g0 -= g.nf[0];
       int g1 = o1 + a1; if (g1 >= g.nf[1]) g1 -= g.nf[1];
       glb_add(&out[2 * (g0 + (int64_t)g.nf[0] * g1) + comp], v);
@@ -1948,8 +1950,9 @@ static const W8Shape& wave8_shape_env() {   // NUFFT_HIP_W8_SHAPE = "NWxCH" (tun
 static int wave8_nw(bool grouped) { const int v = wave8_shape_env().nw; return v > 0 ? v : (grouped ? 12 : 4); }
 static int wave8_ch(bool grouped) { const int v = wave8_shape_env().ch; return v > 0 ? v : 64; }
 constexpr int kW2NW = 4, kW2CH = 64;   // launch shape of spread_wave2_kernel (others measured no better)
-static size_t group_lds(int nw, int ch, bool presorted) {
-  return sizeof(double) * 2 * kWPlane + sizeof(float) * nw * 3 * ((ch < kGroupStage ? ch : kGroupStage) / 4) * kGroupBlk +
+static size_t group_lds(int nw, int ch, bool presorted, int precision = NUFFT_HIP_F32) {
+  const int stage = precision == NUFFT_HIP_F32 ? kGroupStage : kGroupStage / 2;   // kGroupStageOf<T>
+  return sizeof(double) * 2 * kWPlane + (size_t)precision * nw * 3 * ((ch < stage ? ch : stage) / 4) * kGroupBlk +
          (presorted ? 0 : 1024 * 4 + kGroupMaxSub * 2 + 64);   // + counters, permutation, wave sums
 }
 static size_t wave8_lds(bool grouped, bool presorted = false) {
@@ -1963,12 +1966,16 @@ static size_t wave2_lds(const Geom& g, int precision) {
   return (cells * 2 + 256) * sizeof(double) + (size_t)precision * kW2NW * kW2CH * 24;
 }
 
-// Specialised 2-D w = 8 float kernel applicable?
-static bool wave8_supported(const Geom& g, int precision) {
-  static const bool off = getenv("NUFFT_HIP_NO_W8") != nullptr;   // A/B against spread_wave2_kernel<float, 8>
+// Geometry the cell-grouped 2-D kernels need (either precision)
+static bool group2d_geometry(const Geom& g) {
+  static const bool off = getenv("NUFFT_HIP_NO_W8") != nullptr;   // A/B against spread_wave2_kernel
   if (off) return false;
-  return precision == NUFFT_HIP_F32 && g.rank == 2 && g.w <= kWW && g.ncoef <= kWaveCoef &&
-         g.tile[0] == kWT && g.tile[1] == kWT && g.lstride == kWS;
+  return g.rank == 2 && g.w <= kWW && g.ncoef <= kWaveCoef && g.tile[0] == kWT && g.tile[1] == kWT &&
+         g.lstride == kWS;
+}
+// Specialised 2-D float kernels (grouped, per-point w = 8, lazy cell sort) applicable?
+static bool wave8_supported(const Geom& g, int precision) {
+  return precision == NUFFT_HIP_F32 && group2d_geometry(g);
 }
 
 // Wavefront-per-point kernels need w <= 8, rank 2/3 and the tile geometry that
@@ -2041,7 +2048,8 @@ size_t spread_lds_bytes(const Geom& g, int method, int precision) {
     if (wave8_supported(g, precision))   // maximum over the kernels launch_spread may pick
       return std::max(std::max(wave8_lds(true), group_lds(12, 64, false)),
                       g.w == kWW ? wave8_lds(false) : wave2_lds(g, precision));
-    if (g.rank == 2) return wave2_lds(g, precision);
+    if (g.rank == 2)
+      return group2d_geometry(g) ? std::max(wave2_lds(g, precision), group_lds(8, 64, false, precision)) : wave2_lds(g, precision);
     const int nw = g.split_reim ? 12 : wave3d_nw_rt(precision, g.fixed_point != 0);
     return cells * ((g.fixed_point || g.split_reim) ? 1 : 2) * sizeof(double) + 64 * sizeof(double) +
            (size_t)precision * nw * 32 * 2 * (g.w <= 6 ? 6 : 8) + 256;
@@ -2074,14 +2082,14 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
 #define NUFFT_LAUNCH_W8G(WV, NWV, CHV)                                                         \
   case NWV * 100 + CHV:                                                                        \
     if (g.cell_sorted) {                                                                       \
-      e = ensure_lds(spread_2d_w8_group_kernel<WV, NWV, CHV, true>, lds_bytes);                \
+      e = ensure_lds(spread_2d_w8_group_kernel<float, WV, NWV, CHV, true>, lds_bytes);                \
       if (e != hipSuccess) return e;                                                           \
-      spread_2d_w8_group_kernel<WV, NWV, CHV, true><<<grid, NWV * 64, lds_bytes, stream>>>(    \
+      spread_2d_w8_group_kernel<float, WV, NWV, CHV, true><<<grid, NWV * 64, lds_bytes, stream>>>(    \
           g, sp, horner, c, fw, c_stride, fw_stride, scale);                                   \
     } else {                                                                                   \
-      e = ensure_lds(spread_2d_w8_group_kernel<WV, NWV, CHV, false>, lds_bytes);               \
+      e = ensure_lds(spread_2d_w8_group_kernel<float, WV, NWV, CHV, false>, lds_bytes);               \
       if (e != hipSuccess) return e;                                                           \
-      spread_2d_w8_group_kernel<WV, NWV, CHV, false><<<grid, NWV * 64, lds_bytes, stream>>>(   \
+      spread_2d_w8_group_kernel<float, WV, NWV, CHV, false><<<grid, NWV * 64, lds_bytes, stream>>>(   \
           g, sp, horner, c, fw, c_stride, fw_stride, scale);                                   \
     }                                                                                          \
     break;
@@ -2122,6 +2130,27 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
 #undef NUFFT_LAUNCH_W8
         return hipGetLastError();
         }   // narrower kernels at low density: spread_wave2_kernel below
+      }
+    }
+    if constexpr (sizeof(T) == 8) {
+      // double precision: the same cell-grouped kernel (8 waves, 16 staged points: the byte
+      // budget of the float form), in-kernel sort only
+      if (group2d_geometry(g) && wave8_use_group(g, M)) {
+        lds_bytes = group_lds(8, 64, false, NUFFT_HIP_F64);
+#define NUFFT_CASE_W8D(WV)                                                                     \
+  case WV:                                                                                     \
+    e = ensure_lds(spread_2d_w8_group_kernel<double, WV, 8, 64, false>, lds_bytes);            \
+    if (e != hipSuccess) return e;                                                             \
+    spread_2d_w8_group_kernel<double, WV, 8, 64, false><<<grid, 8 * 64, lds_bytes, stream>>>(  \
+        g, sp, horner, c, fw, c_stride, fw_stride, scale);                                     \
+    break;
+        switch (g.w) {
+          NUFFT_CASE_W8D(2) NUFFT_CASE_W8D(3) NUFFT_CASE_W8D(4) NUFFT_CASE_W8D(5)
+          NUFFT_CASE_W8D(6) NUFFT_CASE_W8D(7) NUFFT_CASE_W8D(8)
+          default: return hipErrorInvalidValue;
+        }
+#undef NUFFT_CASE_W8D
+        return hipGetLastError();
       }
     }
     if (g.rank == 2) {
