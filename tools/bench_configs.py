@@ -66,3 +66,4 @@ if '3d6' in which: run('3D t1 256^3 M=3e7 tol1e-6 f32', 'type_1', [256, 256, 256
 if '3d6t2' in which: run('3D t2 256^3 M=3e7 tol1e-6 f32', 'type_2', [256, 256, 256], 30_000_000, 1e-6, steps=3)
 if '3d5' in which: run('3D t1 256^3 M=3e7 tol1e-5 f32', 'type_1', [256, 256, 256], 30_000_000, 1e-5, steps=3)
 if '3d5d' in which: run('3D t1 256^3 M=3e7 tol1e-5 f32, fp64 LDS planes', 'type_1', [256, 256, 256], 30_000_000, 1e-5, steps=3, lds_accumulate=1)
+if '3dd' in which: run('3D t1 128^3 M=2e7 tol1e-4 f64', 'type_1', [128, 128, 128], 20_000_000, 1e-4, dtype=torch.complex128, steps=3)
