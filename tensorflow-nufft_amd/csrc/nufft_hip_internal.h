@@ -85,6 +85,7 @@ struct SortWork {
 
 constexpr int kMaxLdsTiles = 16384;     // 64 KiB of 32-bit LDS counters
 constexpr int kMaxLds16Tiles = 73728;   // 144 KiB of packed 16-bit LDS counters
+constexpr int kMaxRanges16 = 4;         // tile ranges the 16-bit histogram pass may split into
 
 enum Stage {
   STAGE_SORT_COUNT = 0, STAGE_SORT_SCAN, STAGE_SORT_SCATTER, STAGE_ZERO, STAGE_SPREAD,

@@ -464,22 +464,29 @@ __global__ __launch_bounds__(kSortBlock) void scatter_lds_kernel(Geom g, PointsI
   }
 }
 
-// --- path A16 (16384 < ntiles <= kMaxLds16Tiles): same scheme with 16-bit
-// counters packed two per LDS word, so that 65536 tiles (3-D 512^3 at 16x16x8)
+// --- path A16 (16384 < ntiles <= kMaxRanges16 * kMaxLds16Tiles): same scheme with
+// 16-bit counters packed two per LDS word, so that 65536 tiles (3-D 512^3 at 16x16x8)
 // fit in 128 KiB of LDS. A workgroup never takes more than 65535 points, so a
 // packed counter cannot carry into its neighbour. The per-(workgroup, tile)
 // prefix is 32-bit and lives in HBM; the scatter keeps only RELATIVE 16-bit
-// cursors in LDS and adds tile_start + prefix read from L2.
+// cursors in LDS and adds tile_start + prefix read from L2. More tiles than fit LDS
+// (3-D at w = 7, 8: 16x16x4 tiles, 131072 of them on 512^3) are covered by up to
+// kMaxRanges16 tile RANGES: blockIdx.y picks the range a workgroup counts, every range
+// re-reads the block's points (count 1.33 -> 0.35 ms at M = 3e7 against the global-counter
+// path that served these geometries before).
 template <typename T>
 __global__ __launch_bounds__(kSortBlock) void hist16_lds_kernel(Geom g, PointsIn in, int64_t per_block,
-                                                                uint32_t* __restrict__ hist16,
+                                                                int span, uint32_t* __restrict__ hist16,
                                                                 int32_t* __restrict__ tile_of,
                                                                 uint16_t* __restrict__ rank16,
                                                                 int32_t* __restrict__ bad_count) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned* h2 = reinterpret_cast<unsigned*>(smem_raw);
   const int nw = (g.ntiles + 1) >> 1;
-  for (int t = threadIdx.x; t < nw; t += kSortBlock) h2[t] = 0u;
+  const int t_lo = (int)blockIdx.y * span;                                   // span is even
+  const int t_hi = (t_lo + span < g.ntiles) ? t_lo + span : g.ntiles;
+  const int nwr = (t_hi - t_lo + 1) >> 1;                                    // words of this range
+  for (int t = threadIdx.x; t < nwr; t += kSortBlock) h2[t] = 0u;
   __syncthreads();
   const int64_t lo = (int64_t)blockIdx.x * per_block;
   const int64_t hi = (lo + per_block < in.M) ? lo + per_block : in.M;
@@ -496,18 +503,19 @@ __global__ __launch_bounds__(kSortBlock) void hist16_lds_kernel(Geom g, PointsIn
       const int64_t i = i0 + u * kSortBlock;
       Rec<T> r;
       const int tile = fold_coords<T>(g, in, x[u], &r, &bad);
-      if (i < hi) {
-        const int sh = 16 * (tile & 1);
-        const unsigned old = atomicAdd(&h2[tile >> 1], 1u << sh);
+      if (i < hi && tile >= t_lo && tile < t_hi) {
+        const int tl = tile - t_lo;
+        const int sh = 16 * (tl & 1);
+        const unsigned old = atomicAdd(&h2[tl >> 1], 1u << sh);
         tile_of[i] = tile;
         rank16[i] = (uint16_t)((old >> sh) & 0xffffu);   // rank inside (workgroup, tile)
       }
     }
   }
-  if (bad && in.check_range) atomicAdd(bad_count, 1);
+  if (bad && in.check_range && blockIdx.y == 0) atomicAdd(bad_count, 1);
   __syncthreads();
-  uint32_t* out = hist16 + (int64_t)blockIdx.x * nw;
-  for (int t = threadIdx.x; t < nw; t += kSortBlock) out[t] = h2[t];
+  uint32_t* out = hist16 + (int64_t)blockIdx.x * nw + (t_lo >> 1);
+  for (int t = threadIdx.x; t < nwr; t += kSortBlock) out[t] = h2[t];
 }
 
 // hist16[b][t] (uint16) -> pref[b][t] (int32 exclusive prefix over b), totals -> tile_count
@@ -1843,7 +1851,7 @@ int sort_blocks(const Geom& g, int64_t M, int64_t* per_block) {
 // (workgroups capped at 65535 points); 2: global counters.
 int sort_mode(const Geom& g, int64_t M) {
   if (g.ntiles <= kMaxLdsTiles) return 0;
-  if (g.ntiles <= kMaxLds16Tiles) {
+  if ((int64_t)g.ntiles <= (int64_t)kMaxRanges16 * kMaxLds16Tiles) {
     int64_t pb;
     const int64_t nblk = sort_blocks16(M, &pb);
     if (nblk * (int64_t)g.ntiles * 6 <= ((int64_t)2 << 30)) return 1;   // hist16 + pref <= 2 GiB
@@ -1895,15 +1903,17 @@ hipError_t launch_sort(const Geom& g, const PointsIn& in, const SortWork& w, con
     int64_t per_block;
     const int nblk = sort_blocks16(in.M, &per_block);
     const int nw = (g.ntiles + 1) >> 1;
-    const size_t lds = sizeof(unsigned) * (size_t)nw;
+    const int ranges = (g.ntiles + kMaxLds16Tiles - 1) / kMaxLds16Tiles;
+    const int span = (((g.ntiles + ranges - 1) / ranges) + 1) & ~1;         // tiles per range, even
+    const size_t lds = sizeof(unsigned) * (size_t)(span >> 1);
     uint32_t* hist16 = reinterpret_cast<uint32_t*>(w.hist);                 // [nblk][nw] words
     int32_t* pref = w.hist + (int64_t)nblk * nw;                            // [nblk][ntiles]
     e = ensure_lds(hist16_lds_kernel<T>, lds);
     if (e != hipSuccess) return e;
     uint16_t* rank16 = reinterpret_cast<uint16_t*>(w.rank_of);
     hook.begin(STAGE_SORT_COUNT);
-    hist16_lds_kernel<T><<<nblk, kSortBlock, lds, stream>>>(g, in, per_block, hist16, w.tile_of, rank16,
-                                                            w.bad_count);
+    hist16_lds_kernel<T><<<dim3(nblk, ranges), kSortBlock, lds, stream>>>(g, in, per_block, span, hist16,
+                                                                          w.tile_of, rank16, w.bad_count);
     hook.end(STAGE_SORT_COUNT);
     hook.begin(STAGE_SORT_SCAN);
     colscan16_kernel<<<(g.ntiles + 63) / 64, 1024, 0, stream>>>(

@@ -469,10 +469,12 @@ def test_config5_batched_items(tfft):
   assert rel_l2(shared[1].cpu().numpy(), out[1].cpu().numpy()) < 1e-6
 
 
-@pytest.mark.parametrize('tile,mode', [((16, 16, 8), 'lds32'), ((4, 8, 4), 'lds16'), ((4, 4, 4), 'global')])
+@pytest.mark.parametrize('tile,mode', [((16, 16, 8), 'lds32'), ((4, 8, 4), 'lds16'), ((4, 4, 4), 'lds16x2'),
+                                       ((2, 2, 4), 'global')])
 def test_all_three_sort_paths_give_the_same_transform(tfft, tile, mode):
-  # tile counts 3456 / 55296 / 110592 select the 32-bit LDS histogram sort, the packed
-  # 16-bit LDS histogram sort and the global-counter sort (nufft_kernels.hip, sort_mode)
+  # tile counts 3456 / 55296 / 110592 / 442368 select the 32-bit LDS histogram sort, the packed
+  # 16-bit LDS histogram sort (one and two tile ranges) and the global-counter sort
+  # (nufft_kernels.hip, sort_mode)
   import torch
   from oracle import oracle
   rng = np.random.default_rng(41)
@@ -486,7 +488,8 @@ def test_all_three_sort_paths_give_the_same_transform(tfft, tile, mode):
   i = plan.info()
   assert tuple(i.tile_dims) == tile
   ntiles = i.num_tiles[0] * i.num_tiles[1] * i.num_tiles[2]
-  assert {'lds32': ntiles <= 16384, 'lds16': 16384 < ntiles <= 73728, 'global': ntiles > 73728}[mode]
+  assert {'lds32': ntiles <= 16384, 'lds16': 16384 < ntiles <= 73728, 'lds16x2': 73728 < ntiles <= 147456,
+          'global': ntiles > 4 * 73728}[mode]
   plan.set_points(_dev(pts))
   out = plan.execute(_dev(c)).cpu().numpy()
   assert rel_l2(out, truth) < 1e-4, rel_l2(out, truth)
