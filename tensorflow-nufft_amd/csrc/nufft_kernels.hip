@@ -604,42 +604,52 @@ __global__ __launch_bounds__(256) void scatter_global_kernel(Geom g, PointsIn in
 __global__ __launch_bounds__(1024) void scan_tiles_kernel(const int32_t* __restrict__ count, int n,
                                                           int max_sub, int32_t* __restrict__ tile_start,
                                                           int32_t* __restrict__ sub_start) {
+  // One workgroup walks the tiles in blocks of 4096 (4 consecutive tiles per thread, so the
+  // loads and stores of a wave are contiguous), scanning each block with wave shuffles and
+  // carrying the running totals. (A fixed contiguous range per thread made every access of
+  // a wave strided: 135 us for the 65536 tiles of config 4, 25 us this way.)
   __shared__ int ws_a[16], ws_b[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int per = (n + 1023) / 1024;
-  const int lo = tid * per;
-  const int hi = (lo + per < n) ? lo + per : n;
-  int sa = 0, sb = 0;
-  for (int i = lo; i < hi; ++i) {
-    const int c = count[i];
-    sa += c;
-    sb += (c + max_sub - 1) / max_sub;
-  }
-  int ia = sa, ib = sb;   // inclusive scans inside the wave (shuffles), then across the 16 waves
+  int run_a = 0, run_b = 0;
+  for (int base = 0; base < n; base += 4096) {
+    const int i0 = base + 4 * tid;
+    int c[4];
 #pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int ta = __shfl_up(ia, d), tb = __shfl_up(ib, d);
-    if (lane >= d) { ia += ta; ib += tb; }
-  }
-  if (lane == 63) { ws_a[wave] = ia; ws_b[wave] = ib; }
-  __syncthreads();
-  int ea = ia - sa, eb = ib - sb, tot_a = 0, tot_b = 0;
+    for (int k = 0; k < 4; ++k) c[k] = (i0 + k < n) ? count[i0 + k] : 0;
+    int sa = 0, sb = 0;
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    if (k < wave) { ea += ws_a[k]; eb += ws_b[k]; }
-    tot_a += ws_a[k];
-    tot_b += ws_b[k];
-  }
-  for (int i = lo; i < hi; ++i) {
-    const int c = count[i];
-    tile_start[i] = ea;
-    sub_start[i] = eb;
-    ea += c;
-    eb += (c + max_sub - 1) / max_sub;
+    for (int k = 0; k < 4; ++k) { sa += c[k]; sb += (c[k] + max_sub - 1) / max_sub; }
+    int ia = sa, ib = sb;   // inclusive scans inside the wave, then across the 16 waves
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int ta = __shfl_up(ia, d), tb = __shfl_up(ib, d);
+      if (lane >= d) { ia += ta; ib += tb; }
+    }
+    __syncthreads();   // previous block's readers of ws_* are done
+    if (lane == 63) { ws_a[wave] = ia; ws_b[wave] = ib; }
+    __syncthreads();
+    int ea = run_a + ia - sa, eb = run_b + ib - sb, tot_a = 0, tot_b = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      if (k < wave) { ea += ws_a[k]; eb += ws_b[k]; }
+      tot_a += ws_a[k];
+      tot_b += ws_b[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (i0 + k < n) {
+        tile_start[i0 + k] = ea;
+        sub_start[i0 + k] = eb;
+      }
+      ea += c[k];
+      eb += (c[k] + max_sub - 1) / max_sub;
+    }
+    run_a += tot_a;
+    run_b += tot_b;
   }
   if (tid == 0) {
-    tile_start[n] = tot_a;
-    sub_start[n] = tot_b;
+    tile_start[n] = run_a;
+    sub_start[n] = run_b;
   }
 }
 
