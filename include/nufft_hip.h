@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define NUFFT_HIP_ABI_VERSION 1
+#define NUFFT_HIP_ABI_VERSION 2
 
 /* Status codes. They map onto the tensorflow::errors the reference returns. */
 enum {
@@ -60,7 +60,10 @@ enum { NUFFT_HIP_RANGE_STRICT = 0, NUFFT_HIP_RANGE_EXTENDED = 1, NUFFT_HIP_RANGE
 enum {
   NUFFT_HIP_METHOD_AUTO = 0,
   NUFFT_HIP_METHOD_TILE_GENERIC = 1, /* LDS tile, one thread per point (any w, rank, precision) */
-  NUFFT_HIP_METHOD_TILE_WAVE = 2     /* LDS tile, one point per wavefront pass (specialised widths) */
+  NUFFT_HIP_METHOD_TILE_WAVE = 2,    /* LDS tile, one point per wavefront pass (specialised widths) */
+  NUFFT_HIP_METHOD_POINT_GLOBAL = 3  /* no LDS tile: every point adds its stencil to the fine grid with
+                                        global atomics (the reference's nupts-driven method,
+                                        nufft_plan.cu.cc:2325-2436); AUTO picks it for sparse point sets */
 };
 enum { NUFFT_HIP_OP_NUFFT = 0, NUFFT_HIP_OP_INTERP = 1, NUFFT_HIP_OP_SPREAD = 2 };
 
@@ -87,6 +90,21 @@ typedef struct nufft_hip_options {
 
 typedef struct nufft_hip_plan_s* nufft_hip_plan;
 
+/* Device-memory allocator supplied by the host framework. The reference plan
+ * takes its fine grid and Fourier-series buffers from
+ * OpKernelContext::allocate_temp (nufft_plan.cu.cc:1981-1986) and the sort
+ * arrays from the TF device allocator (:2032-2052, :2927-2940); a TensorFlow
+ * binding routes `alloc` to allocate_temp and lets the tensors die with the
+ * Compute call (`free` may be a no-op). Both callbacks must be stream-safe in
+ * the host framework's sense: memory handed back by `free` is not reused before
+ * the work already enqueued on the plan's stream has finished.
+ * A NULL allocator (or NULL members) means hipMalloc / hipFree. */
+typedef struct nufft_hip_allocator {
+  void* (*alloc)(size_t bytes, void* user);   /* 256-byte aligned device memory, NULL on failure */
+  void (*free)(void* ptr, void* user);
+  void* user;
+} nufft_hip_allocator;
+
 typedef struct nufft_hip_plan_info {
   int32_t type, rank, precision, iflag, ntransf, batch_size;
   int32_t kernel_width, ncoef, spread_method;
@@ -110,6 +128,31 @@ int nufft_hip_plan_create(nufft_hip_plan* plan, int type, int rank,
                           const nufft_hip_options* opts, void* stream,
                           char* errbuf, size_t errbuf_len);
 
+/* The same with the plan's WORKSPACE (fine grid, sorted records, sort tables,
+ * FFT work buffer) taken from `allocator`. The small constant tables (kernel
+ * polynomial, Fourier-series reciprocals) and rocFFT's own twiddles stay
+ * internal. nufft_hip_plan_release_workspace hands every workspace buffer back
+ * (the plan forgets its points; the next set_points allocates again), so a
+ * cached plan can outlive the framework's per-call temporaries;
+ * nufft_hip_plan_set_allocator swaps the allocator of a plan that currently
+ * holds no workspace (e.g. the `user` pointer is a per-call context). */
+int nufft_hip_plan_create_ex(nufft_hip_plan* plan, int type, int rank,
+                             const int64_t* grid_dims, int iflag, int ntransf,
+                             double tol, int precision,
+                             const nufft_hip_options* opts, void* stream,
+                             const nufft_hip_allocator* allocator,
+                             char* errbuf, size_t errbuf_len);
+int nufft_hip_plan_release_workspace(nufft_hip_plan plan);
+int nufft_hip_plan_set_allocator(nufft_hip_plan plan, const nufft_hip_allocator* allocator);
+/* Host-only plan: every parameter rule, the kernel polynomial and the Fourier
+ * series, no device state (works without a GPU). Usable with get_info,
+ * debug_fseries, debug_eval_kernel and destroy only. */
+int nufft_hip_plan_create_host(nufft_hip_plan* plan, int type, int rank,
+                               const int64_t* grid_dims, int iflag, int ntransf,
+                               double tol, int precision,
+                               const nufft_hip_options* opts,
+                               char* errbuf, size_t errbuf_len);
+
 /* = Plan::set_points. x, y, z: device pointers (y, z ignored below rank 2, 3).
  * `stride` is the element stride between consecutive points (1 for separate
  * arrays; `rank` when x, y, z point into one [M, rank] array). */
@@ -119,6 +162,14 @@ int nufft_hip_set_points(nufft_hip_plan plan, int64_t num_points,
 
 /* = Plan::execute. Type 1: reads c, writes f. Type 2: reads f, writes c. */
 int nufft_hip_execute(nufft_hip_plan plan, void* c, void* f);
+/* set_points followed by execute, as ONE call: what a NUFFT op invocation does
+ * (nufft_kernels.cc:491-540). Knowing the strengths at sort time lets a type-1
+ * plan with one transform carry them inside the sorted records (no gather in
+ * the spread kernel). The points are consumed: a later nufft_hip_execute on the
+ * same plan needs a new nufft_hip_set_points. */
+int nufft_hip_execute_with_points(nufft_hip_plan plan, int64_t num_points,
+                                  const void* x, const void* y, const void* z,
+                                  int64_t stride, void* c, void* f);
 /* = Plan::spread / Plan::interp (plan created with opts.spread_only = 1):
  * f is the [ntransf][grid] array itself (no upsampling). */
 int nufft_hip_spread(nufft_hip_plan plan, const void* c, void* f);
@@ -150,10 +201,16 @@ int nufft_hip_plan_destroy(nufft_hip_plan plan);
  * next call on the plan): the fine grid of the last batch, and the kernel
  * Fourier-series reciprocals per dimension (host copy). */
 int nufft_hip_debug_fine_grid(nufft_hip_plan plan, void** fine, int64_t* count);
+/* Copies `count` complex elements of the fine grid to the device buffer dst (on the plan's stream). */
+int nufft_hip_debug_copy_fine_grid(nufft_hip_plan plan, void* dst, int64_t count);
 int nufft_hip_debug_fseries(nufft_hip_plan plan, int dim, double* out, int64_t n);
 /* Evaluates the plan's piecewise-polynomial kernel on the host for n offsets
  * x1 in [-w/2, -w/2+1] (out: n*w values, normalised so that phi(0) = 1). */
 int nufft_hip_debug_eval_kernel(nufft_hip_plan plan, int n, const double* x1, double* out);
+/* Makes execute return right after the given stage (index as in
+ * nufft_hip_plan_get_timing: 4 = spread, 5 = fft, 6 = deconvolve/amplify), so
+ * that tests can compare the fine grid stage by stage; -1 = run everything. */
+int nufft_hip_debug_stop_after(nufft_hip_plan plan, int stage);
 
 /* ---- Op-level entry: the host logic of NUFFTBaseOp::Compute/Execute --------
  * (nufft_kernels.cc:54-542): validation with the reference's error messages,
@@ -183,9 +240,20 @@ int nufft_hip_op_shape(const nufft_hip_op_desc* desc, int32_t* target_ndim,
 int nufft_hip_op_compute(const nufft_hip_op_desc* desc, const void* source,
                          const void* points, void* target, void* stream,
                          char* errbuf, size_t errbuf_len);
-/* Plans built by nufft_hip_op_compute are cached per configuration; this
- * releases them (and their device memory). */
+/* The same with the host framework's allocator: the plan workspace and the
+ * batch-permute temporaries come from it and are handed back before the call
+ * returns (cached plans keep only their constant tables and FFT plans). */
+int nufft_hip_op_compute_ex(const nufft_hip_op_desc* desc, const void* source,
+                            const void* points, void* target, void* stream,
+                            const nufft_hip_allocator* allocator,
+                            char* errbuf, size_t errbuf_len);
+/* Plans built by nufft_hip_op_compute are cached per configuration (least
+ * recently used first out, at most 16 plans and `max_bytes` of device memory:
+ * default 8 GiB, nufft_hip_op_set_cache_limit changes it); clear_cache
+ * releases them and their device memory. */
 void nufft_hip_op_clear_cache(void);
+void nufft_hip_op_set_cache_limit(int64_t max_bytes);
+int64_t nufft_hip_op_cache_bytes(void);
 
 #ifdef __cplusplus
 }

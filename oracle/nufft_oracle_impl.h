@@ -222,6 +222,38 @@ static void SUF(add_wrapped_subgrid)(const int64_t off[3],
   for (int d = 0; d < 3; ++d) free(o[d]);
 }
 
+/* The same with one atomic update per element, for concurrent callers.
+ * Reference: add_wrapped_subgrid_thread_safe nufft_plan.cc:1685-1734, chosen
+ * over the critical section when more than atomic_threshold = 10 threads
+ * spread (nufft_plan.cc:923, :1109-1114). */
+static void SUF(add_wrapped_subgrid_atomic)(const int64_t off[3],
+                                            const int64_t size[3],
+                                            const int64_t nf[3], FLT *fw,
+                                            const FLT *du) {
+  int64_t *o[3];
+  for (int d = 0; d < 3; ++d) {
+    o[d] = (int64_t *)malloc(sizeof(int64_t) * (size_t)size[d]);
+    for (int64_t i = 0; i < size[d]; ++i) {
+      int64_t x = (off[d] + i) % nf[d];
+      if (x < 0) x += nf[d];
+      o[d][i] = x;
+    }
+  }
+  for (int64_t dz = 0; dz < size[2]; ++dz)
+    for (int64_t dy = 0; dy < size[1]; ++dy) {
+      const int64_t ro = nf[0] * (o[1][dy] + nf[1] * o[2][dz]);
+      const FLT *s = du + 2 * size[0] * (dy + size[1] * dz);
+      for (int64_t dx = 0; dx < size[0]; ++dx) {
+        const int64_t j = ro + o[0][dx];
+#pragma omp atomic
+        fw[2 * j] += s[2 * dx];
+#pragma omp atomic
+        fw[2 * j + 1] += s[2 * dx + 1];
+      }
+    }
+  for (int d = 0; d < 3; ++d) free(o[d]);
+}
+
 /* Type-1 spreading of sorted points onto the (zeroed) fine grid.
  * Reference: spreadSorted nufft_plan.cc:1027-1132 (subproblem split :1053-1071,
  * gather by permutation :1085-1092, merge :1109-1114, spread-only scale
@@ -262,8 +294,12 @@ static void SUF(spread_sorted)(const int32_t *perm, const int64_t nf[3],
     SUF(get_subgrid)(off, size, M0, k0, kp->w, rank);
     FLT *du0 = (FLT *)malloc(sizeof(FLT) * 2 * (size_t)(size[0] * size[1] * size[2]));
     SUF(spread_subproblem)(off, size, du0, M0, k0, dd0, rank, kp);
+    if (nthreads > 10) { /* atomic_threshold, nufft_plan.cc:923, :1109-1114 */
+      SUF(add_wrapped_subgrid_atomic)(off, size, nf, fw, du0);
+    } else {
 #pragma omp critical(oracle_add_wrapped)
-    SUF(add_wrapped_subgrid)(off, size, nf, fw, du0);
+      SUF(add_wrapped_subgrid)(off, size, nf, fw, du0);
+    }
     free(du0);
     free(dd0);
     for (int d = 0; d < rank; ++d) free(k0[d]);

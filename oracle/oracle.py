@@ -202,6 +202,38 @@ def nudft(source, points, grid_shape=None, transform_type='type_2',
   return out
 
 
+def spread_stage(c, points, grid_shape, tol=1e-6, sigma=2.0, w=0, points_range='extended',
+                 kerevalmeth=0, nthreads=0):
+  """Fine grid after the type-1 spreading step (reference spreadSorted,
+  nufft_plan.cc:1027-1132, with the unnormalised kernel exp(beta sqrt(1 - c x^2))):
+  complex array of shape nf (grid order). c: [M] complex64/128, points: [M, rank]."""
+  c = np.ascontiguousarray(c)
+  cdt = c.dtype
+  rdt = np.float32 if cdt == np.complex64 else np.float64
+  suf = '_f32' if cdt == np.complex64 else '_f64'
+  M, rank = points.shape
+  pts = np.ascontiguousarray(np.asarray(points).T[::-1].astype(rdt))
+  o = _mk_opts('type_1', rank, grid_shape, 'forward', 1, tol, sigma, w, False, points_range,
+               kerevalmeth, nthreads)
+  info = OracleInfo()
+  rc = lib().oracle_query(ctypes.byref(o), 4 if cdt == np.complex64 else 8, ctypes.byref(info))
+  if rc:
+    raise ValueError(f'oracle_query failed with code {rc}')
+  nf = (ctypes.c_int64 * 3)(*[info.nf[d] for d in range(3)])
+  perm = np.zeros(max(M, 1), dtype=np.int32)
+  getattr(lib(), 'oracle_binsort' + suf)(
+      ctypes.c_int64(M), _ptr(pts[0]), _ptr(pts[1]) if rank > 1 else None,
+      _ptr(pts[2]) if rank > 2 else None, rank, nf, RANGE[points_range], _ptr(perm), int(nthreads))
+  shape = [int(info.nf[rank - 1 - d]) for d in range(rank)]
+  fw = np.zeros(shape, dtype=cdt)
+  rc = getattr(lib(), 'oracle_spread_stage' + suf)(
+      ctypes.byref(o), _ptr(perm), ctypes.c_int64(M), _ptr(pts[0]),
+      _ptr(pts[1]) if rank > 1 else None, _ptr(pts[2]) if rank > 2 else None, _ptr(c), _ptr(fw))
+  if rc:
+    raise ValueError(f'oracle_spread_stage failed with code {rc}')
+  return fw, info
+
+
 def fft(a, sign, nthreads=0):
   """In-place-semantics FFT of the oracle (returns a new array); a is complex, C order."""
   a = np.array(a, copy=True, order='C')

@@ -35,6 +35,9 @@ struct Geom {
   int fixed_point;  // 3-D float spread accumulates packed 32+32-bit fixed point in LDS
   int split_reim;   // 3-D float fp64-plane spread: real and imaginary parts in separate launches
   int cell_sorted;  // records of each subproblem are ordered by stencil start cell (set per set_points)
+  int sparse_auto;  // spread_method AUTO: launch_spread may pick the LDS-free kernel for sparse point sets
+  int fused;        // 2-D float records carry the strength instead of the point index (FusedRec)
+  float fx_headroom;  // fixed-point accumulation: bound on prod_d max|P(z)| of the fitted kernel (>= 1)
 };
 
 // Per-point record in tile-sorted order. float: 16 bytes, one dwordx4 access;
@@ -52,25 +55,35 @@ template <> struct alignas(16) Rec<double> {
   double z0, z1, z2;
 };
 
+// 2-D float record of a plan whose strengths are known at sort time (one type-1 transform,
+// nufft_hip_execute_with_points): same 16 bytes, the strength in place of z1 / idx and the
+// positions packed as 5-bit tile-local start | 27-bit fixed-point Horner argument.
+struct alignas(16) FusedRec {
+  uint32_t px, py;           // l << 27 | round((z + 1) 2^26)
+  float re, im;
+};
+constexpr float kFusedScale = 67108864.0f;            // 2^26
+constexpr float kFusedInv = 1.4901161193847656e-08f;  // 2^-26
+
 template <typename T>
 struct SortedPoints {
   const Rec<T>* rec;          // [M] tile-sorted
-  const int32_t* idx3;        // [M] original index (float, rank 3 only)
   const int32_t* tile_start;  // [ntiles + 1]
   const int32_t* sub_start;   // [ntiles + 1] exclusive scan of ceil(count / max_sub)
 };
 template <typename T>
 struct SortedOut {
   Rec<T>* rec;
-  int32_t* idx3;
 };
 
 struct PointsIn {
-  const void* pts[3];
+  const void* pts[3];   // x, y, z (unused dimensions alias x)
   int64_t stride;
   int64_t M;
   int range_mode;
   int check_range;
+  int aos;              // rank when pts[] are the columns of ONE [M, rank] array with x last (stride == rank), else 0
+  const void* strengths;   // [M] interleaved complex: fused sort only (records carry them), else null
 };
 
 struct SortWork {
@@ -110,6 +123,8 @@ bool sort_uses_lds(const Geom& g);
 template <typename T>
 hipError_t launch_sort(const Geom& g, const PointsIn& in, const SortWork& w, const SortedOut<T>& out,
                        hipStream_t stream, const StageHook& hook);
+// The fused sort (records carry the strengths) exists for this geometry / point count?
+bool fused_sort_supported(const Geom& g, int method, int precision, int64_t M);
 // Second sort level: reorders the records of every subproblem by stencil start cell,
 // `in` -> `out` (distinct buffers). cellsort_wanted: the plan's spread kernel exploits the
 // order (2-D, w = 8, float) and the point density makes it pay; the host applies it lazily
@@ -138,6 +153,8 @@ hipError_t launch_permute(const void* src, void* dst, int elem_bytes, int ndim,
 size_t spread_lds_bytes(const Geom& g, int method, int precision);
 size_t interp_lds_bytes(const Geom& g, int method, int precision);
 int wave_lstride(int rank);
+int wave3_pad(int w);   // spill elements behind the LDS planes of the 3-D wavefront kernel
+bool sparse_wanted(const Geom& g, int64_t M);   // point set sparse enough for the LDS-free spreader
 bool wave_method_supported(const Geom& g, int precision);
 
 }  // namespace nufft_hip

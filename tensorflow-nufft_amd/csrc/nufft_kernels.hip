@@ -28,6 +28,7 @@
 //   deconvolve_kernel, permute_kernel; launchers and the launch-shape / LDS-size rules at the end
 #include <algorithm>
 #include <mutex>
+#include <type_traits>
 #include <cstdio>
 #include <cstdlib>
 
@@ -239,10 +240,22 @@ __device__ __forceinline__ bool locate_subproblem(const Geom& g, const int32_t* 
 // Coordinates of point i. All three loads are unconditional (the host points unused
 // dimensions at the x array): loads under a branch are waited for one by one, which
 // defeats the batching in the count / scatter loops below.
-template <typename T>
+// AOS = 2 / 3: the coordinates are the columns of one [M, rank] array with x LAST (what the
+// op hands over, nufft_kernels.cc:282-286 reversed here by the pointer order): one 8- or
+// 12-byte load per point instead of two or three strided 4-byte ones.
+template <typename T, int AOS>
 __device__ __forceinline__ void load_coords(const PointsIn& in, int64_t i, T x[3]) {
+  if constexpr (AOS == 2) {
+    typedef T v2 __attribute__((ext_vector_type(2)));
+    const v2 v = reinterpret_cast<const v2*>(in.pts[1])[i];
+    x[0] = v.y; x[1] = v.x; x[2] = v.y;
+  } else if constexpr (AOS == 3) {
+    const T* b = reinterpret_cast<const T*>(in.pts[2]) + 3 * i;
+    x[2] = b[0]; x[1] = b[1]; x[0] = b[2];
+  } else {
 #pragma unroll
-  for (int d = 0; d < 3; ++d) x[d] = ((const T*)in.pts[d])[i * in.stride];
+    for (int d = 0; d < 3; ++d) x[d] = ((const T*)in.pts[d])[i * in.stride];
+  }
 }
 
 template <typename T>
@@ -307,7 +320,7 @@ template <typename T>
 __device__ __forceinline__ int fold_point(const Geom& g, const PointsIn& in, int64_t i, Rec<T>* r,
                                           bool* bad) {
   T x[3];
-  load_coords<T>(in, i, x);
+  load_coords<T, 0>(in, i, x);
   return fold_coords<T>(g, in, x, r, bad);
 }
 
@@ -354,9 +367,59 @@ __device__ __forceinline__ void store_record<double>(const SortedOut<double>& ou
 // histograms. No global atomics, deterministic tile order. Three passes over
 // the raw points (hist, scatter) + two tiny scans.
 constexpr int kSortBlock = 1024;
-constexpr int kSortBatch = 4;    // points in flight per thread in the count / scatter loops
+constexpr int kSortBatch = 4;    // load slots in flight per thread in the count / scatter loops
 
-template <typename T>
+// Walks the points [lo, hi) of a workgroup, kSortBatch load slots per thread per pass, the
+// loads of a pass issued back to back on clamped indices (with one load in flight per
+// thread the kernels ran at the latency bound: 32 waves x 512 B per CU / ~2 us = 1.7 TB/s;
+// a load under a divergent branch is waited for before the next one is issued).
+// PAIR (float, [M, 2] interleaved points): a slot is ONE 16-byte load = two consecutive
+// points (lo is even; an odd last point is handled by thread 0 after the loop), which
+// halves the load instructions again. body(i, x[3], slot) is called for valid points only;
+// pre(slot, i_clamped, valid) runs in the load phase for callers with a second array.
+template <typename T, int AOS>
+struct PointWalk {
+  static constexpr bool PAIR = (AOS == 2 && sizeof(T) == 4);
+  static constexpr int PP = PAIR ? 2 : 1;
+  template <typename Pre, typename Body>
+  static __device__ __forceinline__ void run(const PointsIn& in, int64_t lo, int64_t hi, Pre pre, Body body) {
+    const int64_t hi_main = PAIR ? (hi & ~(int64_t)1) : hi;
+    for (int64_t i0 = lo + PP * (int64_t)threadIdx.x; i0 < hi_main; i0 += (int64_t)PP * kSortBatch * kSortBlock) {
+      T x[kSortBatch * PP][3];
+#pragma unroll
+      for (int u = 0; u < kSortBatch; ++u) {
+        const int64_t i = i0 + (int64_t)u * PP * kSortBlock;
+        const int64_t ic = i < hi_main ? i : hi_main - PP;
+        if constexpr (PAIR) {
+          const float4 v = reinterpret_cast<const float4*>(in.pts[1])[ic >> 1];
+          x[2 * u][0] = v.y; x[2 * u][1] = v.x; x[2 * u][2] = v.y;
+          x[2 * u + 1][0] = v.w; x[2 * u + 1][1] = v.z; x[2 * u + 1][2] = v.w;
+        } else {
+          load_coords<T, AOS>(in, ic, x[u]);
+        }
+        pre(u, ic, i < hi_main);
+      }
+#pragma unroll
+      for (int u = 0; u < kSortBatch; ++u) {
+        const int64_t i = i0 + (int64_t)u * PP * kSortBlock;
+        if (i < hi_main) {
+#pragma unroll
+          for (int k = 0; k < PP; ++k) body(i + k, x[PP * u + k], PP * u + k);
+        }
+      }
+    }
+    if constexpr (PAIR) {
+      if ((hi & 1) && threadIdx.x == 0) {   // odd tail point (last workgroup only)
+        T x[3];
+        load_coords<T, AOS>(in, hi - 1, x);
+        pre(0, hi - 1, true);
+        body(hi - 1, x, -1);
+      }
+    }
+  }
+};
+
+template <typename T, int AOS>
 __global__ __launch_bounds__(kSortBlock) void hist_lds_kernel(Geom g, PointsIn in, int64_t per_block,
                                                               int32_t* __restrict__ hist,
                                                               int32_t* __restrict__ bad_count) {
@@ -368,23 +431,13 @@ __global__ __launch_bounds__(kSortBlock) void hist_lds_kernel(Geom g, PointsIn i
   const int64_t lo = (int64_t)blockIdx.x * per_block;
   const int64_t hi = (lo + per_block < in.M) ? lo + per_block : in.M;
   bool bad = false;
-  // kSortBatch points per thread per pass, their loads issued back to back on clamped
-  // indices: with one load in flight per thread the kernel ran at the latency bound
-  // (32 waves x 512 B per CU / ~2 us = 1.7 TB/s)
-  for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += kSortBatch * kSortBlock) {
-    T x[kSortBatch][3];
-#pragma unroll
-    for (int u = 0; u < kSortBatch; ++u) {
-      const int64_t i = i0 + u * kSortBlock;
-      load_coords<T>(in, i < hi ? i : hi - 1, x[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < kSortBatch; ++u) {
-      Rec<T> r;
-      const int tile = fold_coords<T>(g, in, x[u], &r, &bad);
-      if (i0 + u * kSortBlock < hi) atomicAdd(&h[tile], 1);
-    }
-  }
+  PointWalk<T, AOS>::run(
+      in, lo, hi, [](int, int64_t, bool) {},
+      [&](int64_t, const T* x, int) {
+        Rec<T> r;
+        const int tile = fold_coords<T>(g, in, x, &r, &bad);
+        atomicAdd(&h[tile], 1);
+      });
   if (bad && in.check_range) atomicAdd(bad_count, 1);
   __syncthreads();
   int32_t* out = hist + (int64_t)blockIdx.x * nt;
@@ -430,7 +483,20 @@ __global__ __launch_bounds__(1024) void colscan_kernel(int nt, int nblk, int32_t
   }
 }
 
-template <typename T>
+// FUSED (float, rank 2): the records carry the strengths (FusedRec) instead of the point
+// index; in.strengths is read alongside the points, one 16-byte load per point pair.
+__device__ __forceinline__ uint32_t fused_pack(uint32_t l, float z) {
+  float q = (z + 1.0f) * kFusedScale;
+  q = fminf(fmaxf(q, 0.0f), 134217727.0f);   // 2^27 - 1
+  uint32_t w = (uint32_t)__float2uint_rn(q);
+  if (w > 134217727u) w = 134217727u;
+  return (l << 27) | w;
+}
+// signed conversion: the 24-bit rounding of the int -> float conversion then acts on |z| (as in a native float z)
+__device__ __forceinline__ float fused_z(uint32_t p) { return (float)((int)(p & 0x7ffffffu) - (1 << 26)) * kFusedInv; }
+__device__ __forceinline__ uint32_t fused_loc(uint32_t px, uint32_t py) { return (px >> 27) | ((py >> 27) << 10); }
+
+template <typename T, int AOS, bool FUSED>
 __global__ __launch_bounds__(kSortBlock) void scatter_lds_kernel(Geom g, PointsIn in, int64_t per_block,
                                                                  const int32_t* __restrict__ hist,
                                                                  const int32_t* __restrict__ tile_start,
@@ -444,23 +510,47 @@ __global__ __launch_bounds__(kSortBlock) void scatter_lds_kernel(Geom g, PointsI
   const int64_t lo = (int64_t)blockIdx.x * per_block;
   const int64_t hi = (lo + per_block < in.M) ? lo + per_block : in.M;
   bool bad = false;
-  for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += kSortBatch * kSortBlock) {
-    T x[kSortBatch][3];
-#pragma unroll
-    for (int u = 0; u < kSortBatch; ++u) {
-      const int64_t i = i0 + u * kSortBlock;
-      load_coords<T>(in, i < hi ? i : hi - 1, x[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < kSortBatch; ++u) {
-      const int64_t i = i0 + u * kSortBlock;
-      Rec<T> r;
-      const int tile = fold_coords<T>(g, in, x[u], &r, &bad);
-      if (i < hi) {
-        const int pos = atomicAdd(&cur[tile], 1);
-        store_record<T>(out, g.rank, pos, r, (int32_t)i);
-      }
-    }
+  using Walk = PointWalk<T, AOS>;
+  if constexpr (FUSED) {
+    static_assert(sizeof(T) == 4, "fused records are float only");
+    float2 cs[kSortBatch * Walk::PP];
+    float2 ctail = make_float2(0.f, 0.f);
+    Walk::run(
+        in, lo, hi,
+        [&](int u, int64_t ic, bool) {
+          if constexpr (Walk::PAIR) {
+            if ((ic & 1) == 0) {
+              const float4 v = reinterpret_cast<const float4*>(in.strengths)[ic >> 1];
+              cs[2 * u] = make_float2(v.x, v.y);
+              cs[2 * u + 1] = make_float2(v.z, v.w);
+            } else {   // the odd tail point
+              ctail = reinterpret_cast<const float2*>(in.strengths)[ic];
+            }
+          } else {
+            cs[u] = reinterpret_cast<const float2*>(in.strengths)[ic];
+          }
+        },
+        [&](int64_t, const T* x, int slot) {
+          Rec<T> r;
+          const int tile = fold_coords<T>(g, in, x, &r, &bad);
+          const float2 cv = slot >= 0 ? cs[slot] : ctail;
+          const int pos = atomicAdd(&cur[tile], 1);
+          FusedRec fr;
+          fr.px = fused_pack(r.loc & 1023u, r.z0);
+          fr.py = fused_pack((r.loc >> 10) & 1023u, r.z1);
+          fr.re = cv.x;
+          fr.im = cv.y;
+          reinterpret_cast<FusedRec*>(out.rec)[pos] = fr;   // one 16-byte store
+        });
+  } else {
+    Walk::run(
+        in, lo, hi, [](int, int64_t, bool) {},
+        [&](int64_t i, const T* x, int) {
+          Rec<T> r;
+          const int tile = fold_coords<T>(g, in, x, &r, &bad);
+          const int pos = atomicAdd(&cur[tile], 1);
+          store_record<T>(out, g.rank, pos, r, (int32_t)i);
+        });
   }
 }
 
@@ -496,7 +586,7 @@ __global__ __launch_bounds__(kSortBlock) void hist16_lds_kernel(Geom g, PointsIn
 #pragma unroll
     for (int u = 0; u < kSortBatch; ++u) {
       const int64_t i = i0 + u * kSortBlock;
-      load_coords<T>(in, i < hi ? i : hi - 1, x[u]);
+      load_coords<T, 0>(in, i < hi ? i : hi - 1, x[u]);
     }
 #pragma unroll
     for (int u = 0; u < kSortBatch; ++u) {
@@ -759,6 +849,63 @@ __global__ __launch_bounds__(kBlock) void spread_tile_generic_kernel(
       const int64_t gi = g0 + (int64_t)g.nf[0] * (g1 + (int64_t)g.nf[1] * g2);
       glb_add(&out[2 * gi], vre);
       glb_add(&out[2 * gi + 1], vim);
+    }
+  }
+}
+
+// ------------------------------------------- spread: sparse point sets, no LDS tile
+
+// The LDS-tile kernels zero-fill and write out a whole tile (25-52 KB of LDS, tile + halo
+// cells of global atomics) for every non-empty tile; below a few points per tile that
+// overhead is all there is. Here every point adds its stencil straight to the fine grid
+// (the reference's nupts-driven method, SpreadNuptsDriven*, nufft_plan.cu.cc:474-527,
+// 707-787, 1190-1292, launched by spread_batch_nupts_driven :2325-2436), but shaped for
+// the memory-side atomic units of gfx950: a stencil ROW is handled by 2 w consecutive lanes
+// carrying (re, im) of consecutive cells, i.e. one contiguous 8 w-byte segment per row (the
+// reference gives a thread a whole point and walks its w^d cells one 4-byte atomic at a
+// time). One workgroup per subproblem of the tile-sorted records, as everywhere else, so
+// empty tiles cost one early exit; the four waves take the subproblem's points in turn.
+template <typename T, int RANK>
+__global__ __launch_bounds__(kBlock) void spread_sparse_kernel(
+    Geom g, SortedPoints<T> sp, const T* __restrict__ horner, const T* __restrict__ c,
+    T* __restrict__ fw, int64_t c_stride, int64_t fw_stride, T scale) {
+  int tb, p0, p1;
+  if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1)) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int w = g.w, nc = g.ncoef;
+  // lanes per stencil row: 2 w rounded up to a power of two (4 .. 32)
+  const int seg = w <= 2 ? 4 : w <= 4 ? 8 : w <= 8 ? 16 : 32;
+  const int rsub = lane / seg, e = lane - rsub * seg;
+  const int rows_per_pass = 64 / seg;
+  const int dx = e >> 1, comp = e & 1;
+  const bool lane_on = e < 2 * w;
+  const int nrows = RANK == 1 ? 1 : RANK == 2 ? w : w * w;
+  const int t0 = tb % g.ntile[0];
+  const int t1 = (tb / g.ntile[0]) % g.ntile[1];
+  const int t2 = tb / (g.ntile[0] * g.ntile[1]);
+  const int o0 = t0 * g.tile[0], o1 = t1 * g.tile[1], o2 = t2 * g.tile[2];
+  const T* cc = c + 2 * (int64_t)blockIdx.y * c_stride;
+  T* out = fw + 2 * (int64_t)blockIdx.y * fw_stride;
+  for (int j = p0 + wave; j < p1; j += kBlock / 64) {
+    const PointView<T> rec = unpack_rec<T, RANK>(sp.rec[j]);   // wave-uniform address: one broadcast load
+    const T cv = cc[2 * (int64_t)rec.idx + comp] * scale;
+    const T kx = lane_on ? horner_cell(horner, nc, dx < w ? dx : 0, rec.z0) : (T)0;
+    const int gx = wrap1(o0 + (int)(rec.loc & 1023) + dx, g.nf[0]);
+    const int b1 = o1 + (int)((rec.loc >> 10) & 1023);
+    const int b2 = o2 + (int)((rec.loc >> 20) & 1023);
+    const T vx = cv * kx;
+    for (int r0 = 0; r0 < nrows; r0 += rows_per_pass) {
+      const int r = r0 + rsub;
+      const bool on = lane_on && r < nrows;
+      const int rc = r < nrows ? r : 0;
+      const int dz = RANK > 2 ? rc / w : 0;
+      const int dy = RANK > 2 ? rc - dz * w : rc;
+      T v = vx;
+      if (RANK > 1) v *= horner_cell(horner, nc, dy, rec.z1);
+      if (RANK > 2) v *= horner_cell(horner, nc, dz, rec.z2);
+      const int g1 = RANK > 1 ? wrap1(b1 + dy, g.nf[1]) : 0;
+      const int g2 = RANK > 2 ? wrap1(b2 + dz, g.nf[2]) : 0;
+      if (on) glb_add(&out[2 * (gx + (int64_t)g.nf[0] * (g1 + (int64_t)g.nf[1] * g2)) + comp], v);
     }
   }
 }
@@ -1028,12 +1175,15 @@ constexpr int kGroupStage = 32; // points whose kernel values are in LDS at a ti
 template <typename T> constexpr int kGroupStageOf = sizeof(T) == 8 ? 16 : kGroupStage;   // double: half, same bytes
 constexpr int kGroupBlk = 36;   // staging words per block of 4 points (8 x 4 + 4 pad)
 template <int CH> constexpr int kGroupStageWave = 3 * (CH / 4) * kGroupBlk;   // words per wave (kx, ky re, ky im)
-template <typename T, int W, int NW, int CH, bool PRE>
+// FUSED: the records are FusedRec (strength inside, no index): no gather at all.
+template <typename T, int W, int NW, int CH, bool PRE, bool FUSED = false>
 __global__ __launch_bounds__(NW * 64) void spread_2d_w8_group_kernel(
     Geom g, SortedPoints<T> sp, const T* __restrict__ horner, const T* __restrict__ c,
     T* __restrict__ fw, int64_t c_stride, int64_t fw_stride, T scale) {
   typedef T v2 __attribute__((ext_vector_type(2)));
   typedef T v4 __attribute__((ext_vector_type(4)));
+  using RecT = std::conditional_t<FUSED, FusedRec, Rec<T>>;
+  const RecT* __restrict__ recs = reinterpret_cast<const RecT*>(sp.rec);
   constexpr int NT = NW * 64;
   constexpr int IT = (kGroupMaxSub + NT - 1) / NT;   // records per thread in the LDS sort
   constexpr int SC = CH < kGroupStageOf<T> ? CH : kGroupStageOf<T>;   // points staged through LDS at a time
@@ -1065,7 +1215,14 @@ __global__ __launch_bounds__(NW * 64) void spread_2d_w8_group_kernel(
     for (int u = 0; u < IT; ++u) {
       const int i = tid + u * NT;
       kr[u] = 0u;
-      if (u * NT < n) kr[u] = sp.rec[p0 + (i < n ? i : n - 1)].loc;
+      if (u * NT < n) {
+        if constexpr (FUSED) {
+          const uint2 pp = *reinterpret_cast<const uint2*>(&recs[p0 + (i < n ? i : n - 1)]);
+          kr[u] = fused_loc(pp.x, pp.y);
+        } else {
+          kr[u] = recs[p0 + (i < n ? i : n - 1)].loc;
+        }
+      }
     }
 #pragma unroll
     for (int u = 0; u < IT; ++u) {
@@ -1101,19 +1258,31 @@ __global__ __launch_bounds__(NW * 64) void spread_2d_w8_group_kernel(
   auto load_rec = [&](int b) {   // lanes past the end re-read the last point; masked below
     const int li = b + lane;
     const int lc = li < n ? li : n - 1;
-    if constexpr (PRE) return sp.rec[p0 + lc];
-    else return sp.rec[p0 + perm[lc]];
+    if constexpr (PRE) return recs[p0 + lc];
+    else return recs[p0 + perm[lc]];
   };
-  auto load_c = [&](const Rec<T>& r) { return c2[r.idx]; };
+  auto load_c = [&](const RecT& r) {
+    if constexpr (FUSED) { v2 v = {(T)r.re, (T)r.im}; return v; }
+    else return c2[r.idx];
+  };
   constexpr int STEP = NW * CH;
-  Rec<T> r_cur = load_rec(wave * CH);
-  Rec<T> r_nxt = load_rec(wave * CH + STEP);
+  RecT r_cur = load_rec(wave * CH);
+  RecT r_nxt = load_rec(wave * CH + STEP);
   v2 c_cur = load_c(r_cur);
   for (int base = wave * CH; base < n; base += STEP) {
     const v2 c_nxt = load_c(r_nxt);
-    const Rec<T> r_nn = load_rec(base + 2 * STEP);
-    const uint32_t loc = r_cur.loc;
-    const T zx = r_cur.z0, zy = r_cur.z1;
+    const RecT r_nn = load_rec(base + 2 * STEP);
+    uint32_t loc;
+    T zx, zy;
+    if constexpr (FUSED) {
+      loc = fused_loc(r_cur.px, r_cur.py);
+      zx = (T)fused_z(r_cur.px);
+      zy = (T)fused_z(r_cur.py);
+    } else {
+      loc = r_cur.loc;
+      zx = r_cur.z0;
+      zy = r_cur.z1;
+    }
     const bool valid = lane < CH && base + lane < n;
     const T re = valid ? c_cur.x * scale : (T)0, im = valid ? c_cur.y * scale : (T)0;
     const uint32_t key = valid ? (loc & 0xfffffu) : 0xffffffffu;
@@ -1331,6 +1500,7 @@ __global__ __launch_bounds__(NW * 64) void spread_wave2_kernel(
 // case 2^-32 n w^1.5 ||c_sub|| (n <= 4096: 1.4e-5), typically ~1e-6 relative.
 // COMP (fp64 planes only): 0 = both components in one launch (two planes); 1 / 2 = only
 // the real / imaginary part (ONE plane, so two workgroups fit a CU; the host launches both).
+template <int W> constexpr int kWave3Pad = (551 - 24 * (15 + W) + 1) > 64 ? ((551 - 24 * (15 + W) + 1 + 7) & ~7) : 64;
 template <typename T, int W, int TZ, int NW, int CH, bool FX, int COMP = 0>
 __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
     Geom g, SortedPoints<T> sp, const T* __restrict__ horner, const T* __restrict__ c,
@@ -1343,8 +1513,12 @@ __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
   double* plane_re = reinterpret_cast<double*>(smem_raw);             // FX: the packed plane
   constexpr int NPL = (FX || COMP != 0) ? 1 : 2;
   double* plane_im = plane_re + (NPL == 1 ? 0 : plane);
-  double* pad = plane_re + NPL * plane;                               // 64 elements of spill room
-  T* stage_all = reinterpret_cast<T*>(pad + 64);
+  // spill room behind the planes: lanes outside the W x W patch add 0 at their natural 8 x 8
+  // patch address, up to row 15 + 7 and column 15 + 7 of the last z-plane, i.e. up to
+  // 22 * 24 + 22 - 24 * L1 elements past the end (47 at W = 6, 143 at W = 2)
+  constexpr int PAD = kWave3Pad<W>;
+  double* pad = plane_re + NPL * plane;
+  T* stage_all = reinterpret_cast<T*>(pad + PAD);
   constexpr int SW = W <= 6 ? 6 : 8;                                  // staging row length
   float* red = reinterpret_cast<float*>(stage_all + NW * CH * 2 * SW);   // [NW] (FX bound reduction)
   int tb, p0, p1;
@@ -1352,7 +1526,7 @@ __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  for (int i = tid; i < NPL * plane + 64; i += NW * 64) plane_re[i] = 0.0;
+  for (int i = tid; i < NPL * plane + PAD; i += NW * 64) plane_re[i] = 0.0;
   const T2* cc = reinterpret_cast<const T2*>(c) + (int64_t)blockIdx.y * c_stride;
   const int npt = p1 - p0;
 
@@ -1371,7 +1545,9 @@ __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
     float bound = 0.f;
 #pragma unroll
     for (int k = 0; k < NW; ++k) bound += red[k];
-    bound *= fabsf((float)scale);
+    // every cell sum is bounded by sum_j |c_j| prod_d max|P_d|; the fitted polynomials overshoot 1
+    // slightly (w = 4: 1.00001 per dimension), which g.fx_headroom (>= 1, from the host fit) covers
+    bound *= fabsf((float)scale) * g.fx_headroom;
     const float room = 2147483000.f - (float)npt;   // 2^31 minus the rounding of every contribution
     pre = bound > 0.f ? (T)((float)scale * (room / bound)) : (T)0;
     lsb = bound > 0.f ? (T)(bound / room) : (T)0;
@@ -1726,8 +1902,8 @@ __global__ __launch_bounds__(kBlock) void interp_tile_generic_kernel(
 //   mode or zero -- the zero-fill of the whole fine batch the reference does
 //   with a separate memset (nufft_plan.cu.cc:2855-2858) is fused in.
 // rf* hold RECIPROCALS of the Fourier series (computed in double on the host).
-template <typename T>
-__global__ __launch_bounds__(256) void deconvolve_kernel(Geom g, int dir, T* __restrict__ f,
+template <typename T, bool FLAT>
+__global__ __launch_bounds__(256) void deconvolve_kernel(Geom g, int dir, int nbatch, T* __restrict__ f,
                                                          T* __restrict__ fw, const T* __restrict__ rf0,
                                                          const T* __restrict__ rf1,
                                                          const T* __restrict__ rf2) {
@@ -1736,10 +1912,21 @@ __global__ __launch_bounds__(256) void deconvolve_kernel(Geom g, int dir, T* __r
   const int N0 = g.nmodes[0], N1 = g.nmodes[1], N2 = g.nmodes[2];
   const int nf0 = g.nf[0], nf1 = g.nf[1], nf2 = g.nf[2];
   const int64_t ntot = (int64_t)N0 * N1 * N2, nftot = (int64_t)nf0 * nf1 * nf2;
+  const int d1 = dir == 1 ? N1 : nf1;
   const int d2 = dir == 1 ? N2 : nf2;
-  const int b = blockIdx.z / d2;
-  const int i2 = blockIdx.z - b * d2;
-  const int i1 = blockIdx.y;
+  int b, i2, i1;
+  if (FLAT) {   // grids beyond the 65535 limit of gridDim.y / .z: rows (i1, i2, b) flattened along y
+    const int64_t row = (int64_t)blockIdx.y + (int64_t)gridDim.y * blockIdx.z;
+    if (row >= (int64_t)d1 * d2 * nbatch) return;
+    const int64_t q = row / d1;
+    i1 = (int)(row - q * d1);
+    b = (int)(q / d2);
+    i2 = (int)(q - (int64_t)b * d2);
+  } else {
+    b = blockIdx.z / d2;
+    i2 = blockIdx.z - b * d2;
+    i1 = blockIdx.y;
+  }
   const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
   T2_t<T>* fb = reinterpret_cast<T2_t<T>*>(f) + (int64_t)b * ntot;
   T2_t<T>* fwb = reinterpret_cast<T2_t<T>*>(fw) + (int64_t)b * nftot;
@@ -1852,6 +2039,7 @@ int sort_blocks(const Geom& g, int64_t M, int64_t* per_block) {
   }();
   int64_t pb = (M + maxblk - 1) / maxblk;
   if (pb < 4096) pb = 4096;
+  pb += pb & 1;   // even: the paired 16-byte loads of interleaved 2-D float points start on a pair
   *per_block = pb;
   (void)g;
   return (int)((M + pb - 1) / pb);
@@ -1878,6 +2066,27 @@ int sort_blocks16(int64_t M, int64_t* per_block) {
   return (int)((M + pb - 1) / pb);
 }
 
+template <typename T, int AOS, bool FUSED>
+static hipError_t sort_lds_pass(const Geom& g, const PointsIn& in, const SortWork& w, const SortedOut<T>& out,
+                                hipStream_t stream, const StageHook& hook, int nblk, int64_t per_block,
+                                size_t lds) {
+  hipError_t e = ensure_lds(hist_lds_kernel<T, AOS>, lds);
+  if (e != hipSuccess) return e;
+  e = ensure_lds(scatter_lds_kernel<T, AOS, FUSED>, lds);
+  if (e != hipSuccess) return e;
+  hook.begin(STAGE_SORT_COUNT);
+  hist_lds_kernel<T, AOS><<<nblk, kSortBlock, lds, stream>>>(g, in, per_block, w.hist, w.bad_count);
+  hook.end(STAGE_SORT_COUNT);
+  hook.begin(STAGE_SORT_SCAN);
+  colscan_kernel<<<(g.ntiles + kScanCols - 1) / kScanCols, 1024, 0, stream>>>(g.ntiles, nblk, w.hist, w.tile_count);
+  scan_tiles_kernel<<<1, 1024, 0, stream>>>(w.tile_count, g.ntiles, g.max_sub, w.tile_start, w.sub_start);
+  hook.end(STAGE_SORT_SCAN);
+  hook.begin(STAGE_SORT_SCATTER);
+  scatter_lds_kernel<T, AOS, FUSED><<<nblk, kSortBlock, lds, stream>>>(g, in, per_block, w.hist, w.tile_start, out);
+  hook.end(STAGE_SORT_SCATTER);
+  return hipGetLastError();
+}
+
 template <typename T>
 hipError_t launch_sort(const Geom& g, const PointsIn& in, const SortWork& w, const SortedOut<T>& out,
                        hipStream_t stream, const StageHook& hook) {
@@ -1889,25 +2098,22 @@ hipError_t launch_sort(const Geom& g, const PointsIn& in, const SortWork& w, con
     return hipGetLastError();
   }
   const int mode = sort_mode(g, in.M);
+  if (in.strengths && (mode != 0 || sizeof(T) != 4 || g.rank != 2)) return hipErrorInvalidValue;   // see fused_sort_supported
   if (mode == 0) {
     int64_t per_block;
     const int nblk = sort_blocks(g, in.M, &per_block);
     const size_t lds = sizeof(int) * (size_t)g.ntiles;
-    e = ensure_lds(hist_lds_kernel<T>, lds);
-    if (e != hipSuccess) return e;
-    e = ensure_lds(scatter_lds_kernel<T>, lds);
-    if (e != hipSuccess) return e;
-    hook.begin(STAGE_SORT_COUNT);
-    hist_lds_kernel<T><<<nblk, kSortBlock, lds, stream>>>(g, in, per_block, w.hist, w.bad_count);
-    hook.end(STAGE_SORT_COUNT);
-    hook.begin(STAGE_SORT_SCAN);
-    colscan_kernel<<<(g.ntiles + kScanCols - 1) / kScanCols, 1024, 0, stream>>>(g.ntiles, nblk, w.hist, w.tile_count);
-    scan_tiles_kernel<<<1, 1024, 0, stream>>>(w.tile_count, g.ntiles, g.max_sub, w.tile_start, w.sub_start);
-    hook.end(STAGE_SORT_SCAN);
-    hook.begin(STAGE_SORT_SCATTER);
-    scatter_lds_kernel<T><<<nblk, kSortBlock, lds, stream>>>(g, in, per_block, w.hist, w.tile_start, out);
-    hook.end(STAGE_SORT_SCATTER);
-    return hipGetLastError();
+    hipError_t (*run)(const Geom&, const PointsIn&, const SortWork&, const SortedOut<T>&, hipStream_t,
+                      const StageHook&, int, int64_t, size_t) = nullptr;
+    // interleaved [M, rank] points (what the op hands over): vector loads
+    const int aos = (in.aos == g.rank && (g.rank == 2 || g.rank == 3)) ? g.rank : 0;
+    if (in.strengths) {
+      if constexpr (sizeof(T) == 4) run = aos == 2 ? sort_lds_pass<T, 2, true> : sort_lds_pass<T, 0, true>;
+    } else {
+      run = aos == 2 ? sort_lds_pass<T, 2, false> : aos == 3 ? sort_lds_pass<T, 3, false> : sort_lds_pass<T, 0, false>;
+    }
+    if (!run) return hipErrorInvalidValue;
+    return run(g, in, w, out, stream, hook, nblk, per_block, lds);
   }
   if (mode == 1) {
     int64_t per_block;
@@ -2020,6 +2226,10 @@ bool wave_method_supported(const Geom& g, int precision) {
   return false;
 }
 int wave_lstride(int rank) { return rank == 2 ? 40 : 24; }
+int wave3_pad(int w) {   // = kWave3Pad<w>
+  const int over = 551 - 24 * (15 + w) + 1;
+  return over > 64 ? ((over + 7) & ~7) : 64;
+}
 
 // Waves per workgroup of the 3-D kernel. LDS decides how many workgroups share a CU and
 // 69 VGPRs allow 7 waves per SIMD: the float fixed-point form (one 52 KB plane) runs two
@@ -2033,6 +2243,25 @@ static int wave3d_nw_rt(int precision, bool fx) { return precision == NUFFT_HIP_
 // sum_b ceil(n_b / S) <= ntiles + M / S.
 static inline unsigned subproblem_grid(const Geom& g, int64_t M) {
   return (unsigned)((int64_t)g.ntiles + M / g.max_sub);
+}
+
+// LDS-free spreader for sparse point sets: below ~kSparseDensity points per fine cell the
+// per-tile zero-fill and write-out of the LDS kernels outweigh the per-point global atomics
+// (crossover measured r02, profiles/r02_sparse_crossover.txt). NUFFT_HIP_SPARSE = 0 / 1 forces it.
+constexpr double kSparseDensity = 0.01;
+bool sparse_wanted(const Geom& g, int64_t M) {
+  static const int mode = [] { const char* e = getenv("NUFFT_HIP_SPARSE"); return e ? atoi(e) : -1; }();
+  if (mode >= 0) return mode != 0;
+  return (double)M < kSparseDensity * (double)g.nf[0] * (double)g.nf[1] * (double)g.nf[2];
+}
+
+// Records that carry the strengths (FusedRec): 2-D float, the cell-grouped kernel's geometry,
+// LDS-histogram sort, and a point set dense enough for the grouped kernel to be the choice.
+bool fused_sort_supported(const Geom& g, int method, int precision, int64_t M) {
+  static const bool off = getenv("NUFFT_HIP_NO_FUSED") != nullptr;   // A/B knob
+  if (off || method != NUFFT_HIP_METHOD_TILE_WAVE || !wave8_supported(g, precision)) return false;
+  if (M <= 0 || sort_mode(g, M) != 0 || g.max_sub > kGroupMaxSub) return false;
+  return wave8_use_group(g, M) && !(g.sparse_auto && sparse_wanted(g, M));
 }
 
 // NUFFT_HIP_CELLSORT = 0 never, 1 whenever the geometry allows; unset: by point density.
@@ -2083,7 +2312,7 @@ size_t spread_lds_bytes(const Geom& g, int method, int precision) {
     if (g.rank == 2)
       return group2d_geometry(g) ? std::max(wave2_lds(g, precision), group_lds(8, 64, false, precision)) : wave2_lds(g, precision);
     const int nw = g.split_reim ? 12 : wave3d_nw_rt(precision, g.fixed_point != 0);
-    return cells * ((g.fixed_point || g.split_reim) ? 1 : 2) * sizeof(double) + 64 * sizeof(double) +
+    return cells * ((g.fixed_point || g.split_reim) ? 1 : 2) * sizeof(double) + (size_t)wave3_pad(g.w) * sizeof(double) +
            (size_t)precision * nw * 32 * 2 * (g.w <= 6 ? 6 : 8) + 256;
   }
   return cells * 2 * sizeof(double);
@@ -2104,16 +2333,29 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
   if (M == 0) return hipSuccess;
   dim3 grid(subproblem_grid(g, M), (unsigned)batch);
   hipError_t e = hipSuccess;
+  if (method == NUFFT_HIP_METHOD_POINT_GLOBAL || (g.sparse_auto && !g.fused && sparse_wanted(g, M))) {
+    switch (g.rank) {
+      case 1: spread_sparse_kernel<T, 1><<<grid, kBlock, 0, stream>>>(g, sp, horner, c, fw, c_stride, fw_stride, scale); break;
+      case 2: spread_sparse_kernel<T, 2><<<grid, kBlock, 0, stream>>>(g, sp, horner, c, fw, c_stride, fw_stride, scale); break;
+      default: spread_sparse_kernel<T, 3><<<grid, kBlock, 0, stream>>>(g, sp, horner, c, fw, c_stride, fw_stride, scale); break;
+    }
+    return hipGetLastError();
+  }
   if (method == NUFFT_HIP_METHOD_TILE_WAVE) {
     if constexpr (sizeof(T) == 4) {
       if (wave8_supported(g, 4)) {
-        const bool grouped = g.cell_sorted || wave8_use_group(g, M);
+        const bool grouped = g.cell_sorted || g.fused || wave8_use_group(g, M);
         const int shape = wave8_nw(grouped) * 100 + wave8_ch(grouped);
         lds_bytes = wave8_lds(grouped, g.cell_sorted);   // the plan's figure is the maximum over the variants
         if (grouped) {
 #define NUFFT_LAUNCH_W8G(WV, NWV, CHV)                                                         \
   case NWV * 100 + CHV:                                                                        \
-    if (g.cell_sorted) {                                                                       \
+    if (g.fused) {                                                                             \
+      e = ensure_lds(spread_2d_w8_group_kernel<float, WV, NWV, CHV, false, true>, lds_bytes);  \
+      if (e != hipSuccess) return e;                                                           \
+      spread_2d_w8_group_kernel<float, WV, NWV, CHV, false, true><<<grid, NWV * 64, lds_bytes, stream>>>( \
+          g, sp, horner, c, fw, c_stride, fw_stride, scale);                                   \
+    } else if (g.cell_sorted) {                                                                       \
       e = ensure_lds(spread_2d_w8_group_kernel<float, WV, NWV, CHV, true>, lds_bytes);                \
       if (e != hipSuccess) return e;                                                           \
       spread_2d_w8_group_kernel<float, WV, NWV, CHV, true><<<grid, NWV * 64, lds_bytes, stream>>>(    \
@@ -2324,16 +2566,29 @@ hipError_t launch_deconvolve(const Geom& g, int dir, T* f, T* fw, const T* const
   const int d1 = dir == 1 ? g.nmodes[1] : g.nf[1];
   const int d2 = dir == 1 ? g.nmodes[2] : g.nf[2];
   if (d0 == 0 || d1 == 0 || d2 == 0 || batch == 0) return hipSuccess;
-  // gridDim.y / .z are limited to 65535: fall back to looping the batch
-  if (d1 > 65535) return hipErrorInvalidValue;
-  const int per_launch = std::max(1, 65535 / d2);
-  for (int b0 = 0; b0 < batch; b0 += per_launch) {
-    const int nb = std::min(per_launch, batch - b0);
-    int64_t nel = (int64_t)g.nmodes[0] * g.nmodes[1] * g.nmodes[2];
-    int64_t nfel = (int64_t)g.nf[0] * g.nf[1] * g.nf[2];
-    dim3 grid(blocks_for(d0, 256), (unsigned)d1, (unsigned)(d2 * nb));
-    deconvolve_kernel<T><<<grid, 256, 0, stream>>>(g, dir, f + 2 * b0 * nel, fw + 2 * b0 * nfel, rfser[0],
-                                                   rfser[1], rfser[2]);
+  const int64_t nel = (int64_t)g.nmodes[0] * g.nmodes[1] * g.nmodes[2];
+  const int64_t nfel = (int64_t)g.nf[0] * g.nf[1] * g.nf[2];
+  if (d1 <= 65535 && d2 <= 65535) {
+    // gridDim.z = d2 * batch is limited to 65535: several launches for large batches
+    const int per_launch = std::max(1, 65535 / d2);
+    for (int b0 = 0; b0 < batch; b0 += per_launch) {
+      const int nb = std::min(per_launch, batch - b0);
+      dim3 grid(blocks_for(d0, 256), (unsigned)d1, (unsigned)(d2 * nb));
+      deconvolve_kernel<T, false><<<grid, 256, 0, stream>>>(g, dir, nb, f + 2 * b0 * nel, fw + 2 * b0 * nfel,
+                                                            rfser[0], rfser[1], rfser[2]);
+    }
+    return hipGetLastError();
+  }
+  // more than 65535 rows in a dimension (e.g. a 40000 x 40000 type-2 fine grid): the rows
+  // (i1, i2) of one transform are flattened over gridDim.y x gridDim.z, one launch per transform
+  for (int b0 = 0; b0 < batch; ++b0) {
+    const int64_t rows = (int64_t)d1 * d2;
+    const unsigned gy = (unsigned)std::min<int64_t>(rows, 32768);
+    const unsigned gz = (unsigned)((rows + gy - 1) / gy);
+    if (gz > 65535) return hipErrorInvalidValue;   // > 2^31 rows: beyond the 2e9-element cap anyway
+    dim3 grid(blocks_for(d0, 256), gy, gz);
+    deconvolve_kernel<T, true><<<grid, 256, 0, stream>>>(g, dir, 1, f + 2 * b0 * nel, fw + 2 * b0 * nfel,
+                                                         rfser[0], rfser[1], rfser[2]);
   }
   return hipGetLastError();
 }

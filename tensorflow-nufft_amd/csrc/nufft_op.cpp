@@ -143,22 +143,34 @@ int analyze(const nufft_hip_op_desc* d, Analysis* a, std::string* err) {
 
 // ----------------------------------------------------------- plan cache
 
+// Plans (and the batch-permute scratch buffers) are kept between calls: the reference
+// rebuilds plan, FFT plan and tables on every Compute (nufft_kernels.cc:474-478). Least
+// recently used first out, bounded by entry count and by device bytes.
 struct CachedPlan {
   std::string key;
   nufft_hip_plan plan;
   hipStream_t own_stream;   // private stream of a pipelining lane (nullptr: caller's stream)
+  int64_t bytes;
+};
+struct CachedScratch {      // permute temporaries of calls whose batch dims interleave
+  void* stream;
+  int device;
+  void* ptr;
+  size_t bytes;
 };
 std::mutex g_cache_mu;
-std::list<CachedPlan> g_cache;    // most recently returned at the front
+std::list<CachedPlan> g_cache;         // most recently returned at the front
+std::list<CachedScratch> g_scratch;
 constexpr size_t kMaxCached = 16;
+int64_t g_cache_limit = (int64_t)8 << 30;
 constexpr int kMaxLanes = 4;   // pipelined plans per op call (nufft_hip_op_compute)
 
 std::string plan_key(const nufft_hip_op_desc* d, const Analysis& a, int type, int ntransf,
-                     double tol, void* stream, int device) {
+                     double tol, void* stream, int device, bool framework_alloc) {
   std::string k;
   char buf[256];
-  snprintf(buf, sizeof(buf), "op%d t%d r%d n%d f%d p%d tol%.17g dev%d s%p|", d->op_type, type, a.rank,
-           ntransf, d->fft_direction, d->precision, tol, device, stream);
+  snprintf(buf, sizeof(buf), "op%d t%d r%d n%d f%d p%d tol%.17g dev%d s%p a%d|", d->op_type, type, a.rank,
+           ntransf, d->fft_direction, d->precision, tol, device, stream, framework_alloc ? 1 : 0);
   k = buf;
   for (auto g : a.grid) k += std::to_string((long long)g) + ",";
   k.append(reinterpret_cast<const char*>(&d->options), sizeof(d->options));
@@ -182,17 +194,75 @@ void release_entry(nufft_hip_plan p, hipStream_t own_stream) {
   if (own_stream) (void)hipStreamDestroy(own_stream);
 }
 
+int64_t cached_bytes_locked() {
+  int64_t b = 0;
+  for (auto& c : g_cache) b += c.bytes;
+  for (auto& c : g_scratch) b += (int64_t)c.bytes;
+  return b;
+}
+
+// Evicts from the cold end until both limits hold (the newest entry always stays).
+void trim_cache() {
+  for (;;) {
+    CachedPlan evict{std::string(), nullptr, nullptr, 0};
+    void* scratch = nullptr;
+    {
+      std::lock_guard<std::mutex> lk(g_cache_mu);
+      const bool over = g_cache.size() > kMaxCached || cached_bytes_locked() > g_cache_limit;
+      if (!over) return;
+      if (!g_scratch.empty() && (g_cache.size() <= 1 || g_scratch.size() > 4)) {
+        scratch = g_scratch.back().ptr;
+        g_scratch.pop_back();
+      } else if (g_cache.size() > 1) {
+        evict = g_cache.back();
+        g_cache.pop_back();
+      } else if (!g_scratch.empty()) {
+        scratch = g_scratch.back().ptr;
+        g_scratch.pop_back();
+      } else {
+        return;
+      }
+    }
+    if (scratch) (void)hipFree(scratch);   // hipFree waits for the device
+    if (evict.plan) release_entry(evict.plan, evict.own_stream);
+  }
+}
+
 void cache_give(const std::string& key, nufft_hip_plan p, hipStream_t own_stream) {
-  CachedPlan evict{std::string(), nullptr, nullptr};
+  nufft_hip_plan_info info;
+  int64_t bytes = 0;
+  if (nufft_hip_plan_get_info(p, &info) == NUFFT_HIP_OK) bytes = info.workspace_bytes;
   {
     std::lock_guard<std::mutex> lk(g_cache_mu);
-    g_cache.push_front({key, p, own_stream});
-    if (g_cache.size() > kMaxCached) {
-      evict = g_cache.back();
-      g_cache.pop_back();
-    }
+    g_cache.push_front({key, p, own_stream, bytes});
   }
-  if (evict.plan) release_entry(evict.plan, evict.own_stream);
+  trim_cache();
+}
+
+// A scratch buffer of at least `bytes` for work enqueued on `stream`: reused only by
+// later calls on the same stream, so stream order protects it. hipMalloc only on growth.
+void* scratch_take(void* stream, int device, size_t bytes, size_t* got) {
+  {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    for (auto it = g_scratch.begin(); it != g_scratch.end(); ++it)
+      if (it->stream == stream && it->device == device && it->bytes >= bytes) {
+        void* p = it->ptr;
+        *got = it->bytes;
+        g_scratch.erase(it);
+        return p;
+      }
+  }
+  void* p = nullptr;
+  if (hipMalloc(&p, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  *got = bytes;
+  return p;
+}
+void scratch_give(void* stream, int device, void* ptr, size_t bytes) {
+  std::lock_guard<std::mutex> lk(g_cache_mu);
+  g_scratch.push_front({stream, device, ptr, bytes});
 }
 
 }  // namespace
@@ -214,14 +284,16 @@ int nufft_hip_op_shape(const nufft_hip_op_desc* desc, int32_t* target_ndim, int6
   return NUFFT_HIP_OK;
 }
 
-int nufft_hip_op_compute(const nufft_hip_op_desc* desc, const void* source, const void* points,
-                         void* target, void* stream_v, char* errbuf, size_t errbuf_len) {
+int nufft_hip_op_compute_ex(const nufft_hip_op_desc* desc, const void* source, const void* points,
+                            void* target, void* stream_v, const nufft_hip_allocator* allocator,
+                            char* errbuf, size_t errbuf_len) {
   if (!desc) return fail(errbuf, errbuf_len, NUFFT_HIP_INVALID_ARGUMENT, "null desc");
   Analysis a;
   std::string err;
   int rc = analyze(desc, &a, &err);
   if (rc) return fail(errbuf, errbuf_len, rc, err);
   hipStream_t stream = (hipStream_t)stream_v;
+  const bool fw_alloc = allocator && allocator->alloc;
   const int rank = a.rank;
   const bool t1 = desc->transform_type == NUFFT_HIP_TYPE_1;
   const int nb = (int)a.source_batch.size();
@@ -255,26 +327,30 @@ int nufft_hip_op_compute(const nufft_hip_op_desc* desc, const void* source, cons
   // NUFFT_HIP_OP_LANES overrides the lane count (1..kMaxLanes); three or four lanes measured
   // no better than two on config 5 (32 items of M = 1e6: 3.6 / 2.9 / 3.2 / 3.1 ms for 1-4
   // lanes): ~14 launches per item keep the host and the whole-GPU kernels equally busy.
+  // With a framework allocator everything stays on the caller's stream (its memory is
+  // ordered against that stream only).
   static const int lanes_env = [] { const char* e = getenv("NUFFT_HIP_OP_LANES"); return e ? atoi(e) : 0; }();
   int want_lanes = 2;
   if (lanes_env > 0) want_lanes = lanes_env < kMaxLanes ? lanes_env : kMaxLanes;
+  if (fw_alloc) want_lanes = 1;
   const int nlanes = (int)std::min<int64_t>(a.num_calls, want_lanes);
   nufft_hip_plan plans[kMaxLanes] = {};
   hipStream_t lane_stream[kMaxLanes] = {};
   std::string keys[kMaxLanes];
   for (int l = 0; l < nlanes; ++l) {
     void* key_stream = nlanes == 1 ? stream_v : reinterpret_cast<void*>((intptr_t)(l + 1));
-    keys[l] = plan_key(desc, a, desc->transform_type, (int)a.num_transforms, tol, key_stream, device);
+    keys[l] = plan_key(desc, a, desc->transform_type, (int)a.num_transforms, tol, key_stream, device, fw_alloc);
     plans[l] = cache_take(keys[l], &lane_stream[l]);
+    if (plans[l] && fw_alloc) rc = nufft_hip_plan_set_allocator(plans[l], allocator);   // this call's context
     if (!plans[l]) {
       if (nlanes > 1 && hipStreamCreateWithFlags(&lane_stream[l], hipStreamNonBlocking) != hipSuccess) {
         for (int k = 0; k < l; ++k) release_entry(plans[k], lane_stream[k]);
         return fail(errbuf, errbuf_len, NUFFT_HIP_INTERNAL, "hipStreamCreate failed");
       }
       char pe[512] = {0};
-      rc = nufft_hip_plan_create(&plans[l], desc->transform_type, rank, dims, desc->fft_direction,
-                                 (int)a.num_transforms, tol, desc->precision, &opts,
-                                 nlanes == 1 ? stream_v : (void*)lane_stream[l], pe, sizeof(pe));
+      rc = nufft_hip_plan_create_ex(&plans[l], desc->transform_type, rank, dims, desc->fft_direction,
+                                    (int)a.num_transforms, tol, desc->precision, &opts,
+                                    nlanes == 1 ? stream_v : (void*)lane_stream[l], allocator, pe, sizeof(pe));
       if (rc) {
         if (lane_stream[l]) (void)hipStreamDestroy(lane_stream[l]);
         for (int k = 0; k < l; ++k) release_entry(plans[k], lane_stream[k]);
@@ -289,9 +365,12 @@ int nufft_hip_op_compute(const nufft_hip_op_desc* desc, const void* source, cons
 
   // Source / target with batch dims permuted to [outer..., inner..., element...]
   // when the original order interleaves them (nufft_kernels.cc:241-345,372-378).
+  // The temporaries come from the framework allocator, or from a scratch buffer cached
+  // per stream (no hipMalloc / hipFree / synchronisation on the steady-state path).
   const void* psource = source;
   void* ptarget = target;
-  void *tsource = nullptr, *ttarget = nullptr;
+  void* scratch = nullptr;
+  size_t scratch_bytes = 0;
   std::vector<int> perm(a.outer);
   perm.insert(perm.end(), a.inner.begin(), a.inner.end());
   const int s_nd = nb + a.source_elem_rank;
@@ -304,8 +383,13 @@ int nufft_hip_op_compute(const nufft_hip_op_desc* desc, const void* source, cons
     return st;
   };
   auto cleanup = [&]() {
-    if (tsource) (void)hipFree(tsource);
-    if (ttarget) (void)hipFree(ttarget);
+    if (!scratch) return;
+    if (fw_alloc) {
+      if (allocator->free) allocator->free(scratch, allocator->user);
+    } else {
+      scratch_give(stream_v, device, scratch, scratch_bytes);
+    }
+    scratch = nullptr;
   };
   auto hip_fail = [&](hipError_t e) {
     cleanup();
@@ -322,14 +406,22 @@ int nufft_hip_op_compute(const nufft_hip_op_desc* desc, const void* source, cons
     }
     int64_t n = 1;
     for (auto v : oshape) n *= v;
-    hipError_t e = hipMalloc(&tsource, std::max<size_t>(16, (size_t)n * csize));
+    const size_t sbytes = (std::max<size_t>(16, (size_t)n * csize) + 255) & ~(size_t)255;
+    const size_t tbytes = std::max<size_t>(16, (size_t)out_elems * csize);
+    if (fw_alloc) {
+      scratch = allocator->alloc(sbytes + tbytes, allocator->user);
+      scratch_bytes = sbytes + tbytes;
+    } else {
+      scratch = scratch_take(stream_v, device, sbytes + tbytes, &scratch_bytes);
+    }
+    if (!scratch) {
+      release_all();
+      return fail(errbuf, errbuf_len, NUFFT_HIP_RESOURCE_EXHAUSTED, "out of device memory for the batch-permute temporaries");
+    }
+    hipError_t e = launch_permute(source, scratch, (int)csize, s_nd, oshape.data(), ostr.data(), stream);
     if (e != hipSuccess) return hip_fail(e);
-    e = launch_permute(source, tsource, (int)csize, s_nd, oshape.data(), ostr.data(), stream);
-    if (e != hipSuccess) return hip_fail(e);
-    psource = tsource;
-    e = hipMalloc(&ttarget, std::max<size_t>(16, (size_t)out_elems * csize));
-    if (e != hipSuccess) return hip_fail(e);
-    ptarget = ttarget;
+    psource = scratch;
+    ptarget = (char*)scratch + sbytes;
   }
 
   // Loop over calls (nufft_kernels.cc:491-540). Batch dims in `outer` order.
@@ -349,15 +441,13 @@ int nufft_hip_op_compute(const nufft_hip_op_desc* desc, const void* source, cons
     for (int l = 0; l < nlanes && e == hipSuccess; ++l) e = hipStreamWaitEvent(lane_stream[l], ev_fork, 0);
     if (e != hipSuccess) return hip_fail(e);
   }
-  for (int64_t call = 0; call < a.num_calls; ++call) {
+  for (int64_t call = 0; call < a.num_calls && !rc; ++call) {
     plan = plans[call % nlanes];
     const char* pb = (const char*)points + (size_t)call * (size_t)a.num_points * rank * rsize;
     // x = LAST coordinate of each point (reverse of the last axis, :282-286)
     const void* px = pb + (size_t)(rank - 1) * rsize;
     const void* py = rank > 1 ? pb + (size_t)(rank - 2) * rsize : nullptr;
     const void* pz = rank > 2 ? pb + (size_t)(rank - 3) * rsize : nullptr;
-    rc = nufft_hip_set_points(plan, a.num_points, px, py, pz, rank);
-    if (rc) break;
     int64_t source_index = 0, tmp = call;
     for (int d2 = 0; d2 < no; ++d2) {
       int64_t ix = tmp / pfac[d2];
@@ -372,13 +462,8 @@ int nufft_hip_op_compute(const nufft_hip_op_desc* desc, const void* source, cons
     char* fbase = (char*)(t1 ? ptarget : const_cast<void*>(psource));
     void* c = cbase + (size_t)c_index * (size_t)a.num_transforms * (size_t)a.num_points * csize;
     void* f = fbase + (size_t)f_index * (size_t)a.num_transforms * (size_t)num_coeffs * csize;
-    switch (desc->op_type) {
-      case NUFFT_HIP_OP_NUFFT: rc = nufft_hip_execute(plan, c, f); break;
-      case NUFFT_HIP_OP_INTERP: rc = nufft_hip_interp(plan, c, f); break;
-      case NUFFT_HIP_OP_SPREAD: rc = nufft_hip_spread(plan, c, f); break;
-      default: rc = NUFFT_HIP_INVALID_ARGUMENT;
-    }
-    if (rc) break;
+    // set_points + execute / interp / spread as one call (:492-539): the plan may fuse them
+    rc = nufft_hip_execute_with_points(plan, a.num_points, px, py, pz, rank, c, f);
   }
   if (rc) {
     const std::string msg = nufft_hip_last_error(plan);
@@ -408,23 +493,46 @@ int nufft_hip_op_compute(const nufft_hip_op_desc* desc, const void* source, cons
     std::vector<int> iperm(t_nd);
     for (int i = 0; i < t_nd; ++i) iperm[i < nb ? perm[i] : i] = i;
     for (int j = 0; j < t_nd; ++j) ostr[j] = tst[iperm[j]];
-    hipError_t e = launch_permute(ttarget, target, (int)csize, t_nd, a.target_shape.data(), ostr.data(), stream);
-    if (e != hipSuccess) return hip_fail(e);
-    e = hipStreamSynchronize(stream);   // temporaries are freed below
+    hipError_t e = launch_permute(ptarget, target, (int)csize, t_nd, a.target_shape.data(), ostr.data(), stream);
     if (e != hipSuccess) return hip_fail(e);
   }
   cleanup();
-  for (int l = 0; l < nlanes; ++l) cache_give(keys[l], plans[l], lane_stream[l]);
+  for (int l = 0; l < nlanes; ++l) {
+    // a framework allocator's memory is per call: hand the workspace back, keep the plan
+    if (fw_alloc) (void)nufft_hip_plan_release_workspace(plans[l]);
+    cache_give(keys[l], plans[l], lane_stream[l]);
+  }
   return NUFFT_HIP_OK;
+}
+
+int nufft_hip_op_compute(const nufft_hip_op_desc* desc, const void* source, const void* points,
+                         void* target, void* stream_v, char* errbuf, size_t errbuf_len) {
+  return nufft_hip_op_compute_ex(desc, source, points, target, stream_v, nullptr, errbuf, errbuf_len);
 }
 
 void nufft_hip_op_clear_cache(void) {
   std::list<CachedPlan> tmp;
+  std::list<CachedScratch> tmp2;
   {
     std::lock_guard<std::mutex> lk(g_cache_mu);
     tmp.swap(g_cache);
+    tmp2.swap(g_scratch);
   }
   for (auto& c : tmp) release_entry(c.plan, c.own_stream);
+  for (auto& c : tmp2) (void)hipFree(c.ptr);
+}
+
+void nufft_hip_op_set_cache_limit(int64_t max_bytes) {
+  {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    g_cache_limit = max_bytes < 0 ? 0 : max_bytes;
+  }
+  trim_cache();
+}
+
+int64_t nufft_hip_op_cache_bytes(void) {
+  std::lock_guard<std::mutex> lk(g_cache_mu);
+  return cached_bytes_locked();
 }
 
 }  // extern "C"

@@ -146,8 +146,9 @@ double spread_only_scale(const KernelSpec& ks, int rank) {
 // P_j(z) ~ phi((z + 1 - w)/2 + j). Chebyshev interpolation -> monomial
 // coefficients, all in double. Plays the role of the reference's generated
 // kernel_horner_*.inc tables (not copied; any sigma works). Returns the max
-// error over a dense sample.
-double fit_horner(const KernelSpec& ks, int nc, double* tab /* [kMaxCoef][kMaxW] */) {
+// error over a dense sample; *max_abs = the largest |P_j(z)| on that sample (the
+// fit overshoots phi(0) = 1 by about its own error, e.g. 1.00001 at w = 4).
+double fit_horner(const KernelSpec& ks, int nc, double* tab /* [kMaxCoef][kMaxW] */, double* max_abs = nullptr) {
   const int w = ks.w;
   std::vector<double> node(nc), val(nc), cheb(nc);
   for (int i = 0; i < kMaxCoef * kMaxW; ++i) tab[i] = 0.0;
@@ -177,15 +178,17 @@ double fit_horner(const KernelSpec& ks, int nc, double* tab /* [kMaxCoef][kMaxW]
     }
     for (int k = 0; k < nc; ++k) tab[k * kMaxW + j] = mono[k];
   }
-  double err = 0.0;
+  double err = 0.0, kmax = 0.0;
   for (int s = 0; s <= 64; ++s) {
     const double z = -1.0 + 2.0 * s / 64.0;
     for (int j = 0; j < w; ++j) {
       double acc = tab[(nc - 1) * kMaxW + j];
       for (int k = nc - 2; k >= 0; --k) acc = acc * z + tab[k * kMaxW + j];
       err = std::max(err, std::fabs(acc - ks.eval((z + 1.0 - w) / 2.0 + j)));
+      kmax = std::max(kmax, std::fabs(acc));
     }
   }
+  if (max_abs) *max_abs = kmax;
   return err;
 }
 
@@ -214,23 +217,27 @@ struct nufft_hip_plan_s {
   void* d_rfser[3] = {nullptr, nullptr, nullptr};
   void* d_fine = nullptr;
   int64_t fine_elems = 0, grid_elems = 0;
-  std::map<int, rocfft_plan> fft_plans;   // by batch count
+  std::map<int, rocfft_plan> fft_plans;   // by batch count (batch_size and the remainder batch)
   rocfft_execution_info fft_info = nullptr;
   void* fft_work = nullptr;
-  size_t fft_work_bytes = 0;
+  size_t fft_work_bytes = 0;      // bytes the FFT plans need (max over them)
 
   int64_t M = 0, cap = 0, cap_global = 0;
   void* rec = nullptr;           // Rec<T>[cap], tile-sorted
   void* rec2 = nullptr;          // Rec<T>[cap2]: target of the lazy cell-sort pass (then swapped with rec)
   int64_t cap2 = 0;
   int64_t spread_uses = 0;       // spread launches fed by the current sorted points
-  int32_t* idx3 = nullptr;       // float rank-3 only
   int32_t *hist = nullptr;       // LDS-histogram sort: [nblk][ntiles]
   int64_t hist_elems = 0;
   int32_t *tile_of = nullptr, *rank_of = nullptr;   // global-counter sort
   int32_t *tile_count = nullptr, *tile_start = nullptr, *sub_start = nullptr, *bad_count = nullptr;
   int64_t workspace_bytes = 0;
   bool points_set = false;
+  bool host_only = false;        // nufft_hip_plan_create_host: no device state at all
+  bool fused = false;            // current records carry the strengths (execute_with_points)
+  int stop_after = -1;           // debug: execute returns after this stage
+  nufft_hip_allocator allocator = {nullptr, nullptr, nullptr};   // workspace allocator (null: hipMalloc)
+  bool fixed_ws = false;         // tile tables / fine grid / FFT work buffer are allocated
   std::string err;
 
   // optional per-stage timing with HIP events on the plan's stream
@@ -321,9 +328,21 @@ static bool fence_free(void* p) {
   return true;
 }
 
+// Workspace buffers (fine grid, sorted records, sort tables, FFT work buffer) come from
+// the plan's allocator when the host framework supplied one (include/nufft_hip.h,
+// nufft_hip_allocator), else from hipMalloc. The constant tables use table_alloc.
 int dev_alloc(nufft_hip_plan p, void** ptr, size_t bytes) {
   *ptr = nullptr;
   if (bytes == 0) bytes = 16;
+  if (p->allocator.alloc) {
+    *ptr = p->allocator.alloc(bytes, p->allocator.user);
+    if (!*ptr) {
+      p->err = format("out of device memory allocating %zu bytes (host allocator)", bytes);
+      return NUFFT_HIP_RESOURCE_EXHAUSTED;
+    }
+    p->workspace_bytes += (int64_t)bytes;
+    return NUFFT_HIP_OK;
+  }
   hipError_t e = fence_enabled() ? fence_alloc(ptr, bytes) : hipMalloc(ptr, bytes);
   if (e != hipSuccess) {
     p->err = format("out of device memory allocating %zu bytes (%s)", bytes, hipGetErrorString(e));
@@ -334,18 +353,40 @@ int dev_alloc(nufft_hip_plan p, void** ptr, size_t bytes) {
   return NUFFT_HIP_OK;
 }
 
-void dev_free(void* p) {
-  if (!p) return;
-  if (fence_enabled() && fence_free(p)) return;
-  (void)hipFree(p);
+void dev_free(nufft_hip_plan p, void* ptr) {
+  if (!ptr) return;
+  if (p->allocator.alloc) {
+    if (p->allocator.free) p->allocator.free(ptr, p->allocator.user);
+    return;
+  }
+  if (fence_enabled() && fence_free(ptr)) return;
+  (void)hipFree(ptr);
 }
 
-int get_fft_plan(nufft_hip_plan p, int batch, rocfft_plan* out) {
-  auto it = p->fft_plans.find(batch);
-  if (it != p->fft_plans.end()) {
-    *out = it->second;
-    return NUFFT_HIP_OK;
+int table_alloc(nufft_hip_plan p, void** ptr, size_t bytes) {
+  *ptr = nullptr;
+  const hipError_t e = hipMalloc(ptr, bytes ? bytes : 16);
+  if (e != hipSuccess) {
+    p->err = format("out of device memory allocating %zu bytes (%s)", bytes, hipGetErrorString(e));
+    (void)hipGetLastError();
+    return NUFFT_HIP_RESOURCE_EXHAUSTED;
   }
+  return NUFFT_HIP_OK;
+}
+
+// Growing a buffer: with hipMalloc the old block may still be in use by queued kernels, so
+// the stream is drained first (hipFree would synchronise the device anyway); a framework
+// allocator orders reuse behind the stream itself.
+int sync_before_regrow(nufft_hip_plan p) {
+  if (p->allocator.alloc) return NUFFT_HIP_OK;
+  HIP_TRY(p, hipStreamSynchronize(p->stream));
+  return NUFFT_HIP_OK;
+}
+
+// Both FFT plans a plan can need (full batches and the remainder batch) are built at plan
+// creation, so that execute never creates a plan, allocates or synchronises.
+int build_fft_plan(nufft_hip_plan p, int batch) {
+  if (batch <= 0 || p->fft_plans.count(batch)) return NUFFT_HIP_OK;
   std::call_once(g_rocfft_once, [] { rocfft_setup(); });
   size_t lengths[3];
   for (int d = 0; d < p->rank; ++d) lengths[d] = (size_t)p->g.nf[d];
@@ -356,36 +397,65 @@ int get_fft_plan(nufft_hip_plan p, int batch, rocfft_plan* out) {
                               : rocfft_transform_type_complex_inverse,
                  p->precision == NUFFT_HIP_F32 ? rocfft_precision_single : rocfft_precision_double,
                  (size_t)p->rank, lengths, (size_t)batch, nullptr));
+  p->fft_plans[batch] = plan;
   size_t wb = 0;
   FFT_TRY(p, rocfft_plan_get_work_buffer_size(plan, &wb));
+  p->fft_work_bytes = std::max(p->fft_work_bytes, wb);
   if (!p->fft_info) FFT_TRY(p, rocfft_execution_info_create(&p->fft_info));
-  if (wb > p->fft_work_bytes) {
-    HIP_TRY(p, hipStreamSynchronize(p->stream));
-    dev_free(p->fft_work);
-    int rc = dev_alloc(p, &p->fft_work, wb);
-    if (rc) return rc;
-    p->fft_work_bytes = wb;
-  }
-  if (p->fft_work_bytes)
-    FFT_TRY(p, rocfft_execution_info_set_work_buffer(p->fft_info, p->fft_work, p->fft_work_bytes));
   FFT_TRY(p, rocfft_execution_info_set_stream(p->fft_info, p->stream));
-  p->fft_plans[batch] = plan;
-  *out = plan;
   return NUFFT_HIP_OK;
+}
+
+// Fixed-size part of the workspace: tile tables, the fine grid and the FFT work buffer.
+// Allocated at plan creation (internal allocator) or at the first set_points after a
+// release (framework allocator).
+int ensure_fixed_workspace(nufft_hip_plan p) {
+  if (p->fixed_ws) return NUFFT_HIP_OK;
+  const Geom& g = p->g;
+  int rc = dev_alloc(p, (void**)&p->tile_count, sizeof(int32_t) * (size_t)g.ntiles);
+  if (!rc) rc = dev_alloc(p, (void**)&p->tile_start, sizeof(int32_t) * ((size_t)g.ntiles + 1));
+  if (!rc) rc = dev_alloc(p, (void**)&p->sub_start, sizeof(int32_t) * ((size_t)g.ntiles + 1));
+  if (!rc) rc = dev_alloc(p, (void**)&p->bad_count, sizeof(int32_t) * 4);
+  if (!rc && !p->opts.spread_only)
+    rc = dev_alloc(p, &p->d_fine, (size_t)p->precision * 2 * (size_t)p->fine_elems * p->batch_size);
+  if (!rc && !p->opts.spread_only && p->fft_work_bytes) {
+    rc = dev_alloc(p, &p->fft_work, p->fft_work_bytes);
+    if (!rc) FFT_TRY(p, rocfft_execution_info_set_work_buffer(p->fft_info, p->fft_work, p->fft_work_bytes));
+  }
+  if (rc) return rc;
+  p->fixed_ws = true;
+  return NUFFT_HIP_OK;
+}
+
+void release_workspace(nufft_hip_plan p) {
+  void** bufs[] = {(void**)&p->tile_count, (void**)&p->tile_start, (void**)&p->sub_start, (void**)&p->bad_count,
+                   &p->d_fine, &p->fft_work, &p->rec, &p->rec2, (void**)&p->hist, (void**)&p->tile_of,
+                   (void**)&p->rank_of};
+  for (void** b : bufs) {
+    dev_free(p, *b);
+    *b = nullptr;
+  }
+  p->cap = p->cap2 = p->cap_global = 0;
+  p->hist_elems = 0;
+  p->workspace_bytes = 0;
+  p->fixed_ws = false;
+  p->points_set = false;
+  p->fused = false;
+  p->M = 0;
 }
 
 template <typename T>
 int upload_tables(nufft_hip_plan p) {
   std::vector<T> tmp(kMaxCoef * kMaxW);
   for (size_t i = 0; i < tmp.size(); ++i) tmp[i] = (T)p->horner_h[i];
-  int rc = dev_alloc(p, &p->d_horner, tmp.size() * sizeof(T));
+  int rc = table_alloc(p, &p->d_horner, tmp.size() * sizeof(T));
   if (rc) return rc;
   HIP_TRY(p, hipMemcpy(p->d_horner, tmp.data(), tmp.size() * sizeof(T), hipMemcpyHostToDevice));
   for (int d = 0; d < p->rank; ++d) {
     const size_t n = p->fser_h[d].size();
     std::vector<T> r(n);
     for (size_t k = 0; k < n; ++k) r[k] = (T)(1.0 / p->fser_h[d][k]);
-    rc = dev_alloc(p, &p->d_rfser[d], n * sizeof(T));
+    rc = table_alloc(p, &p->d_rfser[d], n * sizeof(T));
     if (rc) return rc;
     HIP_TRY(p, hipMemcpy(p->d_rfser[d], r.data(), n * sizeof(T), hipMemcpyHostToDevice));
   }
@@ -427,7 +497,8 @@ StageHook make_hook(nufft_hip_plan p) {
 }
 
 int ensure_point_capacity(nufft_hip_plan p, int64_t M) {
-  int rc;
+  int rc = ensure_fixed_workspace(p);
+  if (rc) return rc;
   const int mode = sort_mode(p->g, M);
   int64_t need = 0, per_block;
   if (mode == 0) need = (int64_t)sort_blocks(p->g, M, &per_block) * p->g.ntiles;
@@ -436,16 +507,16 @@ int ensure_point_capacity(nufft_hip_plan p, int64_t M) {
     need = nblk * ((p->g.ntiles + 1) / 2) + nblk * (int64_t)p->g.ntiles;   // hist16 words + 32-bit prefix
   }
   if (need > p->hist_elems) {
-    HIP_TRY(p, hipStreamSynchronize(p->stream));
-    dev_free(p->hist);
+    if ((rc = sync_before_regrow(p))) return rc;
+    dev_free(p, p->hist);
     p->hist = nullptr;
     p->hist_elems = 0;
     if ((rc = dev_alloc(p, (void**)&p->hist, sizeof(int32_t) * (size_t)need))) return rc;
     p->hist_elems = need;
   }
   if (mode != 0 && M > p->cap_global) {   // per-point tile / rank arrays (modes 1 and 2)
-    HIP_TRY(p, hipStreamSynchronize(p->stream));
-    dev_free(p->tile_of); dev_free(p->rank_of);
+    if ((rc = sync_before_regrow(p))) return rc;
+    dev_free(p, p->tile_of); dev_free(p, p->rank_of);
     p->tile_of = p->rank_of = nullptr;
     p->cap_global = 0;
     if ((rc = dev_alloc(p, (void**)&p->tile_of, (size_t)M * 4))) return rc;
@@ -453,9 +524,9 @@ int ensure_point_capacity(nufft_hip_plan p, int64_t M) {
     p->cap_global = M;
   }
   if (M <= p->cap) return NUFFT_HIP_OK;
-  HIP_TRY(p, hipStreamSynchronize(p->stream));
-  dev_free(p->rec); dev_free(p->idx3);
-  p->rec = nullptr; p->idx3 = nullptr;
+  if ((rc = sync_before_regrow(p))) return rc;
+  dev_free(p, p->rec);
+  p->rec = nullptr;
   p->cap = 0;
   const size_t rec_bytes = p->precision == NUFFT_HIP_F32 ? sizeof(Rec<float>) : sizeof(Rec<double>);
   if ((rc = dev_alloc(p, &p->rec, (size_t)M * rec_bytes))) return rc;
@@ -463,12 +534,15 @@ int ensure_point_capacity(nufft_hip_plan p, int64_t M) {
   return NUFFT_HIP_OK;
 }
 
+// `strengths` non-null: fused sort (the records carry them; the caller has checked
+// fused_sort_supported).
 template <typename T>
 int set_points_impl(nufft_hip_plan p, int64_t M, const void* x, const void* y, const void* z,
-                    int64_t stride) {
+                    int64_t stride, const void* strengths = nullptr) {
   int rc = ensure_point_capacity(p, M);
   if (rc) return rc;
   p->M = M;
+  p->points_set = false;
   const bool check = p->opts.check_points_range && p->opts.points_range != NUFFT_HIP_RANGE_INFINITE;
   if (check) HIP_TRY(p, hipMemsetAsync(p->bad_count, 0, sizeof(int32_t) * 4, p->stream));
   PointsIn in;
@@ -478,18 +552,30 @@ int set_points_impl(nufft_hip_plan p, int64_t M, const void* x, const void* y, c
   in.M = M;
   in.range_mode = p->opts.points_range;
   in.check_range = check ? 1 : 0;
+  in.strengths = strengths;
+  // one interleaved [M, rank] array with x last (the op's layout): vector loads in the sort
+  in.aos = 0;
+  if (p->rank >= 2 && stride == p->rank && M >= 2) {
+    const char* base = (const char*)(p->rank == 2 ? y : z);
+    const bool cols = (const char*)x == base + (size_t)(p->rank - 1) * p->precision &&
+                      (p->rank == 2 || (const char*)y == base + p->precision);
+    const size_t align = p->rank == 2 ? 4 * (size_t)p->precision : (size_t)p->precision;   // point PAIRS in 2-D
+    if (cols && ((uintptr_t)base % align) == 0) in.aos = p->rank;
+  }
   SortWork w;
   w.hist = p->hist; w.tile_of = p->tile_of; w.rank_of = p->rank_of;
   w.tile_count = p->tile_count; w.tile_start = p->tile_start; w.sub_start = p->sub_start;
   w.bad_count = p->bad_count;
   p->g.cell_sorted = 0;   // the 2-D spread's second sort level runs lazily (maybe_cellsort)
+  p->g.fused = strengths ? 1 : 0;
+  p->fused = strengths != nullptr;
   p->spread_uses = 0;
   // 3-D interp plans order every subproblem by start cell right away (rec2 -> rec)
   const bool cells = (p->type == NUFFT_HIP_TYPE_2 || p->opts.spread_only) &&
                      cellsort_wanted_interp(p->g, p->method, p->precision, M);
   if (cells && M > p->cap2) {
-    HIP_TRY(p, hipStreamSynchronize(p->stream));
-    dev_free(p->rec2);
+    if ((rc = sync_before_regrow(p))) return rc;
+    dev_free(p, p->rec2);
     p->rec2 = nullptr;
     p->cap2 = 0;
     if ((rc = dev_alloc(p, &p->rec2, (size_t)M * sizeof(Rec<T>)))) return rc;
@@ -497,7 +583,6 @@ int set_points_impl(nufft_hip_plan p, int64_t M, const void* x, const void* y, c
   }
   SortedOut<T> out;
   out.rec = (Rec<T>*)(cells ? p->rec2 : p->rec);
-  out.idx3 = p->idx3;
   const StageHook hook = make_hook(p);
   HIP_TRY(p, launch_sort<T>(p->g, in, w, out, p->stream, hook));
   if (cells) {
@@ -527,7 +612,6 @@ template <typename T>
 SortedPoints<T> sorted_view(nufft_hip_plan p) {
   SortedPoints<T> sp;
   sp.rec = (const Rec<T>*)p->rec;
-  sp.idx3 = p->idx3;
   sp.tile_start = p->tile_start;
   sp.sub_start = p->sub_start;
   return sp;
@@ -549,16 +633,16 @@ template <typename T>
 int maybe_cellsort(nufft_hip_plan p, int launches) {
   const int64_t before = p->spread_uses;
   p->spread_uses += launches;
-  if (p->g.cell_sorted || before + launches < 3) return NUFFT_HIP_OK;
+  if (p->g.cell_sorted || p->fused || before + launches < 3) return NUFFT_HIP_OK;
   if (!cellsort_wanted(p->g, p->method, p->precision, p->M)) return NUFFT_HIP_OK;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(p->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return NUFFT_HIP_OK;
   if (p->M > p->cap2) {
-    HIP_TRY(p, hipStreamSynchronize(p->stream));
-    dev_free(p->rec2);
+    int rc;
+    if ((rc = sync_before_regrow(p))) return rc;
+    dev_free(p, p->rec2);
     p->rec2 = nullptr;
     p->cap2 = 0;
-    int rc;
     if ((rc = dev_alloc(p, &p->rec2, (size_t)p->M * sizeof(Rec<T>)))) return rc;
     p->cap2 = p->M;
   }
@@ -585,14 +669,18 @@ int execute_impl(nufft_hip_plan p, void* c, void* f) {
   }
   const SortedPoints<T> sp = sorted_view<T>(p);
   const T* rf[3] = {(const T*)p->d_rfser[0], (const T*)p->d_rfser[1], (const T*)p->d_rfser[2]};
+  const int stop = p->stop_after;
   for (int b0 = 0; b0 < p->ntransf; b0 += p->batch_size) {
     const int nb = std::min(p->batch_size, p->ntransf - b0);
     T* cb = (T*)c + 2 * (int64_t)b0 * p->M;
     T* fb = (T*)f + 2 * (int64_t)b0 * p->grid_elems;
     T* fw = (T*)p->d_fine;
-    rocfft_plan fft;
-    int rc = get_fft_plan(p, nb, &fft);
-    if (rc) return rc;
+    const auto it = p->fft_plans.find(nb);   // both batch counts were planned at creation
+    if (it == p->fft_plans.end()) {
+      p->err = format("no FFT plan for a batch of %d transforms", nb);
+      return NUFFT_HIP_INTERNAL;
+    }
+    rocfft_plan fft = it->second;
     void* bufs[1] = {fw};
     const StageHook hook = make_hook(p);
     if (p->type == NUFFT_HIP_TYPE_1) {
@@ -603,9 +691,11 @@ int execute_impl(nufft_hip_plan p, void* c, void* f) {
       HIP_TRY(p, launch_spread<T>(p->g, p->method, sp, p->M, (const T*)p->d_horner, cb, fw, nb,
                                   p->M, p->fine_elems, (T)1, p->lds_bytes, p->stream));
       hook.end(STAGE_SPREAD);
+      if (stop == STAGE_SPREAD) continue;
       hook.begin(STAGE_FFT);
       FFT_TRY(p, rocfft_execute(fft, bufs, nullptr, p->fft_info));
       hook.end(STAGE_FFT);
+      if (stop == STAGE_FFT) continue;
       hook.begin(STAGE_DECONVOLVE);
       HIP_TRY(p, launch_deconvolve<T>(p->g, 1, fb, fw, rf, nb, p->stream));
       hook.end(STAGE_DECONVOLVE);
@@ -613,9 +703,11 @@ int execute_impl(nufft_hip_plan p, void* c, void* f) {
       hook.begin(STAGE_DECONVOLVE);
       HIP_TRY(p, launch_deconvolve<T>(p->g, 2, fb, fw, rf, nb, p->stream));
       hook.end(STAGE_DECONVOLVE);
+      if (stop == STAGE_DECONVOLVE) continue;
       hook.begin(STAGE_FFT);
       FFT_TRY(p, rocfft_execute(fft, bufs, nullptr, p->fft_info));
       hook.end(STAGE_FFT);
+      if (stop == STAGE_FFT) continue;
       hook.begin(STAGE_INTERP);
       HIP_TRY(p, launch_interp<T>(p->g, p->method, sp, p->M, (const T*)p->d_horner, cb, fw, nb,
                                   p->M, p->fine_elems, (T)1, p->stream));
@@ -668,17 +760,19 @@ int spread_interp_impl(nufft_hip_plan p, int dir, void* c, void* f) {
 
 void destroy(nufft_hip_plan p) {
   if (!p) return;
-  (void)hipStreamSynchronize(p->stream);
-  for (auto& kv : p->fft_plans) rocfft_plan_destroy(kv.second);
-  if (p->fft_info) rocfft_execution_info_destroy(p->fft_info);
-  dev_free(p->fft_work);
-  dev_free(p->d_horner);
-  for (int d = 0; d < 3; ++d) dev_free(p->d_rfser[d]);
-  dev_free(p->d_fine);
-  dev_free(p->rec); dev_free(p->rec2); dev_free(p->idx3); dev_free(p->hist); dev_free(p->tile_of); dev_free(p->rank_of);
-  for (auto& pe : p->pending) { (void)hipEventDestroy(pe.e0); (void)hipEventDestroy(pe.e1); }
-  for (auto e : p->free_events) (void)hipEventDestroy(e);
-  dev_free(p->tile_count); dev_free(p->tile_start); dev_free(p->sub_start); dev_free(p->bad_count);
+  if (!p->host_only) {
+    // a framework allocator orders reuse behind the stream itself; ours (hipFree) does not
+    if (!p->allocator.alloc) (void)hipStreamSynchronize(p->stream);
+    release_workspace(p);
+    if (!p->fft_plans.empty() || p->d_horner) (void)hipStreamSynchronize(p->stream);   // tables / twiddles are hipFree'd
+    for (auto& kv : p->fft_plans) rocfft_plan_destroy(kv.second);
+    if (p->fft_info) rocfft_execution_info_destroy(p->fft_info);
+    if (p->d_horner) (void)hipFree(p->d_horner);
+    for (int d = 0; d < 3; ++d)
+      if (p->d_rfser[d]) (void)hipFree(p->d_rfser[d]);
+    for (auto& pe : p->pending) { (void)hipEventDestroy(pe.e0); (void)hipEventDestroy(pe.e1); }
+    for (auto e : p->free_events) (void)hipEventDestroy(e);
+  }
   delete p;
 }
 
@@ -847,12 +941,24 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
   int nc = std::max(3, w / 2 + 1);
   for (; nc < kMaxCoef; ++nc)
     if (fit_horner(p->ks, nc, p->horner_h.data()) <= want) break;
-  if (nc == kMaxCoef) fit_horner(p->ks, nc, p->horner_h.data());
+  double kmax = 1.0;
+  fit_horner(p->ks, nc, p->horner_h.data(), &kmax);
   g.ncoef = nc;
+  // Headroom of the packed fixed-point accumulation (3-D float): cell sums are bounded by
+  // sum |c| * kmax^rank in exact arithmetic; the float evaluation of the polynomial and of the
+  // products adds a few ulp per factor, covered by the 1e-4.
+  g.fx_headroom = (float)(std::pow(std::max(1.0, kmax), rank) * (1.0 + 1e-4));
 
   g.max_sub = p->opts.max_subproblem_size > 0 ? p->opts.max_subproblem_size : 1024;
   bool auto_sub = p->opts.max_subproblem_size <= 0;
   int method = p->opts.spread_method;
+  if (method < NUFFT_HIP_METHOD_AUTO || method > NUFFT_HIP_METHOD_POINT_GLOBAL) {
+    delete p;
+    return fail(NUFFT_HIP_INVALID_ARGUMENT, format("unknown spread_method %d", method));
+  }
+  // AUTO also lets launch_spread take the LDS-free kernel when the point set turns out sparse
+  g.sparse_auto = method == NUFFT_HIP_METHOD_AUTO ? 1 : 0;
+  g.fused = 0;
   if (method == NUFFT_HIP_METHOD_AUTO)
     method = wave_method_supported(g, precision) ? NUFFT_HIP_METHOD_TILE_WAVE : NUFFT_HIP_METHOD_TILE_GENERIC;
   if (method == NUFFT_HIP_METHOD_TILE_WAVE && !wave_method_supported(g, precision)) {
@@ -906,10 +1012,11 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
   return NUFFT_HIP_OK;
 }
 
-int nufft_hip_plan_create(nufft_hip_plan* out, int type, int rank, const int64_t* grid_dims,
-                          int iflag, int ntransf, double tol, int precision,
-                          const nufft_hip_options* opts_in, void* stream, char* errbuf,
-                          size_t errbuf_len) {
+static int create_common(nufft_hip_plan* out, int type, int rank, const int64_t* grid_dims,
+                         int iflag, int ntransf, double tol, int precision,
+                         const nufft_hip_options* opts_in, void* stream,
+                         const nufft_hip_allocator* allocator, bool host_only, char* errbuf,
+                         size_t errbuf_len) {
   auto fail = [&](int code, const std::string& msg) {
     if (errbuf && errbuf_len) snprintf(errbuf, errbuf_len, "%s", msg.c_str());
     if (out) *out = nullptr;
@@ -920,12 +1027,17 @@ int nufft_hip_plan_create(nufft_hip_plan* out, int type, int rank, const int64_t
   std::string msg;
   int rc0 = configure(&p, type, rank, grid_dims, iflag, ntransf, tol, precision, opts_in, stream, &msg);
   if (rc0) return fail(rc0, msg);
+  if (host_only) {
+    p->host_only = true;
+    *out = p;
+    return NUFFT_HIP_OK;
+  }
+  if (allocator && allocator->alloc) p->allocator = *allocator;
   if (hipGetDevice(&p->device) != hipSuccess) {
     delete p;
     (void)hipGetLastError();
     return fail(NUFFT_HIP_INTERNAL, "no HIP device available (this library has no CPU fallback)");
   }
-  Geom& g = p->g;
   // device code first (see preload_device_code), then device state
   if (const hipError_t pe = preload_device_code(); pe != hipSuccess) {
     const std::string m = format("loading the device code failed: %s", hipGetErrorString(pe));
@@ -934,25 +1046,63 @@ int nufft_hip_plan_create(nufft_hip_plan* out, int type, int rank, const int64_t
     return fail(NUFFT_HIP_INTERNAL, m);
   }
   int rc = precision == NUFFT_HIP_F32 ? upload_tables<float>(p) : upload_tables<double>(p);
-  if (!rc) rc = dev_alloc(p, (void**)&p->tile_count, sizeof(int32_t) * (size_t)g.ntiles);
-  if (!rc) rc = dev_alloc(p, (void**)&p->tile_start, sizeof(int32_t) * ((size_t)g.ntiles + 1));
-  if (!rc) rc = dev_alloc(p, (void**)&p->sub_start, sizeof(int32_t) * ((size_t)g.ntiles + 1));
-  if (!rc) rc = dev_alloc(p, (void**)&p->bad_count, sizeof(int32_t) * 4);
-  if (!rc && !p->opts.spread_only)
-    rc = dev_alloc(p, &p->d_fine, (size_t)precision * 2 * (size_t)p->fine_elems * p->batch_size);
   if (!rc && !p->opts.spread_only) {
-    rocfft_plan dummy;
-    rc = get_fft_plan(p, p->batch_size, &dummy);
+    // the FFT of full batches and of the remainder batch, so that execute never plans
+    rc = build_fft_plan(p, p->batch_size);
+    if (!rc) rc = build_fft_plan(p, p->ntransf % p->batch_size);
   }
+  // internal allocation: the fixed workspace now, so that nothing allocates after warm-up;
+  // a framework allocator is asked at the first set_points (its memory is per call)
+  if (!rc && !p->allocator.alloc) rc = ensure_fixed_workspace(p);
   if (rc) {
-    const std::string msg = p->err;
+    const std::string msg2 = p->err;
     destroy(p);
-    return fail(rc, msg);
+    return fail(rc, msg2);
   }
   *out = p;
   return NUFFT_HIP_OK;
 }
 
+int nufft_hip_plan_create(nufft_hip_plan* out, int type, int rank, const int64_t* grid_dims,
+                          int iflag, int ntransf, double tol, int precision,
+                          const nufft_hip_options* opts_in, void* stream, char* errbuf,
+                          size_t errbuf_len) {
+  return create_common(out, type, rank, grid_dims, iflag, ntransf, tol, precision, opts_in, stream,
+                       nullptr, false, errbuf, errbuf_len);
+}
+
+int nufft_hip_plan_create_ex(nufft_hip_plan* out, int type, int rank, const int64_t* grid_dims,
+                             int iflag, int ntransf, double tol, int precision,
+                             const nufft_hip_options* opts_in, void* stream,
+                             const nufft_hip_allocator* allocator, char* errbuf, size_t errbuf_len) {
+  return create_common(out, type, rank, grid_dims, iflag, ntransf, tol, precision, opts_in, stream,
+                       allocator, false, errbuf, errbuf_len);
+}
+
+int nufft_hip_plan_create_host(nufft_hip_plan* out, int type, int rank, const int64_t* grid_dims,
+                               int iflag, int ntransf, double tol, int precision,
+                               const nufft_hip_options* opts_in, char* errbuf, size_t errbuf_len) {
+  return create_common(out, type, rank, grid_dims, iflag, ntransf, tol, precision, opts_in, nullptr,
+                       nullptr, true, errbuf, errbuf_len);
+}
+
+int nufft_hip_plan_release_workspace(nufft_hip_plan p) {
+  if (!p || p->host_only) return NUFFT_HIP_INVALID_ARGUMENT;
+  if (!p->allocator.alloc) HIP_TRY(p, hipStreamSynchronize(p->stream));
+  release_workspace(p);
+  return NUFFT_HIP_OK;
+}
+
+int nufft_hip_plan_set_allocator(nufft_hip_plan p, const nufft_hip_allocator* allocator) {
+  if (!p || p->host_only) return NUFFT_HIP_INVALID_ARGUMENT;
+  if (p->fixed_ws || p->rec || p->rec2 || p->hist || p->tile_of) {
+    p->err = "set_allocator: the plan still holds workspace (call nufft_hip_plan_release_workspace first)";
+    return NUFFT_HIP_INVALID_ARGUMENT;
+  }
+  if (allocator && allocator->alloc) p->allocator = *allocator;
+  else p->allocator = {nullptr, nullptr, nullptr};
+  return NUFFT_HIP_OK;
+}
 
 int nufft_hip_plan_describe(int type, int rank, const int64_t* grid_dims, int iflag, int ntransf,
                             double tol, int precision, const nufft_hip_options* opts,
@@ -972,6 +1122,10 @@ int nufft_hip_plan_describe(int type, int rank, const int64_t* grid_dims, int if
 int nufft_hip_set_points(nufft_hip_plan p, int64_t M, const void* x, const void* y, const void* z,
                          int64_t stride) {
   if (!p) return NUFFT_HIP_INVALID_ARGUMENT;
+  if (p->host_only) {
+    p->err = "this plan was created host-only (no device state)";
+    return NUFFT_HIP_INVALID_ARGUMENT;
+  }
   if (M < 0 || M > kMaxArraySize) {
     p->err = format("invalid number of points %lld", (long long)M);
     return NUFFT_HIP_INVALID_ARGUMENT;
@@ -985,8 +1139,55 @@ int nufft_hip_set_points(nufft_hip_plan p, int64_t M, const void* x, const void*
                                        : set_points_impl<double>(p, M, x, y, z, stride);
 }
 
-int nufft_hip_execute(nufft_hip_plan p, void* c, void* f) {
+#define NUFFT_REQUIRE_DEVICE_PLAN(p)                                        \
+  do {                                                                      \
+    if (!(p)) return NUFFT_HIP_INVALID_ARGUMENT;                            \
+    if ((p)->host_only) {                                                   \
+      (p)->err = "this plan was created host-only (no device state)";      \
+      return NUFFT_HIP_INVALID_ARGUMENT;                                    \
+    }                                                                       \
+  } while (0)
+
+int nufft_hip_execute_with_points(nufft_hip_plan p, int64_t M, const void* x, const void* y,
+                                  const void* z, int64_t stride, void* c, void* f) {
+  NUFFT_REQUIRE_DEVICE_PLAN(p);
+  if (M < 0 || M > kMaxArraySize) {
+    p->err = format("invalid number of points %lld", (long long)M);
+    return NUFFT_HIP_INVALID_ARGUMENT;
+  }
+  if (M > 0 && (!x || (p->rank > 1 && !y) || (p->rank > 2 && !z))) {
+    p->err = "null points pointer";
+    return NUFFT_HIP_INVALID_ARGUMENT;
+  }
+  if (stride < 1) stride = 1;
+  const bool type1 = p->type == NUFFT_HIP_TYPE_1;
+  // one type-1 transform: the sort can carry the strengths inside the records
+  const bool fuse = type1 && p->ntransf == 1 && p->precision == NUFFT_HIP_F32 && c &&
+                    fused_sort_supported(p->g, p->method, p->precision, M);
+  int rc = p->precision == NUFFT_HIP_F32 ? set_points_impl<float>(p, M, x, y, z, stride, fuse ? c : nullptr)
+                                         : set_points_impl<double>(p, M, x, y, z, stride);
+  if (rc) return rc;
+  if (p->opts.spread_only)
+    rc = p->precision == NUFFT_HIP_F32 ? spread_interp_impl<float>(p, type1 ? 1 : 2, c, f)
+                                       : spread_interp_impl<double>(p, type1 ? 1 : 2, c, f);
+  else
+    rc = p->precision == NUFFT_HIP_F32 ? execute_impl<float>(p, c, f) : execute_impl<double>(p, c, f);
+  if (fuse) {   // the records hold THESE strengths: the points are consumed
+    p->points_set = false;
+    p->fused = false;
+    p->g.fused = 0;
+  }
+  return rc;
+}
+
+int nufft_hip_debug_stop_after(nufft_hip_plan p, int stage) {
   if (!p) return NUFFT_HIP_INVALID_ARGUMENT;
+  p->stop_after = stage;
+  return NUFFT_HIP_OK;
+}
+
+int nufft_hip_execute(nufft_hip_plan p, void* c, void* f) {
+  NUFFT_REQUIRE_DEVICE_PLAN(p);
   if (p->opts.spread_only) {
     p->err = "execute is not available on a spread_only plan";
     return NUFFT_HIP_INVALID_ARGUMENT;
@@ -995,13 +1196,13 @@ int nufft_hip_execute(nufft_hip_plan p, void* c, void* f) {
 }
 
 int nufft_hip_spread(nufft_hip_plan p, const void* c, void* f) {
-  if (!p) return NUFFT_HIP_INVALID_ARGUMENT;
+  NUFFT_REQUIRE_DEVICE_PLAN(p);
   return p->precision == NUFFT_HIP_F32 ? spread_interp_impl<float>(p, 1, const_cast<void*>(c), f)
                                        : spread_interp_impl<double>(p, 1, const_cast<void*>(c), f);
 }
 
 int nufft_hip_interp(nufft_hip_plan p, void* c, const void* f) {
-  if (!p) return NUFFT_HIP_INVALID_ARGUMENT;
+  NUFFT_REQUIRE_DEVICE_PLAN(p);
   return p->precision == NUFFT_HIP_F32 ? spread_interp_impl<float>(p, 2, c, const_cast<void*>(f))
                                        : spread_interp_impl<double>(p, 2, c, const_cast<void*>(f));
 }
@@ -1024,7 +1225,7 @@ int nufft_hip_plan_get_info(nufft_hip_plan p, nufft_hip_plan_info* info) {
 }
 
 int nufft_hip_plan_set_stream(nufft_hip_plan p, void* stream) {
-  if (!p) return NUFFT_HIP_INVALID_ARGUMENT;
+  if (!p || p->host_only) return NUFFT_HIP_INVALID_ARGUMENT;
   p->stream = (hipStream_t)stream;
   if (p->fft_info) FFT_TRY(p, rocfft_execution_info_set_stream(p->fft_info, p->stream));
   return NUFFT_HIP_OK;
@@ -1037,7 +1238,7 @@ int nufft_hip_plan_set_timing(nufft_hip_plan p, int enable) {
 }
 
 int nufft_hip_plan_get_timing(nufft_hip_plan p, double* ms, int32_t* calls, int n) {
-  if (!p) return NUFFT_HIP_INVALID_ARGUMENT;
+  if (!p || p->host_only) return NUFFT_HIP_INVALID_ARGUMENT;
   HIP_TRY(p, hipStreamSynchronize(p->stream));
   for (auto& pe : p->pending) {
     float t = 0.f;
@@ -1068,6 +1269,14 @@ int nufft_hip_debug_fine_grid(nufft_hip_plan p, void** fine, int64_t* count) {
   if (!p || !fine || !count) return NUFFT_HIP_INVALID_ARGUMENT;
   *fine = p->d_fine;
   *count = p->fine_elems * p->batch_size;
+  return NUFFT_HIP_OK;
+}
+
+int nufft_hip_debug_copy_fine_grid(nufft_hip_plan p, void* dst, int64_t count) {
+  if (!p || p->host_only || !dst || !p->d_fine || count < 0 || count > p->fine_elems * p->batch_size)
+    return NUFFT_HIP_INVALID_ARGUMENT;
+  HIP_TRY(p, hipMemcpyAsync(dst, p->d_fine, (size_t)count * 2 * (size_t)p->precision, hipMemcpyDeviceToDevice,
+                            p->stream));
   return NUFFT_HIP_OK;
 }
 

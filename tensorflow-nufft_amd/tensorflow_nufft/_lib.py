@@ -19,7 +19,7 @@ TYPE_1, TYPE_2 = 1, 2
 FORWARD, BACKWARD = -1, 1
 F32, F64 = 4, 8
 OP_NUFFT, OP_INTERP, OP_SPREAD = 0, 1, 2
-METHOD_AUTO, METHOD_TILE_GENERIC, METHOD_TILE_WAVE = 0, 1, 2
+METHOD_AUTO, METHOD_TILE_GENERIC, METHOD_TILE_WAVE, METHOD_POINT_GLOBAL = 0, 1, 2, 3
 STAGES = ('sort_count', 'sort_scan', 'sort_scatter', 'zero', 'spread', 'fft', 'deconvolve', 'interp', 'sort_cell')
 
 
@@ -66,6 +66,15 @@ class PlanInfo(ctypes.Structure):
                ('num_points', ctypes.c_int64), ('workspace_bytes', ctypes.c_int64)])
 
 
+ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
+FREE_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p)
+
+
+class Allocator(ctypes.Structure):
+  """nufft_hip_allocator: device-memory callbacks of the host framework."""
+  _fields_ = [('alloc', ALLOC_FN), ('free', FREE_FN), ('user', ctypes.c_void_p)]
+
+
 class OpDesc(ctypes.Structure):
   _fields_ = [('op_type', ctypes.c_int32), ('transform_type', ctypes.c_int32),
               ('fft_direction', ctypes.c_int32), ('precision', ctypes.c_int32),
@@ -86,6 +95,21 @@ SYMBOLS = {
         ctypes.POINTER(ctypes.c_int64), ctypes.c_int, ctypes.c_int, ctypes.c_double,
         ctypes.c_int, ctypes.POINTER(OptionsStruct), ctypes.c_void_p,
         ctypes.c_char_p, ctypes.c_size_t]),
+    'nufft_hip_plan_create_ex': (ctypes.c_int, [
+        ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int,
+        ctypes.POINTER(ctypes.c_int64), ctypes.c_int, ctypes.c_int, ctypes.c_double,
+        ctypes.c_int, ctypes.POINTER(OptionsStruct), ctypes.c_void_p,
+        ctypes.POINTER(Allocator), ctypes.c_char_p, ctypes.c_size_t]),
+    'nufft_hip_plan_create_host': (ctypes.c_int, [
+        ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int,
+        ctypes.POINTER(ctypes.c_int64), ctypes.c_int, ctypes.c_int, ctypes.c_double,
+        ctypes.c_int, ctypes.POINTER(OptionsStruct), ctypes.c_char_p, ctypes.c_size_t]),
+    'nufft_hip_plan_release_workspace': (ctypes.c_int, [ctypes.c_void_p]),
+    'nufft_hip_plan_set_allocator': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Allocator)]),
+    'nufft_hip_execute_with_points': (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
+    'nufft_hip_debug_stop_after': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     'nufft_hip_set_points': (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
         ctypes.c_void_p, ctypes.c_int64]),
@@ -105,6 +129,7 @@ SYMBOLS = {
     'nufft_hip_plan_destroy': (ctypes.c_int, [ctypes.c_void_p]),
     'nufft_hip_debug_fine_grid': (ctypes.c_int, [
         ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64)]),
+    'nufft_hip_debug_copy_fine_grid': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]),
     'nufft_hip_debug_fseries': (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.c_int64]),
     'nufft_hip_debug_eval_kernel': (ctypes.c_int, [
@@ -116,7 +141,12 @@ SYMBOLS = {
     'nufft_hip_op_compute': (ctypes.c_int, [
         ctypes.POINTER(OpDesc), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
         ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]),
+    'nufft_hip_op_compute_ex': (ctypes.c_int, [
+        ctypes.POINTER(OpDesc), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.POINTER(Allocator), ctypes.c_char_p, ctypes.c_size_t]),
     'nufft_hip_op_clear_cache': (None, []),
+    'nufft_hip_op_set_cache_limit': (None, [ctypes.c_int64]),
+    'nufft_hip_op_cache_bytes': (ctypes.c_int64, []),
 }
 
 _lib = None

@@ -16,18 +16,25 @@ class Plan:
 
   def __init__(self, transform_type, grid_shape, fft_direction='forward', num_transforms=1,
                tol=1e-6, dtype=torch.complex64, options=None, device=None, spread_only=False,
-               **internal):
+               host_only=False, allocator=None, **internal):
+    """host_only: every parameter rule and table, no device state (works without a GPU;
+    info / fseries / eval_kernel only). allocator: a `_lib.Allocator` for the workspace."""
     self._handle = None
     self.lib = _lib.lib()
+    self.host_only = bool(host_only)
+    self._allocator = allocator   # keep the callbacks alive
     self.rank = len(grid_shape)
     self.grid_shape = [int(g) for g in grid_shape]
     self.type = transform_type
     self.ntransf = int(num_transforms)
     self.cdtype = dtype
     self.rdtype = torch.float32 if dtype == torch.complex64 else torch.float64
-    self.device = torch.device(device if device is not None else 'cuda')
-    if self.device.index is None:
-      self.device = torch.device('cuda', torch.cuda.current_device())
+    if host_only:
+      self.device = None
+    else:
+      self.device = torch.device(device if device is not None else 'cuda')
+      if self.device.index is None:
+        self.device = torch.device('cuda', torch.cuda.current_device())
     o = _options_struct(options)
     o.spread_only = int(spread_only)
     for k, v in internal.items():
@@ -40,12 +47,17 @@ class Plan:
                                   [1] * (3 - self.rank)))
     err = ctypes.create_string_buffer(1024)
     h = ctypes.c_void_p()
-    with torch.cuda.device(self.device):
-      stream = torch.cuda.current_stream(self.device).cuda_stream
-      rc = self.lib.nufft_hip_plan_create(
-          ctypes.byref(h), 1 if transform_type == 'type_1' else 2, self.rank, dims,
-          -1 if fft_direction == 'forward' else 1, self.ntransf, float(tol),
-          4 if dtype == torch.complex64 else 8, ctypes.byref(o), ctypes.c_void_p(stream), err, len(err))
+    args = (1 if transform_type == 'type_1' else 2, self.rank, dims,
+            -1 if fft_direction == 'forward' else 1, self.ntransf, float(tol),
+            4 if dtype == torch.complex64 else 8, ctypes.byref(o))
+    if host_only:
+      rc = self.lib.nufft_hip_plan_create_host(ctypes.byref(h), *args, err, len(err))
+    else:
+      with torch.cuda.device(self.device):
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = self.lib.nufft_hip_plan_create_ex(
+            ctypes.byref(h), *args, ctypes.c_void_p(stream),
+            ctypes.byref(allocator) if allocator is not None else None, err, len(err))
     _lib.raise_for_status(rc, err.value)
     self._handle = h
     self.M = 0
@@ -87,6 +99,69 @@ class Plan:
       c, f = out, source
     with torch.cuda.device(self.device):
       self._check(self.lib.nufft_hip_execute(self._handle, c.data_ptr(), f.data_ptr()))
+    return out
+
+  def execute_with_points(self, points, source, out=None):
+    """set_points + execute as one call (what a NUFFT op invocation does); a type-1 plan
+    with one transform sorts the strengths along with the points. The points are consumed."""
+    points = points.to(self.device, self.rdtype).contiguous()
+    assert points.dim() == 2 and points.shape[1] == self.rank
+    source = source.to(self.device, self.cdtype).contiguous()
+    self._points = points
+    self.M = points.shape[0]
+    lead = [self.ntransf] if self.ntransf > 1 else []
+    if self.type == 'type_1':
+      if out is None:
+        out = torch.empty(lead + self.grid_shape, dtype=self.cdtype, device=self.device)
+      c, f = source, out
+    else:
+      if out is None:
+        out = torch.empty(lead + [self.M], dtype=self.cdtype, device=self.device)
+      c, f = out, source
+    es = points.element_size()
+    base = points.data_ptr()
+    r = self.rank
+    with torch.cuda.device(self.device):
+      self._check(self.lib.nufft_hip_execute_with_points(
+          self._handle, self.M, base + (r - 1) * es,
+          base + (r - 2) * es if r > 1 else None,
+          base + (r - 3) * es if r > 2 else None, r, c.data_ptr(), f.data_ptr()))
+    return out
+
+  def stop_after(self, stage):
+    """Debug: execute returns after the named stage ('spread', 'fft', 'deconvolve'); None = run all."""
+    self._check(self.lib.nufft_hip_debug_stop_after(
+        self._handle, -1 if stage is None else _lib.STAGES.index(stage)))
+
+  def fine_grid(self):
+    """Debug: the plan's fine grid [batch, nf...] (array order) as a tensor view copy."""
+    i = self.info()
+    shape = [i.batch_size] + [int(i.fine_dims[self.rank - 1 - d]) for d in range(self.rank)]
+    out = torch.empty(shape, dtype=self.cdtype, device=self.device)
+    with torch.cuda.device(self.device):
+      self._check(self.lib.nufft_hip_debug_copy_fine_grid(self._handle, out.data_ptr(), out.numel()))
+    return out
+
+  def fseries(self, dim):
+    """The kernel's Fourier series phi-hat[0..nf/2] of grid dimension `dim` (array order), float64."""
+    import numpy as np
+    i = self.info()
+    d = self.rank - 1 - dim
+    n = int(i.fine_dims[d]) // 2 + 1
+    out = np.zeros(n)
+    self._check(self.lib.nufft_hip_debug_fseries(
+        self._handle, d, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), n))
+    return out
+
+  def eval_kernel(self, x1):
+    """Host evaluation of the plan's piecewise polynomial at offsets x1 in [-w/2, -w/2+1]: [n, w]."""
+    import numpy as np
+    x1 = np.ascontiguousarray(x1, dtype=np.float64)
+    w = int(self.info().kernel_width)
+    out = np.zeros((x1.size, w))
+    self._check(self.lib.nufft_hip_debug_eval_kernel(
+        self._handle, x1.size, x1.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+        out.ctypes.data_as(ctypes.POINTER(ctypes.c_double))))
     return out
 
   def spread(self, c, out=None):
