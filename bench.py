@@ -1,28 +1,40 @@
 #!/usr/bin/env python3
-"""Headline benchmark: BASELINE.json `configs[1]` -- 2D type-1 NUFFT, 1024 x 1024
-modes, M = 1e7 random points, tol = 1e-6, fp32, on MI355X.
+"""Benchmark of the NUFFT hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one batch of synthetic input already
-resident in HBM: `set_points` (fold + tile sort) followed by `execute`
-(spread -> rocFFT -> deconvolve) on a plan that is reused across steps, i.e.
-what one `tfft.nufft(source, points, grid_shape, 'type_1')` call costs once its
-plan is cached. With N > 1 (launched by torch.distributed.run, one rank per
-GPU) every rank runs the same workload on its own points/strengths -- the
-transforms of a batch are independent, so the path shards with no data-path
-collective ("weak" scaling); RCCL is used only for the barrier and the
-max-over-ranks time.
+N = 1 (default): BASELINE.json `configs[1]`, the configuration the metric is
+  quoted on -- 2D type-1 NUFFT, 1024 x 1024 modes, M = 1e7 random points,
+  tol = 1e-6, complex64. A "step" is one pass of the hot path over one batch of
+  synthetic input already resident in HBM: what one
+  `tfft.nufft(source, points, grid_shape, 'type_1')` call runs once its plan is
+  cached, i.e. `nufft_hip_execute_with_points` = fold + tile sort (the strengths
+  travel inside the sorted records) -> spread -> rocFFT -> deconvolve.
+N > 1: BASELINE.json `configs[4]`, the configuration north_star shards --
+  batched 2D type-1, 512 x 512, batch = 256 items of M = 1e6 points each,
+  complex64, split over the N ranks in contiguous blocks
+  (`tensorflow_nufft.sharding.shard_bounds`); every rank runs its block through
+  `tfft.nufft` (one op call = its items' set_points + execute calls). The items
+  are independent, so there is no data-path collective; RCCL carries the barrier,
+  the max-over-ranks time and the optional result all_gather (reported beside the
+  headline, never inside it). Total work is fixed at 256 items ("strong").
+
+When `--gpus N` > 1 and the process was not started by torch.distributed.run
+(no WORLD_SIZE in the environment), bench.py starts the N ranks itself as child
+processes BEFORE anything touches the GPU, one device each, and exits with their
+status.
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  roofline      dominant kernel (spread) against the HBM roofline, from HIP
-                events recorded on the plan's stream inside the timed region
+  roofline      the dominant kernel (spread) against the HBM roofline, timed with
+                HIP events on the plan's stream inside the timed region, and
+                `roofline.lds`: the same launches against the LDS-atomic pipe
   cpu_baseline  the CPU oracle (a port of the reference CPU path, NOT the
-                upstream binary) timed on this host's cores, rank 0 at N = 1
+                upstream binary) on this host's cores, rank 0 at N = 1
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -30,13 +42,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tensorflow-nufft_amd'))
 
-import numpy as np   # noqa: E402
-import torch         # noqa: E402
-
 GRID = [1024, 1024]
 M = 10_000_000
 TOL = 1e-6
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
+C5_GRID = [512, 512]
+C5_ITEMS = 256
+C5_M = 1_000_000
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
+LDS_ADD_F64_CYCLES = 8.6   # cycles per ds_add_f64 wave-instruction per CU, conflict free (profiles/r01_lds_atomic_ubench.txt)
+NUM_CUS = 256
+CLOCK_GHZ = 2.4
 
 
 def algorithmic_spread_bytes(m, nf, rank):
@@ -57,49 +72,109 @@ def pmc_traffic(kernel_name, m):
   under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs,
   corrected as MI355X_MICROARCH.md prescribes: 2*FETCH_SIZE + WRITE_SIZE).
   bench.py cannot run the profiler on itself, so the figure is the one measured
-  offline for the same kernel and point count; None when it does not apply."""
+  offline for the same kernel and point count (`traffic_source` says so); None
+  when it does not apply."""
   try:
     d = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_spread_traffic.json')))
     if d.get('points') == m and kernel_name in d.get('kernel', ''):
-      return int(d['traffic_bytes_corrected'])
-  except (OSError, ValueError):
+      return int(d['traffic_bytes_corrected']), d.get('source', 'profiles/pmc_spread_traffic.json')
+  except (OSError, ValueError, KeyError):
     pass
-  return None
+  return None, None
 
 
 def cpu_baseline(args):
-  """Times the CPU oracle on a bounded sample of the same workload."""
+  """Times the CPU oracle (port of the reference CPU path) on a bounded sample of the
+  same workload: median of >= 5 runs after a warm-up, full transform and spreader
+  alone, over a few OpenMP thread counts (the best median is reported)."""
+  import numpy as np
   from oracle import oracle
   cores = os.cpu_count() or 1
   m = args.cpu_points
   rng = np.random.default_rng(2)
   pts = rng.uniform(-np.pi, np.pi, (m, 2)).astype(np.float32)
   c = (rng.uniform(-.5, .5, m) + 1j * rng.uniform(-.5, .5, m)).astype(np.complex64)
+  tol = float(np.float32(TOL))
   # reference CPU rule for this config: sigma = 1.25, w = 10 (SURVEY.md section 8),
-  # float arithmetic, own piecewise-polynomial kernel (kerevalmeth 1), all cores
-  # OpenMP thread counts to try: all hardware threads, the physical cores of a
-  # 2-way SMT part, and a NUMA-friendly 64 / 32; the best one is reported.
+  # float arithmetic, piecewise-polynomial kernel (kerevalmeth 1). Above 10 threads the
+  # subgrids merge with atomics, below under a critical section (nufft_plan.cc:1109-1114).
   cand = sorted({cores, max(1, cores // 2), min(cores, 64), min(cores, 32)}, reverse=True)
-  best, best_threads, total, runs = float('inf'), cores, 0.0, 0
+  budget = time.perf_counter() + 40.0
+  best = None
   for nt in cand:
-    for _ in range(2):
-      if total > 30.0:
-        break
+    full, spread = [], []
+    oracle.nufft(c, pts, GRID, 'type_1', 'forward', tol=TOL, kerevalmeth=1, nthreads=nt)   # warm-up
+    for _ in range(5):
       t0 = time.perf_counter()
       oracle.nufft(c, pts, GRID, 'type_1', 'forward', tol=TOL, kerevalmeth=1, nthreads=nt)
-      dt = time.perf_counter() - t0
-      total += dt
-      runs += 1
-      if dt < best:
-        best, best_threads = dt, nt
-  cores = best_threads
-  sigma, w, _, nf = oracle.query(2, GRID, float(np.float32(TOL)), 'f32')
+      full.append(time.perf_counter() - t0)
+      spread.append(oracle.time_spread(c, pts, GRID, tol=tol, sigma=0.0, kerevalmeth=1, nthreads=nt))
+    med_full, med_spread = float(np.median(full)), float(np.median(spread))
+    if best is None or med_full < best[0]:
+      best = (med_full, med_spread, nt, sorted(full))
+    if time.perf_counter() > budget:
+      break
+  med_full, med_spread, nt, runs = best
+  sigma, w, _, nf = oracle.query(2, GRID, tol, 'f32')
   return {
-      'value': round(m / best / 1e6, 3), 'unit': 'Mpts/s', 'cores': cores, 'kind': 'port',
-      'sample': f'full type-1 transform (sort+spread+FFT+deconvolve) of {m} of the {M} points on the '
-                f'same 1024x1024 grid, reference CPU rule sigma={sigma} w={w} fine grid {nf[0]}x{nf[1]}, '
-                f'fp32, best of {runs} runs over thread counts {cand}: {cores} OpenMP threads, {best:.2f} s',
+      'value': round(m / med_full / 1e6, 3), 'unit': 'Mpts/s', 'cores': nt, 'kind': 'port',
+      'spread_only_Mpts_s': round(m / med_spread / 1e6, 3),
+      'sample': f'{m} of the {M} points on the same 1024x1024 grid, reference CPU rule sigma={sigma} w={w} '
+                f'fine grid {nf[0]}x{nf[1]}, fp32; value = full type-1 transform (sort + spread + FFT + '
+                f'deconvolve), spread_only = the spreader on pre-sorted points; median of 5 runs after a '
+                f'warm-up at the best of the thread counts {cand}: {nt} OpenMP threads of {cores} hardware '
+                f'threads; full-transform runs {[round(r, 3) for r in runs]} s',
   }
+
+
+def lds_roofline(pts, info, spread_ms):
+  """The spread launches against the LDS-atomic pipe: ds_add_f64 wave-instructions per
+  launch / kernel time, against CUs x clock / 8.6 cycles. The cell-grouped kernel issues
+  one (re, im) pair per run of points sharing a stencil start cell; the runs are counted
+  here from the points (distinct start cells + the forced run ends every 32 staged
+  points), not assumed."""
+  import numpy as np
+  import torch
+  nf = [int(info.fine_dims[1]), int(info.fine_dims[0])]
+  w = int(info.kernel_width)
+  p = pts.to(torch.float64)
+  keys = None
+  for d in range(2):
+    xs = (p[:, d] + np.pi) * (nf[d] / (2 * np.pi))
+    i0 = torch.ceil(xs - w / 2).to(torch.int64) % nf[d]
+    keys = i0 if keys is None else keys * nf[d] + i0
+  groups = int(torch.unique(keys).numel())
+  m = pts.shape[0]
+  groups += (m - groups) // 32      # a run also ends where the 32-point staging block ends
+  instr = 2.0 * groups
+  peak = NUM_CUS * CLOCK_GHZ * 1e9 / LDS_ADD_F64_CYCLES
+  achieved = instr / (spread_ms * 1e-3)
+  return {
+      'bound': 'lds-atomic', 'achieved': round(achieved / 1e9, 2), 'peak': round(peak / 1e9, 2),
+      'unit': 'G wave-instr/s (ds_add_f64)', 'frac': round(achieved / peak, 4),
+      'atomics_per_point': round(instr / m, 3),
+      'note': 'peak = 256 CUs x 2.4 GHz / 8.6 cycles per conflict-free ds_add_f64 wave-instruction '
+              '(tools/ubench/lds_atomic_bench.hip); achieved counts only the atomics, the same pipe also '
+              'serves 0.75 ds_read_b128 + 0.375 ds_write_b32 wave-instructions per point',
+  }
+
+
+def spawn_ranks(args, argv):
+  """--gpus N > 1 without a launcher: one child process per rank, started before any GPU
+  call in this process (a process that touched the GPU must not exec or fork workers)."""
+  port = int(os.environ.get('MASTER_PORT', '29533'))
+  procs = []
+  for r in range(args.gpus):
+    env = dict(os.environ)
+    env.update({'RANK': str(r), 'LOCAL_RANK': str(r), 'WORLD_SIZE': str(args.gpus),
+                'LOCAL_WORLD_SIZE': str(args.gpus), 'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port),
+                'HSA_ENABLE_IPC_MODE_LEGACY': os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0')})
+    procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+  rc = 0
+  for p in procs:
+    p.wait()
+    rc = rc or p.returncode
+  return rc
 
 
 def main():
@@ -109,15 +184,22 @@ def main():
   ap.add_argument('--warmup', type=int, default=5)
   ap.add_argument('--points', type=int, default=M)
   ap.add_argument('--cpu-points', type=int, default=M)
+  ap.add_argument('--items', type=int, default=C5_ITEMS, help='batch size of the sharded workload (N > 1)')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-extras', action='store_true',
-                  help='skip the informational two-stream leg (used under rocprofv3 so that its per-kernel '
-                       'average covers single-stream launches only)')
+                  help='skip the informational legs (used under rocprofv3 so that its per-kernel '
+                       'average covers the timed launches only)')
   ap.add_argument('--dist-backend', default='nccl', help='nccl (= RCCL, default) | gloo (testing)')
   ap.add_argument('--device', type=int, default=None, help='force a device index (testing)')
   ap.add_argument('--force-dist', action='store_true', help='initialise torch.distributed even at world size 1 (testing)')
+  ap.add_argument('--workload', default='auto', help='auto | config2 | config5 (testing: config5 on one GPU)')
   args = ap.parse_args()
 
+  if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+    sys.exit(spawn_ranks(args, sys.argv[1:]))
+
+  import numpy as np
+  import torch
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -138,11 +220,46 @@ def main():
       dist.init_process_group('nccl', device_id=dev)   # "nccl" is RCCL on ROCm
     else:
       dist.init_process_group(args.dist_backend)
+  workload = args.workload
+  if workload == 'auto':
+    workload = 'config5' if world > 1 else 'config2'
+  if workload == 'config5':
+    result = run_config5(args, dev, dist, world, rank)
+  else:
+    result = run_config2(args, dev, dist, world, rank)
+  if rank == 0:
+    print(json.dumps(result), flush=True)
+  if dist is not None:
+    dist.destroy_process_group()
 
+
+def timed(fn, steps, dist, dev, backend):
+  """EXACTLY `steps` calls of fn bracketed by barrier + synchronize; max over ranks."""
+  import torch
+  if dist is not None:
+    dist.barrier()
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(steps):
+    fn()
+  torch.cuda.synchronize()
+  if dist is not None:
+    dist.barrier()
+  elapsed = time.perf_counter() - t0
+  if dist is not None:
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+  return elapsed
+
+
+def run_config2(args, dev, dist, world, rank):
+  import numpy as np
+  import torch
   import tensorflow_nufft as tfft
   m = args.points
   # synthetic inputs (BASELINE.md section 3, config 2): points ~ U(-pi, pi)^2,
-  # strengths ~ U(-.5,.5) + i U(-.5,.5); seed 2 (+rank so shards differ)
+  # strengths ~ U(-.5,.5) + i U(-.5,.5); seed 2 (+rank so replicas differ)
   g = torch.Generator(device=dev).manual_seed(2 + rank)
   pts = (torch.rand((m, 2), generator=g, device=dev) * 2 - 1) * np.pi
   c = torch.complex(torch.rand(m, generator=g, device=dev) - .5,
@@ -152,8 +269,7 @@ def main():
   out = torch.empty(GRID, dtype=torch.complex64, device=dev)
 
   def step():
-    plan.set_points(pts)
-    plan.execute(c, out=out)
+    plan.execute_with_points(pts, c, out=out)
 
   for _ in range(args.warmup):
     step()
@@ -167,93 +283,161 @@ def main():
   # on the plan's stream, i.e. the stream the kernel is launched on
   plan.set_timing(2)
   plan.get_timing()
-  if dist is not None:
-    dist.barrier()
-  torch.cuda.synchronize()
-  t0 = time.perf_counter()
-  for _ in range(args.steps):
-    step()
-  torch.cuda.synchronize()
-  if dist is not None:
-    dist.barrier()
-  elapsed = time.perf_counter() - t0
+  elapsed = timed(step, args.steps, dist, dev, args.dist_backend)
   stages = plan.get_timing()
-  if dist is not None:
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == 'nccl' else 'cpu')
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-
-  # exec-only rate (set_points amortised), same plan
   plan.set_timing(False)
-  torch.cuda.synchronize()
-  t1 = time.perf_counter()
-  for _ in range(args.steps):
-    plan.execute(c, out=out)
-  torch.cuda.synchronize()
-  exec_only = (time.perf_counter() - t1) / args.steps
 
-  # informational: two independent transforms in flight on two streams (the sort is
-  # memory-bound, the spread LDS-bound, so they overlap); NOT the headline value
-  two_stream = None
-  if world == 1 and not args.no_extras:
-    s2 = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
-    lanes = []
-    for st in s2:
-      with torch.cuda.stream(st):
-        lanes.append((tfft.Plan('type_1', GRID, 'forward', tol=TOL, dtype=torch.complex64, device=dev),
-                      torch.empty(GRID, dtype=torch.complex64, device=dev)))
-    def run2(n):
-      for i in range(n):
-        with torch.cuda.stream(s2[i % 2]):
-          lanes[i % 2][0].set_points(pts)
-          lanes[i % 2][0].execute(c, out=lanes[i % 2][1])
-    run2(4)
+  extras = {}
+  if not args.no_extras:
+    # the two-call form (set_points, then execute with the strengths gathered through the
+    # sort permutation) and the exec-only rate of a plan whose points stay set
+    def step2():
+      plan.set_points(pts)
+      plan.execute(c, out=out)
+    for _ in range(3):
+      step2()
     torch.cuda.synchronize()
-    t2 = time.perf_counter()
-    run2(args.steps)
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+      step2()
     torch.cuda.synchronize()
-    two_stream = m / ((time.perf_counter() - t2) / args.steps) / 1e6
-    for pl, _ in lanes:
-      pl.close()
+    extras['two_call_Mpts_s'] = round(m / ((time.perf_counter() - t1) / args.steps) / 1e6, 2)
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+      plan.execute(c, out=out)
+    torch.cuda.synchronize()
+    extras['exec_only_Mpts_s'] = round(m / ((time.perf_counter() - t1) / args.steps) / 1e6, 2)
+    # the drop-in surface itself (op-level entry: validation, plan cache, fused call)
+    for _ in range(3):
+      tfft.nufft(c, pts, grid_shape=GRID, transform_type='type_1', tol=TOL)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+      tfft.nufft(c, pts, grid_shape=GRID, transform_type='type_1', tol=TOL)
+    torch.cuda.synchronize()
+    extras['tfft_nufft_Mpts_s'] = round(m / ((time.perf_counter() - t1) / args.steps) / 1e6, 2)
 
-  if rank == 0:
-    ms_per_step = elapsed / args.steps * 1e3
-    value = world * m / (elapsed / args.steps) / 1e6
-    nf = [int(info.fine_dims[1]), int(info.fine_dims[0])]
-    spread_ms = stages['spread'][0] / max(stages['spread'][1], 1)
-    algo = algorithmic_spread_bytes(m, nf, 2)
-    achieved = algo / (spread_ms * 1e-3) / 1e9
-    result = {
-        'metric': 'non-uniform pts/s, 2D type-1 1024^2 tol=1e-6 (set_points + execute)',
-        'value': round(value, 2), 'unit': 'Mpts/s', 'n_gpus': world, 'steps': args.steps,
-        'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {
-            'workload': 'BASELINE configs[1]: 2D type-1, 1024x1024 modes, M=1e7 uniform random points, '
-                        'tol=1e-6, complex64; per GPU one independent transform per step',
-            'points_per_gpu': m, 'grid': GRID, 'fine_grid': nf, 'kernel_width': int(info.kernel_width),
-            'upsampling_factor': info.upsampling_factor, 'spread_method': int(info.spread_method),
-            'exec_only_Mpts_s': round(m / exec_only / 1e6, 2),
-            'two_streams_Mpts_s': None if two_stream is None else round(two_stream, 2),
-            'stage_us': {k: round(v[0] / max(v[1], 1) * 1e3, 1) for k, v in stage_all.items() if v[1]},
-        },
-        'roofline': {
-            'bound': 'hbm', 'kernel': SPREAD_KERNEL, 'achieved': round(achieved, 1),
-            'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
-            'traffic': pmc_traffic(SPREAD_KERNEL, m), 'algorithmic_bytes': algo,
-            'kernel_ms': round(spread_ms, 4),
-            'note': 'the kernel is bound by the LDS pipe (per point 3/4 ds_read_b128 + ~0.8 ds_add_f64 after '
-                    'grouping points by start cell) plus its per-tile LDS sort, not by HBM: DESIGN.md section 4. '
-                    'traffic = offline PMC pass '
-                    '(profiles/r01_pmc_traffic.txt); the excess over algorithmic_bytes is the 8-byte strength '
-                    'gather through the sort permutation (one 64-B sector per random point)',
-        },
-    }
-    if world == 1 and not args.no_cpu_baseline:
-      result['cpu_baseline'] = cpu_baseline(args)
-    print(json.dumps(result))
-  if dist is not None:
-    dist.destroy_process_group()
+  if rank != 0:
+    return None
+  ms_per_step = elapsed / args.steps * 1e3
+  value = world * m / (elapsed / args.steps) / 1e6
+  nf = [int(info.fine_dims[1]), int(info.fine_dims[0])]
+  spread_ms = stages['spread'][0] / max(stages['spread'][1], 1)
+  algo = algorithmic_spread_bytes(m, nf, 2)
+  achieved = algo / (spread_ms * 1e-3) / 1e9
+  traffic, traffic_src = pmc_traffic(SPREAD_KERNEL, m)
+  result = {
+      'metric': 'non-uniform pts/s, 2D type-1 1024^2 tol=1e-6 (set_points + execute)',
+      'value': round(value, 2), 'unit': 'Mpts/s', 'n_gpus': world, 'steps': args.steps,
+      'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True,
+      'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+      'config': {
+          'workload': 'BASELINE configs[1]: 2D type-1, 1024x1024 modes, M=1e7 uniform random points, '
+                      'tol=1e-6, complex64; one transform per step through nufft_hip_execute_with_points '
+                      '(the call tfft.nufft makes)',
+          'points_per_gpu': m, 'grid': GRID, 'fine_grid': nf, 'kernel_width': int(info.kernel_width),
+          'upsampling_factor': info.upsampling_factor, 'spread_method': int(info.spread_method),
+          'stage_us': {k: round(v[0] / max(v[1], 1) * 1e3, 1) for k, v in stage_all.items() if v[1]},
+          **extras,
+      },
+      'roofline': {
+          'bound': 'hbm', 'kernel': SPREAD_KERNEL, 'achieved': round(achieved, 1),
+          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
+          'traffic': traffic, 'traffic_source': 'offline: ' + traffic_src if traffic else None,
+          'algorithmic_bytes': algo, 'kernel_ms': round(spread_ms, 4),
+          'lds': lds_roofline(pts, info, spread_ms),
+          'note': 'algorithmic bytes = M (4 d + 8) + 8 nf^d (SURVEY.md 8d). The kernel is bound by the LDS '
+                  'pipe and its per-tile phases, not by HBM (DESIGN.md section 4): roofline.lds is the bound '
+                  'that tracks it.',
+      },
+  }
+  if world == 1 and not args.no_cpu_baseline:
+    result['cpu_baseline'] = cpu_baseline(args)
+  return result
+
+
+def run_config5(args, dev, dist, world, rank):
+  import numpy as np
+  import torch
+  import tensorflow_nufft as tfft
+  from tensorflow_nufft import sharding
+  items, m = args.items, C5_M
+  lo, hi = sharding.shard_bounds(items, world, rank)
+  nloc = hi - lo
+  # per-item points; seed 5 (+ rank: every rank draws its own block)
+  g = torch.Generator(device=dev).manual_seed(5 + rank)
+  pts = (torch.rand((nloc, m, 2), generator=g, device=dev) * 2 - 1) * np.pi
+  c = torch.complex(torch.rand((nloc, m), generator=g, device=dev) - .5,
+                    torch.rand((nloc, m), generator=g, device=dev) - .5)
+
+  def transform(s, p):
+    return tfft.nufft(s, p, grid_shape=C5_GRID, transform_type='type_1', tol=TOL)
+
+  def step():
+    transform(c, pts)
+
+  for _ in range(args.warmup):
+    step()
+  elapsed = timed(step, args.steps, dist, dev, args.dist_backend)
+
+  extras = {}
+  if not args.no_extras:
+    # the same with the results all-gathered onto every rank (RCCL over xGMI at N > 1)
+    if dist is not None and args.dist_backend == 'nccl':
+      def step_gather():
+        sharding.gather_blocks(transform(c, pts), items)
+      for _ in range(2):
+        step_gather()
+      tg = timed(step_gather, args.steps, dist, dev, args.dist_backend)
+      extras['with_all_gather_Mpts_s'] = round(items * m / (tg / args.steps) / 1e6, 2)
+    # points shared by the whole batch: one sort, nloc transforms
+    shared = pts[0]
+    for _ in range(2):
+      transform(c, shared)
+    ts = timed(lambda: transform(c, shared), args.steps, dist, dev, args.dist_backend)
+    extras['shared_points_Mpts_s'] = round(items * m / (ts / args.steps) / 1e6, 2)
+    if world > 1 and rank == 0:
+      # the WHOLE 256-item job on this one GPU, for the scaling comparison on equal work
+      torch.cuda.synchronize()
+      g1 = torch.Generator(device=dev).manual_seed(105)
+      chunk = 32
+      pc = (torch.rand((chunk, m, 2), generator=g1, device=dev) * 2 - 1) * np.pi
+      cc = torch.complex(torch.rand((chunk, m), generator=g1, device=dev) - .5,
+                         torch.rand((chunk, m), generator=g1, device=dev) - .5)
+      def whole():
+        for _ in range(items // chunk):
+          transform(cc, pc)
+      whole()
+      torch.cuda.synchronize()
+      t1 = time.perf_counter()
+      for _ in range(3):
+        whole()
+      torch.cuda.synchronize()
+      extras['one_gpu_whole_job_Mpts_s'] = round(items * m / ((time.perf_counter() - t1) / 3) / 1e6, 2)
+    if dist is not None:
+      dist.barrier()
+
+  if rank != 0:
+    return None
+  ms_per_step = elapsed / args.steps * 1e3
+  value = items * m / (elapsed / args.steps) / 1e6
+  return {
+      'metric': 'non-uniform pts/s, batched 2D type-1 512^2 x 256 items, M=1e6 each, tol=1e-6 (set_points + execute), '
+                'batch sharded over the GPUs',
+      'value': round(value, 2), 'unit': 'Mpts/s', 'n_gpus': world, 'steps': args.steps,
+      'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True,
+      'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+      'config': {
+          'workload': f'BASELINE configs[4]: batched 2D type-1, 512x512 modes, batch={items}, M=1e6 per item, '
+                      f'per-item points, tol=1e-6, complex64; contiguous blocks of the batch per rank '
+                      f'(shard_bounds), each rank one tfft.nufft call per step over its block; no data-path '
+                      f'collective. The N=1 line of this script is configs[1] (a different workload); '
+                      f'config.one_gpu_whole_job_Mpts_s is this workload on one GPU.',
+          'items': items, 'items_per_rank': nloc, 'points_per_item': m, 'grid': C5_GRID,
+          'rccl_world_size': world if dist is not None else 1, 'backend': args.dist_backend if dist is not None else None,
+          **extras,
+      },
+  }
 
 
 if __name__ == '__main__':

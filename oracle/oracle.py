@@ -234,6 +234,36 @@ def spread_stage(c, points, grid_shape, tol=1e-6, sigma=2.0, w=0, points_range='
   return fw, info
 
 
+def time_spread(c, points, grid_shape, tol=1e-6, sigma=0.0, w=0, kerevalmeth=1, nthreads=0):
+  """Seconds of the type-1 spreader alone (spreadSorted on pre-sorted points; the bin sort
+  runs before the clock starts). For bench.py's cpu_baseline leg."""
+  import time
+  c = np.ascontiguousarray(c)
+  cdt = c.dtype
+  rdt = np.float32 if cdt == np.complex64 else np.float64
+  suf = '_f32' if cdt == np.complex64 else '_f64'
+  M, rank = points.shape
+  pts = np.ascontiguousarray(np.asarray(points).T[::-1].astype(rdt))
+  o = _mk_opts('type_1', rank, grid_shape, 'forward', 1, tol, sigma, w, False, 'extended',
+               kerevalmeth, nthreads)
+  info = OracleInfo()
+  if lib().oracle_query(ctypes.byref(o), 4 if cdt == np.complex64 else 8, ctypes.byref(info)):
+    raise ValueError('oracle_query failed')
+  nf = (ctypes.c_int64 * 3)(*[info.nf[d] for d in range(3)])
+  perm = np.zeros(max(M, 1), dtype=np.int32)
+  args = (_ptr(pts[0]), _ptr(pts[1]) if rank > 1 else None, _ptr(pts[2]) if rank > 2 else None)
+  getattr(lib(), 'oracle_binsort' + suf)(ctypes.c_int64(M), *args, rank, nf, RANGE['extended'], _ptr(perm),
+                                         int(nthreads))
+  fw = np.zeros([int(info.nf[rank - 1 - d]) for d in range(rank)], dtype=cdt)
+  fn = getattr(lib(), 'oracle_spread_stage' + suf)
+  t0 = time.perf_counter()
+  rc = fn(ctypes.byref(o), _ptr(perm), ctypes.c_int64(M), *args, _ptr(c), _ptr(fw))
+  dt = time.perf_counter() - t0
+  if rc:
+    raise ValueError(f'oracle_spread_stage failed with code {rc}')
+  return dt
+
+
 def fft(a, sign, nthreads=0):
   """In-place-semantics FFT of the oracle (returns a new array); a is complex, C order."""
   a = np.array(a, copy=True, order='C')

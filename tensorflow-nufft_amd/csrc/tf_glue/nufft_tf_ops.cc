@@ -18,6 +18,7 @@
 //     $(python -c 'import tensorflow as tf; print(" ".join(tf.sysconfig.get_link_flags()))')
 #define EIGEN_USE_GPU
 #include <string>
+#include <vector>
 
 #include "nufft_hip.h"
 #include "tensorflow/core/framework/common_shape_fns.h"
@@ -114,6 +115,11 @@ static bool ReadVarint(const string& s, size_t* pos, uint64_t* v) {
 }
 static void ParseOptions(const string& bytes, nufft_hip_options* o) {
   nufft_hip_default_options(o);
+  // proto3 does not serialise default-valued fields: an absent field 4 means
+  // PointsRange.STRICT (= 0), exactly what options_.ParseFromString gives the
+  // reference kernel (nufft_kernels.cc:364-366). The Python wrapper always sends
+  // its own default, EXTENDED (= 1), explicitly.
+  o->points_range = NUFFT_HIP_RANGE_STRICT;
   size_t pos = 0;
   uint64_t key, v;
   while (pos < bytes.size() && ReadVarint(bytes, &pos, &key)) {
@@ -191,7 +197,20 @@ class NufftHipOp : public OpKernel {
     OP_REQUIRES_OK(ctx, ctx->allocate_output(0, target_shape, &target));
     // TF-ROCm exposes the compute stream as a hipStream_t through the Eigen device.
     void* stream = reinterpret_cast<void*>(ctx->eigen_gpu_device().stream());
-    rc = nufft_hip_op_compute(&d, source.data(), points.data(), target->data(), stream, err, sizeof(err));
+    // workspace and batch-permute temporaries come from allocate_temp, like the reference
+    // plan's fine grid (nufft_plan.cu.cc:1981-1986); the tensors die with this Compute
+    struct TempPool { OpKernelContext* ctx; std::vector<Tensor> keep; } pool{ctx, {}};
+    nufft_hip_allocator alloc;
+    alloc.user = &pool;
+    alloc.alloc = [](size_t bytes, void* user) -> void* {
+      TempPool* p = static_cast<TempPool*>(user);
+      Tensor t;
+      if (!p->ctx->allocate_temp(DT_UINT8, TensorShape({static_cast<int64_t>(bytes)}), &t).ok()) return nullptr;
+      p->keep.push_back(t);
+      return t.data();
+    };
+    alloc.free = [](void*, void*) {};   // released when `pool` goes out of scope (stream-ordered by TF)
+    rc = nufft_hip_op_compute_ex(&d, source.data(), points.data(), target->data(), stream, &alloc, err, sizeof(err));
     OP_REQUIRES(ctx, rc == NUFFT_HIP_OK, ToStatus(rc, err));
   }
 

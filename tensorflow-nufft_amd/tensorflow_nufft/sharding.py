@@ -35,10 +35,22 @@ def nufft_sharded(source, points, transform_fn, group=None, gather=True):
   local = transform_fn(source[lo:hi], pts)
   if not gather or world == 1:
     return local
-  # ragged blocks: pad to the largest block, gather, then trim
-  maxb = shard_bounds(b, world, 0)[1]
-  pad = torch.zeros((maxb,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-  pad[:hi - lo] = local
+  return gather_blocks(local, b, group)
+
+
+def gather_blocks(local, num_items, group=None):
+  """all_gather of every rank's contiguous block (as split by shard_bounds) into the full
+  [num_items, ...] result on every rank. Ragged blocks are padded to the largest one."""
+  import torch.distributed as dist
+  world = dist.get_world_size(group)
+  rank = dist.get_rank(group)
+  lo, hi = shard_bounds(num_items, world, rank)
+  maxb = shard_bounds(num_items, world, 0)[1]
+  if hi - lo == maxb:
+    pad = local.contiguous()
+  else:
+    pad = torch.zeros((maxb,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[:hi - lo] = local
   if pad.is_complex():
     buf = torch.view_as_real(pad).contiguous()
     outs = [torch.empty_like(buf) for _ in range(world)]
@@ -49,6 +61,6 @@ def nufft_sharded(source, points, transform_fn, group=None, gather=True):
     dist.all_gather(outs, pad, group=group)
   parts = []
   for r, o in enumerate(outs):
-    s, e = shard_bounds(b, world, r)
+    s, e = shard_bounds(num_items, world, r)
     parts.append(o[:e - s])
   return torch.cat(parts, dim=0)

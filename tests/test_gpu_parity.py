@@ -333,16 +333,58 @@ def test_linearity_and_adjointness_full_size(tfft):
   # linearity
   A2c = tfft.nufft(2.5 * c, pts, grid_shape=[1024, 1024], transform_type='type_1', fft_direction='forward')
   assert float((A2c - 2.5 * Ac).abs().max() / Ac.abs().max()) < 1e-5
-  # a 64x64 low-frequency corner of the result against the dense NUDFT of the same inputs
-  k = torch.arange(-32, 32, device='cuda', dtype=torch.float64)
-  sub = torch.zeros((64, 64), dtype=torch.complex128, device='cuda')
-  for s in range(0, M, 1_000_000):
-    p = pts[s:s + 1_000_000].to(torch.float64)
-    e0 = torch.exp(-1j * p[:, 0:1] * k)
-    e1 = torch.exp(-1j * p[:, 1:2] * k)
-    sub += torch.einsum('j,ja,jb->ab', c[s:s + 1_000_000].to(torch.complex128), e0, e1)
-  got = Ac[512 - 32:512 + 32, 512 - 32:512 + 32].to(torch.complex128)
-  assert float(torch.linalg.norm(got - sub) / torch.linalg.norm(sub)) < 1e-6
+  # blocks of the result against the dense NUDFT of the same 1e7 points: the centre (low
+  # frequencies), the most negative corner, an edge, and the most positive corner -- the
+  # NUFFT error peaks at |k| -> N/2, where 1 / phihat is largest
+  for r0, c0 in ((480, 480), (0, 0), (0, 496), (992, 992)):
+    sub = _dense_block_t1(pts, c, 1024, r0, c0, 32)
+    got = Ac[r0:r0 + 32, c0:c0 + 32].to(torch.complex128)
+    err = float(torch.linalg.norm(got - sub) / torch.linalg.norm(sub))
+    assert err < 1e-6, (r0, c0, err)
+
+
+def _dense_block_t1(pts, c, N, r0, c0, n, chunk=1_000_000):
+  """Modes [r0, r0 + n) x [c0, c0 + n) (array indices; mode = index - N/2) of the 2-D type-1
+  forward NUDFT of (pts, c), in float64 on the GPU."""
+  import torch
+  k0 = torch.arange(r0 - N // 2, r0 - N // 2 + n, device='cuda', dtype=torch.float64)
+  k1 = torch.arange(c0 - N // 2, c0 - N // 2 + n, device='cuda', dtype=torch.float64)
+  sub = torch.zeros((n, n), dtype=torch.complex128, device='cuda')
+  for s in range(0, pts.shape[0], chunk):
+    p = pts[s:s + chunk].to(torch.float64)
+    e0 = torch.exp(-1j * p[:, 0:1] * k0)
+    e1 = torch.exp(-1j * p[:, 1:2] * k1)
+    sub += torch.einsum('j,ja,jb->ab', c[s:s + chunk].to(torch.complex128), e0, e1)
+  return sub
+
+
+def test_config3_full_size_direct(tfft):
+  # BASELINE config 3 at full size: 2D type 2, 1024^2 modes, M = 1e7, tol 1e-6, complex64.
+  # 4096 of the output points against the dense sum over ALL 1024^2 modes (float64).
+  import torch
+  M, N = 10_000_000, 1024
+  g = torch.Generator(device='cuda').manual_seed(3)
+  f = torch.complex(torch.rand((N, N), generator=g, device='cuda') - .5, torch.rand((N, N), generator=g, device='cuda') - .5)
+  pts = (torch.rand((M, 2), generator=g, device='cuda') * 2 - 1) * np.pi
+  out = tfft.nufft(f, pts, transform_type='type_2', fft_direction='forward', tol=1e-6)
+  assert out.shape == (M,)
+  sel = torch.randint(0, M, (4096,), generator=g, device='cuda')
+  p = pts[sel].to(torch.float64)
+  k = torch.arange(-N // 2, N // 2, device='cuda', dtype=torch.float64)
+  e0 = torch.exp(-1j * p[:, 0:1] * k)            # [4096, N]
+  e1 = torch.exp(-1j * p[:, 1:2] * k)
+  ref = torch.einsum('ja,ab,jb->j', e0, f.to(torch.complex128), e1)
+  got = out[sel].to(torch.complex128)
+  err = float(torch.linalg.norm(got - ref) / torch.linalg.norm(ref))
+  assert err < 1e-6, err
+  # and the same transform through a reused plan (set_points once, execute twice) is bit-identical
+  plan = tfft.Plan('type_2', [N, N], 'forward', tol=1e-6)
+  plan.set_points(pts)
+  a = plan.execute(f)
+  b = plan.execute(f)
+  assert torch.equal(a, b)
+  assert float((a - out).abs().max() / out.abs().max()) < 1e-6
+  plan.close()
 
 
 @pytest.mark.parametrize('grid', [[8], [6, 8], [4, 8, 6]])
@@ -438,6 +480,20 @@ def test_config4_full_size_properties(tfft):
   got = Ac[128 - 6:128 + 6, 128 - 6:128 + 6, 128 - 6:128 + 6].to(torch.complex128)
   err = float(torch.linalg.norm(got - sub) / torch.linalg.norm(sub))
   assert err < 1e-4, err
+  # the most negative corner (k = -128 .. -121 per dimension) and an edge block, where the
+  # error of the kernel approximation peaks; 1e7 of the points' contributions would not do --
+  # all 1e8 points enter every mode
+  for origin in ((0, 0, 0), (0, 124, 248)):
+    ks = [torch.arange(o - 128, o - 128 + 8, device='cuda', dtype=torch.float64) for o in origin]
+    sub = torch.zeros((8, 8, 8), dtype=torch.complex128, device='cuda')
+    for s in range(0, M, 4_000_000):
+      p = pts[s:s + 4_000_000].to(torch.float64)
+      t = torch.einsum('j,ja->ja', c[s:s + 4_000_000].to(torch.complex128), torch.exp(-1j * p[:, 0:1] * ks[0]))
+      sub += torch.einsum('ja,jb,jc->abc', t, torch.exp(-1j * p[:, 1:2] * ks[1]), torch.exp(-1j * p[:, 2:3] * ks[2]))
+    o = origin
+    got = Ac[o[0]:o[0] + 8, o[1]:o[1] + 8, o[2]:o[2] + 8].to(torch.complex128)
+    err = float(torch.linalg.norm(got - sub) / torch.linalg.norm(sub))
+    assert err < 1e-4, (origin, err)
   f = torch.complex(torch.rand(grid, generator=g, device='cuda') - .5, torch.rand(grid, generator=g, device='cuda') - .5)
   lhs = torch.vdot(f.reshape(-1).to(torch.complex128), Ac.reshape(-1).to(torch.complex128))
   del Ac, sub
@@ -448,25 +504,71 @@ def test_config4_full_size_properties(tfft):
 
 
 def test_config5_batched_items(tfft):
-  # BASELINE config 5 flavour: batched 2D type 1, 512^2, M = 1e6 per item; a
-  # GPU's share of per-item points (calls) and of shared points (transforms)
+  # BASELINE config 5, ONE GPU's share of the 8-GPU split: 32 of the 256 items of batched 2D
+  # type 1, 512^2, M = 1e6 each; per-item points (32 set_points + execute calls) and points
+  # shared by the items (32 transforms of one plan); two items of each against the oracle
   import torch
   from oracle import oracle
-  B, M, grid = 4, 1_000_000, [512, 512]
+  from tensorflow_nufft import sharding
+  lo, hi = sharding.shard_bounds(256, 8, 3)
+  B, M, grid = hi - lo, 1_000_000, [512, 512]
+  assert B == 32
   g = torch.Generator(device='cuda').manual_seed(5)
   pts = (torch.rand((B, M, 2), generator=g, device='cuda') * 2 - 1) * np.pi
   c = torch.complex(torch.rand((B, M), generator=g, device='cuda') - .5, torch.rand((B, M), generator=g, device='cuda') - .5)
   out = tfft.nufft(c, pts, grid_shape=grid, transform_type='type_1')
   assert out.shape == (B, 512, 512)
   shared = tfft.nufft(c, pts[1], grid_shape=grid, transform_type='type_1')
-  for b in (1, 3):
+  assert shared.shape == (B, 512, 512)
+  for b in (1, 31):
     ref = oracle.nufft(c[b].cpu().numpy().astype(np.complex128), pts[b].cpu().numpy(), grid, 'type_1', 'forward',
                        tol=1e-12, sigma=2.0)
     assert rel_l2(out[b].cpu().numpy(), ref) < 1e-6
-  ref = oracle.nufft(c[2].cpu().numpy().astype(np.complex128), pts[1].cpu().numpy(), grid, 'type_1', 'forward',
-                     tol=1e-12, sigma=2.0)
-  assert rel_l2(shared[2].cpu().numpy(), ref) < 1e-6
+  for b in (2, 30):
+    ref = oracle.nufft(c[b].cpu().numpy().astype(np.complex128), pts[1].cpu().numpy(), grid, 'type_1', 'forward',
+                       tol=1e-12, sigma=2.0)
+    assert rel_l2(shared[b].cpu().numpy(), ref) < 1e-6
   assert rel_l2(shared[1].cpu().numpy(), out[1].cpu().numpy()) < 1e-6
+  # every item is an independent transform: item b of the batch == the same item alone
+  alone = tfft.nufft(c[17], pts[17], grid_shape=grid, transform_type='type_1')
+  assert rel_l2(out[17].cpu().numpy(), alone.cpu().numpy()) < 2e-7
+
+
+def test_sharded_batch_under_rccl_world_of_one(tfft):
+  # the batch-sharding path of config 5 (tensorflow_nufft/sharding.py) driving the HIP
+  # transform under torch.distributed with the nccl (= RCCL) backend; a 1-GPU box gives a
+  # world of one, which still runs init, the barrier and the collective entry points
+  import os
+  import torch
+  import torch.distributed as dist
+  from tensorflow_nufft import sharding
+  os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+  os.environ.setdefault('MASTER_PORT', '29631')
+  dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+  try:
+    B, M, grid = 6, 100_000, [128, 128]
+    g = torch.Generator(device='cuda').manual_seed(6)
+    pts = (torch.rand((B, M, 2), generator=g, device='cuda') * 2 - 1) * np.pi
+    c = torch.complex(torch.rand((B, M), generator=g, device='cuda') - .5, torch.rand((B, M), generator=g, device='cuda') - .5)
+    fn = lambda s, p: tfft.nufft(s, p, grid_shape=grid, transform_type='type_1')
+    full = sharding.nufft_sharded(c, pts, fn, gather=True)
+    assert full.shape == (B, 128, 128)
+    t = torch.ones(1, device='cuda')
+    dist.all_reduce(t)          # RCCL collective on the same communicator
+    dist.barrier()
+    assert float(t.item()) == 1.0
+    ref = tfft.nudft(c[4], pts[4].to(torch.float32), grid_shape=grid, transform_type='type_1')
+    # (float32 dense sum of 1e5 terms: 1e-4 is its own accuracy, not the transform's)
+    assert rel_l2(full[4].cpu().numpy(), ref.cpu().numpy()) < 1e-4
+    # emulate two ranks by hand: the blocks shard_bounds hands out concatenate to the full result
+    parts = []
+    for r in range(2):
+      lo, hi = sharding.shard_bounds(B, 2, r)
+      parts.append(fn(c[lo:hi], pts[lo:hi]))
+    # (type-1 sums are float atomics: equal to rounding, not bitwise)
+    assert rel_l2(torch.cat(parts, 0).cpu().numpy(), full.cpu().numpy()) < 2e-7
+  finally:
+    dist.destroy_process_group()
 
 
 @pytest.mark.parametrize('tile,mode', [((16, 16, 8), 'lds32'), ((4, 8, 4), 'lds16'), ((4, 4, 4), 'lds16x2'),
@@ -932,3 +1034,215 @@ def test_plan_buffers_under_electric_fence():
   r = subprocess.run([sys.executable, '-c', _EFENCE_CHILD, ROOT, PKG], env=env, capture_output=True, text=True, timeout=900)
   assert r.returncode == 0, r.stderr[-2000:]
   assert r.stdout.strip().splitlines()[-1] == 'PLANS 50', r.stdout[-500:]
+
+
+# ----------------------------------------------------------------- round 2
+
+@pytest.mark.parametrize('tol', [1e-2, 1e-4])
+def test_fixed_point_accumulation_coincident_points(tfft, tol):
+  # 3-D float fixed-point LDS accumulation: many same-phase points ON one grid node (x = 0 is
+  # fine cell nf/2 exactly, kernel value = the polynomial's peak, which overshoots 1 by the
+  # fit error): the 32-bit fields must not wrap. The bound carries the fitted maximum
+  # (Geom::fx_headroom), see nufft_kernels.hip spread_wave3_kernel.
+  import torch
+  from oracle import oracle
+  grid = [32, 32, 32]
+  M = 4000
+  pts = np.zeros((M, 3), np.float32)
+  pts[M // 2:] = np.random.default_rng(3).uniform(-np.pi, np.pi, (M - M // 2, 3)).astype(np.float32)
+  c = np.full(M, 1.0 + 0.5j, np.complex64)          # same phase: sums add up coherently
+  out = tfft.nufft(_dev(c), _dev(pts), grid_shape=grid, transform_type='type_1', tol=tol).cpu().numpy()
+  truth = oracle.nufft(c.astype(np.complex128), pts, grid, 'type_1', 'forward', tol=1e-12, sigma=2.0)
+  assert rel_l2(out, truth) < tol, rel_l2(out, truth)
+
+
+@pytest.mark.parametrize('M', [1, 1000, 100_000])
+def test_sparse_point_sets_on_a_large_3d_grid(tfft, M):
+  # LDS-free spreader (global atomics per point; reference spread_batch_nupts_driven,
+  # nufft_plan.cu.cc:2325-2436) picked for M << fine cells: 512^3 fine grid, tol 1e-4
+  import torch
+  from oracle import oracle
+  grid = [256, 256, 256]
+  rng = np.random.default_rng(M)
+  pts = rng.uniform(-np.pi, np.pi, (M, 3)).astype(np.float32)
+  c = (rng.uniform(-.5, .5, M) + 1j * rng.uniform(-.5, .5, M)).astype(np.complex64)
+  out = tfft.nufft(_dev(c), _dev(pts), grid_shape=grid, transform_type='type_1', tol=1e-4)
+  # the tile kernels on the same input (spread_method 2) agree to rounding
+  plan = tfft.Plan('type_1', grid, tol=1e-4, spread_method=2)
+  plan.set_points(_dev(pts))
+  tiled = plan.execute(_dev(c))
+  plan.close()
+  assert rel_l2(out.cpu().numpy(), tiled.cpu().numpy()) < 1e-5
+  # 16^3 blocks of modes (centre and most negative corner) against the dense float64 sum
+  p = torch.from_numpy(pts).cuda().to(torch.float64)
+  cc = torch.from_numpy(c).cuda().to(torch.complex128)
+  for o in (120, 0):
+    k = torch.arange(o - 128, o - 128 + 16, device='cuda', dtype=torch.float64)
+    e = [torch.exp(-1j * p[:, d:d + 1] * k) for d in range(3)]
+    sub = torch.einsum('j,ja,jb,jc->abc', cc, e[0], e[1], e[2])
+    got = out[o:o + 16, o:o + 16, o:o + 16].to(torch.complex128)
+    err = float(torch.linalg.norm(got - sub) / torch.linalg.norm(sub))
+    assert err < 1e-4, (M, o, err)
+  tfft._lib.lib().nufft_hip_op_clear_cache()
+
+
+def test_sparse_2d_and_type2_agree_with_oracle(tfft):
+  from oracle import oracle
+  rng = np.random.default_rng(21)
+  grid, M = [512, 384], 700
+  pts = rng.uniform(-np.pi, np.pi, (M, 2)).astype(np.float32)
+  c = (rng.uniform(-.5, .5, M) + 1j * rng.uniform(-.5, .5, M)).astype(np.complex64)
+  truth = oracle.nufft(c.astype(np.complex128), pts, grid, 'type_1', 'backward', tol=1e-12, sigma=2.0)
+  out = tfft.nufft(_dev(c), _dev(pts), grid_shape=grid, transform_type='type_1', fft_direction='backward').cpu().numpy()
+  assert rel_l2(out, truth) < 1e-6
+  for dt, tol in ((np.complex128, 1e-9),):
+    out = tfft.nufft(_dev(c.astype(dt)), _dev(pts.astype(np.float64)), grid_shape=grid, transform_type='type_1',
+                     fft_direction='backward', tol=tol).cpu().numpy()
+    assert rel_l2(out, truth) < tol
+
+
+def test_one_call_entry_matches_two_calls(tfft):
+  # nufft_hip_execute_with_points (strengths sorted into the records for one dense 2-D float
+  # type-1 transform) against set_points + execute, odd and even point counts, both layouts
+  import torch
+  from oracle import oracle
+  rng = np.random.default_rng(22)
+  for M in (200_001, 150_000, 3):
+    grid = [200, 256]
+    pts = rng.uniform(-np.pi, np.pi, (M, 2)).astype(np.float32)
+    c = (rng.uniform(-.5, .5, M) + 1j * rng.uniform(-.5, .5, M)).astype(np.complex64)
+    plan = tfft.Plan('type_1', grid, tol=1e-6)
+    plan.set_points(_dev(pts))
+    two = plan.execute(_dev(c)).cpu().numpy()
+    one = plan.execute_with_points(_dev(pts), _dev(c)).cpu().numpy()
+    if M > 1000:   # the dense cases fuse the strengths into the records: the points are consumed
+      with pytest.raises(ValueError, match='set_points must be called'):
+        plan.execute(_dev(c))
+    else:          # no fusion for a sparse set: the plan keeps its points
+      again = plan.execute(_dev(c)).cpu().numpy()
+      assert rel_l2(again, two) < 3e-7
+    plan.close()
+    truth = oracle.nufft(c.astype(np.complex128), pts, grid, 'type_1', 'forward', tol=1e-12, sigma=2.0)
+    assert rel_l2(two, truth) < 1e-6 and rel_l2(one, truth) < 1e-6, (M, rel_l2(two, truth), rel_l2(one, truth))
+    assert rel_l2(one, two) < 3e-7
+  # separate coordinate arrays (stride 1) take the generic loads
+  M = 100_000
+  x = _dev(rng.uniform(-np.pi, np.pi, M).astype(np.float32))
+  y = _dev(rng.uniform(-np.pi, np.pi, M).astype(np.float32))
+  c = _dev((rng.uniform(-.5, .5, M) + 1j * rng.uniform(-.5, .5, M)).astype(np.complex64))
+  lib = tfft._lib.lib()
+  plan = tfft.Plan('type_1', [128, 128], tol=1e-6)
+  out = torch.empty((128, 128), dtype=torch.complex64, device='cuda')
+  rc = lib.nufft_hip_execute_with_points(plan._handle, M, x.data_ptr(), y.data_ptr(), None, 1, c.data_ptr(), out.data_ptr())
+  assert rc == 0
+  ref = tfft.nufft(c, torch.stack([y, x], dim=1), grid_shape=[128, 128], transform_type='type_1')
+  assert rel_l2(out.cpu().numpy(), ref.cpu().numpy()) < 3e-7
+  plan.close()
+
+
+def test_framework_allocator_and_workspace_lease(tfft):
+  # nufft_hip_op_compute_ex with the host framework's allocator (include/nufft_hip.h,
+  # nufft_hip_allocator): every workspace buffer and the batch-permute temporaries come from
+  # the callbacks and are handed back before the call returns; the cached plan keeps none
+  import ctypes
+  import torch
+  from tensorflow_nufft import _lib
+  lib = _lib.lib()
+  lib.nufft_hip_op_clear_cache()
+  live, log = {}, []
+
+  def alloc(nbytes, user):
+    t = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device='cuda')
+    p = (t.data_ptr() + 255) & ~255
+    live[p] = t
+    log.append(int(nbytes))
+    return p
+
+  def free(ptr, user):
+    del live[ptr]
+
+  a = _lib.Allocator(_lib.ALLOC_FN(alloc), _lib.FREE_FN(free), None)
+  rng = np.random.default_rng(23)
+  # batch dims that interleave (points batch [2, 1], source batch [2, 3]) -> permute temporaries too
+  pts = _dev(rng.uniform(-np.pi, np.pi, (2, 1, 5000, 2)).astype(np.float32))
+  src = _dev((rng.standard_normal((2, 3, 5000)) + 1j * rng.standard_normal((2, 3, 5000))).astype(np.complex64))
+  ref = tfft.nufft(src, pts, grid_shape=[40, 48], transform_type='type_1')
+  d = _lib.OpDesc()
+  d.op_type, d.transform_type, d.fft_direction, d.precision, d.tol = 0, 1, -1, 4, 1e-6
+  lib.nufft_hip_default_options(ctypes.byref(d.options))
+  d.source_ndim, d.points_ndim, d.grid_shape_len = 3, 4, 2
+  for i, s in enumerate(src.shape): d.source_shape[i] = s
+  for i, s in enumerate(pts.shape): d.points_shape[i] = s
+  d.grid_shape[0], d.grid_shape[1] = 40, 48
+  out = torch.empty((2, 3, 40, 48), dtype=torch.complex64, device='cuda')
+  err = ctypes.create_string_buffer(512)
+  stream = torch.cuda.current_stream().cuda_stream
+  for rep in range(3):
+    rc = lib.nufft_hip_op_compute_ex(ctypes.byref(d), src.data_ptr(), pts.data_ptr(), out.data_ptr(),
+                                     ctypes.c_void_p(stream), ctypes.byref(a), err, 512)
+    assert rc == 0, err.value
+    torch.cuda.synchronize()
+    assert not live, 'every buffer is handed back before the call returns'
+    assert rel_l2(out.cpu().numpy(), ref.cpu().numpy()) < 3e-7
+  assert len(log) >= 3 * 5 and max(log) >= 8 * 80 * 96   # fine grid among them
+  assert lib.nufft_hip_op_cache_bytes() == 0            # the cached plan holds no workspace
+  lib.nufft_hip_op_clear_cache()
+
+
+def test_plan_cache_is_byte_capped(tfft):
+  import torch
+  lib = tfft._lib.lib()
+  lib.nufft_hip_op_clear_cache()
+  rng = np.random.default_rng(24)
+  pts = _dev(rng.uniform(-np.pi, np.pi, (1000, 2)).astype(np.float32))
+  c = _dev((rng.standard_normal(1000) + 1j * rng.standard_normal(1000)).astype(np.complex64))
+  try:
+    lib.nufft_hip_op_set_cache_limit(200 << 20)
+    for n in (512, 768, 1024, 1280, 1536):    # fine grids of 8 .. 75 MB each
+      tfft.nufft(c, pts, grid_shape=[n, n], transform_type='type_1')
+      assert lib.nufft_hip_op_cache_bytes() <= (200 << 20) or n == 512
+    assert 0 < lib.nufft_hip_op_cache_bytes() <= (200 << 20)
+  finally:
+    lib.nufft_hip_op_set_cache_limit(8 << 30)
+    lib.nufft_hip_op_clear_cache()
+
+
+def test_transposed_batch_call_captures_into_a_hip_graph(tfft):
+  # op-level call whose batch dims interleave (permute kernels + scratch buffer) under stream
+  # capture: no allocation, no synchronisation after the first (warm-up) call
+  import torch
+  rng = np.random.default_rng(25)
+  pts = _dev(rng.uniform(-np.pi, np.pi, (2, 1, 20000, 2)).astype(np.float32))
+  src = _dev((rng.standard_normal((2, 3, 20000)) + 1j * rng.standard_normal((2, 3, 20000))).astype(np.complex64))
+  s = torch.cuda.Stream()
+  with torch.cuda.stream(s):
+    ref = tfft.nufft(src, pts, grid_shape=[64, 64], transform_type='type_1')   # warm-up: plans + scratch
+    s.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+      out = tfft.nufft(src, pts, grid_shape=[64, 64], transform_type='type_1')
+    out.zero_()
+    graph.replay()
+    s.synchronize()
+  assert rel_l2(out.cpu().numpy(), ref.cpu().numpy()) < 3e-7
+
+
+def test_bench_spawns_its_own_ranks():
+  # `python bench.py --gpus 2` without a launcher starts two ranks itself (here both on
+  # device 0 over gloo -- a 1-GPU box; the driver's 8-GPU run uses nccl) and prints one line
+  import json
+  import os
+  import subprocess
+  import sys
+  from conftest import ROOT
+  env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+  env['MASTER_PORT'] = '29644'
+  r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+                      '--items', '6', '--dist-backend', 'gloo', '--device', '0', '--no-extras'],
+                     capture_output=True, text=True, env=env, timeout=600)
+  assert r.returncode == 0, r.stderr[-2000:]
+  lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+  assert len(lines) == 1, r.stdout
+  d = json.loads(lines[0])
+  assert d['n_gpus'] == 2 and d['config']['items'] == 6 and d['config']['items_per_rank'] == 3
+  assert d['scaling'] == 'strong' and d['value'] > 0
