@@ -85,7 +85,12 @@ typedef struct nufft_hip_options {
   int32_t lds_accumulate;      /* LDS tile accumulation: 0 auto, 1 double, 2 packed 32+32-bit fixed
                                   point (3-D float, kernel width <= 7 only; width 7 caps
                                   max_subproblem_size at 512) */
-  int32_t reserved[7];
+  int32_t num_point_sets;      /* K > 1: the plan sorts and transforms K independent point sets at once
+                                  (batched transforms with per-item points, nufft_kernels.cc:491-540 run as
+                                  one pass): set_points takes K * num_points points, set k at
+                                  [k num_points, (k+1) num_points); c is [K][ntransf][M], f [K][ntransf][grid];
+                                  every transform of every set is in flight together (one fine grid each) */
+  int32_t reserved[6];
 } nufft_hip_options;
 
 typedef struct nufft_hip_plan_s* nufft_hip_plan;

@@ -35,6 +35,8 @@ struct Geom {
   int fixed_point;  // 3-D float spread accumulates packed 32+32-bit fixed point in LDS
   int split_reim;   // 3-D float fp64-plane spread: real and imaginary parts in separate launches
   int cell_sorted;  // records of each subproblem are ordered by stencil start cell (set per set_points)
+  int nitems;       // point sets sorted together (batched per-item points); tiles are then composite:
+  int ntiles_item;  //   item * ntiles_item + tile, ntiles = nitems * ntiles_item
   int sparse_auto;  // spread_method AUTO: launch_spread may pick the LDS-free kernel for sparse point sets
   int fused;        // 2-D float records carry the strength instead of the point index (FusedRec)
   float fx_headroom;  // fixed-point accumulation: bound on prod_d max|P(z)| of the fitted kernel (>= 1)
@@ -79,7 +81,9 @@ struct SortedOut {
 struct PointsIn {
   const void* pts[3];   // x, y, z (unused dimensions alias x)
   int64_t stride;
-  int64_t M;
+  int64_t M;            // all points: nitems * M_item
+  int64_t M_item;       // points per set (set k = points [k M_item, (k + 1) M_item))
+  int blocks_per_item;  // sort workgroups per set (a workgroup never straddles two sets)
   int range_mode;
   int check_range;
   int aos;              // rank when pts[] are the columns of ONE [M, rank] array with x last (stride == rank), else 0
@@ -116,8 +120,10 @@ struct StageHook {
 // Forces the (otherwise lazy) load of this library's device code and waits for it.
 hipError_t preload_device_code();
 // Launchers (nufft_kernels.hip). All enqueue on `stream` and return hipGetLastError().
+// Workgroups of the LDS-histogram sorts: returns blocks PER ITEM (total = g.nitems * that);
+// M is the total point count.
 int sort_blocks(const Geom& g, int64_t M, int64_t* per_block);
-int sort_blocks16(int64_t M, int64_t* per_block);
+int sort_blocks16(const Geom& g, int64_t M, int64_t* per_block);
 int sort_mode(const Geom& g, int64_t M);
 bool sort_uses_lds(const Geom& g);
 template <typename T>

@@ -192,9 +192,13 @@ __device__ __forceinline__ void tile_to_grid(const Geom& g, const double* plane_
 
 // Which subproblem does workgroup `s` own? sub_start is the exclusive scan of
 // per-tile subproblem counts; returns the tile and the point range.
+// With several point sets in one plan (Geom::nitems > 1) the tile index is composite,
+// item * ntiles_item + tile: *tile gets the tile inside its item and *slot the index of the
+// (item, transform) pair this workgroup works on, item * gridDim.y + blockIdx.y -- the
+// strengths of that pair start at c + slot * c_stride, its fine grid at fw + slot * fw_stride.
 __device__ __forceinline__ bool locate_subproblem(const Geom& g, const int32_t* __restrict__ tile_start,
                                                   const int32_t* __restrict__ sub_start, int s,
-                                                  int* tile, int* p0, int* p1) {
+                                                  int* tile, int* p0, int* p1, int* slot) {
   const int nt = g.ntiles;
   if (s >= sub_start[nt]) return false;
   // Invariant: sub_start[lo] <= s < sub_start[hi]. Most tiles own exactly one
@@ -222,7 +226,14 @@ __device__ __forceinline__ bool locate_subproblem(const Geom& g, const int32_t* 
   const int chunk = s - sub_start[lo];
   const int a = tile_start[lo] + chunk * g.max_sub;
   const int e = tile_start[lo + 1];
-  *tile = lo;
+  if (g.nitems > 1) {
+    const int item = lo / g.ntiles_item;
+    *tile = lo - item * g.ntiles_item;
+    *slot = item * (int)gridDim.y + (int)blockIdx.y;
+  } else {
+    *tile = lo;
+    *slot = (int)blockIdx.y;
+  }
   *p0 = a;
   *p1 = (a + g.max_sub < e) ? a + g.max_sub : e;
   return true;
@@ -367,6 +378,11 @@ __device__ __forceinline__ void store_record<double>(const SortedOut<double>& ou
 // histograms. No global atomics, deterministic tile order. Three passes over
 // the raw points (hist, scatter) + two tiny scans.
 constexpr int kSortBlock = 1024;
+// Minimum waves per SIMD the count / scatter kernels are compiled for: 8 = two 1024-thread
+// workgroups per CU (needs <= 64 VGPRs: the compiler spills 16-90 bytes per lane), 4 = one.
+#ifndef NUFFT_SORT_MIN_WAVES
+#define NUFFT_SORT_MIN_WAVES 8
+#endif
 constexpr int kSortBatch = 4;    // load slots in flight per thread in the count / scatter loops
 
 // Walks the points [lo, hi) of a workgroup, kSortBatch load slots per thread per pass, the
@@ -375,19 +391,37 @@ constexpr int kSortBatch = 4;    // load slots in flight per thread in the count
 // a load under a divergent branch is waited for before the next one is issued).
 // PAIR (float, [M, 2] interleaved points): a slot is ONE 16-byte load = two consecutive
 // points (lo is even; an odd last point is handled by thread 0 after the loop), which
-// halves the load instructions again. body(i, x[3], slot) is called for valid points only;
-// pre(slot, i_clamped, valid) runs in the load phase for callers with a second array.
+// halves the load instructions again. body(i, x[3], point_slot) is called for valid points
+// only; pre(load_slot, i_clamped, valid) runs in the load phase for callers with a second
+// array (load_slot = point_slot = -1 for the odd tail point).
+// The points a sort workgroup handles: a contiguous range inside ONE point set (item).
+struct BlockRange {
+  int64_t lo, hi, base;   // global point indices; base = first point of the item
+  int tile_off;           // item * ntiles_item
+  __device__ __forceinline__ BlockRange(const PointsIn& in, int64_t per_block, const Geom& g) {
+    const int item = (int)blockIdx.x / in.blocks_per_item;
+    const int bi = (int)blockIdx.x - item * in.blocks_per_item;
+    base = (int64_t)item * in.M_item;
+    lo = base + (int64_t)bi * per_block;
+    const int64_t end = base + in.M_item;
+    if (lo > end) lo = end;
+    hi = lo + per_block < end ? lo + per_block : end;
+    tile_off = item * g.ntiles_item;
+  }
+};
+
 template <typename T, int AOS>
 struct PointWalk {
   static constexpr bool PAIR = (AOS == 2 && sizeof(T) == 4);
   static constexpr int PP = PAIR ? 2 : 1;
+  static constexpr int NS = PAIR ? kSortBatch / 2 : kSortBatch;   // load slots per pass: 4 points per thread either way
   template <typename Pre, typename Body>
   static __device__ __forceinline__ void run(const PointsIn& in, int64_t lo, int64_t hi, Pre pre, Body body) {
     const int64_t hi_main = PAIR ? (hi & ~(int64_t)1) : hi;
-    for (int64_t i0 = lo + PP * (int64_t)threadIdx.x; i0 < hi_main; i0 += (int64_t)PP * kSortBatch * kSortBlock) {
-      T x[kSortBatch * PP][3];
+    for (int64_t i0 = lo + PP * (int64_t)threadIdx.x; i0 < hi_main; i0 += (int64_t)PP * NS * kSortBlock) {
+      T x[NS * PP][3];
 #pragma unroll
-      for (int u = 0; u < kSortBatch; ++u) {
+      for (int u = 0; u < NS; ++u) {
         const int64_t i = i0 + (int64_t)u * PP * kSortBlock;
         const int64_t ic = i < hi_main ? i : hi_main - PP;
         if constexpr (PAIR) {
@@ -400,7 +434,7 @@ struct PointWalk {
         pre(u, ic, i < hi_main);
       }
 #pragma unroll
-      for (int u = 0; u < kSortBatch; ++u) {
+      for (int u = 0; u < NS; ++u) {
         const int64_t i = i0 + (int64_t)u * PP * kSortBlock;
         if (i < hi_main) {
 #pragma unroll
@@ -412,7 +446,7 @@ struct PointWalk {
       if ((hi & 1) && threadIdx.x == 0) {   // odd tail point (last workgroup only)
         T x[3];
         load_coords<T, AOS>(in, hi - 1, x);
-        pre(0, hi - 1, true);
+        pre(-1, hi - 1, true);   // slot -1 = the tail point
         body(hi - 1, x, -1);
       }
     }
@@ -420,7 +454,7 @@ struct PointWalk {
 };
 
 template <typename T, int AOS>
-__global__ __launch_bounds__(kSortBlock) void hist_lds_kernel(Geom g, PointsIn in, int64_t per_block,
+__global__ __launch_bounds__(kSortBlock, NUFFT_SORT_MIN_WAVES) void hist_lds_kernel(Geom g, PointsIn in, int64_t per_block,
                                                               int32_t* __restrict__ hist,
                                                               int32_t* __restrict__ bad_count) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -428,14 +462,13 @@ __global__ __launch_bounds__(kSortBlock) void hist_lds_kernel(Geom g, PointsIn i
   const int nt = g.ntiles;
   for (int t = threadIdx.x; t < nt; t += kSortBlock) h[t] = 0;
   __syncthreads();
-  const int64_t lo = (int64_t)blockIdx.x * per_block;
-  const int64_t hi = (lo + per_block < in.M) ? lo + per_block : in.M;
+  const BlockRange br(in, per_block, g);
   bool bad = false;
   PointWalk<T, AOS>::run(
-      in, lo, hi, [](int, int64_t, bool) {},
+      in, br.lo, br.hi, [](int, int64_t, bool) {},
       [&](int64_t, const T* x, int) {
         Rec<T> r;
-        const int tile = fold_coords<T>(g, in, x, &r, &bad);
+        const int tile = fold_coords<T>(g, in, x, &r, &bad) + br.tile_off;
         atomicAdd(&h[tile], 1);
       });
   if (bad && in.check_range) atomicAdd(bad_count, 1);
@@ -497,7 +530,7 @@ __device__ __forceinline__ float fused_z(uint32_t p) { return (float)((int)(p & 
 __device__ __forceinline__ uint32_t fused_loc(uint32_t px, uint32_t py) { return (px >> 27) | ((py >> 27) << 10); }
 
 template <typename T, int AOS, bool FUSED>
-__global__ __launch_bounds__(kSortBlock) void scatter_lds_kernel(Geom g, PointsIn in, int64_t per_block,
+__global__ __launch_bounds__(kSortBlock, NUFFT_SORT_MIN_WAVES) void scatter_lds_kernel(Geom g, PointsIn in, int64_t per_block,
                                                                  const int32_t* __restrict__ hist,
                                                                  const int32_t* __restrict__ tile_start,
                                                                  SortedOut<T> out) {
@@ -507,19 +540,19 @@ __global__ __launch_bounds__(kSortBlock) void scatter_lds_kernel(Geom g, PointsI
   const int32_t* hb = hist + (int64_t)blockIdx.x * nt;
   for (int t = threadIdx.x; t < nt; t += kSortBlock) cur[t] = tile_start[t] + hb[t];
   __syncthreads();
-  const int64_t lo = (int64_t)blockIdx.x * per_block;
-  const int64_t hi = (lo + per_block < in.M) ? lo + per_block : in.M;
+  const BlockRange br(in, per_block, g);
+  const int64_t lo = br.lo, hi = br.hi;
   bool bad = false;
   using Walk = PointWalk<T, AOS>;
   if constexpr (FUSED) {
     static_assert(sizeof(T) == 4, "fused records are float only");
-    float2 cs[kSortBatch * Walk::PP];
+    float2 cs[Walk::NS * Walk::PP];
     float2 ctail = make_float2(0.f, 0.f);
     Walk::run(
         in, lo, hi,
         [&](int u, int64_t ic, bool) {
           if constexpr (Walk::PAIR) {
-            if ((ic & 1) == 0) {
+            if (u >= 0) {
               const float4 v = reinterpret_cast<const float4*>(in.strengths)[ic >> 1];
               cs[2 * u] = make_float2(v.x, v.y);
               cs[2 * u + 1] = make_float2(v.z, v.w);
@@ -532,7 +565,7 @@ __global__ __launch_bounds__(kSortBlock) void scatter_lds_kernel(Geom g, PointsI
         },
         [&](int64_t, const T* x, int slot) {
           Rec<T> r;
-          const int tile = fold_coords<T>(g, in, x, &r, &bad);
+          const int tile = fold_coords<T>(g, in, x, &r, &bad) + br.tile_off;
           const float2 cv = slot >= 0 ? cs[slot] : ctail;
           const int pos = atomicAdd(&cur[tile], 1);
           FusedRec fr;
@@ -547,9 +580,9 @@ __global__ __launch_bounds__(kSortBlock) void scatter_lds_kernel(Geom g, PointsI
         in, lo, hi, [](int, int64_t, bool) {},
         [&](int64_t i, const T* x, int) {
           Rec<T> r;
-          const int tile = fold_coords<T>(g, in, x, &r, &bad);
+          const int tile = fold_coords<T>(g, in, x, &r, &bad) + br.tile_off;
           const int pos = atomicAdd(&cur[tile], 1);
-          store_record<T>(out, g.rank, pos, r, (int32_t)i);
+          store_record<T>(out, g.rank, pos, r, (int32_t)(i - br.base));   // index inside the point set
         });
   }
 }
@@ -578,8 +611,8 @@ __global__ __launch_bounds__(kSortBlock) void hist16_lds_kernel(Geom g, PointsIn
   const int nwr = (t_hi - t_lo + 1) >> 1;                                    // words of this range
   for (int t = threadIdx.x; t < nwr; t += kSortBlock) h2[t] = 0u;
   __syncthreads();
-  const int64_t lo = (int64_t)blockIdx.x * per_block;
-  const int64_t hi = (lo + per_block < in.M) ? lo + per_block : in.M;
+  const BlockRange br(in, per_block, g);
+  const int64_t lo = br.lo, hi = br.hi;
   bool bad = false;
   for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += kSortBatch * kSortBlock) {
     T x[kSortBatch][3];
@@ -592,7 +625,7 @@ __global__ __launch_bounds__(kSortBlock) void hist16_lds_kernel(Geom g, PointsIn
     for (int u = 0; u < kSortBatch; ++u) {
       const int64_t i = i0 + u * kSortBlock;
       Rec<T> r;
-      const int tile = fold_coords<T>(g, in, x[u], &r, &bad);
+      const int tile = fold_coords<T>(g, in, x[u], &r, &bad) + br.tile_off;
       if (i < hi && tile >= t_lo && tile < t_hi) {
         const int tl = tile - t_lo;
         const int sh = 16 * (tl & 1);
@@ -645,15 +678,16 @@ __global__ __launch_bounds__(256) void scatter_ranked_kernel(Geom g, PointsIn in
                                                              const int32_t* __restrict__ pref,
                                                              const int32_t* __restrict__ tile_start,
                                                              SortedOut<T> out) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= in.M) return;
+  const int64_t il = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // index inside the point set blockIdx.y
+  if (il >= in.M_item) return;
+  const int64_t i = (int64_t)blockIdx.y * in.M_item + il;
   Rec<T> r;
   bool bad = false;
   fold_point<T>(g, in, i, &r, &bad);
   const int tile = tile_of[i];
-  const int64_t blk = i / per_block;
+  const int64_t blk = (int64_t)blockIdx.y * in.blocks_per_item + il / per_block;
   const int pos = tile_start[tile] + pref[blk * g.ntiles + tile] + (int)rank16[i];
-  store_record<T>(out, g.rank, pos, r, (int32_t)i);
+  store_record<T>(out, g.rank, pos, r, (int32_t)il);
 }
 
 // --- path B (many tiles): per-point rank from a global counter (the
@@ -664,11 +698,12 @@ __global__ __launch_bounds__(256) void count_global_kernel(Geom g, PointsIn in,
                                                            int32_t* __restrict__ rank_of,
                                                            int32_t* __restrict__ tile_count,
                                                            int32_t* __restrict__ bad_count) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= in.M) return;
+  const int64_t il = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (il >= in.M_item) return;
+  const int64_t i = (int64_t)blockIdx.y * in.M_item + il;
   Rec<T> r;
   bool bad = false;
-  const int tile = fold_point<T>(g, in, i, &r, &bad);
+  const int tile = fold_point<T>(g, in, i, &r, &bad) + (int)blockIdx.y * g.ntiles_item;
   tile_of[i] = tile;
   rank_of[i] = atomicAdd(&tile_count[tile], 1);
   if (bad && in.check_range) atomicAdd(bad_count, 1);
@@ -680,13 +715,14 @@ __global__ __launch_bounds__(256) void scatter_global_kernel(Geom g, PointsIn in
                                                              const int32_t* __restrict__ rank_of,
                                                              const int32_t* __restrict__ tile_start,
                                                              SortedOut<T> out) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= in.M) return;
+  const int64_t il = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (il >= in.M_item) return;
+  const int64_t i = (int64_t)blockIdx.y * in.M_item + il;
   Rec<T> r;
   bool bad = false;
   fold_point<T>(g, in, i, &r, &bad);
   const int pos = tile_start[tile_of[i]] + rank_of[i];
-  store_record<T>(out, g.rank, pos, r, (int32_t)i);
+  store_record<T>(out, g.rank, pos, r, (int32_t)il);
 }
 
 // Single-workgroup exclusive scans over the tiles: point offsets and
@@ -762,8 +798,8 @@ __global__ __launch_bounds__(kBlock) void spread_tile_generic_kernel(
     T* __restrict__ fw, int64_t c_stride, int64_t fw_stride, T scale) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* tile = reinterpret_cast<double*>(smem_raw);
-  int tb, p0, p1;
-  if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1)) return;
+  int tb, p0, p1, slot;
+  if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1, &slot)) return;
   const int tid = threadIdx.x;
   const int w = g.w, nc = g.ncoef;
   const int L0 = g.ldim[0], LS = g.lstride;
@@ -773,7 +809,7 @@ __global__ __launch_bounds__(kBlock) void spread_tile_generic_kernel(
   for (int i = tid; i < 2 * ncell_padded; i += kBlock) tile[i] = 0.0;
   __syncthreads();
 
-  const T* cc = c + 2 * (int64_t)blockIdx.y * c_stride;
+  const T* cc = c + 2 * (int64_t)slot * c_stride;
   for (int j = p0 + tid; j < p1; j += kBlock) {
     const PointView<T> rec = unpack_rec<T, RANK>(sp.rec[j]);
     const uint32_t loc = rec.loc;
@@ -834,7 +870,7 @@ __global__ __launch_bounds__(kBlock) void spread_tile_generic_kernel(
   const int t1 = (tb / g.ntile[0]) % g.ntile[1];
   const int t2 = tb / (g.ntile[0] * g.ntile[1]);
   const int o0 = t0 * g.tile[0], o1 = t1 * g.tile[1], o2 = t2 * g.tile[2];
-  T* out = fw + 2 * (int64_t)blockIdx.y * fw_stride;
+  T* out = fw + 2 * (int64_t)slot * fw_stride;
   const int ncell = L0 * L1 * L2;
   for (int i = tid; i < ncell; i += kBlock) {
     const int a0 = i % L0;
@@ -869,8 +905,8 @@ template <typename T, int RANK>
 __global__ __launch_bounds__(kBlock) void spread_sparse_kernel(
     Geom g, SortedPoints<T> sp, const T* __restrict__ horner, const T* __restrict__ c,
     T* __restrict__ fw, int64_t c_stride, int64_t fw_stride, T scale) {
-  int tb, p0, p1;
-  if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1)) return;
+  int tb, p0, p1, slot;
+  if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1, &slot)) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int w = g.w, nc = g.ncoef;
   // lanes per stencil row: 2 w rounded up to a power of two (4 .. 32)
@@ -884,8 +920,8 @@ __global__ __launch_bounds__(kBlock) void spread_sparse_kernel(
   const int t1 = (tb / g.ntile[0]) % g.ntile[1];
   const int t2 = tb / (g.ntile[0] * g.ntile[1]);
   const int o0 = t0 * g.tile[0], o1 = t1 * g.tile[1], o2 = t2 * g.tile[2];
-  const T* cc = c + 2 * (int64_t)blockIdx.y * c_stride;
-  T* out = fw + 2 * (int64_t)blockIdx.y * fw_stride;
+  const T* cc = c + 2 * (int64_t)slot * c_stride;
+  T* out = fw + 2 * (int64_t)slot * fw_stride;
   for (int j = p0 + wave; j < p1; j += kBlock / 64) {
     const PointView<T> rec = unpack_rec<T, RANK>(sp.rec[j]);   // wave-uniform address: one broadcast load
     const T cv = cc[2 * (int64_t)rec.idx + comp] * scale;
@@ -925,6 +961,12 @@ __global__ __launch_bounds__(kBlock) void spread_sparse_kernel(
 __device__ __forceinline__ float bcast_lane(float v, int lane) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
+__device__ __forceinline__ double bcast_lane(double v, int lane) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), lane);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
 constexpr int kWT = 32;              // tile edge
 constexpr int kWW = 8;               // kernel width
 constexpr int kWL = kWT + kWW - 1;   // 39 rows/cols used
@@ -939,8 +981,8 @@ __global__ __launch_bounds__(NW * 64) void spread_2d_w8_wave_kernel(
   double* plane_re = reinterpret_cast<double*>(smem_raw);
   double* plane_im = plane_re + kWPlane;
   float* stage_all = reinterpret_cast<float*>(plane_im + kWPlane);
-  int tb, p0, p1;
-  if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1)) return;
+  int tb, p0, p1, slot;
+  if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1, &slot)) return;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -951,7 +993,7 @@ __global__ __launch_bounds__(NW * 64) void spread_2d_w8_wave_kernel(
   float2* kyc = reinterpret_cast<float2*>(kxs + CH * kWW);  // [CH][8] (ky*re, ky*im)
   const int dx = lane & 7, dy = lane >> 3;
   const int cell = dy * kWS + dx;
-  const float* cc = c + 2 * (int64_t)blockIdx.y * c_stride;
+  const float* cc = c + 2 * (int64_t)slot * c_stride;
 
   // coefficients of the piecewise polynomial: uniform loads, kept in SGPRs/VGPRs
   for (int base = p0 + wave * CH; base < p1; base += NW * CH) {
@@ -1024,7 +1066,7 @@ __global__ __launch_bounds__(NW * 64) void spread_2d_w8_wave_kernel(
   const int t0 = tb % g.ntile[0];
   const int t1 = tb / g.ntile[0];
   const int o0 = t0 * kWT, o1 = t1 * kWT;
-  float* out = fw + 2 * (int64_t)blockIdx.y * fw_stride;
+  float* out = fw + 2 * (int64_t)slot * fw_stride;
   for (int i = tid; i < 2 * kWL * kWL; i += NW * 64) {
     const int comp = i & 1;
     const int cellid = i >> 1;
@@ -1085,8 +1127,8 @@ __global__ __launch_bounds__(kCellSortThreads) void cellsort2d_kernel(
   constexpr int IT = kCellSortMaxSub / NT;
   __shared__ uint32_t cnt[1024];
   __shared__ uint32_t wsum[16];
-  int tb, p0, p1;
-  if (!locate_subproblem(g, tile_start, sub_start, blockIdx.x, &tb, &p0, &p1)) return;
+  int tb, p0, p1, slot;
+  if (!locate_subproblem(g, tile_start, sub_start, blockIdx.x, &tb, &p0, &p1, &slot)) return;
   const int n = p1 - p0;
   const int tid = threadIdx.x;
   for (int i = tid; i < 1024; i += NT) cnt[i] = 0u;
@@ -1128,8 +1170,8 @@ __global__ __launch_bounds__(kCellSortThreads) void cellsort3d_kernel(
   constexpr int IT = kCellSortMaxSub / NT;
   __shared__ uint32_t cnt[2048];
   __shared__ uint32_t wsum[16];
-  int tb, p0, p1;
-  if (!locate_subproblem(g, tile_start, sub_start, blockIdx.x, &tb, &p0, &p1)) return;
+  int tb, p0, p1, slot;
+  if (!locate_subproblem(g, tile_start, sub_start, blockIdx.x, &tb, &p0, &p1, &slot)) return;
   const int n = p1 - p0;
   const int tid = threadIdx.x;
   for (int i = tid; i < 2048; i += NT) cnt[i] = 0u;
@@ -1171,7 +1213,13 @@ __global__ __launch_bounds__(kCellSortThreads) void cellsort3d_kernel(
 constexpr int kGroupMaxSub = 4096;
 constexpr double kGroupMinDensity = 0.5;   // points per fine cell
 constexpr double kInterpSortMinDensity = 0.3;   // 3-D interp cell sort pays from here (r01: 0.075 loses, 0.75 and 1.8 win)
-constexpr int kGroupStage = 32; // points whose kernel values are in LDS at a time (per wave)
+#ifndef NUFFT_W8_STAGE
+#define NUFFT_W8_STAGE 32
+#endif
+#ifndef NUFFT_W8_CLANE
+#define NUFFT_W8_CLANE 0
+#endif
+constexpr int kGroupStage = NUFFT_W8_STAGE; // points whose kernel values are in LDS at a time (per wave)
 template <typename T> constexpr int kGroupStageOf = sizeof(T) == 8 ? 16 : kGroupStage;   // double: half, same bytes
 constexpr int kGroupBlk = 36;   // staging words per block of 4 points (8 x 4 + 4 pad)
 template <int CH> constexpr int kGroupStageWave = 3 * (CH / 4) * kGroupBlk;   // words per wave (kx, ky re, ky im)
@@ -1195,8 +1243,8 @@ __global__ __launch_bounds__(NW * 64) void spread_2d_w8_group_kernel(
   uint32_t* cnt = reinterpret_cast<uint32_t*>(stage_all + NW * kGroupStageWave<SC>);   // [1024]
   uint16_t* perm = reinterpret_cast<uint16_t*>(cnt + 1024);                     // [4096]
   uint32_t* wsum = reinterpret_cast<uint32_t*>(perm + kGroupMaxSub);            // [16]
-  int tb, p0, p1;
-  if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1)) return;
+  int tb, p0, p1, slot;
+  if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1, &slot)) return;
   const int n = p1 - p0;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1249,7 +1297,7 @@ __global__ __launch_bounds__(NW * 64) void spread_2d_w8_group_kernel(
   T* kyi = kyr + kGroupStageWave<SC> / 3;            // ky * im(c)
   const int dx = lane & 7, dy = lane >> 3;
   const int cell = (dy * kWS + dx) * (int)sizeof(double);
-  const T* cc = c + 2 * (int64_t)blockIdx.y * c_stride;
+  const T* cc = c + 2 * (int64_t)slot * c_stride;
 
   // Two-deep software pipeline over the wave's chunks: the record gather of chunk
   // i+2 and the strength gather of chunk i+1 (which needs record i+1's index)
@@ -1265,11 +1313,15 @@ __global__ __launch_bounds__(NW * 64) void spread_2d_w8_group_kernel(
     if constexpr (FUSED) { v2 v = {(T)r.re, (T)r.im}; return v; }
     else return c2[r.idx];
   };
+  // (Equal CONTIGUOUS shares per wave instead of round-robin chunks measured slower, r02:
+  // 283 -> 295 us at config 2 -- every wave then pays a fourth, mostly empty, phase 1.)
+  const int first = wave * CH;
+  const int limit = n;
   constexpr int STEP = NW * CH;
-  RecT r_cur = load_rec(wave * CH);
-  RecT r_nxt = load_rec(wave * CH + STEP);
+  RecT r_cur = load_rec(first);
+  RecT r_nxt = load_rec(first + STEP);
   v2 c_cur = load_c(r_cur);
-  for (int base = wave * CH; base < n; base += STEP) {
+  for (int base = first; base < limit; base += STEP) {
     const v2 c_nxt = load_c(r_nxt);
     const RecT r_nn = load_rec(base + 2 * STEP);
     uint32_t loc;
@@ -1283,7 +1335,7 @@ __global__ __launch_bounds__(NW * 64) void spread_2d_w8_group_kernel(
       zx = r_cur.z0;
       zy = r_cur.z1;
     }
-    const bool valid = lane < CH && base + lane < n;
+    const bool valid = lane < CH && base + lane < limit;
     const T re = valid ? c_cur.x * scale : (T)0, im = valid ? c_cur.y * scale : (T)0;
     const uint32_t key = valid ? (loc & 0xfffffu) : 0xffffffffu;
     const int off = (((loc >> 10) & 1023) * kWS + (loc & 1023)) * (int)sizeof(double);
@@ -1314,7 +1366,7 @@ __global__ __launch_bounds__(NW * 64) void spread_2d_w8_group_kernel(
     r_cur = r_nxt;
     c_cur = c_nxt;
     r_nxt = r_nn;
-    int npts = n - base;
+    int npts = limit - base;
     if (npts > CH) npts = CH;
     // a pass ends a group when the next point starts in a different cell (or the staged half ends)
     const uint32_t nxt = __shfl_down(key, 1);
@@ -1332,8 +1384,12 @@ __global__ __launch_bounds__(NW * 64) void spread_2d_w8_group_kernel(
 #pragma unroll
         for (int q = 0; q < kWW; ++q) {
           kxs[sb + 4 * q] = kx[q];
+#if NUFFT_W8_CLANE
+          kyr[sb + 4 * q] = ky[q];
+#else
           kyr[sb + 4 * q] = ky[q] * re;
           kyi[sb + 4 * q] = ky[q] * im;
+#endif
         }
       }
       int nh = npts - h;
@@ -1344,15 +1400,25 @@ __global__ __launch_bounds__(NW * 64) void spread_2d_w8_group_kernel(
       for (int q = 0; q < nround; q += 4) {
         const v4 ax4 = *reinterpret_cast<const v4*>(kxs + (q >> 2) * kGroupBlk + 4 * dx);
         const v4 br4 = *reinterpret_cast<const v4*>(kyr + (q >> 2) * kGroupBlk + 4 * dy);
-        const v4 bi4 = *reinterpret_cast<const v4*>(kyi + (q >> 2) * kGroupBlk + 4 * dy);
         const T a[4] = {ax4.x, ax4.y, ax4.z, ax4.w};
         const T br[4] = {br4.x, br4.y, br4.z, br4.w};
+#if !NUFFT_W8_CLANE
+        const v4 bi4 = *reinterpret_cast<const v4*>(kyi + (q >> 2) * kGroupBlk + 4 * dy);
         const T bi[4] = {bi4.x, bi4.y, bi4.z, bi4.w};
+#endif
         const unsigned t4 = (tails >> q) & 15u;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
+#if NUFFT_W8_CLANE
+          // strength broadcast from the point's lane (v_readlane -> SGPR operand) instead of a
+          // third staged array: two ds_read_b128 per four points instead of three
+          const T pk = a[u] * br[u];
+          ar = fma(pk, bcast_lane(re, h + q + u), ar);
+          ai = fma(pk, bcast_lane(im, h + q + u), ai);
+#else
           ar = fma(a[u], br[u], ar);
           ai = fma(a[u], bi[u], ai);
+#endif
           if (t4 & (1u << u)) {
             const int o = __builtin_amdgcn_readlane(off, h + q + u) + cell;   // byte offset into the re plane
             lds_add(reinterpret_cast<double*>(smem_raw + o), (double)ar);
@@ -1369,7 +1435,7 @@ __global__ __launch_bounds__(NW * 64) void spread_2d_w8_group_kernel(
   const int t0 = tb % g.ntile[0];
   const int t1 = tb / g.ntile[0];
   const int o0 = t0 * kWT, o1 = t1 * kWT;
-  T* out = fw + 2 * (int64_t)blockIdx.y * fw_stride;
+  T* out = fw + 2 * (int64_t)slot * fw_stride;
   for (int i = tid; i < 2 * kWL * kWL; i += NT) {
     const int comp = i & 1;
     const int cellid = i >> 1;
@@ -1383,12 +1449,6 @@ __global__ __launch_bounds__(NW * 64) void spread_2d_w8_group_kernel(
   }
 }
 
-__device__ __forceinline__ double bcast_lane(double v, int lane) {
-  const long long b = __builtin_bit_cast(long long, v);
-  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), lane);
-  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
-  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
-}
 
 template <typename T> struct Pair;
 template <> struct Pair<float> { using type = float2; };
@@ -1412,8 +1472,8 @@ __global__ __launch_bounds__(NW * 64) void spread_wave2_kernel(
   double* plane_re = reinterpret_cast<double*>(smem_raw);
   double* plane_im = plane_re + plane;
   T* stage_all = reinterpret_cast<T*>(plane_im + plane + 256);
-  int tb, p0, p1;
-  if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1)) return;
+  int tb, p0, p1, slot;
+  if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1, &slot)) return;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -1426,7 +1486,7 @@ __global__ __launch_bounds__(NW * 64) void spread_wave2_kernel(
   const int dx = lane & 7, dy = lane >> 3;
   const bool active = dx < W && dy < W;
   const int cell = dy * LS + dx;
-  const T2* cc = reinterpret_cast<const T2*>(c) + (int64_t)blockIdx.y * c_stride;
+  const T2* cc = reinterpret_cast<const T2*>(c) + (int64_t)slot * c_stride;
 
   for (int base = p0 + wave * CH; base < p1; base += NW * CH) {
     const int j = base + lane;
@@ -1473,7 +1533,7 @@ __global__ __launch_bounds__(NW * 64) void spread_wave2_kernel(
   __syncthreads();
   Geom gl = g;   // tile_to_grid reads the extents from the geometry
   (void)L0;
-  tile_to_grid<T, 2>(gl, plane_re, plane_im, LS, plane, tb, fw + 2 * (int64_t)blockIdx.y * fw_stride, wave, NW, lane);
+  tile_to_grid<T, 2>(gl, plane_re, plane_im, LS, plane, tb, fw + 2 * (int64_t)slot * fw_stride, wave, NW, lane);
 }
 
 // ------------------------- spread: 3-D wavefront path with compile-time width
@@ -1521,13 +1581,13 @@ __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
   T* stage_all = reinterpret_cast<T*>(pad + PAD);
   constexpr int SW = W <= 6 ? 6 : 8;                                  // staging row length
   float* red = reinterpret_cast<float*>(stage_all + NW * CH * 2 * SW);   // [NW] (FX bound reduction)
-  int tb, p0, p1;
-  if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1)) return;
+  int tb, p0, p1, slot;
+  if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1, &slot)) return;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   for (int i = tid; i < NPL * plane + PAD; i += NW * 64) plane_re[i] = 0.0;
-  const T2* cc = reinterpret_cast<const T2*>(c) + (int64_t)blockIdx.y * c_stride;
+  const T2* cc = reinterpret_cast<const T2*>(c) + (int64_t)slot * c_stride;
   const int npt = p1 - p0;
 
   T pre = scale;     // multiplies the strengths (FX: also converts to LSB units)
@@ -1639,7 +1699,7 @@ __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
   const int t1 = (tb / g.ntile[0]) % g.ntile[1];
   const int t2 = tb / (g.ntile[0] * g.ntile[1]);
   const int o0 = t0 * 16, o1 = t1 * 16, o2 = t2 * TZ;
-  T* out = fw + 2 * (int64_t)blockIdx.y * fw_stride;
+  T* out = fw + 2 * (int64_t)slot * fw_stride;
   for (RowWalk r(wave, L1); r.a2 < L2; r.advance(NW, L1)) {
     const int g1 = wrap1(o1 + r.a1, g.nf[1]);
     const int g2 = wrap1(o2 + r.a2, g.nf[2]);
@@ -1725,8 +1785,8 @@ __global__ __launch_bounds__(kInterpThreads<RANK>) void interp_point_kernel(
   const int L2 = RANK > 2 ? g.ldim[2] : 1;
   const int PS = LS * L1;
   T2* tile = reinterpret_cast<T2*>(smem_raw);
-  int tb, p0, p1;
-  if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1)) return;
+  int tb, p0, p1, slot;
+  if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1, &slot)) return;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -1734,7 +1794,7 @@ __global__ __launch_bounds__(kInterpThreads<RANK>) void interp_point_kernel(
   const int t1 = (tb / g.ntile[0]) % g.ntile[1];
   const int t2 = tb / (g.ntile[0] * g.ntile[1]);
   const int o0 = t0 * g.tile[0], o1 = t1 * g.tile[1], o2 = t2 * g.tile[2];
-  const T2* in = reinterpret_cast<const T2*>(fw) + (int64_t)blockIdx.y * fw_stride;
+  const T2* in = reinterpret_cast<const T2*>(fw) + (int64_t)slot * fw_stride;
   constexpr int NT = kInterpThreads<RANK>;
   // Tile rows (L0 <= 39 cells: one lane per cell) are fetched kRowBatch at a time: the
   // loads of a batch are issued back to back on clamped addresses and only then stored
@@ -1765,7 +1825,7 @@ __global__ __launch_bounds__(kInterpThreads<RANK>) void interp_point_kernel(
   __syncthreads();
 
   const int nc = g.ncoef;
-  T2* cc = reinterpret_cast<T2*>(c) + (int64_t)blockIdx.y * c_stride;
+  T2* cc = reinterpret_cast<T2*>(c) + (int64_t)slot * c_stride;
   // the next record is requested (on a clamped index, outside any branch) before this
   // point's ~300 dependent instructions, so its HBM latency is off the critical path
   Rec<T> raw = sp.rec[p0 + tid < p1 ? p0 + tid : p1 - 1];
@@ -1817,15 +1877,15 @@ template <typename T, int RANK>
 __global__ __launch_bounds__(kBlock) void interp_tile_generic_kernel(
     Geom g, SortedPoints<T> sp, const T* __restrict__ horner, T* __restrict__ c,
     const T* __restrict__ fw, int64_t c_stride, int64_t fw_stride, T scale) {
-  int tb, p0, p1;
-  if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1)) return;
+  int tb, p0, p1, slot;
+  if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1, &slot)) return;
   const int w = g.w, nc = g.ncoef;
   const int t0 = tb % g.ntile[0];
   const int t1 = (tb / g.ntile[0]) % g.ntile[1];
   const int t2 = tb / (g.ntile[0] * g.ntile[1]);
   const int o0 = t0 * g.tile[0], o1 = t1 * g.tile[1], o2 = t2 * g.tile[2];
-  const T* in = fw + 2 * (int64_t)blockIdx.y * fw_stride;
-  T* cc = c + 2 * (int64_t)blockIdx.y * c_stride;
+  const T* in = fw + 2 * (int64_t)slot * fw_stride;
+  T* cc = c + 2 * (int64_t)slot * c_stride;
   for (int j = p0 + (int)threadIdx.x; j < p1; j += kBlock) {
     const PointView<T> rec = unpack_rec<T, RANK>(sp.rec[j]);
     const uint32_t loc = rec.loc;
@@ -2030,40 +2090,50 @@ hipError_t preload_device_code() {
 }
 
 int sort_blocks(const Geom& g, int64_t M, int64_t* per_block) {
-  // at most 512 workgroups (longer per-tile runs per workgroup => better write
-  // combining in the scatter; measured r01), at least 4096 points each
+  // at most ~512 workgroups (longer per-tile runs per workgroup => better write
+  // combining in the scatter; measured r01), at least 4096 points each; a workgroup
+  // stays inside one point set, so the count is per set
   static const int maxblk = [] {
     const char* e = getenv("NUFFT_HIP_SORT_BLOCKS");   // tuning knob (tools/sweep_sort.py)
     const int v = e ? atoi(e) : 0;
     return v > 0 ? (v < kScanGroups * kScanRowsMax ? v : kScanGroups * kScanRowsMax) : 512;   // colscan_kernel's capacity
   }();
+  const int items = g.nitems > 1 ? g.nitems : 1;
+  const int64_t m_item = M / items;
   int64_t pb = (M + maxblk - 1) / maxblk;
   if (pb < 4096) pb = 4096;
   pb += pb & 1;   // even: the paired 16-byte loads of interleaved 2-D float points start on a pair
+  int64_t bpi = (m_item + pb - 1) / pb;
+  if (bpi < 1) bpi = 1;
+  // colscan_kernel scans at most kScanGroups * kScanRowsMax rows
+  while (bpi * items > kScanGroups * kScanRowsMax && bpi > 1) { pb *= 2; bpi = (m_item + pb - 1) / pb; }
   *per_block = pb;
-  (void)g;
-  return (int)((M + pb - 1) / pb);
+  return (int)bpi;
 }
 
 // 0: LDS histogram, 32-bit counters; 1: LDS histogram, packed 16-bit counters
 // (workgroups capped at 65535 points); 2: global counters.
 int sort_mode(const Geom& g, int64_t M) {
-  if (g.ntiles <= kMaxLdsTiles) return 0;
+  const int items = g.nitems > 1 ? g.nitems : 1;
+  if (g.ntiles <= kMaxLdsTiles && items <= kScanGroups * kScanRowsMax) return 0;
   if ((int64_t)g.ntiles <= (int64_t)kMaxRanges16 * kMaxLds16Tiles) {
     int64_t pb;
-    const int64_t nblk = sort_blocks16(M, &pb);
+    const int64_t nblk = (int64_t)sort_blocks16(g, M, &pb) * items;
     if (nblk * (int64_t)g.ntiles * 6 <= ((int64_t)2 << 30)) return 1;   // hist16 + pref <= 2 GiB
   }
   return 2;
 }
 bool sort_uses_lds(const Geom& g) { return g.ntiles <= kMaxLdsTiles; }
 
-int sort_blocks16(int64_t M, int64_t* per_block) {
+int sort_blocks16(const Geom& g, int64_t M, int64_t* per_block) {
+  const int items = g.nitems > 1 ? g.nitems : 1;
+  const int64_t m_item = M / items;
   int64_t pb = (M + 511) / 512;
   if (pb < 4096) pb = 4096;
   if (pb > 65535) pb = 65535;
   *per_block = pb;
-  return (int)((M + pb - 1) / pb);
+  const int64_t bpi = (m_item + pb - 1) / pb;
+  return (int)(bpi < 1 ? 1 : bpi);
 }
 
 template <typename T, int AOS, bool FUSED>
@@ -2088,20 +2158,25 @@ static hipError_t sort_lds_pass(const Geom& g, const PointsIn& in, const SortWor
 }
 
 template <typename T>
-hipError_t launch_sort(const Geom& g, const PointsIn& in, const SortWork& w, const SortedOut<T>& out,
+hipError_t launch_sort(const Geom& g, const PointsIn& in_arg, const SortWork& w, const SortedOut<T>& out,
                        hipStream_t stream, const StageHook& hook) {
   hipError_t e;
-  if (in.M == 0) {
+  if (in_arg.M == 0) {
     e = hipMemsetAsync(w.tile_count, 0, sizeof(int32_t) * (size_t)g.ntiles, stream);
     if (e != hipSuccess) return e;
     scan_tiles_kernel<<<1, 1024, 0, stream>>>(w.tile_count, g.ntiles, g.max_sub, w.tile_start, w.sub_start);
     return hipGetLastError();
   }
+  const int items = g.nitems > 1 ? g.nitems : 1;
+  PointsIn in = in_arg;
+  in.M_item = in.M / items;
+  in.blocks_per_item = 1;
   const int mode = sort_mode(g, in.M);
   if (in.strengths && (mode != 0 || sizeof(T) != 4 || g.rank != 2)) return hipErrorInvalidValue;   // see fused_sort_supported
   if (mode == 0) {
     int64_t per_block;
-    const int nblk = sort_blocks(g, in.M, &per_block);
+    in.blocks_per_item = sort_blocks(g, in.M, &per_block);
+    const int nblk = in.blocks_per_item * items;
     const size_t lds = sizeof(int) * (size_t)g.ntiles;
     hipError_t (*run)(const Geom&, const PointsIn&, const SortWork&, const SortedOut<T>&, hipStream_t,
                       const StageHook&, int, int64_t, size_t) = nullptr;
@@ -2117,7 +2192,8 @@ hipError_t launch_sort(const Geom& g, const PointsIn& in, const SortWork& w, con
   }
   if (mode == 1) {
     int64_t per_block;
-    const int nblk = sort_blocks16(in.M, &per_block);
+    in.blocks_per_item = sort_blocks16(g, in.M, &per_block);
+    const int nblk = in.blocks_per_item * items;
     const int nw = (g.ntiles + 1) >> 1;
     const int ranges = (g.ntiles + kMaxLds16Tiles - 1) / kMaxLds16Tiles;
     const int span = (((g.ntiles + ranges - 1) / ranges) + 1) & ~1;         // tiles per range, even
@@ -2137,7 +2213,7 @@ hipError_t launch_sort(const Geom& g, const PointsIn& in, const SortWork& w, con
     scan_tiles_kernel<<<1, 1024, 0, stream>>>(w.tile_count, g.ntiles, g.max_sub, w.tile_start, w.sub_start);
     hook.end(STAGE_SORT_SCAN);
     hook.begin(STAGE_SORT_SCATTER);
-    scatter_ranked_kernel<T><<<blocks_for(in.M, 256), 256, 0, stream>>>(g, in, per_block, w.tile_of, rank16,
+    scatter_ranked_kernel<T><<<dim3(blocks_for(in.M_item, 256), items), 256, 0, stream>>>(g, in, per_block, w.tile_of, rank16,
                                                                         pref, w.tile_start, out);
     hook.end(STAGE_SORT_SCATTER);
     return hipGetLastError();
@@ -2145,14 +2221,15 @@ hipError_t launch_sort(const Geom& g, const PointsIn& in, const SortWork& w, con
   e = hipMemsetAsync(w.tile_count, 0, sizeof(int32_t) * (size_t)g.ntiles, stream);
   if (e != hipSuccess) return e;
   hook.begin(STAGE_SORT_COUNT);
-  count_global_kernel<T><<<blocks_for(in.M, 256), 256, 0, stream>>>(g, in, w.tile_of, w.rank_of,
+  in.blocks_per_item = 1;
+  count_global_kernel<T><<<dim3(blocks_for(in.M_item, 256), items), 256, 0, stream>>>(g, in, w.tile_of, w.rank_of,
                                                                     w.tile_count, w.bad_count);
   hook.end(STAGE_SORT_COUNT);
   hook.begin(STAGE_SORT_SCAN);
   scan_tiles_kernel<<<1, 1024, 0, stream>>>(w.tile_count, g.ntiles, g.max_sub, w.tile_start, w.sub_start);
   hook.end(STAGE_SORT_SCAN);
   hook.begin(STAGE_SORT_SCATTER);
-  scatter_global_kernel<T><<<blocks_for(in.M, 256), 256, 0, stream>>>(g, in, w.tile_of, w.rank_of,
+  scatter_global_kernel<T><<<dim3(blocks_for(in.M_item, 256), items), 256, 0, stream>>>(g, in, w.tile_of, w.rank_of,
                                                                       w.tile_start, out);
   hook.end(STAGE_SORT_SCATTER);
   return hipGetLastError();
@@ -2260,7 +2337,7 @@ bool sparse_wanted(const Geom& g, int64_t M) {
 bool fused_sort_supported(const Geom& g, int method, int precision, int64_t M) {
   static const bool off = getenv("NUFFT_HIP_NO_FUSED") != nullptr;   // A/B knob
   if (off || method != NUFFT_HIP_METHOD_TILE_WAVE || !wave8_supported(g, precision)) return false;
-  if (M <= 0 || sort_mode(g, M) != 0 || g.max_sub > kGroupMaxSub) return false;
+  if (M <= 0 || sort_mode(g, M * (g.nitems > 1 ? g.nitems : 1)) != 0 || g.max_sub > kGroupMaxSub) return false;   // M: per set
   return wave8_use_group(g, M) && !(g.sparse_auto && sparse_wanted(g, M));
 }
 
@@ -2333,7 +2410,8 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
   if (M == 0) return hipSuccess;
   dim3 grid(subproblem_grid(g, M), (unsigned)batch);
   hipError_t e = hipSuccess;
-  if (method == NUFFT_HIP_METHOD_POINT_GLOBAL || (g.sparse_auto && !g.fused && sparse_wanted(g, M))) {
+  const int64_t Md = M / (g.nitems > 1 ? g.nitems : 1);   // points per set: what the density rules look at
+  if (method == NUFFT_HIP_METHOD_POINT_GLOBAL || (g.sparse_auto && !g.fused && sparse_wanted(g, Md))) {
     switch (g.rank) {
       case 1: spread_sparse_kernel<T, 1><<<grid, kBlock, 0, stream>>>(g, sp, horner, c, fw, c_stride, fw_stride, scale); break;
       case 2: spread_sparse_kernel<T, 2><<<grid, kBlock, 0, stream>>>(g, sp, horner, c, fw, c_stride, fw_stride, scale); break;
@@ -2344,7 +2422,7 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
   if (method == NUFFT_HIP_METHOD_TILE_WAVE) {
     if constexpr (sizeof(T) == 4) {
       if (wave8_supported(g, 4)) {
-        const bool grouped = g.cell_sorted || g.fused || wave8_use_group(g, M);
+        const bool grouped = g.cell_sorted || g.fused || wave8_use_group(g, Md);
         const int shape = wave8_nw(grouped) * 100 + wave8_ch(grouped);
         lds_bytes = wave8_lds(grouped, g.cell_sorted);   // the plan's figure is the maximum over the variants
         if (grouped) {
@@ -2379,7 +2457,7 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
             NUFFT_CASE_W8G(6) NUFFT_CASE_W8G(7)
             case 8:
               switch (shape) {
-                NUFFT_LAUNCH_W8G(8, 8, 64) NUFFT_LAUNCH_W8G(8, 12, 64) NUFFT_LAUNCH_W8G(8, 12, 32)   // r01 sweep kept these
+                NUFFT_LAUNCH_W8G(8, 8, 64) NUFFT_LAUNCH_W8G(8, 12, 64) NUFFT_LAUNCH_W8G(8, 16, 64)
                 default: return hipErrorInvalidValue;
               }
               break;
@@ -2409,7 +2487,7 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
     if constexpr (sizeof(T) == 8) {
       // double precision: the same cell-grouped kernel (8 waves, 16 staged points: the byte
       // budget of the float form), in-kernel sort only
-      if (group2d_geometry(g) && wave8_use_group(g, M)) {
+      if (group2d_geometry(g) && wave8_use_group(g, Md)) {
         lds_bytes = group_lds(8, 64, false, NUFFT_HIP_F64);
 #define NUFFT_CASE_W8D(WV)                                                                     \
   case WV:                                                                                     \

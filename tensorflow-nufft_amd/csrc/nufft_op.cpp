@@ -165,15 +165,15 @@ constexpr size_t kMaxCached = 16;
 int64_t g_cache_limit = (int64_t)8 << 30;
 constexpr int kMaxLanes = 4;   // pipelined plans per op call (nufft_hip_op_compute)
 
-std::string plan_key(const nufft_hip_op_desc* d, const Analysis& a, int type, int ntransf,
-                     double tol, void* stream, int device, bool framework_alloc) {
+std::string plan_key(const nufft_hip_op_desc* d, const nufft_hip_options& opts, const Analysis& a, int type,
+                     int ntransf, double tol, void* stream, int device, bool framework_alloc) {
   std::string k;
   char buf[256];
   snprintf(buf, sizeof(buf), "op%d t%d r%d n%d f%d p%d tol%.17g dev%d s%p a%d|", d->op_type, type, a.rank,
            ntransf, d->fft_direction, d->precision, tol, device, stream, framework_alloc ? 1 : 0);
   k = buf;
   for (auto g : a.grid) k += std::to_string((long long)g) + ",";
-  k.append(reinterpret_cast<const char*>(&d->options), sizeof(d->options));
+  k.append(reinterpret_cast<const char*>(&opts), sizeof(opts));
   return k;
 }
 
@@ -320,37 +320,74 @@ int nufft_hip_op_compute_ex(const nufft_hip_op_desc* desc, const void* source, c
     return fail(errbuf, errbuf_len, NUFFT_HIP_INTERNAL,
                 "no HIP device available (this library has no CPU fallback)");
   }
-  // One plan on the caller's stream, or -- when the batch needs several
-  // sequential set_points + execute calls -- two plans on private streams that
-  // alternate calls: the memory-bound sort of one call overlaps the LDS-bound
-  // spread of the other (measured r01: 0.126 -> 0.092 ms per 512^2, M = 1e6 item).
-  // NUFFT_HIP_OP_LANES overrides the lane count (1..kMaxLanes); three or four lanes measured
-  // no better than two on config 5 (32 items of M = 1e6: 3.6 / 2.9 / 3.2 / 3.1 ms for 1-4
-  // lanes): ~14 launches per item keep the host and the whole-GPU kernels equally busy.
-  // With a framework allocator everything stays on the caller's stream (its memory is
-  // ordered against that stream only).
+  // Calls (= distinct point sets of the batch, nufft_kernels.cc:491-540) are run in GROUPS of
+  // up to K sets through one plan with K point sets (options.num_point_sets): one sort, one
+  // spread, one batched FFT and one deconvolve launch for the whole group instead of ~12
+  // launches per set -- a 512^2 / M = 1e6 item keeps the GPU busy for only ~60 us of the
+  // ~90 us its own launches take. Needs the source to carry the same batch dims as the
+  // points (otherwise the strengths of consecutive calls are not consecutive in memory).
+  // NUFFT_HIP_OP_GROUP overrides K (1 = the r01 behaviour, one call at a time).
+  // Groups alternate between two plans on private streams, so that the memory-bound sort of
+  // one overlaps the LDS-bound spread of the other (r01: 0.126 -> 0.092 ms per item);
+  // NUFFT_HIP_OP_LANES overrides the lane count (1..kMaxLanes). With a framework allocator
+  // everything stays on the caller's stream (its memory is ordered against that stream only).
   static const int lanes_env = [] { const char* e = getenv("NUFFT_HIP_OP_LANES"); return e ? atoi(e) : 0; }();
+  static const int group_env = [] { const char* e = getenv("NUFFT_HIP_OP_GROUP"); return e ? atoi(e) : 0; }();
+  std::vector<int64_t> src_outer, pts_outer;
+  for (int i : a.outer) { src_outer.push_back(a.source_batch[i]); pts_outer.push_back(a.points_batch[i]); }
+  bool groupable = a.num_calls > 1 && !a.transpose;
+  for (size_t i = 0; i < src_outer.size(); ++i)
+    if (src_outer[i] != pts_outer[i]) groupable = false;
+  int64_t group = 1;
+  if (groupable) {
+    group = group_env > 0 ? group_env : 16;
+    nufft_hip_plan_info pi;
+    char pe[256];
+    if (nufft_hip_plan_describe(desc->transform_type, rank, dims, desc->fft_direction, (int)a.num_transforms, tol,
+                                desc->precision, &opts, &pi, pe, sizeof(pe)) == NUFFT_HIP_OK) {
+      const double fine_bytes = (double)pi.fine_dims[0] * pi.fine_dims[1] * pi.fine_dims[2] * csize *
+                                (opts.spread_only ? 0.0 : (double)a.num_transforms);
+      const int64_t ntiles = (int64_t)pi.num_tiles[0] * pi.num_tiles[1] * pi.num_tiles[2];
+      while (group > 1 && (fine_bytes * group > 1.5 * (1 << 30) || ntiles * group > 65536 ||
+                           a.num_points * group > 1500000000LL))
+        group /= 2;
+    } else {
+      group = 1;
+    }
+    group = std::min<int64_t>(group, a.num_calls);
+    if (group < 2) group = 1;
+  }
+  const int64_t ngroups = (a.num_calls + group - 1) / group;
+  const int64_t tail = a.num_calls - (ngroups - 1) * group;   // sets in the last group
   int want_lanes = 2;
   if (lanes_env > 0) want_lanes = lanes_env < kMaxLanes ? lanes_env : kMaxLanes;
   if (fw_alloc) want_lanes = 1;
-  const int nlanes = (int)std::min<int64_t>(a.num_calls, want_lanes);
-  nufft_hip_plan plans[kMaxLanes] = {};
-  hipStream_t lane_stream[kMaxLanes] = {};
-  std::string keys[kMaxLanes];
-  for (int l = 0; l < nlanes; ++l) {
-    void* key_stream = nlanes == 1 ? stream_v : reinterpret_cast<void*>((intptr_t)(l + 1));
-    keys[l] = plan_key(desc, a, desc->transform_type, (int)a.num_transforms, tol, key_stream, device, fw_alloc);
+  const int64_t nfull = tail != group ? ngroups - 1 : ngroups;   // groups of the full size (>= 1)
+  const int nlanes = (int)std::min<int64_t>(nfull, want_lanes);
+  // plans: one per lane for full groups, plus one for a shorter last group
+  const int nplans = nlanes + (tail != group ? 1 : 0);
+  nufft_hip_plan plans[kMaxLanes + 1] = {};
+  hipStream_t lane_stream[kMaxLanes + 1] = {};
+  std::string keys[kMaxLanes + 1];
+  for (int l = 0; l < nplans; ++l) {
+    const bool is_tail = l == nlanes;   // the shorter last group runs on the caller's stream, after the lanes joined
+    nufft_hip_options o = opts;
+    o.num_point_sets = (int32_t)(is_tail ? tail : group);
+    if (o.num_point_sets <= 1) o.num_point_sets = 0;
+    const bool own_lane = nlanes > 1 && !is_tail;
+    void* key_stream = own_lane ? reinterpret_cast<void*>((intptr_t)(l + 1)) : stream_v;
+    keys[l] = plan_key(desc, o, a, desc->transform_type, (int)a.num_transforms, tol, key_stream, device, fw_alloc);
     plans[l] = cache_take(keys[l], &lane_stream[l]);
     if (plans[l] && fw_alloc) rc = nufft_hip_plan_set_allocator(plans[l], allocator);   // this call's context
     if (!plans[l]) {
-      if (nlanes > 1 && hipStreamCreateWithFlags(&lane_stream[l], hipStreamNonBlocking) != hipSuccess) {
+      if (own_lane && hipStreamCreateWithFlags(&lane_stream[l], hipStreamNonBlocking) != hipSuccess) {
         for (int k = 0; k < l; ++k) release_entry(plans[k], lane_stream[k]);
         return fail(errbuf, errbuf_len, NUFFT_HIP_INTERNAL, "hipStreamCreate failed");
       }
       char pe[512] = {0};
       rc = nufft_hip_plan_create_ex(&plans[l], desc->transform_type, rank, dims, desc->fft_direction,
-                                    (int)a.num_transforms, tol, desc->precision, &opts,
-                                    nlanes == 1 ? stream_v : (void*)lane_stream[l], allocator, pe, sizeof(pe));
+                                    (int)a.num_transforms, tol, desc->precision, &o,
+                                    own_lane ? (void*)lane_stream[l] : stream_v, allocator, pe, sizeof(pe));
       if (rc) {
         if (lane_stream[l]) (void)hipStreamDestroy(lane_stream[l]);
         for (int k = 0; k < l; ++k) release_entry(plans[k], lane_stream[k]);
@@ -360,7 +397,7 @@ int nufft_hip_op_compute_ex(const nufft_hip_op_desc* desc, const void* source, c
   }
   nufft_hip_plan plan = plans[0];
   auto release_all = [&]() {
-    for (int l = 0; l < nlanes; ++l) release_entry(plans[l], lane_stream[l]);
+    for (int l = 0; l < nplans; ++l) release_entry(plans[l], lane_stream[l]);
   };
 
   // Source / target with batch dims permuted to [outer..., inner..., element...]
@@ -424,9 +461,8 @@ int nufft_hip_op_compute_ex(const nufft_hip_op_desc* desc, const void* source, c
     ptarget = (char*)scratch + sbytes;
   }
 
-  // Loop over calls (nufft_kernels.cc:491-540). Batch dims in `outer` order.
-  std::vector<int64_t> src_outer, pts_outer;
-  for (int i : a.outer) { src_outer.push_back(a.source_batch[i]); pts_outer.push_back(a.points_batch[i]); }
+  // Loop over calls (nufft_kernels.cc:491-540), `group` of them per plan call. Batch dims in
+  // `outer` order.
   const int no = (int)a.outer.size();
   std::vector<int64_t> sfac(no, 1), pfac(no, 1);
   for (int d2 = no - 2; d2 >= 0; --d2) {
@@ -441,8 +477,9 @@ int nufft_hip_op_compute_ex(const nufft_hip_op_desc* desc, const void* source, c
     for (int l = 0; l < nlanes && e == hipSuccess; ++l) e = hipStreamWaitEvent(lane_stream[l], ev_fork, 0);
     if (e != hipSuccess) return hip_fail(e);
   }
-  for (int64_t call = 0; call < a.num_calls && !rc; ++call) {
-    plan = plans[call % nlanes];
+  auto run_group = [&](int64_t gi, nufft_hip_plan pl) {
+    const int64_t call = gi * group;
+    plan = pl;
     const char* pb = (const char*)points + (size_t)call * (size_t)a.num_points * rank * rsize;
     // x = LAST coordinate of each point (reverse of the last axis, :282-286)
     const void* px = pb + (size_t)(rank - 1) * rsize;
@@ -462,9 +499,11 @@ int nufft_hip_op_compute_ex(const nufft_hip_op_desc* desc, const void* source, c
     char* fbase = (char*)(t1 ? ptarget : const_cast<void*>(psource));
     void* c = cbase + (size_t)c_index * (size_t)a.num_transforms * (size_t)a.num_points * csize;
     void* f = fbase + (size_t)f_index * (size_t)a.num_transforms * (size_t)num_coeffs * csize;
-    // set_points + execute / interp / spread as one call (:492-539): the plan may fuse them
-    rc = nufft_hip_execute_with_points(plan, a.num_points, px, py, pz, rank, c, f);
-  }
+    // set_points + execute / interp / spread as one call (:492-539): the plan may fuse them.
+    // A grouped plan takes its K point sets, strength blocks and grids from consecutive memory.
+    return nufft_hip_execute_with_points(pl, a.num_points, px, py, pz, rank, c, f);
+  };
+  for (int64_t gi = 0; gi < nfull && !rc; ++gi) rc = run_group(gi, plans[gi % nlanes]);
   if (rc) {
     const std::string msg = nufft_hip_last_error(plan);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
@@ -484,6 +523,15 @@ int nufft_hip_op_compute_ex(const nufft_hip_op_desc* desc, const void* source, c
       if (ev_join[l]) (void)hipEventDestroy(ev_join[l]);
     if (e != hipSuccess) return hip_fail(e);
   }
+  if (tail != group) {   // the shorter last group, on the caller's stream
+    rc = run_group(ngroups - 1, plans[nlanes]);
+    if (rc) {
+      const std::string msg = nufft_hip_last_error(plans[nlanes]);
+      cleanup();
+      release_all();
+      return fail(errbuf, errbuf_len, rc, msg);
+    }
+  }
   if (a.transpose) {
     // target[original order] = ttarget[outer.., inner.., elem..]: for output dim j
     // (original position), its stride in ttarget is that of position iperm[j].
@@ -497,7 +545,7 @@ int nufft_hip_op_compute_ex(const nufft_hip_op_desc* desc, const void* source, c
     if (e != hipSuccess) return hip_fail(e);
   }
   cleanup();
-  for (int l = 0; l < nlanes; ++l) {
+  for (int l = 0; l < nplans; ++l) {
     // a framework allocator's memory is per call: hand the workspace back, keep the plan
     if (fw_alloc) (void)nufft_hip_plan_release_workspace(plans[l]);
     cache_give(keys[l], plans[l], lane_stream[l]);

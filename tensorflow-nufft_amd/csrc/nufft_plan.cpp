@@ -222,7 +222,8 @@ struct nufft_hip_plan_s {
   void* fft_work = nullptr;
   size_t fft_work_bytes = 0;      // bytes the FFT plans need (max over them)
 
-  int64_t M = 0, cap = 0, cap_global = 0;
+  int nitems = 1;                // point sets handled together (options.num_point_sets)
+  int64_t M = 0, cap = 0, cap_global = 0;   // M: points per set
   void* rec = nullptr;           // Rec<T>[cap], tile-sorted
   void* rec2 = nullptr;          // Rec<T>[cap2]: target of the lazy cell-sort pass (then swapped with rec)
   int64_t cap2 = 0;
@@ -417,7 +418,7 @@ int ensure_fixed_workspace(nufft_hip_plan p) {
   if (!rc) rc = dev_alloc(p, (void**)&p->sub_start, sizeof(int32_t) * ((size_t)g.ntiles + 1));
   if (!rc) rc = dev_alloc(p, (void**)&p->bad_count, sizeof(int32_t) * 4);
   if (!rc && !p->opts.spread_only)
-    rc = dev_alloc(p, &p->d_fine, (size_t)p->precision * 2 * (size_t)p->fine_elems * p->batch_size);
+    rc = dev_alloc(p, &p->d_fine, (size_t)p->precision * 2 * (size_t)p->fine_elems * p->batch_size * p->nitems);
   if (!rc && !p->opts.spread_only && p->fft_work_bytes) {
     rc = dev_alloc(p, &p->fft_work, p->fft_work_bytes);
     if (!rc) FFT_TRY(p, rocfft_execution_info_set_work_buffer(p->fft_info, p->fft_work, p->fft_work_bytes));
@@ -500,10 +501,11 @@ int ensure_point_capacity(nufft_hip_plan p, int64_t M) {
   int rc = ensure_fixed_workspace(p);
   if (rc) return rc;
   const int mode = sort_mode(p->g, M);
+  const int items = p->g.nitems > 1 ? p->g.nitems : 1;
   int64_t need = 0, per_block;
-  if (mode == 0) need = (int64_t)sort_blocks(p->g, M, &per_block) * p->g.ntiles;
+  if (mode == 0) need = (int64_t)sort_blocks(p->g, M, &per_block) * items * p->g.ntiles;
   if (mode == 1) {
-    const int64_t nblk = sort_blocks16(M, &per_block);
+    const int64_t nblk = (int64_t)sort_blocks16(p->g, M, &per_block) * items;
     need = nblk * ((p->g.ntiles + 1) / 2) + nblk * (int64_t)p->g.ntiles;   // hist16 words + 32-bit prefix
   }
   if (need > p->hist_elems) {
@@ -539,7 +541,8 @@ int ensure_point_capacity(nufft_hip_plan p, int64_t M) {
 template <typename T>
 int set_points_impl(nufft_hip_plan p, int64_t M, const void* x, const void* y, const void* z,
                     int64_t stride, const void* strengths = nullptr) {
-  int rc = ensure_point_capacity(p, M);
+  const int64_t Mtot = M * p->nitems;   // M points in each of the nitems sets
+  int rc = ensure_point_capacity(p, Mtot);
   if (rc) return rc;
   p->M = M;
   p->points_set = false;
@@ -549,7 +552,9 @@ int set_points_impl(nufft_hip_plan p, int64_t M, const void* x, const void* y, c
   // unused dimensions alias x so that the kernels can load all three unconditionally
   in.pts[0] = x; in.pts[1] = p->rank > 1 ? y : x; in.pts[2] = p->rank > 2 ? z : x;
   in.stride = stride;
-  in.M = M;
+  in.M = Mtot;
+  in.M_item = M;
+  in.blocks_per_item = 1;
   in.range_mode = p->opts.points_range;
   in.check_range = check ? 1 : 0;
   in.strengths = strengths;
@@ -560,7 +565,9 @@ int set_points_impl(nufft_hip_plan p, int64_t M, const void* x, const void* y, c
     const bool cols = (const char*)x == base + (size_t)(p->rank - 1) * p->precision &&
                       (p->rank == 2 || (const char*)y == base + p->precision);
     const size_t align = p->rank == 2 ? 4 * (size_t)p->precision : (size_t)p->precision;   // point PAIRS in 2-D
-    if (cols && ((uintptr_t)base % align) == 0) in.aos = p->rank;
+    // (paired float loads start every set on a pair: an odd set size keeps them for one set only)
+    const bool pair_ok = !(p->rank == 2 && p->precision == NUFFT_HIP_F32 && p->nitems > 1 && (M & 1));
+    if (cols && pair_ok && ((uintptr_t)base % align) == 0) in.aos = p->rank;
   }
   SortWork w;
   w.hist = p->hist; w.tile_of = p->tile_of; w.rank_of = p->rank_of;
@@ -573,13 +580,13 @@ int set_points_impl(nufft_hip_plan p, int64_t M, const void* x, const void* y, c
   // 3-D interp plans order every subproblem by start cell right away (rec2 -> rec)
   const bool cells = (p->type == NUFFT_HIP_TYPE_2 || p->opts.spread_only) &&
                      cellsort_wanted_interp(p->g, p->method, p->precision, M);
-  if (cells && M > p->cap2) {
+  if (cells && Mtot > p->cap2) {
     if ((rc = sync_before_regrow(p))) return rc;
     dev_free(p, p->rec2);
     p->rec2 = nullptr;
     p->cap2 = 0;
-    if ((rc = dev_alloc(p, &p->rec2, (size_t)M * sizeof(Rec<T>)))) return rc;
-    p->cap2 = M;
+    if ((rc = dev_alloc(p, &p->rec2, (size_t)Mtot * sizeof(Rec<T>)))) return rc;
+    p->cap2 = Mtot;
   }
   SortedOut<T> out;
   out.rec = (Rec<T>*)(cells ? p->rec2 : p->rec);
@@ -587,7 +594,7 @@ int set_points_impl(nufft_hip_plan p, int64_t M, const void* x, const void* y, c
   HIP_TRY(p, launch_sort<T>(p->g, in, w, out, p->stream, hook));
   if (cells) {
     hook.begin(STAGE_SORT_CELL);
-    HIP_TRY(p, launch_cellsort<T>(p->g, M, p->tile_start, p->sub_start, (const Rec<T>*)p->rec2,
+    HIP_TRY(p, launch_cellsort<T>(p->g, Mtot, p->tile_start, p->sub_start, (const Rec<T>*)p->rec2,
                                   (Rec<T>*)p->rec, p->stream));
     hook.end(STAGE_SORT_CELL);
   }
@@ -637,18 +644,19 @@ int maybe_cellsort(nufft_hip_plan p, int launches) {
   if (!cellsort_wanted(p->g, p->method, p->precision, p->M)) return NUFFT_HIP_OK;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(p->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return NUFFT_HIP_OK;
-  if (p->M > p->cap2) {
+  const int64_t Mtot = p->M * p->nitems;
+  if (Mtot > p->cap2) {
     int rc;
     if ((rc = sync_before_regrow(p))) return rc;
     dev_free(p, p->rec2);
     p->rec2 = nullptr;
     p->cap2 = 0;
-    if ((rc = dev_alloc(p, &p->rec2, (size_t)p->M * sizeof(Rec<T>)))) return rc;
-    p->cap2 = p->M;
+    if ((rc = dev_alloc(p, &p->rec2, (size_t)Mtot * sizeof(Rec<T>)))) return rc;
+    p->cap2 = Mtot;
   }
   const StageHook hook = make_hook(p);
   hook.begin(STAGE_SORT_CELL);
-  HIP_TRY(p, launch_cellsort<T>(p->g, p->M, p->tile_start, p->sub_start, (const Rec<T>*)p->rec,
+  HIP_TRY(p, launch_cellsort<T>(p->g, Mtot, p->tile_start, p->sub_start, (const Rec<T>*)p->rec,
                                 (Rec<T>*)p->rec2, p->stream));
   hook.end(STAGE_SORT_CELL);
   std::swap(p->rec, p->rec2);
@@ -675,7 +683,8 @@ int execute_impl(nufft_hip_plan p, void* c, void* f) {
     T* cb = (T*)c + 2 * (int64_t)b0 * p->M;
     T* fb = (T*)f + 2 * (int64_t)b0 * p->grid_elems;
     T* fw = (T*)p->d_fine;
-    const auto it = p->fft_plans.find(nb);   // both batch counts were planned at creation
+    const int slots = nb * p->nitems;        // fine grids in flight: every point set x nb transforms
+    const auto it = p->fft_plans.find(slots);   // both batch counts were planned at creation
     if (it == p->fft_plans.end()) {
       p->err = format("no FFT plan for a batch of %d transforms", nb);
       return NUFFT_HIP_INTERNAL;
@@ -685,10 +694,10 @@ int execute_impl(nufft_hip_plan p, void* c, void* f) {
     const StageHook hook = make_hook(p);
     if (p->type == NUFFT_HIP_TYPE_1) {
       hook.begin(STAGE_ZERO);
-      HIP_TRY(p, hipMemsetAsync(fw, 0, sizeof(T) * 2 * (size_t)p->fine_elems * nb, p->stream));
+      HIP_TRY(p, hipMemsetAsync(fw, 0, sizeof(T) * 2 * (size_t)p->fine_elems * slots, p->stream));
       hook.end(STAGE_ZERO);
       hook.begin(STAGE_SPREAD);
-      HIP_TRY(p, launch_spread<T>(p->g, p->method, sp, p->M, (const T*)p->d_horner, cb, fw, nb,
+      HIP_TRY(p, launch_spread<T>(p->g, p->method, sp, p->M * p->nitems, (const T*)p->d_horner, cb, fw, nb,
                                   p->M, p->fine_elems, (T)1, p->lds_bytes, p->stream));
       hook.end(STAGE_SPREAD);
       if (stop == STAGE_SPREAD) continue;
@@ -697,11 +706,11 @@ int execute_impl(nufft_hip_plan p, void* c, void* f) {
       hook.end(STAGE_FFT);
       if (stop == STAGE_FFT) continue;
       hook.begin(STAGE_DECONVOLVE);
-      HIP_TRY(p, launch_deconvolve<T>(p->g, 1, fb, fw, rf, nb, p->stream));
+      HIP_TRY(p, launch_deconvolve<T>(p->g, 1, fb, fw, rf, slots, p->stream));
       hook.end(STAGE_DECONVOLVE);
     } else {
       hook.begin(STAGE_DECONVOLVE);
-      HIP_TRY(p, launch_deconvolve<T>(p->g, 2, fb, fw, rf, nb, p->stream));
+      HIP_TRY(p, launch_deconvolve<T>(p->g, 2, fb, fw, rf, slots, p->stream));
       hook.end(STAGE_DECONVOLVE);
       if (stop == STAGE_DECONVOLVE) continue;
       hook.begin(STAGE_FFT);
@@ -709,7 +718,7 @@ int execute_impl(nufft_hip_plan p, void* c, void* f) {
       hook.end(STAGE_FFT);
       if (stop == STAGE_FFT) continue;
       hook.begin(STAGE_INTERP);
-      HIP_TRY(p, launch_interp<T>(p->g, p->method, sp, p->M, (const T*)p->d_horner, cb, fw, nb,
+      HIP_TRY(p, launch_interp<T>(p->g, p->method, sp, p->M * p->nitems, (const T*)p->d_horner, cb, fw, nb,
                                   p->M, p->fine_elems, (T)1, p->stream));
       hook.end(STAGE_INTERP);
     }
@@ -735,22 +744,23 @@ int spread_interp_impl(nufft_hip_plan p, int dir, void* c, void* f) {
   const T scale = (T)p->spread_scale;
   // The op output IS the grid here; batch over all transforms in one launch
   // group of at most 65535 (grid.y limit).
-  for (int b0 = 0; b0 < p->ntransf; b0 += 32768) {
+  for (int b0 = 0; b0 < p->ntransf; b0 += 32768) {   // (one pass when nitems > 1: ntransf <= 32768 then)
     const int nb = std::min(32768, p->ntransf - b0);
+    const int slots = nb * p->nitems;
     T* cb = (T*)c + 2 * (int64_t)b0 * p->M;
     T* fb = (T*)f + 2 * (int64_t)b0 * p->fine_elems;
     const StageHook hook = make_hook(p);
     if (dir == 1) {
       hook.begin(STAGE_ZERO);
-      HIP_TRY(p, hipMemsetAsync(fb, 0, sizeof(T) * 2 * (size_t)p->fine_elems * nb, p->stream));
+      HIP_TRY(p, hipMemsetAsync(fb, 0, sizeof(T) * 2 * (size_t)p->fine_elems * slots, p->stream));
       hook.end(STAGE_ZERO);
       hook.begin(STAGE_SPREAD);
-      HIP_TRY(p, launch_spread<T>(p->g, p->method, sp, p->M, (const T*)p->d_horner, cb, fb, nb,
+      HIP_TRY(p, launch_spread<T>(p->g, p->method, sp, p->M * p->nitems, (const T*)p->d_horner, cb, fb, nb,
                                   p->M, p->fine_elems, scale, p->lds_bytes, p->stream));
       hook.end(STAGE_SPREAD);
     } else {
       hook.begin(STAGE_INTERP);
-      HIP_TRY(p, launch_interp<T>(p->g, p->method, sp, p->M, (const T*)p->d_horner, cb, fb, nb,
+      HIP_TRY(p, launch_interp<T>(p->g, p->method, sp, p->M * p->nitems, (const T*)p->d_horner, cb, fb, nb,
                                   p->M, p->fine_elems, scale, p->stream));
       hook.end(STAGE_INTERP);
     }
@@ -885,8 +895,18 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
   p->batch_size = p->opts.max_batch_size > 0 ? std::min(p->opts.max_batch_size, ntransf)
                                              : std::min(ntransf, 8);
   p->batch_size = std::min(p->batch_size, 32768);   // grid.y limit of the batched launches
-  if (p->fine_elems * p->batch_size > kMaxArraySize) {
-    const long long sz = (long long)(p->fine_elems * p->batch_size);
+  p->nitems = std::max(1, p->opts.num_point_sets);
+  if (p->nitems > 1) {
+    // every transform of every point set in ONE pass (the kernels index the fine grids by
+    // item * ntransf + transform)
+    if (p->nitems > 4096 || ntransf > 32768) {
+      delete p;
+      return fail(NUFFT_HIP_INVALID_ARGUMENT, "num_point_sets must be <= 4096 (and num_transforms <= 32768 with it)");
+    }
+    p->batch_size = ntransf;
+  }
+  if (p->fine_elems * p->batch_size * p->nitems > kMaxArraySize) {
+    const long long sz = (long long)(p->fine_elems * p->batch_size * p->nitems);
     delete p;
     return fail(NUFFT_HIP_INVALID_ARGUMENT, format("Fine grid is too big: size %lld > %lld", sz, (long long)kMaxArraySize));
   }
@@ -905,12 +925,19 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
   }
   const size_t lds_limit = 96 * 1024;
   for (;;) {
-    g.ntiles = 1;
+    int64_t nt = 1;
     for (int d = 0; d < 3; ++d) {
       g.ntile[d] = d < rank ? (g.nf[d] + g.tile[d] - 1) / g.tile[d] : 1;
       g.ldim[d] = d < rank ? g.tile[d] + w - 1 : 1;
-      g.ntiles *= g.ntile[d];
+      nt *= g.ntile[d];
     }
+    g.nitems = p->nitems;
+    g.ntiles_item = (int)nt;
+    if (nt * p->nitems > ((int64_t)1 << 30)) {
+      delete p;
+      return fail(NUFFT_HIP_INVALID_ARGUMENT, "too many tiles (fine grid x num_point_sets)");
+    }
+    g.ntiles = (int)(nt * p->nitems);
     g.lstride = g.ldim[0];
     for (int d = 0; d < 3; ++d) {
       g.tile_shift[d] = -1;
@@ -1048,8 +1075,8 @@ static int create_common(nufft_hip_plan* out, int type, int rank, const int64_t*
   int rc = precision == NUFFT_HIP_F32 ? upload_tables<float>(p) : upload_tables<double>(p);
   if (!rc && !p->opts.spread_only) {
     // the FFT of full batches and of the remainder batch, so that execute never plans
-    rc = build_fft_plan(p, p->batch_size);
-    if (!rc) rc = build_fft_plan(p, p->ntransf % p->batch_size);
+    rc = build_fft_plan(p, p->batch_size * p->nitems);
+    if (!rc && p->nitems == 1) rc = build_fft_plan(p, p->ntransf % p->batch_size);
   }
   // internal allocation: the fixed workspace now, so that nothing allocates after warm-up;
   // a framework allocator is asked at the first set_points (its memory is per call)
@@ -1268,12 +1295,12 @@ int nufft_hip_plan_destroy(nufft_hip_plan p) {
 int nufft_hip_debug_fine_grid(nufft_hip_plan p, void** fine, int64_t* count) {
   if (!p || !fine || !count) return NUFFT_HIP_INVALID_ARGUMENT;
   *fine = p->d_fine;
-  *count = p->fine_elems * p->batch_size;
+  *count = p->fine_elems * p->batch_size * p->nitems;
   return NUFFT_HIP_OK;
 }
 
 int nufft_hip_debug_copy_fine_grid(nufft_hip_plan p, void* dst, int64_t count) {
-  if (!p || p->host_only || !dst || !p->d_fine || count < 0 || count > p->fine_elems * p->batch_size)
+  if (!p || p->host_only || !dst || !p->d_fine || count < 0 || count > p->fine_elems * p->batch_size * p->nitems)
     return NUFFT_HIP_INVALID_ARGUMENT;
   HIP_TRY(p, hipMemcpyAsync(dst, p->d_fine, (size_t)count * 2 * (size_t)p->precision, hipMemcpyDeviceToDevice,
                             p->stream));

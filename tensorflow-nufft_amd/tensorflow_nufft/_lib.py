@@ -51,7 +51,8 @@ class OptionsStruct(ctypes.Structure):
               ('max_subproblem_size', ctypes.c_int32),
               ('tile_dims', ctypes.c_int32 * 3),
               ('lds_accumulate', ctypes.c_int32),
-              ('reserved', ctypes.c_int32 * 7)]
+              ('num_point_sets', ctypes.c_int32),
+              ('reserved', ctypes.c_int32 * 6)]
 
 
 class PlanInfo(ctypes.Structure):

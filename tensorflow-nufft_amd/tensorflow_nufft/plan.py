@@ -37,6 +37,7 @@ class Plan:
         self.device = torch.device('cuda', torch.cuda.current_device())
     o = _options_struct(options)
     o.spread_only = int(spread_only)
+    self.nsets = max(1, int(internal.get('num_point_sets', 0) or 0))   # K point sets handled together
     for k, v in internal.items():
       if k == 'tile_dims':
         for i, t in enumerate(v):
@@ -72,11 +73,25 @@ class Plan:
     self._check(self.lib.nufft_hip_plan_get_info(self._handle, ctypes.byref(i)))
     return i
 
-  def set_points(self, points):
+  def _check_points(self, points):
     points = points.to(self.device, self.rdtype).contiguous()
-    assert points.dim() == 2 and points.shape[1] == self.rank
+    if self.nsets > 1:
+      assert points.dim() == 3 and points.shape[0] == self.nsets and points.shape[2] == self.rank, \
+          'a plan with num_point_sets = K takes points [K, M, rank]'
+    else:
+      assert points.dim() == 2 and points.shape[1] == self.rank
+    return points
+
+  def _lead(self, source, elem_rank):
+    lead = [self.nsets] if self.nsets > 1 else []
+    if self.ntransf > 1 or source.dim() > len(lead) + elem_rank:
+      lead = lead + [self.ntransf]
+    return lead
+
+  def set_points(self, points):
+    points = self._check_points(points)
     self._points = points   # keep alive until the sort kernels have consumed it
-    self.M = points.shape[0]
+    self.M = points.shape[-2]
     es = points.element_size()
     base = points.data_ptr()
     r = self.rank
@@ -88,7 +103,7 @@ class Plan:
 
   def execute(self, source, out=None):
     source = source.to(self.device, self.cdtype).contiguous()
-    lead = [self.ntransf] if self.ntransf > 1 or source.dim() > (1 if self.type == 'type_1' else self.rank) else []
+    lead = self._lead(source, 1 if self.type == 'type_1' else self.rank)
     if self.type == 'type_1':
       if out is None:
         out = torch.empty(lead + self.grid_shape, dtype=self.cdtype, device=self.device)
@@ -104,12 +119,11 @@ class Plan:
   def execute_with_points(self, points, source, out=None):
     """set_points + execute as one call (what a NUFFT op invocation does); a type-1 plan
     with one transform sorts the strengths along with the points. The points are consumed."""
-    points = points.to(self.device, self.rdtype).contiguous()
-    assert points.dim() == 2 and points.shape[1] == self.rank
+    points = self._check_points(points)
     source = source.to(self.device, self.cdtype).contiguous()
     self._points = points
-    self.M = points.shape[0]
-    lead = [self.ntransf] if self.ntransf > 1 else []
+    self.M = points.shape[-2]
+    lead = self._lead(source, 1 if self.type == 'type_1' else self.rank)
     if self.type == 'type_1':
       if out is None:
         out = torch.empty(lead + self.grid_shape, dtype=self.cdtype, device=self.device)
@@ -136,7 +150,7 @@ class Plan:
   def fine_grid(self):
     """Debug: the plan's fine grid [batch, nf...] (array order) as a tensor view copy."""
     i = self.info()
-    shape = [i.batch_size] + [int(i.fine_dims[self.rank - 1 - d]) for d in range(self.rank)]
+    shape = [i.batch_size * self.nsets] + [int(i.fine_dims[self.rank - 1 - d]) for d in range(self.rank)]
     out = torch.empty(shape, dtype=self.cdtype, device=self.device)
     with torch.cuda.device(self.device):
       self._check(self.lib.nufft_hip_debug_copy_fine_grid(self._handle, out.data_ptr(), out.numel()))
@@ -166,7 +180,7 @@ class Plan:
 
   def spread(self, c, out=None):
     c = c.to(self.device, self.cdtype).contiguous()
-    lead = [self.ntransf] if self.ntransf > 1 or c.dim() > 1 else []
+    lead = self._lead(c, 1)
     if out is None:
       out = torch.empty(lead + self.grid_shape, dtype=self.cdtype, device=self.device)
     with torch.cuda.device(self.device):
@@ -175,7 +189,7 @@ class Plan:
 
   def interp(self, f, out=None):
     f = f.to(self.device, self.cdtype).contiguous()
-    lead = [self.ntransf] if self.ntransf > 1 or f.dim() > self.rank else []
+    lead = self._lead(f, self.rank)
     if out is None:
       out = torch.empty(lead + [self.M], dtype=self.cdtype, device=self.device)
     with torch.cuda.device(self.device):

@@ -1167,6 +1167,7 @@ def test_framework_allocator_and_workspace_lease(tfft):
   pts = _dev(rng.uniform(-np.pi, np.pi, (2, 1, 5000, 2)).astype(np.float32))
   src = _dev((rng.standard_normal((2, 3, 5000)) + 1j * rng.standard_normal((2, 3, 5000))).astype(np.complex64))
   ref = tfft.nufft(src, pts, grid_shape=[40, 48], transform_type='type_1')
+  lib.nufft_hip_op_clear_cache()   # (that call cached plans with internal workspace)
   d = _lib.OpDesc()
   d.op_type, d.transform_type, d.fft_direction, d.precision, d.tol = 0, 1, -1, 4, 1e-6
   lib.nufft_hip_default_options(ctypes.byref(d.options))
@@ -1246,3 +1247,84 @@ def test_bench_spawns_its_own_ranks():
   d = json.loads(lines[0])
   assert d['n_gpus'] == 2 and d['config']['items'] == 6 and d['config']['items_per_rank'] == 3
   assert d['scaling'] == 'strong' and d['value'] > 0
+
+
+@pytest.mark.parametrize('rank,grid,M,dtype,tol,ntransf', [
+    (2, [96, 80], 60_001, 'c64', 1e-6, 1),     # dense 2-D float (odd set size): fused records, LDS-histogram sort
+    (2, [96, 80], 5_000, 'c64', 1e-6, 2),      # per-point 2-D kernel, two transforms per set
+    (2, [64, 64], 40, 'c64', 1e-6, 1),         # sparse sets: LDS-free kernel
+    (3, [24, 32, 20], 30_000, 'c64', 1e-4, 1), # 3-D fixed point
+    (2, [40, 48], 20_000, 'c128', 1e-9, 1),    # double
+    (1, [256], 9_000, 'c128', 1e-9, 1),        # 1-D
+])
+@pytest.mark.parametrize('ttype', ['type_1', 'type_2'])
+def test_plan_with_several_point_sets(tfft, rank, grid, M, dtype, tol, ntransf, ttype):
+  # options.num_point_sets = K: K independent point sets sorted and transformed in one pass
+  # (composite tiles item * ntiles + tile). Must equal K single-set plans.
+  import torch
+  K = 3
+  cdt = torch.complex64 if dtype == 'c64' else torch.complex128
+  rdt = torch.float32 if dtype == 'c64' else torch.float64
+  g = torch.Generator(device='cuda').manual_seed(31)
+  pts = ((torch.rand((K, M, rank), generator=g, device='cuda', dtype=torch.float64) * 2 - 1) * np.pi).to(rdt)
+  lead = [K, ntransf] if ntransf > 1 else [K]
+  shape = lead + ([M] if ttype == 'type_1' else grid)
+  src = torch.complex(torch.rand(shape, generator=g, device='cuda', dtype=torch.float64) - .5,
+                      torch.rand(shape, generator=g, device='cuda', dtype=torch.float64) - .5).to(cdt)
+  plan = tfft.Plan(ttype, grid, tol=tol, dtype=cdt, num_transforms=ntransf, num_point_sets=K)
+  plan.set_points(pts)
+  out = plan.execute(src)
+  out1 = plan.execute_with_points(pts, src)
+  plan.close()
+  single = tfft.Plan(ttype, grid, tol=tol, dtype=cdt, num_transforms=ntransf)
+  for k in range(K):
+    single.set_points(pts[k])
+    ref = single.execute(src[k])
+    assert rel_l2(out[k].cpu().numpy(), ref.cpu().numpy()) < max(3e-7, tol * 1e-2), k
+    assert rel_l2(out1[k].cpu().numpy(), ref.cpu().numpy()) < max(3e-7, tol * 1e-2), k
+  single.close()
+  # and one set against the dense float64 sum
+  k = K - 1
+  s1 = src[k][0] if ntransf > 1 else src[k]
+  o1 = out[k][0] if ntransf > 1 else out[k]
+  dense = tfft.nudft(s1.to(torch.complex128), pts[k].to(torch.float64), grid_shape=grid, transform_type=ttype)
+  assert rel_l2(o1.cpu().numpy(), dense.cpu().numpy()) < tol
+
+
+def test_op_groups_per_item_points_into_multi_set_plans(tfft):
+  # tfft.nufft on a batch with per-item points runs groups of items through one plan
+  # (nufft_op.cpp); a batch that is not a multiple of the group size exercises the tail plan,
+  # a broadcast source (shared by the items) the ungrouped path
+  import torch
+  from oracle import oracle
+  B, M, grid = 37, 30_000, [64, 80]
+  g = torch.Generator(device='cuda').manual_seed(32)
+  pts = (torch.rand((B, M, 2), generator=g, device='cuda') * 2 - 1) * np.pi
+  c = torch.complex(torch.rand((B, M), generator=g, device='cuda') - .5, torch.rand((B, M), generator=g, device='cuda') - .5)
+  out = tfft.nufft(c, pts, grid_shape=grid, transform_type='type_1')
+  assert out.shape == (B, 64, 80)
+  for b in (0, 15, 16, 31, 32, 36):
+    ref = oracle.nufft(c[b].cpu().numpy().astype(np.complex128), pts[b].cpu().numpy(), grid, 'type_1', 'forward',
+                       tol=1e-12, sigma=2.0)
+    assert rel_l2(out[b].cpu().numpy(), ref) < 1e-6, b
+  # type 2 with per-item points
+  f = torch.complex(torch.rand([B] + grid, generator=g, device='cuda') - .5, torch.rand([B] + grid, generator=g, device='cuda') - .5)
+  out2 = tfft.nufft(f, pts, transform_type='type_2')
+  for b in (0, 17, 36):
+    ref = oracle.nufft(f[b].cpu().numpy().astype(np.complex128), pts[b].cpu().numpy(), None, 'type_2', 'forward',
+                       tol=1e-12, sigma=2.0)
+    assert rel_l2(out2[b].cpu().numpy(), ref) < 1e-6, b
+  # one strengths vector shared by every item (source batch 1): ungrouped calls
+  out3 = tfft.nufft(c[:1], pts[:5], grid_shape=grid, transform_type='type_1')
+  assert out3.shape == (5, 64, 80)
+  ref = oracle.nufft(c[0].cpu().numpy().astype(np.complex128), pts[3].cpu().numpy(), grid, 'type_1', 'forward',
+                     tol=1e-12, sigma=2.0)
+  assert rel_l2(out3[3].cpu().numpy(), ref) < 1e-6
+  # two batch dims, both carried by the points: [2, 3] items, 2 inner transforms each
+  pts4 = pts[:6].reshape(2, 3, 1, M, 2)
+  c4 = torch.stack([c[:6], c[6:12]], dim=1).reshape(2, 3, 2, M)
+  out4 = tfft.nufft(c4, pts4, grid_shape=grid, transform_type='type_1')
+  assert out4.shape == (2, 3, 2, 64, 80)
+  ref = oracle.nufft(c4[1, 2, 1].cpu().numpy().astype(np.complex128), pts4[1, 2, 0].cpu().numpy(), grid, 'type_1',
+                     'forward', tol=1e-12, sigma=2.0)
+  assert rel_l2(out4[1, 2, 1].cpu().numpy(), ref) < 1e-6

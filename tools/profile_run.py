@@ -11,6 +11,7 @@ ap.add_argument('--M', type=float, default=1e7); ap.add_argument('--tol', type=f
 ap.add_argument('--method', type=int, default=0); ap.add_argument('--S', type=int, default=0)
 ap.add_argument('--steps', type=int, default=5); ap.add_argument('--ntransf', type=int, default=1)
 ap.add_argument('--acc', type=int, default=0)
+ap.add_argument('--one-call', action='store_true', help='nufft_hip_execute_with_points instead of set_points + execute')
 a = ap.parse_args()
 grid = [int(g) for g in a.grid.split(',')]; M = int(a.M); rank = len(grid)
 g = torch.Generator(device='cuda').manual_seed(2)
@@ -22,7 +23,10 @@ else:
   src = torch.complex(torch.rand(lead + grid, generator=g, device='cuda') - .5, torch.rand(lead + grid, generator=g, device='cuda') - .5)
 plan = tfft.Plan(a.type, grid, 'forward', num_transforms=a.ntransf, tol=a.tol, spread_method=a.method, max_subproblem_size=a.S, lds_accumulate=a.acc)
 for _ in range(a.steps):
-  plan.set_points(pts)
-  out = plan.execute(src)
+  if a.one_call:
+    out = plan.execute_with_points(pts, src)
+  else:
+    plan.set_points(pts)
+    out = plan.execute(src)
 torch.cuda.synchronize()
 print('done', out.shape)

@@ -34,6 +34,11 @@ __global__ void bench(float* out, int stride_words) {
       else if (MODE == 6) { lds[a] = v; }                                            // plain write
       else if (MODE == 7) { v += lds[a]; }                                           // plain read
       else if (MODE == 8) atomicMax(reinterpret_cast<int*>(&lds[a]), lane);          // ds_max_i32
+      // ds_add_f64 with part of the wave active: does the cost scale with the active lanes?
+      else if (MODE == 9) { if (lane < 32) unsafeAtomicAdd(reinterpret_cast<double*>(&lds[a & ~1]), (double)v); }
+      else if (MODE == 10) { if (lane < 16) unsafeAtomicAdd(reinterpret_cast<double*>(&lds[a & ~1]), (double)v); }
+      else if (MODE == 11) { if (lane < 8) unsafeAtomicAdd(reinterpret_cast<double*>(&lds[a & ~1]), (double)v); }
+      else if (MODE == 12) { if ((lane & 7) == 0) unsafeAtomicAdd(reinterpret_cast<double*>(&lds[a & ~1]), (double)v); }
     }
     base = (base + 37) & (LDSW - 1);
   }
@@ -64,19 +69,22 @@ int main() {
   printf("device %s CUs %d clock %.0f MHz\n", prop.name, cus, clk / 1e6);
   float* dout;
   CHECK(hipMalloc(&dout, 1 << 20));
-  const char* names[] = {"ds_add_f32", "ds_add_rtn_f32", "ds_add_u32", "ds_add_u64", "ds_add_f64", "rmw_plain", "write_b32", "read_b32", "ds_max_i32"};
+  const char* names[] = {"ds_add_f32", "ds_add_rtn_f32", "ds_add_u32", "ds_add_u64", "ds_add_f64", "rmw_plain", "write_b32", "read_b32", "ds_max_i32",
+                         "f64_lanes<32", "f64_lanes<16", "f64_lanes<8", "f64_lanes%8==0"};
   for (int stride : {1, 2}) {
     for (int wpb : {1, 4, 8, 16}) {
       const int threads = wpb * 64;
       const int blocks = cus;  // one block per CU
       printf("stride %d words, %2d waves/CU:", stride, wpb);
-      float ms[9];
+      float ms[13];
       ms[0] = run<0>(blocks, threads, stride, dout); ms[1] = run<1>(blocks, threads, stride, dout);
       ms[2] = run<2>(blocks, threads, stride, dout); ms[3] = run<3>(blocks, threads, stride, dout);
       ms[4] = run<4>(blocks, threads, stride, dout); ms[5] = run<5>(blocks, threads, stride, dout);
       ms[6] = run<6>(blocks, threads, stride, dout); ms[7] = run<7>(blocks, threads, stride, dout);
       ms[8] = run<8>(blocks, threads, stride, dout);
-      for (int m = 0; m < 9; ++m) {
+      ms[9] = run<9>(blocks, threads, stride, dout); ms[10] = run<10>(blocks, threads, stride, dout);
+      ms[11] = run<11>(blocks, threads, stride, dout); ms[12] = run<12>(blocks, threads, stride, dout);
+      for (int m = 0; m < 13; ++m) {
         const double ops = (double)ITER * 8 * wpb;            // wave-instructions per CU
         const double cyc = ms[m] * 1e-3 * clk / ops;          // cycles per wave-instruction per CU
         printf("  %s %.1f", names[m], cyc);
