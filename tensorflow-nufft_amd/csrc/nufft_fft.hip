@@ -1,0 +1,479 @@
+// Pruned FFT passes of the NUFFT plan for power-of-two fine grids (gfx950).
+//
+// The reference runs a full in-place FFT of the oversampled grid (cuFFT / FFTW,
+// nufft_plan.cu.cc:2147-2152, nufft_plan.cc:336) and then a separate deconvolve kernel
+// that keeps only the N of the nf = sigma N modes per dimension
+// (Deconvolve*/Amplify*, nufft_plan.cu.cc:326-435). Only those N modes are ever used, so
+// here the transform is done one dimension at a time and every pass already crops (type 1)
+// or zero-pads (type 2) its dimension and applies that dimension's deconvolution factor:
+//
+//   type 1:  fine[z][y][x] --x--> B1[kx][z][y] --y--> B2[ky][kx][z] --z--> f[kz][ky][kx]
+//   type 2:  f[kz][ky][kx] --x--> B1[x][kz][ky] --y--> B2[y][x][kz] --z--> fine[z][y][x]
+//
+// Every pass reads contiguous lines, transforms them in LDS and writes its output
+// TRANSPOSED ([bin][line]), which makes the next dimension contiguous and, after `rank`
+// passes, restores the original axis order. Type 1 at sigma = 2 moves 1 + 1/2 (+ 1/4 ...)
+// grids instead of the 8 the rocFFT transpose pipeline moves for a 2-D grid (4 kernels,
+// each reading and writing the whole grid) plus the deconvolve pass: 2048^2 complex64,
+// 72 us (rocFFT) + 9 us (deconvolve) -> see DESIGN.md for the measured figure.
+//
+// One workgroup of 256 threads transforms R lines (n / 8 threads per line, 2048 / n lines at
+// a time): Stockham autosort passes of radix 8 / 4 / 2 with the butterflies in registers and
+// the exchange through an LDS line buffer; the results collect in an LDS tile [bins][R] that
+// is written out with R consecutive lines per bin (64-128 byte segments).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "nufft_hip_internal.h"
+
+namespace nufft_hip {
+
+namespace {
+
+template <typename T> struct C2;
+template <> struct C2<float> { using type = float2; };
+template <> struct C2<double> { using type = double2; };
+
+template <typename V, typename T>
+__device__ __forceinline__ V cmul(V a, V b) {
+  V r;
+  r.x = a.x * b.x - a.y * b.y;
+  r.y = a.x * b.y + a.y * b.x;
+  return r;
+}
+template <typename V> __device__ __forceinline__ V cadd(V a, V b) { V r; r.x = a.x + b.x; r.y = a.y + b.y; return r; }
+template <typename V> __device__ __forceinline__ V csub(V a, V b) { V r; r.x = a.x - b.x; r.y = a.y - b.y; return r; }
+// multiply by sgn * i  (sgn = -1: forward transform, exp(-i ...))
+template <typename V, typename T>
+__device__ __forceinline__ V mul_i(V a, T sgn) { V r; r.x = -sgn * a.y; r.y = sgn * a.x; return r; }
+
+template <typename V, typename T>
+__device__ __forceinline__ void dft2(V& a, V& b) {
+  const V t = csub(a, b);
+  a = cadd(a, b);
+  b = t;
+}
+// in-place DFT of size 4, natural output order
+template <typename V, typename T>
+__device__ __forceinline__ void dft4(V& v0, V& v1, V& v2, V& v3, T sgn) {
+  const V a = cadd(v0, v2), b = csub(v0, v2), c = cadd(v1, v3), d = mul_i<V, T>(csub(v1, v3), sgn);
+  v0 = cadd(a, c);
+  v1 = cadd(b, d);
+  v2 = csub(a, c);
+  v3 = csub(b, d);
+}
+template <typename V, typename T>
+__device__ __forceinline__ void dft8(V (&v)[8], T sgn) {
+  V e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
+  V o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+  dft4<V, T>(e0, e1, e2, e3, sgn);
+  dft4<V, T>(o0, o1, o2, o3, sgn);
+  const T h = (T)0.70710678118654752440;
+  // w8^t = exp(sgn i pi t / 4)
+  V w1; w1.x = h; w1.y = sgn * h;
+  V w3; w3.x = -h; w3.y = sgn * h;
+  o1 = cmul<V, T>(o1, w1);
+  o2 = mul_i<V, T>(o2, sgn);
+  o3 = cmul<V, T>(o3, w3);
+  v[0] = cadd(e0, o0); v[4] = csub(e0, o0);
+  v[1] = cadd(e1, o1); v[5] = csub(e1, o1);
+  v[2] = cadd(e2, o2); v[6] = csub(e2, o2);
+  v[3] = cadd(e3, o3); v[7] = csub(e3, o3);
+}
+
+constexpr int kFftMaxThreads = 1024;
+
+template <typename T>
+struct FftPassArgs {
+  const typename C2<T>::type* in;
+  typename C2<T>::type* out;
+  const typename C2<T>::type* tw;   // exp(sgn 2 pi i m / n), m = 0 .. n-1
+  const T* rf;                      // reciprocal kernel Fourier series of this dimension, [n / 2 + 1]
+  int n, kin, kout;                 // FFT length; input / output line lengths (n: all bins; < n: CMCL modes)
+  int64_t nlines;                   // lines per transform
+  int64_t in_batch, out_batch;      // elements between consecutive transforms
+  int R;                            // lines per workgroup
+  int LW;                           // lines in flight (blockDim.x = LW * n / 8)
+  int npass;
+  unsigned radpack;                 // radix of pass p in bits [4 p, 4 p + 4) (an indexed array in the kernel
+                                    // arguments makes the compiler copy them to scratch memory)
+  float sgn;
+};
+
+// bin m of an n-point transform <-> mode k in [-(K/2), (K-1)/2] stored at index k + K/2
+// (CMCL order); returns -1 for bins outside the kept modes
+__device__ __forceinline__ int bin_to_mode_index(int m, int n, int K, int* absk) {
+  int k;
+  if (m <= (K - 1) / 2) k = m;
+  else if (m >= n - K / 2) k = m - n;
+  else return -1;
+  *absk = k < 0 ? -k : k;
+  return k + K / 2;
+}
+
+// Line buffer index with one pad element per 32: the first exchange writes with a stride of
+// `radix` elements between consecutive lanes (16-way bank conflicts on 8-byte elements
+// without the pad, none with it); reads are always consecutive.
+__device__ __forceinline__ int lpad(int i) { return i + (i >> 5); }
+__host__ __device__ __forceinline__ int lpad_len(int n) { return n + (n >> 5) + 1; }
+
+// Per-thread maps between the 8 bins a thread touches in the first / last pass and the CMCL
+// mode array of a line (type 2 input: zero-padded; type 1 output: cropped), with the
+// deconvolution factor of each. Computed once per workgroup: they do not depend on the line.
+template <typename T>
+struct BinMap { int idx[8]; T sc[8]; };
+
+// First-pass inputs of one line, straight from global memory. Butterfly u of the thread takes
+// elements lt + u TL + t n / RAD, t < RAD. PAD: the line holds kin < n modes (see BinMap).
+template <typename T, int RAD, bool PAD>
+__device__ __forceinline__ void fft_load_line(const typename C2<T>::type* __restrict__ rowp, bool live, int lt,
+                                              int TL, int n, const BinMap<T>& map, typename C2<T>::type (&x)[8]) {
+  using V = typename C2<T>::type;
+  const int stride = n / RAD;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int u = q / RAD, t = q % RAD;
+    V y; y.x = (T)0; y.y = (T)0;
+    if constexpr (PAD) {
+      const V z = rowp[map.idx[q] >= 0 ? map.idx[q] : 0];   // unconditional loads
+      if (live && map.idx[q] >= 0) { y.x = z.x * map.sc[q]; y.y = z.y * map.sc[q]; }
+    } else {
+      const V z = rowp[lt + u * TL + t * stride];
+      if (live) y = z;
+    }
+    x[q] = y;
+  }
+}
+
+// One Stockham pass of radix RAD on the 8 values of a thread (8 / RAD butterflies).
+template <typename T, int RAD, bool CROP>
+__device__ __forceinline__ void fft_pass(const typename C2<T>::type* twp, int n, const BinMap<T>& map,
+                                         typename C2<T>::type (&v)[8], typename C2<T>::type* mybuf,
+                                         typename C2<T>::type* trow, int lt, int TL, int Ns, bool first, bool last,
+                                         bool row_ok, T sgn) {
+  using V = typename C2<T>::type;
+  const int stride = n / RAD;
+  if (!first) {
+    // inputs from the line buffer, then the twiddles exp(sgn 2 pi i t k / (Ns RAD)), k = j mod Ns
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int u = q / RAD, t = q % RAD;
+      v[q] = mybuf[lpad(lt + u * TL + t * stride)];
+    }
+    const int tstep = n / (Ns * RAD);
+#pragma unroll
+    for (int u = 0; u < 8 / RAD; ++u) {
+      const int k = (lt + u * TL) & (Ns - 1);
+      const int base = k * tstep;
+#pragma unroll
+      for (int t = 1; t < RAD; ++t) {
+        // half table in LDS: exp(i pi) = -1 gives the other half
+        const int ti = (t * base) & (n - 1);
+        V w = twp[ti & (n / 2 - 1)];
+        if (ti & (n / 2)) { w.x = -w.x; w.y = -w.y; }
+        v[u * RAD + t] = cmul<V, T>(v[u * RAD + t], w);
+      }
+    }
+  }
+  if constexpr (RAD == 8) {
+    dft8<V, T>(v, sgn);
+  } else if constexpr (RAD == 4) {
+    dft4<V, T>(v[0], v[1], v[2], v[3], sgn);
+    dft4<V, T>(v[4], v[5], v[6], v[7], sgn);
+  } else {
+    dft2<V, T>(v[0], v[1]); dft2<V, T>(v[2], v[3]); dft2<V, T>(v[4], v[5]); dft2<V, T>(v[6], v[7]);
+  }
+  if (!last) {
+    __syncthreads();   // every thread has read its inputs of this pass
+#pragma unroll
+    for (int u = 0; u < 8 / RAD; ++u) {
+      const int j = lt + u * TL;
+      const int k = j & (Ns - 1);
+      const int o = (j - k) * RAD + k;
+#pragma unroll
+      for (int t = 0; t < RAD; ++t) mybuf[lpad(o + t * Ns)] = v[u * RAD + t];
+    }
+    __syncthreads();
+  } else if (row_ok) {
+    // natural-order bins -> tile [line][bin]; CROP: only the kept modes, deconvolved (map)
+#pragma unroll
+    for (int u = 0; u < 8 / RAD; ++u) {
+      const int j = lt + u * TL;
+      const int k = j & (Ns - 1);
+      const int o = (j - k) * RAD + k;
+#pragma unroll
+      for (int t = 0; t < RAD; ++t) {
+        const V val = v[u * RAD + t];
+        if constexpr (CROP) {
+          const int idx = map.idx[u * RAD + t];
+          if (idx >= 0) {
+            const T sc = map.sc[u * RAD + t];
+            V y; y.x = val.x * sc; y.y = val.y * sc;
+            trow[idx] = y;
+          }
+        } else {
+          trow[o + t * Ns] = val;
+        }
+      }
+    }
+  }
+}
+
+// Radix of pass P of a 2^LOGN-point transform: radix 8 while three bits remain, then 4 or 2.
+template <int LOGN, int P> constexpr int fft_radix() {
+  constexpr int done = 3 * P;
+  constexpr int rem = LOGN - done;
+  return rem >= 3 ? 8 : rem == 2 ? 4 : rem == 1 ? 2 : 1;
+}
+template <int LOGN> constexpr int fft_npass() { return (LOGN + 2) / 3; }
+
+template <typename T, int LOGN, int P, bool CROP>
+__device__ __forceinline__ void fft_all_passes(const typename C2<T>::type* twp, const BinMap<T>& map,
+                                               typename C2<T>::type (&v)[8], typename C2<T>::type* mybuf,
+                                               typename C2<T>::type* trow, int lt, bool row_ok, T sgn) {
+  constexpr int NP = fft_npass<LOGN>();
+  if constexpr (P < NP) {
+    constexpr int RAD = fft_radix<LOGN, P>();
+    constexpr int Ns = 1 << (3 * P);   // every earlier pass has radix 8
+    fft_pass<T, RAD, CROP>(twp, 1 << LOGN, map, v, mybuf, trow, lt, (1 << LOGN) / 8, Ns, P == 0, P == NP - 1, row_ok, sgn);
+    fft_all_passes<T, LOGN, P + 1, CROP>(twp, map, v, mybuf, trow, lt, row_ok, sgn);
+  }
+}
+
+// PAD = false: type-1 pass (plain input lines of n points, output cropped to kout modes);
+// PAD = true: type-2 pass (input lines of kin modes zero-padded to n, all n bins written).
+template <typename T, int LOGN, bool PAD>
+__global__ __launch_bounds__(kFftMaxThreads, 4) void fft_rotate_kernel(FftPassArgs<T> a) {
+  using V = typename C2<T>::type;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int n = 1 << LOGN;
+  constexpr int TL = n >> 3;              // threads per line
+  constexpr int RAD0 = fft_radix<LOGN, 0>();
+  constexpr int NP = fft_npass<LOGN>();
+  constexpr int RADL = fft_radix<LOGN, NP - 1>();
+  const int LW = a.LW;                    // lines in flight
+  constexpr int LB = n + (n >> 5) + 1;
+  const int TS = a.kout + 1;              // tile row pitch (+1: the transposed read-out is conflict free)
+  V* lbuf = reinterpret_cast<V*>(smem_raw);               // [LW][LB]
+  V* tile = lbuf + (size_t)LW * LB;                        // [R][TS]
+  V* twl = tile + (size_t)a.R * TS;                        // [n / 2]: twiddles (a global table costs an L2 latency per pass)
+  const int tid = threadIdx.x;
+  for (int i = tid; i < n / 2; i += blockDim.x) twl[i] = a.tw[i];
+  const int lw = tid / TL, lt = tid - lw * TL;
+  const int64_t line0 = (int64_t)blockIdx.x * a.R;
+  const V* __restrict__ in = a.in + (int64_t)blockIdx.y * a.in_batch;
+  V* __restrict__ out = a.out + (int64_t)blockIdx.y * a.out_batch;
+  const V* twp = twl;
+  const T sgn = (T)a.sgn;
+  V* mybuf = lbuf + (size_t)lw * LB;
+  const int inlen = PAD ? a.kin : n;
+
+  BinMap<T> map;
+  if constexpr (PAD) {          // first-pass element q of this thread <- mode index / factor
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int u = q / RAD0, t = q % RAD0;
+      int ak = 0;
+      map.idx[q] = bin_to_mode_index(lt + u * TL + t * (n / RAD0), n, a.kin, &ak);
+      map.sc[q] = a.rf[ak];
+    }
+  } else {                      // last-pass output q of this thread -> mode index / factor
+    constexpr int NsL = n / RADL;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int u = q / RADL, t = q % RADL;
+      const int j = lt + u * TL;
+      const int k = j & (NsL - 1);
+      int ak = 0;
+      map.idx[q] = bin_to_mode_index((j - k) * RADL + k + t * NsL, n, a.kout, &ak);
+      map.sc[q] = a.rf[ak];
+    }
+  }
+
+  __syncthreads();   // twiddle table
+  V v[8], vn[8];
+  {
+    const int64_t line = line0 + lw;
+    const bool live = lw < a.R && line < a.nlines;
+    fft_load_line<T, RAD0, PAD>(in + (live ? line : 0) * inlen, live, lt, TL, n, map, v);
+  }
+  for (int g = 0; g < a.R; g += LW) {
+    const int r = g + lw;                       // line inside the workgroup's block
+    const bool more = g + LW < a.R;
+    if (more) {                                 // next group's loads are in flight during this group's passes
+      const int64_t line = line0 + r + LW;
+      const bool live = r + LW < a.R && line < a.nlines;
+      fft_load_line<T, RAD0, PAD>(in + (live ? line : 0) * inlen, live, lt, TL, n, map, vn);
+    }
+    V* trow = tile + (r < a.R ? r : 0) * TS;
+    // (opaque copy of the lane's index: otherwise the compiler hoists the LDS and twiddle
+    // addresses of every pass out of this loop and spills them: 70-280 bytes per lane)
+    int ltv = lt;
+    asm volatile("" : "+v"(ltv));
+    fft_all_passes<T, LOGN, 0, !PAD>(twp, map, v, mybuf, trow, ltv, r < a.R, sgn);
+    if (more) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = vn[q];
+    }
+  }
+  __syncthreads();
+  // ---- tile -> out[bin][line]: R consecutive lines per bin
+  const int R = a.R;
+  const int64_t nl = a.nlines;
+  const int nthreads = blockDim.x;
+  for (int e = tid; e < a.kout * R; e += nthreads) {
+    const int bin = e / R, r = e - bin * R;
+    const int64_t line = line0 + r;
+    if (line < nl) out[(int64_t)bin * nl + line] = tile[r * TS + bin];
+  }
+}
+
+template <typename T, int LOGN>
+hipError_t launch_fft_pass(const FftPassArgs<T>& a, unsigned nblk, unsigned batch, size_t lds, hipStream_t stream) {
+  const bool pad = a.kin != a.n;
+  if (pad && a.kout != a.n) return hipErrorInvalidValue;   // a pass either pads or crops
+  const void* fn = pad ? reinterpret_cast<const void*>(fft_rotate_kernel<T, LOGN, true>)
+                       : reinterpret_cast<const void*>(fft_rotate_kernel<T, LOGN, false>);
+  if (lds > 64 * 1024) {
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  if (pad) fft_rotate_kernel<T, LOGN, true><<<dim3(nblk, batch), a.LW * (a.n / 8), lds, stream>>>(a);
+  else fft_rotate_kernel<T, LOGN, false><<<dim3(nblk, batch), a.LW * (a.n / 8), lds, stream>>>(a);
+  return hipGetLastError();
+}
+
+// Lines per workgroup (R), lines in flight (LW) and dynamic LDS of one pass; R = 0: not
+// supported. Longer output segments (R consecutive lines per bin) write faster; more, smaller
+// workgroups fill the chip when a pass has few lines (2048 lines of 2048 points at config 2).
+int fft_pass_shape(int n, int kout, int csize, int64_t nlines, int* lw_out, size_t* lds) {
+  if (n < 16 || n > 2048 || (n & (n - 1))) return 0;
+  const int TL = n / 8;
+  int best = 0, best_lw = 0;
+  size_t best_lds = 0;
+  int tier = 0;
+  for (int R = 16; R >= 2; R /= 2) {
+    if (R * csize < 32) break;                                     // output segments of at least 32 bytes
+    int LW = kFftMaxThreads / TL;
+    if (LW > R) LW = R;
+    if (LW < 1) LW = 1;
+    // fewer lines in flight when the tile of R lines leaves no room for more line buffers
+    // (2048-point lines with all 2048 bins written: 8 x 16 KB of tile + ONE 16 KB buffer)
+    size_t bytes = 0;
+    for (; LW >= 1; LW /= 2) {
+      bytes = ((size_t)LW * lpad_len(n) + (size_t)R * (kout + 1) + (size_t)n / 2) * csize;
+      if (bytes <= 160 * 1024) break;
+    }
+    if (LW < 1 || LW * TL < 64) continue;                          // at least one full wavefront
+    const int64_t wgs = (nlines + R - 1) / R;
+    // tier 4: >= 512 workgroups that fit two to a CU, 64-byte segments; tier 3: >= 256 workgroups
+    // and 64-byte segments; tier 2: >= 256 workgroups; tier 1: feasible
+    const bool seg64 = R * csize >= 64;
+    const int t = (wgs >= 512 && bytes <= 80 * 1024 && seg64) ? 4 : (wgs >= 256 && seg64) ? 3 : (wgs >= 256 ? 2 : 1);
+    if (t > tier) { tier = t; best = R; best_lw = LW; best_lds = bytes; }
+  }
+  if (!best) return 0;
+  *lw_out = best_lw;
+  *lds = best_lds;
+  return best;
+}
+
+}  // namespace
+
+bool pruned_fft_supported(const Geom& g, int precision) {
+  static const bool off = getenv("NUFFT_HIP_NO_OWN_FFT") != nullptr;   // A/B against rocFFT + deconvolve
+  if (off) return false;
+  const int csize = 2 * precision;
+  for (int d = 0; d < g.rank; ++d) {
+    size_t lds;
+    int lw;
+    if (g.nmodes[d] > g.nf[d]) return false;
+    // type 1 crops to nmodes, type 2 writes all nf bins: both shapes must fit
+    if (!fft_pass_shape(g.nf[d], g.nmodes[d], csize, 1 << 20, &lw, &lds)) return false;
+    if (!fft_pass_shape(g.nf[d], g.nf[d], csize, 1 << 20, &lw, &lds)) return false;
+  }
+  return true;
+}
+
+// Complex elements (per transform) each of the two intermediate buffers must hold.
+int64_t pruned_fft_tmp_elems(const Geom& g) {
+  if (g.rank < 2) return 0;
+  int64_t best = 0;
+  // type 1: B1 = N0 nf1 nf2, B2 = N1 N0 nf2; type 2: B1 = nf0 N1 N2, B2 = nf1 nf0 N2
+  const int64_t N0 = g.nmodes[0], N1 = g.nmodes[1], N2 = g.nmodes[2];
+  const int64_t f0 = g.nf[0], f1 = g.nf[1], f2 = g.nf[2];
+  best = std::max(best, N0 * f1 * f2);
+  best = std::max(best, f0 * N1 * N2);
+  if (g.rank > 2) {
+    best = std::max(best, N1 * N0 * f2);
+    best = std::max(best, f1 * f0 * N2);
+  }
+  return best;
+}
+
+template <typename T>
+hipError_t launch_pruned_fft(const Geom& g, int type, int iflag, T* fine, T* f, T* tmp0, T* tmp1,
+                             const T* const rf[3], const T* const tw[3], int batch, hipStream_t stream) {
+  using V = typename C2<T>::type;
+  const int rank = g.rank;
+  const int csize = 2 * (int)sizeof(T);
+  int64_t fine_elems = 1, mode_elems = 1;
+  for (int d = 0; d < rank; ++d) { fine_elems *= g.nf[d]; mode_elems *= g.nmodes[d]; }
+  // sizes of the array before pass d: dims [0..d) already transformed (type 1: cropped to
+  // nmodes, type 2: expanded to nf), dims [d..rank) not yet
+  const V* src = reinterpret_cast<const V*>(type == 1 ? fine : f);
+  int64_t src_batch = type == 1 ? fine_elems : mode_elems;
+  for (int d = 0; d < rank; ++d) {
+    FftPassArgs<T> a;
+    a.n = g.nf[d];
+    a.kin = type == 1 ? g.nf[d] : g.nmodes[d];
+    a.kout = type == 1 ? g.nmodes[d] : g.nf[d];
+    int64_t lines = 1;
+    for (int e = 0; e < rank; ++e) {
+      if (e == d) continue;
+      const bool done = e < d;
+      lines *= (type == 1) ? (done ? g.nmodes[e] : g.nf[e]) : (done ? g.nf[e] : g.nmodes[e]);
+    }
+    a.nlines = lines;
+    a.in = src;
+    a.in_batch = src_batch;
+    const bool last = d == rank - 1;
+    V* dst = last ? reinterpret_cast<V*>(type == 1 ? f : fine) : reinterpret_cast<V*>((d & 1) ? tmp1 : tmp0);
+    a.out = dst;
+    a.out_batch = (int64_t)a.kout * lines;
+    a.tw = reinterpret_cast<const V*>(tw[d]);
+    a.rf = rf[d];
+    a.sgn = iflag < 0 ? -1.0f : 1.0f;
+    a.npass = 0;
+    a.radpack = 0;
+    size_t lds = 0;
+    a.LW = 1;
+    a.R = fft_pass_shape(a.n, a.kout, csize, lines, &a.LW, &lds);
+    if (a.R == 0) return hipErrorInvalidValue;
+    const int64_t nblk = (lines + a.R - 1) / a.R;
+    if (nblk > 2147483647LL || batch > 65535) return hipErrorInvalidValue;
+    hipError_t e = hipErrorInvalidValue;
+    switch (a.n) {
+      case 16: e = launch_fft_pass<T, 4>(a, (unsigned)nblk, (unsigned)batch, lds, stream); break;
+      case 32: e = launch_fft_pass<T, 5>(a, (unsigned)nblk, (unsigned)batch, lds, stream); break;
+      case 64: e = launch_fft_pass<T, 6>(a, (unsigned)nblk, (unsigned)batch, lds, stream); break;
+      case 128: e = launch_fft_pass<T, 7>(a, (unsigned)nblk, (unsigned)batch, lds, stream); break;
+      case 256: e = launch_fft_pass<T, 8>(a, (unsigned)nblk, (unsigned)batch, lds, stream); break;
+      case 512: e = launch_fft_pass<T, 9>(a, (unsigned)nblk, (unsigned)batch, lds, stream); break;
+      case 1024: e = launch_fft_pass<T, 10>(a, (unsigned)nblk, (unsigned)batch, lds, stream); break;
+      case 2048: e = launch_fft_pass<T, 11>(a, (unsigned)nblk, (unsigned)batch, lds, stream); break;
+      default: break;
+    }
+    if (e != hipSuccess) return e;
+    src = dst;
+    src_batch = a.out_batch;
+  }
+  return hipGetLastError();
+}
+template hipError_t launch_pruned_fft<float>(const Geom&, int, int, float*, float*, float*, float*,
+                                             const float* const[3], const float* const[3], int, hipStream_t);
+template hipError_t launch_pruned_fft<double>(const Geom&, int, int, double*, double*, double*, double*,
+                                              const double* const[3], const double* const[3], int, hipStream_t);
+
+}  // namespace nufft_hip

@@ -156,6 +156,15 @@ hipError_t launch_deconvolve(const Geom& g, int dir, T* f, T* fw, const T* const
 hipError_t launch_permute(const void* src, void* dst, int elem_bytes, int ndim,
                           const int64_t* out_shape, const int64_t* src_strides,
                           hipStream_t stream);
+// Pruned per-dimension FFT passes with the deconvolution fused in (nufft_fft.hip): power-of-two
+// fine grids up to 2048 per dimension. fine / f: [batch] fine grids / mode arrays; tmp0, tmp1:
+// intermediates of pruned_fft_tmp_elems(g) complex elements per transform (tmp1: rank 3 only);
+// tw[d]: exp(iflag 2 pi i m / nf_d), m < nf_d; rf[d]: reciprocal kernel Fourier series.
+bool pruned_fft_supported(const Geom& g, int precision);
+int64_t pruned_fft_tmp_elems(const Geom& g);
+template <typename T>
+hipError_t launch_pruned_fft(const Geom& g, int type, int iflag, T* fine, T* f, T* tmp0, T* tmp1,
+                             const T* const rf[3], const T* const tw[3], int batch, hipStream_t stream);
 size_t spread_lds_bytes(const Geom& g, int method, int precision);
 size_t interp_lds_bytes(const Geom& g, int method, int precision);
 int wave_lstride(int rank);

@@ -221,6 +221,9 @@ struct nufft_hip_plan_s {
   rocfft_execution_info fft_info = nullptr;
   void* fft_work = nullptr;
   size_t fft_work_bytes = 0;      // bytes the FFT plans need (max over them)
+  bool own_fft = false;           // pruned per-dimension passes (nufft_fft.hip) instead of rocFFT + deconvolve
+  void* d_twiddle[3] = {nullptr, nullptr, nullptr};   // exp(iflag 2 pi i m / nf_d)
+  void* fft_tmp[2] = {nullptr, nullptr};              // intermediates of the pruned passes
 
   int nitems = 1;                // point sets handled together (options.num_point_sets)
   int64_t M = 0, cap = 0, cap_global = 0;   // M: points per set
@@ -419,6 +422,11 @@ int ensure_fixed_workspace(nufft_hip_plan p) {
   if (!rc) rc = dev_alloc(p, (void**)&p->bad_count, sizeof(int32_t) * 4);
   if (!rc && !p->opts.spread_only)
     rc = dev_alloc(p, &p->d_fine, (size_t)p->precision * 2 * (size_t)p->fine_elems * p->batch_size * p->nitems);
+  if (!rc && p->own_fft) {
+    const size_t tmp_bytes = (size_t)p->precision * 2 * (size_t)pruned_fft_tmp_elems(p->g) * p->batch_size * p->nitems;
+    if (p->rank >= 2) rc = dev_alloc(p, &p->fft_tmp[0], tmp_bytes);
+    if (!rc && p->rank >= 3) rc = dev_alloc(p, &p->fft_tmp[1], tmp_bytes);
+  }
   if (!rc && !p->opts.spread_only && p->fft_work_bytes) {
     rc = dev_alloc(p, &p->fft_work, p->fft_work_bytes);
     if (!rc) FFT_TRY(p, rocfft_execution_info_set_work_buffer(p->fft_info, p->fft_work, p->fft_work_bytes));
@@ -430,7 +438,7 @@ int ensure_fixed_workspace(nufft_hip_plan p) {
 
 void release_workspace(nufft_hip_plan p) {
   void** bufs[] = {(void**)&p->tile_count, (void**)&p->tile_start, (void**)&p->sub_start, (void**)&p->bad_count,
-                   &p->d_fine, &p->fft_work, &p->rec, &p->rec2, (void**)&p->hist, (void**)&p->tile_of,
+                   &p->d_fine, &p->fft_work, &p->fft_tmp[0], &p->fft_tmp[1], &p->rec, &p->rec2, (void**)&p->hist, (void**)&p->tile_of,
                    (void**)&p->rank_of};
   for (void** b : bufs) {
     dev_free(p, *b);
@@ -459,6 +467,20 @@ int upload_tables(nufft_hip_plan p) {
     rc = table_alloc(p, &p->d_rfser[d], n * sizeof(T));
     if (rc) return rc;
     HIP_TRY(p, hipMemcpy(p->d_rfser[d], r.data(), n * sizeof(T), hipMemcpyHostToDevice));
+  }
+  if (p->own_fft) {
+    for (int d = 0; d < p->rank; ++d) {
+      const int64_t n = p->g.nf[d];
+      std::vector<T> tw(2 * (size_t)n);
+      for (int64_t m = 0; m < n; ++m) {
+        const double ang = (double)p->iflag * 2.0 * kPi * (double)m / (double)n;
+        tw[2 * m] = (T)std::cos(ang);
+        tw[2 * m + 1] = (T)std::sin(ang);
+      }
+      rc = table_alloc(p, &p->d_twiddle[d], tw.size() * sizeof(T));
+      if (rc) return rc;
+      HIP_TRY(p, hipMemcpy(p->d_twiddle[d], tw.data(), tw.size() * sizeof(T), hipMemcpyHostToDevice));
+    }
   }
   return NUFFT_HIP_OK;
 }
@@ -684,12 +706,19 @@ int execute_impl(nufft_hip_plan p, void* c, void* f) {
     T* fb = (T*)f + 2 * (int64_t)b0 * p->grid_elems;
     T* fw = (T*)p->d_fine;
     const int slots = nb * p->nitems;        // fine grids in flight: every point set x nb transforms
-    const auto it = p->fft_plans.find(slots);   // both batch counts were planned at creation
-    if (it == p->fft_plans.end()) {
-      p->err = format("no FFT plan for a batch of %d transforms", nb);
-      return NUFFT_HIP_INTERNAL;
+    // pruned passes with the deconvolution fused in, unless a test wants to look at the fine
+    // grid between FFT and deconvolution (then the rocFFT path, planned by debug_stop_after)
+    const bool own = p->own_fft && stop != STAGE_FFT && stop != STAGE_DECONVOLVE;
+    rocfft_plan fft = nullptr;
+    if (!own) {
+      const auto it = p->fft_plans.find(slots);   // both batch counts were planned at creation
+      if (it == p->fft_plans.end()) {
+        p->err = format("no FFT plan for a batch of %d transforms", nb);
+        return NUFFT_HIP_INTERNAL;
+      }
+      fft = it->second;
     }
-    rocfft_plan fft = it->second;
+    const T* tw[3] = {(const T*)p->d_twiddle[0], (const T*)p->d_twiddle[1], (const T*)p->d_twiddle[2]};
     void* bufs[1] = {fw};
     const StageHook hook = make_hook(p);
     if (p->type == NUFFT_HIP_TYPE_1) {
@@ -701,6 +730,13 @@ int execute_impl(nufft_hip_plan p, void* c, void* f) {
                                   p->M, p->fine_elems, (T)1, p->lds_bytes, p->stream));
       hook.end(STAGE_SPREAD);
       if (stop == STAGE_SPREAD) continue;
+      if (own) {
+        hook.begin(STAGE_FFT);
+        HIP_TRY(p, launch_pruned_fft<T>(p->g, 1, p->iflag, fw, fb, (T*)p->fft_tmp[0], (T*)p->fft_tmp[1], rf, tw,
+                                        slots, p->stream));
+        hook.end(STAGE_FFT);
+        continue;
+      }
       hook.begin(STAGE_FFT);
       FFT_TRY(p, rocfft_execute(fft, bufs, nullptr, p->fft_info));
       hook.end(STAGE_FFT);
@@ -709,14 +745,21 @@ int execute_impl(nufft_hip_plan p, void* c, void* f) {
       HIP_TRY(p, launch_deconvolve<T>(p->g, 1, fb, fw, rf, slots, p->stream));
       hook.end(STAGE_DECONVOLVE);
     } else {
-      hook.begin(STAGE_DECONVOLVE);
-      HIP_TRY(p, launch_deconvolve<T>(p->g, 2, fb, fw, rf, slots, p->stream));
-      hook.end(STAGE_DECONVOLVE);
-      if (stop == STAGE_DECONVOLVE) continue;
-      hook.begin(STAGE_FFT);
-      FFT_TRY(p, rocfft_execute(fft, bufs, nullptr, p->fft_info));
-      hook.end(STAGE_FFT);
-      if (stop == STAGE_FFT) continue;
+      if (own) {
+        hook.begin(STAGE_FFT);
+        HIP_TRY(p, launch_pruned_fft<T>(p->g, 2, p->iflag, fw, fb, (T*)p->fft_tmp[0], (T*)p->fft_tmp[1], rf, tw,
+                                        slots, p->stream));
+        hook.end(STAGE_FFT);
+      } else {
+        hook.begin(STAGE_DECONVOLVE);
+        HIP_TRY(p, launch_deconvolve<T>(p->g, 2, fb, fw, rf, slots, p->stream));
+        hook.end(STAGE_DECONVOLVE);
+        if (stop == STAGE_DECONVOLVE) continue;
+        hook.begin(STAGE_FFT);
+        FFT_TRY(p, rocfft_execute(fft, bufs, nullptr, p->fft_info));
+        hook.end(STAGE_FFT);
+        if (stop == STAGE_FFT) continue;
+      }
       hook.begin(STAGE_INTERP);
       HIP_TRY(p, launch_interp<T>(p->g, p->method, sp, p->M * p->nitems, (const T*)p->d_horner, cb, fw, nb,
                                   p->M, p->fine_elems, (T)1, p->stream));
@@ -778,8 +821,10 @@ void destroy(nufft_hip_plan p) {
     for (auto& kv : p->fft_plans) rocfft_plan_destroy(kv.second);
     if (p->fft_info) rocfft_execution_info_destroy(p->fft_info);
     if (p->d_horner) (void)hipFree(p->d_horner);
-    for (int d = 0; d < 3; ++d)
+    for (int d = 0; d < 3; ++d) {
       if (p->d_rfser[d]) (void)hipFree(p->d_rfser[d]);
+      if (p->d_twiddle[d]) (void)hipFree(p->d_twiddle[d]);
+    }
     for (auto& pe : p->pending) { (void)hipEventDestroy(pe.e0); (void)hipEventDestroy(pe.e1); }
     for (auto e : p->free_events) (void)hipEventDestroy(e);
   }
@@ -1072,8 +1117,9 @@ static int create_common(nufft_hip_plan* out, int type, int rank, const int64_t*
     delete p;
     return fail(NUFFT_HIP_INTERNAL, m);
   }
+  p->own_fft = !p->opts.spread_only && pruned_fft_supported(p->g, precision);
   int rc = precision == NUFFT_HIP_F32 ? upload_tables<float>(p) : upload_tables<double>(p);
-  if (!rc && !p->opts.spread_only) {
+  if (!rc && !p->opts.spread_only && !p->own_fft) {
     // the FFT of full batches and of the remainder batch, so that execute never plans
     rc = build_fft_plan(p, p->batch_size * p->nitems);
     if (!rc && p->nitems == 1) rc = build_fft_plan(p, p->ntransf % p->batch_size);
@@ -1210,6 +1256,17 @@ int nufft_hip_execute_with_points(nufft_hip_plan p, int64_t M, const void* x, co
 int nufft_hip_debug_stop_after(nufft_hip_plan p, int stage) {
   if (!p) return NUFFT_HIP_INVALID_ARGUMENT;
   p->stop_after = stage;
+  if (!p->host_only && p->own_fft && !p->opts.spread_only && (stage == STAGE_FFT || stage == STAGE_DECONVOLVE)) {
+    // the fine grid between FFT and deconvolution only exists on the rocFFT path: plan it now
+    // (debug only: this allocates and synchronises)
+    int rc = build_fft_plan(p, p->batch_size * p->nitems);
+    if (!rc && p->nitems == 1) rc = build_fft_plan(p, p->ntransf % p->batch_size);
+    if (rc) return rc;
+    if (p->fft_work_bytes && !p->fft_work) {
+      if ((rc = dev_alloc(p, &p->fft_work, p->fft_work_bytes))) return rc;
+      FFT_TRY(p, rocfft_execution_info_set_work_buffer(p->fft_info, p->fft_work, p->fft_work_bytes));
+    }
+  }
   return NUFFT_HIP_OK;
 }
 

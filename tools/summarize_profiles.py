@@ -21,7 +21,7 @@ def counters(d):
   return agg
 fe, wr = counters('pmc2_fetch'), counters('pmc2_write')
 out = {}
-txt = ['# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace -- python3 tools/profile_run.py --steps 3',
+txt = ['# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace -- python3 tools/profile_run.py --steps 3 --one-call',
        '# config 2 (2D t1 1024^2, M=1e7). KiB per dispatch. Corrected traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 per',
        '# MI355X_MICROARCH.md (FETCH_SIZE counts 128-B requests as 64 B on gfx950; the hist kernel below, which reads',
        '# exactly 80 MB of points, calibrates it: FETCH_SIZE = 40 MB).']
@@ -32,7 +32,8 @@ for k in fe:
     txt.append(f'{k[:48]:48s} FETCH_SIZE={f:10.0f} KiB  WRITE_SIZE={w:10.0f} KiB  corrected_bytes={(2*f+w)*1024:.4g}')
     if 'spread' in k:
       out = {'kernel': k, 'config': '2D t1 1024^2 M=1e7 tol=1e-6 fp32', 'FETCH_SIZE_KiB': f, 'WRITE_SIZE_KiB': w,
-             'traffic_bytes_corrected': (2 * f + w) * 1024, 'traffic_bytes_raw': (f + w) * 1024, 'points': 10000000}
+             'traffic_bytes_corrected': (2 * f + w) * 1024, 'traffic_bytes_raw': (f + w) * 1024, 'points': 10000000,
+             'source': f'profiles/{tag}_pmc_traffic.txt'}
 open(f'profiles/{tag}_pmc_traffic.txt', 'w').write('\n'.join(txt) + '\n')
 json.dump(out, open('profiles/pmc_spread_traffic.json', 'w'), indent=1)
 print('\n'.join(txt[4:]))
