@@ -2322,14 +2322,17 @@ static inline unsigned subproblem_grid(const Geom& g, int64_t M) {
   return (unsigned)((int64_t)g.ntiles + M / g.max_sub);
 }
 
-// LDS-free spreader for sparse point sets: below ~kSparseDensity points per fine cell the
-// per-tile zero-fill and write-out of the LDS kernels outweigh the per-point global atomics
-// (crossover measured r02, profiles/r02_sparse_crossover.txt). NUFFT_HIP_SPARSE = 0 / 1 forces it.
-constexpr double kSparseDensity = 0.01;
+// LDS-free spreader for sparse point sets: below a few points per thousand fine cells the
+// per-tile zero-fill and write-out of the LDS kernels outweigh the per-point global atomics.
+// Crossover measured r02 (profiles/r02_sparse_crossover.txt, spread stage): 3-D 512^3 w = 6
+// between 7.5e-4 (LDS-free 0.80 ms vs 0.99 ms) and 2.2e-3 points per cell (1.94 vs 1.34 ms);
+// 2-D 2048^2 w = 8 between 2.4e-3 (25 vs 31 us) and 7.2e-3 (47 vs 34 us).
+// NUFFT_HIP_SPARSE = 0 / 1 forces it off / on.
 bool sparse_wanted(const Geom& g, int64_t M) {
   static const int mode = [] { const char* e = getenv("NUFFT_HIP_SPARSE"); return e ? atoi(e) : -1; }();
   if (mode >= 0) return mode != 0;
-  return (double)M < kSparseDensity * (double)g.nf[0] * (double)g.nf[1] * (double)g.nf[2];
+  const double density = g.rank == 3 ? 1.2e-3 : 4e-3;
+  return (double)M < density * (double)g.nf[0] * (double)g.nf[1] * (double)g.nf[2];
 }
 
 // Records that carry the strengths (FusedRec): 2-D float, the cell-grouped kernel's geometry,
