@@ -1802,25 +1802,30 @@ __global__ __launch_bounds__(kInterpThreads<RANK>) void interp_point_kernel(
   // wave in 2-D, 35 in 3-D) at the head of every workgroup.
   constexpr int kRowBatch = 8;
   const int nrows = L1 * L2;
-  const int a0c = lane < L0 ? lane : L0 - 1;
-  const int64_t gx = wrap1(o0 + a0c, g.nf[0]);
-  for (int rb = wave; rb < nrows; rb += kRowBatch * (NT / 64)) {
-    T2 v[kRowBatch];
-    int lofs[kRowBatch];
+  // (rows of more than 64 cells -- the 64 x 64 tiles of 2-D type-2 plans, 71 cells with the
+  // halo -- take a second sweep for the remaining columns)
+  for (int c0 = 0; c0 < L0; c0 += 64) {
+    const int col = c0 + lane;
+    const int a0c = col < L0 ? col : L0 - 1;
+    const int64_t gx = wrap1(o0 + a0c, g.nf[0]);
+    for (int rb = wave; rb < nrows; rb += kRowBatch * (NT / 64)) {
+      T2 v[kRowBatch];
+      int lofs[kRowBatch];
 #pragma unroll
-    for (int u = 0; u < kRowBatch; ++u) {
-      const int row = rb + u * (NT / 64);
-      const int rc = row < nrows ? row : nrows - 1;
-      const int a2 = RANK > 2 ? rc / L1 : 0;
-      const int a1 = rc - a2 * L1;
-      const int g1 = wrap1(o1 + a1, g.nf[1]);
-      const int g2 = RANK > 2 ? wrap1(o2 + a2, g.nf[2]) : 0;
-      v[u] = in[(int64_t)g.nf[0] * (g1 + (int64_t)g.nf[1] * g2) + gx];
-      lofs[u] = row < nrows ? a2 * PS + a1 * LS + lane : -1;
+      for (int u = 0; u < kRowBatch; ++u) {
+        const int row = rb + u * (NT / 64);
+        const int rc = row < nrows ? row : nrows - 1;
+        const int a2 = RANK > 2 ? rc / L1 : 0;
+        const int a1 = rc - a2 * L1;
+        const int g1 = wrap1(o1 + a1, g.nf[1]);
+        const int g2 = RANK > 2 ? wrap1(o2 + a2, g.nf[2]) : 0;
+        v[u] = in[(int64_t)g.nf[0] * (g1 + (int64_t)g.nf[1] * g2) + gx];
+        lofs[u] = row < nrows ? a2 * PS + a1 * LS + col : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < kRowBatch; ++u)
+        if (lofs[u] >= 0 && col < L0) tile[lofs[u]] = v[u];
     }
-#pragma unroll
-    for (int u = 0; u < kRowBatch; ++u)
-      if (lofs[u] >= 0 && lane < L0) tile[lofs[u]] = v[u];
   }
   __syncthreads();
 

@@ -960,7 +960,16 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
   // until the LDS tile fits.
   // 3-D: 8 z-planes per tile when the wavefront kernel's LDS planes still fit
   // (w <= 6): fewer halo cells per point (r01: 22.7 -> 21.2 ms at M = 1e8).
-  const int def_tile[3][3] = {{1024, 1, 1}, {32, 32, 1}, {16, 16, w <= 6 ? 8 : 4}};
+  // 2-D float type-2 (and interp-only) plans: 64 x 64. Their LDS tile is single-precision
+  // complex (71^2 x 8 B = 40 KB), and four times fewer tiles make the (workgroup, tile) runs
+  // of the scatter four times longer (the scatter is transaction bound).
+  static const bool no_t2_big = getenv("NUFFT_HIP_NO_BIG_T2_TILES") != nullptr;   // A/B knob
+  const bool t2_big = type == NUFFT_HIP_TYPE_2 && rank == 2 && precision == NUFFT_HIP_F32 && w <= 8 &&
+                      p->opts.spread_method == NUFFT_HIP_METHOD_AUTO && p->opts.tile_dims[0] == 0 &&
+                      p->opts.tile_dims[1] == 0 && p->opts.max_subproblem_size <= 0 && !no_t2_big &&
+                      g.nf[0] >= 64 && g.nf[1] >= 64;
+  const int t2d = t2_big ? 64 : 32;
+  const int def_tile[3][3] = {{1024, 1, 1}, {t2d, t2d, 1}, {16, 16, w <= 6 ? 8 : 4}};
   for (int d = 0; d < 3; ++d) {
     int t = d < rank ? (p->opts.tile_dims[d] > 0 ? p->opts.tile_dims[d] : def_tile[rank - 1][d]) : 1;
     t = std::max(1, std::min(t, 1024));
@@ -1031,9 +1040,10 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
   // AUTO also lets launch_spread take the LDS-free kernel when the point set turns out sparse
   g.sparse_auto = method == NUFFT_HIP_METHOD_AUTO ? 1 : 0;
   g.fused = 0;
+  const bool t2_wave = t2_big && g.tile[0] == 64 && g.tile[1] == 64;   // (not shrunk by a tiny grid)
   if (method == NUFFT_HIP_METHOD_AUTO)
-    method = wave_method_supported(g, precision) ? NUFFT_HIP_METHOD_TILE_WAVE : NUFFT_HIP_METHOD_TILE_GENERIC;
-  if (method == NUFFT_HIP_METHOD_TILE_WAVE && !wave_method_supported(g, precision)) {
+    method = (t2_wave || wave_method_supported(g, precision)) ? NUFFT_HIP_METHOD_TILE_WAVE : NUFFT_HIP_METHOD_TILE_GENERIC;
+  if (method == NUFFT_HIP_METHOD_TILE_WAVE && !t2_wave && !wave_method_supported(g, precision)) {
     delete p;
     return fail(NUFFT_HIP_INVALID_ARGUMENT,
                 "spread_method TILE_WAVE needs rank 2 or 3, kernel width <= 8 and the default tile sizes");
@@ -1060,10 +1070,10 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
   // one plane per launch, so that two workgroups share a CU
   g.split_reim = (method == NUFFT_HIP_METHOD_TILE_WAVE && rank == 3 && precision == NUFFT_HIP_F32 &&
                   !g.fixed_point && g.tile[2] == 4 && getenv("NUFFT_HIP_NO_SPLIT") == nullptr) ? 1 : 0;
-  if (method == NUFFT_HIP_METHOD_TILE_WAVE) g.lstride = wave_lstride(rank);
+  if (method == NUFFT_HIP_METHOD_TILE_WAVE) g.lstride = t2_wave ? 72 : wave_lstride(rank);
   // wavefront kernels: one subproblem per typical tile measured fastest (r01 sweeps);
   // every extra subproblem of a tile repeats its zero-fill and write-out
-  if (method == NUFFT_HIP_METHOD_TILE_WAVE && auto_sub) g.max_sub = 4096;
+  if (method == NUFFT_HIP_METHOD_TILE_WAVE && auto_sub) g.max_sub = t2_wave ? 16384 : 4096;   // (interp: one tile load per subproblem)
   if (g.fixed_point && w > 6) g.max_sub = std::min(g.max_sub, 512);
   p->lds_bytes = spread_lds_bytes(g, method, precision);
   if (p->lds_bytes > 160 * 1024 || interp_lds_bytes(g, method, precision) > 160 * 1024) {

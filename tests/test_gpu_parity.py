@@ -1328,3 +1328,23 @@ def test_op_groups_per_item_points_into_multi_set_plans(tfft):
   ref = oracle.nufft(c4[1, 2, 1].cpu().numpy().astype(np.complex128), pts4[1, 2, 0].cpu().numpy(), grid, 'type_1',
                      'forward', tol=1e-12, sigma=2.0)
   assert rel_l2(out4[1, 2, 1].cpu().numpy(), ref) < 1e-6
+
+
+@pytest.mark.parametrize('ttype', ['type_1', 'type_2'])
+def test_grid_with_more_than_65535_rows(tfft, ttype):
+  # a second-fastest dimension of 40000 modes (fine grid 80000 rows: beyond the 65535 limit of
+  # gridDim.y / .z) takes the flattened-row form of the deconvolve kernel; the reference accepts
+  # such grids up to its 2e9-element cap (nufft_plan.h:62)
+  from oracle import oracle
+  rng = np.random.default_rng(41)
+  grid, M = [40000, 8], 3000
+  pts = rng.uniform(-np.pi, np.pi, (M, 2)).astype(np.float32)
+  if ttype == 'type_1':
+    src = (rng.uniform(-.5, .5, M) + 1j * rng.uniform(-.5, .5, M)).astype(np.complex64)
+    gs = grid
+  else:
+    src = (rng.uniform(-.5, .5, grid) + 1j * rng.uniform(-.5, .5, grid)).astype(np.complex64)
+    gs = None
+  truth = oracle.nufft(src.astype(np.complex128), pts, gs, ttype, 'forward', tol=1e-12, sigma=2.0)
+  out = tfft.nufft(_dev(src), _dev(pts), grid_shape=gs, transform_type=ttype).cpu().numpy()
+  assert rel_l2(out, truth) < 1e-6, rel_l2(out, truth)
