@@ -1274,6 +1274,9 @@ def test_plan_with_several_point_sets(tfft, rank, grid, M, dtype, tol, ntransf, 
   plan = tfft.Plan(ttype, grid, tol=tol, dtype=cdt, num_transforms=ntransf, num_point_sets=K)
   plan.set_points(pts)
   out = plan.execute(src)
+  for _ in range(3):      # plan reuse: the dense 2-D float case switches to cell-sorted records on the way
+    again = plan.execute(src)
+  assert rel_l2(again.cpu().numpy(), out.cpu().numpy()) < 3e-7
   out1 = plan.execute_with_points(pts, src)
   plan.close()
   single = tfft.Plan(ttype, grid, tol=tol, dtype=cdt, num_transforms=ntransf)
