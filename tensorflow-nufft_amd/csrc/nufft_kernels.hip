@@ -1213,13 +1213,7 @@ __global__ __launch_bounds__(kCellSortThreads) void cellsort3d_kernel(
 constexpr int kGroupMaxSub = 4096;
 constexpr double kGroupMinDensity = 0.5;   // points per fine cell
 constexpr double kInterpSortMinDensity = 0.3;   // 3-D interp cell sort pays from here (r01: 0.075 loses, 0.75 and 1.8 win)
-#ifndef NUFFT_W8_STAGE
-#define NUFFT_W8_STAGE 32
-#endif
-#ifndef NUFFT_W8_CLANE
-#define NUFFT_W8_CLANE 0
-#endif
-constexpr int kGroupStage = NUFFT_W8_STAGE; // points whose kernel values are in LDS at a time (per wave)
+constexpr int kGroupStage = 32; // points whose kernel values are in LDS at a time (per wave; 16 measured 12 % slower, r02)
 template <typename T> constexpr int kGroupStageOf = sizeof(T) == 8 ? 16 : kGroupStage;   // double: half, same bytes
 constexpr int kGroupBlk = 36;   // staging words per block of 4 points (8 x 4 + 4 pad)
 template <int CH> constexpr int kGroupStageWave = 3 * (CH / 4) * kGroupBlk;   // words per wave (kx, ky re, ky im)
@@ -1384,12 +1378,8 @@ __global__ __launch_bounds__(NW * 64) void spread_2d_w8_group_kernel(
 #pragma unroll
         for (int q = 0; q < kWW; ++q) {
           kxs[sb + 4 * q] = kx[q];
-#if NUFFT_W8_CLANE
-          kyr[sb + 4 * q] = ky[q];
-#else
           kyr[sb + 4 * q] = ky[q] * re;
           kyi[sb + 4 * q] = ky[q] * im;
-#endif
         }
       }
       int nh = npts - h;
@@ -1400,25 +1390,17 @@ __global__ __launch_bounds__(NW * 64) void spread_2d_w8_group_kernel(
       for (int q = 0; q < nround; q += 4) {
         const v4 ax4 = *reinterpret_cast<const v4*>(kxs + (q >> 2) * kGroupBlk + 4 * dx);
         const v4 br4 = *reinterpret_cast<const v4*>(kyr + (q >> 2) * kGroupBlk + 4 * dy);
+        const v4 bi4 = *reinterpret_cast<const v4*>(kyi + (q >> 2) * kGroupBlk + 4 * dy);
         const T a[4] = {ax4.x, ax4.y, ax4.z, ax4.w};
         const T br[4] = {br4.x, br4.y, br4.z, br4.w};
-#if !NUFFT_W8_CLANE
-        const v4 bi4 = *reinterpret_cast<const v4*>(kyi + (q >> 2) * kGroupBlk + 4 * dy);
         const T bi[4] = {bi4.x, bi4.y, bi4.z, bi4.w};
-#endif
         const unsigned t4 = (tails >> q) & 15u;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-#if NUFFT_W8_CLANE
-          // strength broadcast from the point's lane (v_readlane -> SGPR operand) instead of a
-          // third staged array: two ds_read_b128 per four points instead of three
-          const T pk = a[u] * br[u];
-          ar = fma(pk, bcast_lane(re, h + q + u), ar);
-          ai = fma(pk, bcast_lane(im, h + q + u), ai);
-#else
+          // (broadcasting the strength with v_readlane instead of staging ky * re and ky * im
+          // separately saves a ds_read_b128 per four points and measured 3 % slower, r02: VALU)
           ar = fma(a[u], br[u], ar);
           ai = fma(a[u], bi[u], ai);
-#endif
           if (t4 & (1u << u)) {
             const int o = __builtin_amdgcn_readlane(off, h + q + u) + cell;   // byte offset into the re plane
             lds_add(reinterpret_cast<double*>(smem_raw + o), (double)ar);

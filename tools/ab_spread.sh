@@ -13,8 +13,9 @@ run() {  # tag, build flags, shapes
     echo "== $1 ($2) shape $shape"; python3 tools/kstats.py $O/prof_$1_$shape 4 | grep -E "spread|scatter|hist"
   done
 }
-run base "-DNUFFT_W8_CLANE=0" "12x64"
-run clane "-DNUFFT_W8_CLANE=1" "12x64 16x64 8x64"
-run clane_occ8 "-DNUFFT_W8_CLANE=1 -DNUFFT_SORT_MIN_WAVES=8" "12x64"
+# (the r02 variants -- balanced shares, 16-point staging, readlane strengths -- were built with -D macros
+# that have since been removed from the kernel; see DESIGN.md section 4 for their numbers)
+run base "" "12x64 8x64 16x64"
+run occ4 "-DNUFFT_SORT_MIN_WAVES=4" "12x64"
 touch tensorflow-nufft_amd/csrc/nufft_kernels.hip
 make -C tensorflow-nufft_amd/csrc > /dev/null 2>&1
