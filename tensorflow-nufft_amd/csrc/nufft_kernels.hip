@@ -973,7 +973,7 @@ constexpr int kWL = kWT + kWW - 1;   // 39 rows/cols used
 constexpr int kWS = 40;              // row stride in words: 8 mod 32
 constexpr int kWPlane = kWS * kWL;   // 1560 words per plane
 
-template <int NW, int CH>
+template <int NW, int CH, bool FUSED = false>
 __global__ __launch_bounds__(NW * 64) void spread_2d_w8_wave_kernel(
     Geom g, SortedPoints<float> sp, const float* __restrict__ horner, const float* __restrict__ c,
     float* __restrict__ fw, int64_t c_stride, int64_t fw_stride, float scale) {
@@ -1002,12 +1002,24 @@ __global__ __launch_bounds__(NW * 64) void spread_2d_w8_wave_kernel(
     int off = 0;
     float kx[kWW], kyr[kWW], kyi[kWW];
     if (valid) {
-      const Rec<float> rec = sp.rec[j];   // one 16-byte load: loc, zx, zy, idx
-      const uint32_t loc = rec.loc;
-      const int idx = rec.idx;
-      const float zx = rec.z0, zy = rec.z1;
-      const float2 cv = reinterpret_cast<const float2*>(cc)[idx];
-      const float re = cv.x * scale, im = cv.y * scale;
+      uint32_t loc;
+      float zx, zy, re, im;
+      if constexpr (FUSED) {   // the record carries the strength (FusedRec): no gather
+        const FusedRec fr = reinterpret_cast<const FusedRec*>(sp.rec)[j];
+        loc = fused_loc(fr.px, fr.py);
+        zx = fused_z(fr.px);
+        zy = fused_z(fr.py);
+        re = fr.re * scale;
+        im = fr.im * scale;
+      } else {
+        const Rec<float> rec = sp.rec[j];   // one 16-byte load: loc, zx, zy, idx
+        loc = rec.loc;
+        zx = rec.z0;
+        zy = rec.z1;
+        const float2 cv = reinterpret_cast<const float2*>(cc)[rec.idx];
+        re = cv.x * scale;
+        im = cv.y * scale;
+      }
       off = ((loc >> 10) & 1023) * kWS + (loc & 1023);
 #pragma unroll
       for (int q = 0; q < kWW; ++q) {
@@ -1443,7 +1455,7 @@ template <typename T> using T2_t = typename Pair<T>::type;
 // form of the 3-D kernel below: tile 32 x 32, row stride 40, lanes outside the
 // W x W patch add 0 at their natural 8 x 8 patch address (rows beyond the tile
 // fall into the next component plane or the 256-element pad behind the planes).
-template <typename T, int W, int NW, int CH>
+template <typename T, int W, int NW, int CH, bool FUSED = false>
 __global__ __launch_bounds__(NW * 64) void spread_wave2_kernel(
     Geom g, SortedPoints<T> sp, const T* __restrict__ horner, const T* __restrict__ c,
     T* __restrict__ fw, int64_t c_stride, int64_t fw_stride, T scale) {
@@ -1479,10 +1491,20 @@ __global__ __launch_bounds__(NW * 64) void spread_wave2_kernel(
 #pragma unroll
       for (int q = 0; q < 8; ++q) { kx[q] = (T)0; ky[q] = (T)0; }
       if (j < p1) {
-        const PointView<T> rec = unpack_rec<T, 2>(sp.rec[j]);
-        const T2 cv = cc[rec.idx];
-        re = cv.x * scale;
-        im = cv.y * scale;
+        PointView<T> rec;
+        if constexpr (FUSED) {
+          const FusedRec fr = reinterpret_cast<const FusedRec*>(sp.rec)[j];
+          rec.loc = fused_loc(fr.px, fr.py);
+          rec.z0 = (T)fused_z(fr.px);
+          rec.z1 = (T)fused_z(fr.py);
+          re = (T)fr.re * scale;
+          im = (T)fr.im * scale;
+        } else {
+          rec = unpack_rec<T, 2>(sp.rec[j]);
+          const T2 cv = cc[rec.idx];
+          re = cv.x * scale;
+          im = cv.y * scale;
+        }
         off = (int)(rec.loc & 1023) + (int)((rec.loc >> 10) & 1023) * LS;
         horner8<T, 2>(horner, nc, rec.z0, rec.z1, (T)0, kx, ky, kdummy);
       }
@@ -2322,13 +2344,14 @@ bool sparse_wanted(const Geom& g, int64_t M) {
   return (double)M < density * (double)g.nf[0] * (double)g.nf[1] * (double)g.nf[2];
 }
 
-// Records that carry the strengths (FusedRec): 2-D float, the cell-grouped kernel's geometry,
-// LDS-histogram sort, and a point set dense enough for the grouped kernel to be the choice.
+// Records that carry the strengths (FusedRec): 2-D float, the 32 x 32-tile geometry of the
+// wavefront spreaders (grouped, per-point w = 8, per-point narrower), LDS-histogram sort, and
+// a point set that does not go to the LDS-free kernel.
 bool fused_sort_supported(const Geom& g, int method, int precision, int64_t M) {
   static const bool off = getenv("NUFFT_HIP_NO_FUSED") != nullptr;   // A/B knob
   if (off || method != NUFFT_HIP_METHOD_TILE_WAVE || !wave8_supported(g, precision)) return false;
   if (M <= 0 || sort_mode(g, M * (g.nitems > 1 ? g.nitems : 1)) != 0 || g.max_sub > kGroupMaxSub) return false;   // M: per set
-  return wave8_use_group(g, M) && !(g.sparse_auto && sparse_wanted(g, M));
+  return !(g.sparse_auto && sparse_wanted(g, M));   // every LDS-tile 2-D float spreader reads fused records
 }
 
 // NUFFT_HIP_CELLSORT = 0 never, 1 whenever the geometry allows; unset: by point density.
@@ -2412,7 +2435,7 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
   if (method == NUFFT_HIP_METHOD_TILE_WAVE) {
     if constexpr (sizeof(T) == 4) {
       if (wave8_supported(g, 4)) {
-        const bool grouped = g.cell_sorted || g.fused || wave8_use_group(g, Md);
+        const bool grouped = g.cell_sorted || wave8_use_group(g, Md);
         const int shape = wave8_nw(grouped) * 100 + wave8_ch(grouped);
         lds_bytes = wave8_lds(grouped, g.cell_sorted);   // the plan's figure is the maximum over the variants
         if (grouped) {
@@ -2460,10 +2483,17 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
         if (g.w == kWW) {
 #define NUFFT_LAUNCH_W8(NWV, CHV)                                                              \
   case NWV * 100 + CHV:                                                                        \
-    e = ensure_lds(spread_2d_w8_wave_kernel<NWV, CHV>, lds_bytes);                             \
-    if (e != hipSuccess) return e;                                                             \
-    spread_2d_w8_wave_kernel<NWV, CHV><<<grid, NWV * 64, lds_bytes, stream>>>(                 \
-        g, sp, horner, c, fw, c_stride, fw_stride, scale);                                     \
+    if (g.fused) {                                                                             \
+      e = ensure_lds(spread_2d_w8_wave_kernel<NWV, CHV, true>, lds_bytes);                     \
+      if (e != hipSuccess) return e;                                                           \
+      spread_2d_w8_wave_kernel<NWV, CHV, true><<<grid, NWV * 64, lds_bytes, stream>>>(         \
+          g, sp, horner, c, fw, c_stride, fw_stride, scale);                                   \
+    } else {                                                                                   \
+      e = ensure_lds(spread_2d_w8_wave_kernel<NWV, CHV>, lds_bytes);                           \
+      if (e != hipSuccess) return e;                                                           \
+      spread_2d_w8_wave_kernel<NWV, CHV><<<grid, NWV * 64, lds_bytes, stream>>>(               \
+          g, sp, horner, c, fw, c_stride, fw_stride, scale);                                   \
+    }                                                                                          \
     break;
         switch (shape) {
           NUFFT_LAUNCH_W8(4, 64) NUFFT_LAUNCH_W8(4, 32) NUFFT_LAUNCH_W8(8, 64) NUFFT_LAUNCH_W8(8, 32)
@@ -2499,10 +2529,19 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
       lds_bytes = wave2_lds(g, (int)sizeof(T));
 #define NUFFT_CASE_W2(WW)                                                                    \
   case WW:                                                                                   \
-    e = ensure_lds(spread_wave2_kernel<T, WW, kW2NW, kW2CH>, lds_bytes);                            \
-    if (e != hipSuccess) return e;                                                           \
-    spread_wave2_kernel<T, WW, kW2NW, kW2CH><<<grid, kW2NW * 64, lds_bytes, stream>>>(g, sp, horner, c, fw, \
-                                                                        c_stride, fw_stride, scale); \
+    if (g.fused) {                                                                           \
+      if constexpr (sizeof(T) == 4) {                                                        \
+        e = ensure_lds(spread_wave2_kernel<T, WW, kW2NW, kW2CH, true>, lds_bytes);           \
+        if (e != hipSuccess) return e;                                                       \
+        spread_wave2_kernel<T, WW, kW2NW, kW2CH, true><<<grid, kW2NW * 64, lds_bytes, stream>>>( \
+            g, sp, horner, c, fw, c_stride, fw_stride, scale);                               \
+      } else { return hipErrorInvalidValue; }                                                \
+    } else {                                                                                 \
+      e = ensure_lds(spread_wave2_kernel<T, WW, kW2NW, kW2CH>, lds_bytes);                   \
+      if (e != hipSuccess) return e;                                                         \
+      spread_wave2_kernel<T, WW, kW2NW, kW2CH><<<grid, kW2NW * 64, lds_bytes, stream>>>(     \
+          g, sp, horner, c, fw, c_stride, fw_stride, scale);                                 \
+    }                                                                                        \
     break;
       switch (g.w) {
         NUFFT_CASE_W2(2) NUFFT_CASE_W2(3) NUFFT_CASE_W2(4) NUFFT_CASE_W2(5)
