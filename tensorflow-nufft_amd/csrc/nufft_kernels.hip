@@ -335,12 +335,11 @@ __device__ __forceinline__ int fold_point(const Geom& g, const PointsIn& in, int
   return fold_coords<T>(g, in, x, r, bad);
 }
 
+// Final form of a record: the point index joins it; 3-D float packs the Horner arguments.
 template <typename T>
-__device__ __forceinline__ void store_record(const SortedOut<T>& out, int rank, int pos, Rec<T> r,
-                                             int32_t idx);
+__device__ __forceinline__ Rec<T> pack_record(int rank, Rec<T> r, int32_t idx);
 template <>
-__device__ __forceinline__ void store_record<float>(const SortedOut<float>& out, int rank, int pos,
-                                                    Rec<float> r, int32_t idx) {
+__device__ __forceinline__ Rec<float> pack_record<float>(int rank, Rec<float> r, int32_t idx) {
   if (rank < 3) {
     r.idx = idx;
   } else {
@@ -364,14 +363,17 @@ __device__ __forceinline__ void store_record<float>(const SortedOut<float>& out,
     r.z1 = __uint_as_float(w[2]);
     r.idx = idx;
   }
-  out.rec[pos] = r;   // one 16-byte store
+  return r;
 }
 template <>
-__device__ __forceinline__ void store_record<double>(const SortedOut<double>& out, int rank, int pos,
-                                                     Rec<double> r, int32_t idx) {
+__device__ __forceinline__ Rec<double> pack_record<double>(int rank, Rec<double> r, int32_t idx) {
   (void)rank;
   r.idx = idx;
-  out.rec[pos] = r;   // 32 bytes
+  return r;
+}
+template <typename T>
+__device__ __forceinline__ void store_record(const SortedOut<T>& out, int rank, int pos, Rec<T> r, int32_t idx) {
+  out.rec[pos] = pack_record<T>(rank, r, idx);   // one 16-byte (float) / 32-byte (double) store
 }
 
 // --- path A (ntiles <= kMaxLdsTiles): counting sort with per-workgroup LDS
@@ -584,6 +586,120 @@ __global__ __launch_bounds__(kSortBlock, NUFFT_SORT_MIN_WAVES) void scatter_lds_
           const int pos = atomicAdd(&cur[tile], 1);
           store_record<T>(out, g.rank, pos, r, (int32_t)(i - br.base));   // index inside the point set
         });
+  }
+}
+
+// --- path A, staged scatter (at most kStagedMaxTiles tiles per point set: 2-D type-2 plans
+// with 64 x 64 tiles, batches of 512^2-sized items, small grids). Scattered 16-byte stores are
+// bound by write TRANSACTIONS, and records of one (workgroup, tile) run that arrive at
+// different times are separate transactions. Here a workgroup takes its
+// points kStagedChunk at a time, orders the chunk by tile in LDS (counting sort: returning LDS
+// atomics for the ranks, a 1024-entry scan) and writes every tile's records of the chunk with
+// CONSECUTIVE LANES: ~8 records = 128 bytes per store group at 1024 tiles.
+constexpr int kStagedMaxTiles = 1024;
+constexpr int kStagedBytes = 128 * 1024;   // LDS for the staged records
+template <typename T> constexpr int kStagedChunk = kStagedBytes / (int)sizeof(Rec<T>);   // 8192 float, 4096 double
+
+template <typename T, int AOS, bool FUSED>
+__global__ __launch_bounds__(kSortBlock, 4) void scatter_staged_kernel(Geom g, PointsIn in, int64_t per_block,
+                                                                      const int32_t* __restrict__ hist,
+                                                                      const int32_t* __restrict__ tile_start,
+                                                                      SortedOut<T> out) {
+  using RecT = std::conditional_t<FUSED, FusedRec, Rec<T>>;
+  static_assert(sizeof(RecT) == sizeof(Rec<T>), "record sizes");
+  constexpr int CHUNK = kStagedChunk<T>;
+  constexpr int PER = CHUNK / kSortBlock;            // points per thread and chunk
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  RecT* stage = reinterpret_cast<RecT*>(smem_raw);                       // [CHUNK]
+  uint16_t* tl = reinterpret_cast<uint16_t*>(stage + CHUNK);             // [CHUNK] tile of the staged record
+  int* cur = reinterpret_cast<int*>(tl + CHUNK);                         // [kStagedMaxTiles] global cursor
+  int* cnt = cur + kStagedMaxTiles;                                      // records of the chunk per tile
+  int* off = cnt + kStagedMaxTiles;                                      // their exclusive scan
+  int* wsum = off + kStagedMaxTiles;                                     // [16]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ntl = g.ntiles_item;
+  const BlockRange br(in, per_block, g);
+  const int32_t* hb = hist + (int64_t)blockIdx.x * g.ntiles + br.tile_off;
+  if (tid < kStagedMaxTiles) {
+    cur[tid] = tid < ntl ? tile_start[br.tile_off + tid] + hb[tid] : 0;
+    cnt[tid] = 0;
+  }
+  __syncthreads();
+  bool bad = false;
+  for (int64_t cb = br.lo; cb < br.hi; cb += CHUNK) {
+    const int64_t ce = cb + CHUNK < br.hi ? cb + CHUNK : br.hi;
+    // ---- phase 1: load, fold, count (loads of a thread issued back to back on clamped indices;
+    // fetching the next chunk during phases 2-5 was tried: it spills 90-160 bytes per lane and
+    // gains nothing, 101 -> 98 us at config 3)
+    T x[PER][3];
+    float2 cs[FUSED ? PER : 1];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int64_t i = cb + (int64_t)u * kSortBlock + tid;
+      const int64_t ic = i < ce ? i : ce - 1;
+      load_coords<T, AOS>(in, ic, x[u]);
+      if constexpr (FUSED) cs[u] = reinterpret_cast<const float2*>(in.strengths)[ic];
+    }
+    RecT rec[PER];
+    int tr[PER];     // tile | rank << 10, -1 past the end
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int64_t i = cb + (int64_t)u * kSortBlock + tid;
+      Rec<T> r;
+      const int tile = fold_coords<T>(g, in, x[u], &r, &bad);
+      tr[u] = -1;
+      if (i < ce) tr[u] = tile | (atomicAdd(&cnt[tile], 1) << 10);
+      if constexpr (FUSED) {
+        FusedRec fr;
+        fr.px = fused_pack(r.loc & 1023u, r.z0);
+        fr.py = fused_pack((r.loc >> 10) & 1023u, r.z1);
+        fr.re = cs[u].x;
+        fr.im = cs[u].y;
+        rec[u] = fr;
+      } else {
+        rec[u] = pack_record<T>(g.rank, r, (int32_t)(i - br.base));
+      }
+    }
+    __syncthreads();
+    // ---- phase 2: exclusive scan of the chunk's tile counts (one entry per thread)
+    {
+      const int v = cnt[tid];
+      int incl = v;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+      }
+      if (lane == 63) wsum[wave] = incl;
+      __syncthreads();
+      int base = 0;
+      for (int k = 0; k < wave; ++k) base += wsum[k];
+      off[tid] = base + incl - v;
+    }
+    __syncthreads();
+    // ---- phase 3: records to their place in the chunk's tile order
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      if (tr[u] >= 0) {
+        const int tile = tr[u] & 1023;
+        const int sidx = off[tile] + (tr[u] >> 10);
+        stage[sidx] = rec[u];
+        tl[sidx] = (uint16_t)tile;
+      }
+    }
+    __syncthreads();
+    // ---- phase 4: write out, consecutive lanes = consecutive records of a tile
+    const int nchunk = (int)(ce - cb);
+    RecT* dst = reinterpret_cast<RecT*>(out.rec);
+    for (int sidx = tid; sidx < nchunk; sidx += kSortBlock) {
+      const int tile = tl[sidx];
+      dst[cur[tile] + sidx - off[tile]] = stage[sidx];
+    }
+    __syncthreads();
+    // ---- phase 5: advance the cursors
+    cur[tid] += cnt[tid];
+    cnt[tid] = 0;
+    __syncthreads();
   }
 }
 
@@ -2161,7 +2277,17 @@ static hipError_t sort_lds_pass(const Geom& g, const PointsIn& in, const SortWor
   scan_tiles_kernel<<<1, 1024, 0, stream>>>(w.tile_count, g.ntiles, g.max_sub, w.tile_start, w.sub_start);
   hook.end(STAGE_SORT_SCAN);
   hook.begin(STAGE_SORT_SCATTER);
-  scatter_lds_kernel<T, AOS, FUSED><<<nblk, kSortBlock, lds, stream>>>(g, in, per_block, w.hist, w.tile_start, out);
+  static const int staged_env = [] { const char* e2 = getenv("NUFFT_HIP_STAGED_SCATTER"); return e2 ? atoi(e2) : -1; }();
+  const bool staged = g.ntiles_item <= kStagedMaxTiles && staged_env != 0 &&
+                      (staged_env > 0 || in.M_item >= 4 * kStagedChunk<T>);
+  if (staged) {
+    const size_t slds = (size_t)kStagedBytes + (size_t)kStagedChunk<T> * 2 + 3 * kStagedMaxTiles * 4 + 64;
+    e = ensure_lds(scatter_staged_kernel<T, AOS, FUSED>, slds);
+    if (e != hipSuccess) return e;
+    scatter_staged_kernel<T, AOS, FUSED><<<nblk, kSortBlock, slds, stream>>>(g, in, per_block, w.hist, w.tile_start, out);
+  } else {
+    scatter_lds_kernel<T, AOS, FUSED><<<nblk, kSortBlock, lds, stream>>>(g, in, per_block, w.hist, w.tile_start, out);
+  }
   hook.end(STAGE_SORT_SCATTER);
   return hipGetLastError();
 }
