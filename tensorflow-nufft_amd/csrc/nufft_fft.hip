@@ -95,6 +95,8 @@ struct FftPassArgs {
   int64_t in_batch, out_batch;      // elements between consecutive transforms
   int R;                            // lines per workgroup
   int LW;                           // lines in flight (blockDim.x = LW * n / 8)
+  int zero_in;                      // store zeros over every input element after reading it (type 1, first
+                                    // dimension: leaves the fine grid cleared for the next spread)
   int npass;
   unsigned radpack;                 // radix of pass p in bits [4 p, 4 p + 4) (an indexed array in the kernel
                                     // arguments makes the compiler copy them to scratch memory)
@@ -127,8 +129,9 @@ struct BinMap { int idx[8]; T sc[8]; };
 // First-pass inputs of one line, straight from global memory. Butterfly u of the thread takes
 // elements lt + u TL + t n / RAD, t < RAD. PAD: the line holds kin < n modes (see BinMap).
 template <typename T, int RAD, bool PAD>
-__device__ __forceinline__ void fft_load_line(const typename C2<T>::type* __restrict__ rowp, bool live, int lt,
-                                              int TL, int n, const BinMap<T>& map, typename C2<T>::type (&x)[8]) {
+__device__ __forceinline__ void fft_load_line(const typename C2<T>::type* rowp, bool live, int lt,
+                                              int TL, int n, const BinMap<T>& map, typename C2<T>::type (&x)[8],
+                                              bool zero_in = false) {
   using V = typename C2<T>::type;
   const int stride = n / RAD;
 #pragma unroll
@@ -143,6 +146,14 @@ __device__ __forceinline__ void fft_load_line(const typename C2<T>::type* __rest
       if (live) y = z;
     }
     x[q] = y;
+  }
+  if constexpr (!PAD) {
+    if (zero_in && live) {   // (same thread, same addresses: ordered behind the loads)
+      V zero; zero.x = (T)0; zero.y = (T)0;
+      V* w = const_cast<V*>(rowp);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) w[lt + (q / RAD) * TL + (q % RAD) * stride] = zero;
+    }
   }
 }
 
@@ -262,7 +273,7 @@ __global__ __launch_bounds__(kFftMaxThreads, 4) void fft_rotate_kernel(FftPassAr
   for (int i = tid; i < n / 2; i += blockDim.x) twl[i] = a.tw[i];
   const int lw = tid / TL, lt = tid - lw * TL;
   const int64_t line0 = (int64_t)blockIdx.x * a.R;
-  const V* __restrict__ in = a.in + (int64_t)blockIdx.y * a.in_batch;
+  const V* in = a.in + (int64_t)blockIdx.y * a.in_batch;
   V* __restrict__ out = a.out + (int64_t)blockIdx.y * a.out_batch;
   const V* twp = twl;
   const T sgn = (T)a.sgn;
@@ -296,7 +307,7 @@ __global__ __launch_bounds__(kFftMaxThreads, 4) void fft_rotate_kernel(FftPassAr
   {
     const int64_t line = line0 + lw;
     const bool live = lw < a.R && line < a.nlines;
-    fft_load_line<T, RAD0, PAD>(in + (live ? line : 0) * inlen, live, lt, TL, n, map, v);
+    fft_load_line<T, RAD0, PAD>(in + (live ? line : 0) * inlen, live, lt, TL, n, map, v, a.zero_in != 0);
   }
   for (int g = 0; g < a.R; g += LW) {
     const int r = g + lw;                       // line inside the workgroup's block
@@ -304,7 +315,7 @@ __global__ __launch_bounds__(kFftMaxThreads, 4) void fft_rotate_kernel(FftPassAr
     if (more) {                                 // next group's loads are in flight during this group's passes
       const int64_t line = line0 + r + LW;
       const bool live = r + LW < a.R && line < a.nlines;
-      fft_load_line<T, RAD0, PAD>(in + (live ? line : 0) * inlen, live, lt, TL, n, map, vn);
+      fft_load_line<T, RAD0, PAD>(in + (live ? line : 0) * inlen, live, lt, TL, n, map, vn, a.zero_in != 0);
     }
     V* trow = tile + (r < a.R ? r : 0) * TS;
     // (opaque copy of the lane's index: otherwise the compiler hoists the LDS and twiddle
@@ -414,7 +425,8 @@ int64_t pruned_fft_tmp_elems(const Geom& g) {
 
 template <typename T>
 hipError_t launch_pruned_fft(const Geom& g, int type, int iflag, T* fine, T* f, T* tmp0, T* tmp1,
-                             const T* const rf[3], const T* const tw[3], int batch, hipStream_t stream) {
+                             const T* const rf[3], const T* const tw[3], int batch, hipStream_t stream,
+                             bool zero_fine) {
   using V = typename C2<T>::type;
   const int rank = g.rank;
   const int csize = 2 * (int)sizeof(T);
@@ -445,6 +457,7 @@ hipError_t launch_pruned_fft(const Geom& g, int type, int iflag, T* fine, T* f, 
     a.tw = reinterpret_cast<const V*>(tw[d]);
     a.rf = rf[d];
     a.sgn = iflag < 0 ? -1.0f : 1.0f;
+    a.zero_in = (zero_fine && type == 1 && d == 0) ? 1 : 0;
     a.npass = 0;
     a.radpack = 0;
     size_t lds = 0;
@@ -472,8 +485,8 @@ hipError_t launch_pruned_fft(const Geom& g, int type, int iflag, T* fine, T* f, 
   return hipGetLastError();
 }
 template hipError_t launch_pruned_fft<float>(const Geom&, int, int, float*, float*, float*, float*,
-                                             const float* const[3], const float* const[3], int, hipStream_t);
+                                             const float* const[3], const float* const[3], int, hipStream_t, bool);
 template hipError_t launch_pruned_fft<double>(const Geom&, int, int, double*, double*, double*, double*,
-                                              const double* const[3], const double* const[3], int, hipStream_t);
+                                              const double* const[3], const double* const[3], int, hipStream_t, bool);
 
 }  // namespace nufft_hip

@@ -164,7 +164,8 @@ bool pruned_fft_supported(const Geom& g, int precision);
 int64_t pruned_fft_tmp_elems(const Geom& g);
 template <typename T>
 hipError_t launch_pruned_fft(const Geom& g, int type, int iflag, T* fine, T* f, T* tmp0, T* tmp1,
-                             const T* const rf[3], const T* const tw[3], int batch, hipStream_t stream);
+                             const T* const rf[3], const T* const tw[3], int batch, hipStream_t stream,
+                             bool zero_fine = false);   // type 1: leave `fine` zeroed (its first pass reads it all)
 size_t spread_lds_bytes(const Geom& g, int method, int precision);
 size_t interp_lds_bytes(const Geom& g, int method, int precision);
 int wave_lstride(int rank);

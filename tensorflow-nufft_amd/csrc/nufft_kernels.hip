@@ -2431,10 +2431,12 @@ static bool wave8_supported(const Geom& g, int precision) {
 // Wavefront-per-point kernels need w <= 8, rank 2/3 and the tile geometry that
 // makes their LDS accesses conflict free.
 bool wave_method_supported(const Geom& g, int precision) {
-  (void)precision;
   if (g.w > 8) return false;
   if (g.rank == 2) return g.tile[0] == 32 && g.tile[1] == 32;
-  if (g.rank == 3) return g.tile[0] == 16 && g.tile[1] == 16 && (g.tile[2] == 4 || (g.tile[2] == 8 && g.w <= 6));
+  // (depth 8 at w = 8: float only, one fp64 plane per launch -- see configure())
+  if (g.rank == 3)
+    return g.tile[0] == 16 && g.tile[1] == 16 &&
+           (g.tile[2] == 4 || (g.tile[2] == 8 && (g.w <= 6 || (g.w == 8 && precision == NUFFT_HIP_F32))));
   return false;
 }
 int wave_lstride(int rank) { return rank == 2 ? 40 : 24; }
@@ -2528,8 +2530,9 @@ size_t spread_lds_bytes(const Geom& g, int method, int precision) {
     if (g.rank == 2)
       return group2d_geometry(g) ? std::max(wave2_lds(g, precision), group_lds(8, 64, false, precision)) : wave2_lds(g, precision);
     const int nw = g.split_reim ? 12 : wave3d_nw_rt(precision, g.fixed_point != 0);
+    const int ch = (g.split_reim && g.tile[2] == 8) ? 16 : 32;   // (staging chunk: keeps two workgroups per CU)
     return cells * ((g.fixed_point || g.split_reim) ? 1 : 2) * sizeof(double) + (size_t)wave3_pad(g.w) * sizeof(double) +
-           (size_t)precision * nw * 32 * 2 * (g.w <= 6 ? 6 : 8) + 256;
+           (size_t)precision * nw * ch * 2 * (g.w <= 6 ? 6 : 8) + 256;
   }
   return cells * 2 * sizeof(double);
 }
@@ -2686,10 +2689,20 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
   if (e != hipSuccess) return e;                                                                 \
   spread_wave3_kernel<T, WW, TZV, 12, 32, false, CV>                                              \
       <<<grid, 12 * 64, lds_bytes, stream>>>(g, sp, horner, c, fw, c_stride, fw_stride, scale);
+#define NUFFT_LAUNCH_W3S8(WW, CV)                                                                \
+  e = ensure_lds(spread_wave3_kernel<T, WW, 8, 12, 16, false, CV>, lds_bytes);                    \
+  if (e != hipSuccess) return e;                                                                 \
+  spread_wave3_kernel<T, WW, 8, 12, 16, false, CV>                                                \
+      <<<grid, 12 * 64, lds_bytes, stream>>>(g, sp, horner, c, fw, c_stride, fw_stride, scale);
 #define NUFFT_CASE_W3(WW)                                                                        \
   case WW:                                                                                       \
     if (g.tile[2] == 8) {                                                                        \
-      if constexpr (WW <= 6) {                                                                   \
+      if constexpr (WW == 8) {                                                                   \
+        if constexpr (sizeof(T) == 4) {                                                          \
+          if (!g.split_reim) return hipErrorInvalidValue;                                        \
+          NUFFT_LAUNCH_W3S8(WW, 1) NUFFT_LAUNCH_W3S8(WW, 2)                                       \
+        } else { return hipErrorInvalidValue; }                                                  \
+      } else if constexpr (WW <= 6) {                                                            \
         if (g.fixed_point) {                                                                     \
           if constexpr (sizeof(T) == 4) { NUFFT_LAUNCH_W3(WW, 8, true) } else { return hipErrorInvalidValue; } \
         } else { NUFFT_LAUNCH_W3(WW, 8, false) }                                                 \
@@ -2709,6 +2722,7 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
         default: return hipErrorInvalidValue;
       }
 #undef NUFFT_CASE_W3
+#undef NUFFT_LAUNCH_W3S8
 #undef NUFFT_LAUNCH_W3S
 #undef NUFFT_LAUNCH_W3
     }

@@ -222,6 +222,7 @@ struct nufft_hip_plan_s {
   void* fft_work = nullptr;
   size_t fft_work_bytes = 0;      // bytes the FFT plans need (max over them)
   bool own_fft = false;           // pruned per-dimension passes (nufft_fft.hip) instead of rocFFT + deconvolve
+  int64_t fine_clear_slots = 0;   // leading fine grids known to be all zero (left so by the last type-1 FFT pass)
   void* d_twiddle[3] = {nullptr, nullptr, nullptr};   // exp(iflag 2 pi i m / nf_d)
   void* fft_tmp[2] = {nullptr, nullptr};              // intermediates of the pruned passes
 
@@ -448,6 +449,7 @@ void release_workspace(nufft_hip_plan p) {
   p->hist_elems = 0;
   p->workspace_bytes = 0;
   p->fixed_ws = false;
+  p->fine_clear_slots = 0;
   p->points_set = false;
   p->fused = false;
   p->M = 0;
@@ -722,9 +724,14 @@ int execute_impl(nufft_hip_plan p, void* c, void* f) {
     void* bufs[1] = {fw};
     const StageHook hook = make_hook(p);
     if (p->type == NUFFT_HIP_TYPE_1) {
-      hook.begin(STAGE_ZERO);
-      HIP_TRY(p, hipMemsetAsync(fw, 0, sizeof(T) * 2 * (size_t)p->fine_elems * slots, p->stream));
-      hook.end(STAGE_ZERO);
+      // the pruned FFT's first pass reads the whole fine grid and leaves it zeroed for the next
+      // spread: the memset only runs when that is not known to have happened
+      if (p->fine_clear_slots < slots) {
+        hook.begin(STAGE_ZERO);
+        HIP_TRY(p, hipMemsetAsync(fw, 0, sizeof(T) * 2 * (size_t)p->fine_elems * slots, p->stream));
+        hook.end(STAGE_ZERO);
+      }
+      p->fine_clear_slots = 0;   // (dirty from here on, until the FFT pass has cleared it again)
       hook.begin(STAGE_SPREAD);
       HIP_TRY(p, launch_spread<T>(p->g, p->method, sp, p->M * p->nitems, (const T*)p->d_horner, cb, fw, nb,
                                   p->M, p->fine_elems, (T)1, p->lds_bytes, p->stream));
@@ -733,8 +740,9 @@ int execute_impl(nufft_hip_plan p, void* c, void* f) {
       if (own) {
         hook.begin(STAGE_FFT);
         HIP_TRY(p, launch_pruned_fft<T>(p->g, 1, p->iflag, fw, fb, (T*)p->fft_tmp[0], (T*)p->fft_tmp[1], rf, tw,
-                                        slots, p->stream));
+                                        slots, p->stream, /*zero_fine=*/true));
         hook.end(STAGE_FFT);
+        p->fine_clear_slots = slots;
         continue;
       }
       hook.begin(STAGE_FFT);
@@ -969,7 +977,12 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
                       p->opts.tile_dims[1] == 0 && p->opts.max_subproblem_size <= 0 && !no_t2_big &&
                       g.nf[0] >= 64 && g.nf[1] >= 64;
   const int t2d = t2_big ? 64 : 32;
-  const int def_tile[3][3] = {{1024, 1, 1}, {t2d, t2d, 1}, {16, 16, w <= 6 ? 8 : 4}};
+  // 3-D float at w = 8 (fp64 planes, one component per launch): depth 8 as well -- the padded tile
+  // (23 x 23 x 15 cells, 66 KB) still lets two workgroups share a CU with a 16-point staging chunk,
+  // and the halo written out per fine cell falls from 5.7x to 3.9x.
+  static const bool w8_flat = getenv("NUFFT_HIP_W8_DEPTH4") != nullptr;   // A/B knob
+  const bool deep8 = w <= 6 || (w == 8 && precision == NUFFT_HIP_F32 && p->opts.lds_accumulate != 2 && !w8_flat);
+  const int def_tile[3][3] = {{1024, 1, 1}, {t2d, t2d, 1}, {16, 16, deep8 ? 8 : 4}};
   for (int d = 0; d < 3; ++d) {
     int t = d < rank ? (p->opts.tile_dims[d] > 0 ? p->opts.tile_dims[d] : def_tile[rank - 1][d]) : 1;
     t = std::max(1, std::min(t, 1024));
@@ -999,6 +1012,12 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
         if (g.tile[d] == (1 << b)) g.tile_shift[d] = b;
     }
     if (spread_lds_bytes(g, NUFFT_HIP_METHOD_TILE_GENERIC, precision) <= lds_limit) break;
+    // the depth-8 tile of the 3-D float wavefront kernel at w = 8 holds one fp64 plane per launch:
+    // it fits although two full planes (what the generic kernel would need) do not
+    if (rank == 3 && w == 8 && precision == NUFFT_HIP_F32 && g.tile[0] == 16 && g.tile[1] == 16 && g.tile[2] == 8 &&
+        (p->opts.spread_method == NUFFT_HIP_METHOD_AUTO || p->opts.spread_method == NUFFT_HIP_METHOD_TILE_WAVE) &&
+        p->opts.lds_accumulate != 2)
+      break;
     int big = 0;
     for (int d = 1; d < rank; ++d)
       if (g.tile[d] > g.tile[big]) big = d;
@@ -1069,7 +1088,8 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
   // fp64 planes in 3-D float at tile depth 4 (w = 8, or w <= 7 with lds_accumulate = 1):
   // one plane per launch, so that two workgroups share a CU
   g.split_reim = (method == NUFFT_HIP_METHOD_TILE_WAVE && rank == 3 && precision == NUFFT_HIP_F32 &&
-                  !g.fixed_point && g.tile[2] == 4 && getenv("NUFFT_HIP_NO_SPLIT") == nullptr) ? 1 : 0;
+                  !g.fixed_point && (g.tile[2] == 4 || (g.tile[2] == 8 && w == 8)) &&
+                  (getenv("NUFFT_HIP_NO_SPLIT") == nullptr || g.tile[2] == 8)) ? 1 : 0;
   if (method == NUFFT_HIP_METHOD_TILE_WAVE) g.lstride = t2_wave ? 72 : wave_lstride(rank);
   // wavefront kernels: one subproblem per typical tile measured fastest (r01 sweeps);
   // every extra subproblem of a tile repeats its zero-fill and write-out
