@@ -39,6 +39,7 @@ struct Geom {
   int ntiles_item;  //   item * ntiles_item + tile, ntiles = nitems * ntiles_item
   int sparse_auto;  // spread_method AUTO: launch_spread may pick the LDS-free kernel for sparse point sets
   int fused;        // 2-D float records carry the strength instead of the point index (FusedRec)
+  int wide;         // w = 9..16, rank 2 / 3: tiles and LDS strides of the 16 x 4-lane kernels (nufft_wide.hip)
   float fx_headroom;  // fixed-point accumulation: bound on prod_d max|P(z)| of the fitted kernel (>= 1)
 };
 
@@ -169,6 +170,15 @@ hipError_t launch_pruned_fft(const Geom& g, int type, int iflag, T* fine, T* f, 
 size_t spread_lds_bytes(const Geom& g, int method, int precision);
 size_t interp_lds_bytes(const Geom& g, int method, int precision);
 int wave_lstride(int rank);
+// widths 9..16 (nufft_wide.hip): the tile the plan must sort by, its LDS row stride and the kernel's LDS bytes
+bool wide_spread_supported(int rank, int w);
+void wide_spread_tile(int rank, int w, int tile[3]);
+int wide_spread_lstride(int rank, int w);
+size_t wide_spread_lds_bytes(int rank, int w, int precision);
+template <typename T>
+hipError_t launch_spread_wide(const Geom& g, const SortedPoints<T>& sp, int64_t M, const T* horner, const T* c,
+                              T* fw, int batch, int64_t c_stride, int64_t fw_stride, T scale,
+                              hipStream_t stream);
 int wave3_pad(int w);   // spill elements behind the LDS planes of the 3-D wavefront kernel
 bool sparse_wanted(const Geom& g, int64_t M);   // point set sparse enough for the LDS-free spreader
 bool wave_method_supported(const Geom& g, int precision);

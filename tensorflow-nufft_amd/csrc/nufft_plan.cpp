@@ -982,7 +982,21 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
   // and the halo written out per fine cell falls from 5.7x to 3.9x.
   static const bool w8_flat = getenv("NUFFT_HIP_W8_DEPTH4") != nullptr;   // A/B knob
   const bool deep8 = w <= 6 || (w == 8 && precision == NUFFT_HIP_F32 && p->opts.lds_accumulate != 2 && !w8_flat);
-  const int def_tile[3][3] = {{1024, 1, 1}, {t2d, t2d, 1}, {16, 16, deep8 ? 8 : 4}};
+  int def_tile[3][3] = {{1024, 1, 1}, {t2d, t2d, 1}, {16, 16, deep8 ? 8 : 4}};
+  // w = 9..16 (tol < 1e-7): the 16 x 4-lane spread kernels of nufft_wide.hip and their tiles
+  // (2-D 32 x 32; 3-D 16 x 8 x 4 up to w = 12, 8 x 8 x 4 above: one fp64 plane of LDS per launch)
+  static const bool no_wide = getenv("NUFFT_HIP_NO_WIDE") != nullptr;   // A/B knob
+  bool wide = !no_wide && wide_spread_supported(rank, w) &&
+              (p->opts.spread_method == NUFFT_HIP_METHOD_AUTO || p->opts.spread_method == NUFFT_HIP_METHOD_TILE_WAVE) &&
+              p->opts.tile_dims[0] == 0 && p->opts.tile_dims[1] == 0 && p->opts.tile_dims[2] == 0;
+  int wide_tile[3] = {1, 1, 1};
+  if (wide) {
+    wide_spread_tile(rank, w, wide_tile);
+    for (int d = 0; d < rank; ++d) {
+      if (g.nf[d] < wide_tile[d]) wide = false;
+      def_tile[rank - 1][d] = wide_tile[d];
+    }
+  }
   for (int d = 0; d < 3; ++d) {
     int t = d < rank ? (p->opts.tile_dims[d] > 0 ? p->opts.tile_dims[d] : def_tile[rank - 1][d]) : 1;
     t = std::max(1, std::min(t, 1024));
@@ -1011,6 +1025,7 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
       for (int b = 0; b <= 10; ++b)
         if (g.tile[d] == (1 << b)) g.tile_shift[d] = b;
     }
+    if (wide) break;   // (fixed tiles; the kernel's LDS need is known to fit)
     if (spread_lds_bytes(g, NUFFT_HIP_METHOD_TILE_GENERIC, precision) <= lds_limit) break;
     // the depth-8 tile of the 3-D float wavefront kernel at w = 8 holds one fp64 plane per launch:
     // it fits although two full planes (what the generic kernel would need) do not
@@ -1024,7 +1039,8 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
     if (g.tile[big] == 1) break;
     g.tile[big] = (g.tile[big] + 1) / 2;
   }
-  if (spread_lds_bytes(g, NUFFT_HIP_METHOD_TILE_GENERIC, precision) > 160 * 1024) {
+  g.wide = wide ? 1 : 0;
+  if (!wide && spread_lds_bytes(g, NUFFT_HIP_METHOD_TILE_GENERIC, precision) > 160 * 1024) {
     delete p;
     return fail(NUFFT_HIP_RESOURCE_EXHAUSTED, "kernel too wide for an LDS tile");  // cf. nufft_plan.cu.cc:2458-2463
   }
@@ -1061,11 +1077,12 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
   g.fused = 0;
   const bool t2_wave = t2_big && g.tile[0] == 64 && g.tile[1] == 64;   // (not shrunk by a tiny grid)
   if (method == NUFFT_HIP_METHOD_AUTO)
-    method = (t2_wave || wave_method_supported(g, precision)) ? NUFFT_HIP_METHOD_TILE_WAVE : NUFFT_HIP_METHOD_TILE_GENERIC;
-  if (method == NUFFT_HIP_METHOD_TILE_WAVE && !t2_wave && !wave_method_supported(g, precision)) {
+    method = (wide || t2_wave || wave_method_supported(g, precision)) ? NUFFT_HIP_METHOD_TILE_WAVE : NUFFT_HIP_METHOD_TILE_GENERIC;
+  if (method != NUFFT_HIP_METHOD_TILE_WAVE) g.wide = 0;
+  if (method == NUFFT_HIP_METHOD_TILE_WAVE && !wide && !t2_wave && !wave_method_supported(g, precision)) {
     delete p;
     return fail(NUFFT_HIP_INVALID_ARGUMENT,
-                "spread_method TILE_WAVE needs rank 2 or 3, kernel width <= 8 and the default tile sizes");
+                "spread_method TILE_WAVE needs rank 2 or 3 and the default tile sizes");
   }
   p->method = method;
   // packed 32+32-bit fixed-point accumulation: the 3-D float wavefront kernel at w <= 7.
@@ -1090,10 +1107,12 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
   g.split_reim = (method == NUFFT_HIP_METHOD_TILE_WAVE && rank == 3 && precision == NUFFT_HIP_F32 &&
                   !g.fixed_point && (g.tile[2] == 4 || (g.tile[2] == 8 && w == 8)) &&
                   (getenv("NUFFT_HIP_NO_SPLIT") == nullptr || g.tile[2] == 8)) ? 1 : 0;
-  if (method == NUFFT_HIP_METHOD_TILE_WAVE) g.lstride = t2_wave ? 72 : wave_lstride(rank);
+  if (method == NUFFT_HIP_METHOD_TILE_WAVE)
+    g.lstride = g.wide ? wide_spread_lstride(rank, w) : (t2_wave ? 72 : wave_lstride(rank));
   // wavefront kernels: one subproblem per typical tile measured fastest (r01 sweeps);
   // every extra subproblem of a tile repeats its zero-fill and write-out
   if (method == NUFFT_HIP_METHOD_TILE_WAVE && auto_sub) g.max_sub = t2_wave ? 16384 : 4096;   // (interp: one tile load per subproblem)
+  if (g.wide && auto_sub && rank == 3) g.max_sub = 1024;   // (hundreds of LDS atomics per point: keep workgroups short)
   if (g.fixed_point && w > 6) g.max_sub = std::min(g.max_sub, 512);
   p->lds_bytes = spread_lds_bytes(g, method, precision);
   if (p->lds_bytes > 160 * 1024 || interp_lds_bytes(g, method, precision) > 160 * 1024) {

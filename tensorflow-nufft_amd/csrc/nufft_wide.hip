@@ -1,0 +1,300 @@
+// gfx950 spread kernels for kernel widths 9..16 (tol < 1e-7: double precision in
+// practice), 2-D and 3-D. Replaces, for those widths, the thread-per-point tile kernel
+// (spread_tile_generic_kernel in nufft_kernels.hip; reference SpreadSubproblem2D/3DKernel,
+// nufft_plan.cu.cc:790-960, 1295-1511, where one thread walks a point's whole stencil and the
+// 64 unrelated points of a wavefront collide on LDS banks).
+//
+// One wavefront works on one point at a time. Lanes are 16 (x) by 4 (the slowest
+// dimension: y in 2-D, z in 3-D); a ds_add_f64 wave-instruction therefore covers a
+// 16 x 4 slab of the stencil, and the stencil takes ceil(W / 4) of them per component
+// (2-D) or W ceil(W / 4) (3-D, looping over y). The stride of the lane-split dimension is
+// 16 (mod 32) doubles -- the row stride 48 in 2-D, the padded plane stride in 3-D -- so the
+// two 16-cell rows of a half-wave cover the 64 LDS banks exactly once: conflict free for
+// every point position (the same rule as the 8 x 8 kernels of nufft_kernels.hip, whose
+// stride is 8 mod 32 for four 8-cell rows).
+//
+// Accumulation is fp64 in LDS for both precisions (ds_add_f32 is 22x slower on this
+// chip). 3-D runs one launch per component (one fp64 plane of
+// 45-85 KB in LDS), 2-D both in one launch (2 x 18 KB).
+//
+// Kernel values: CH points of a wave's share at a time, lane = (point, dimension)
+// evaluates all 16 polynomial columns of one dimension of one point (wave-uniform
+// coefficient loads); x and the lane-split dimension go through a small LDS staging
+// area, the middle dimension of 3-D stays in the evaluating lane and is broadcast with
+// v_readlane.
+#include <cstdio>
+#include <cstdlib>
+
+#include "nufft_hip_internal.h"
+#include "nufft_device.h"
+
+namespace nufft_hip {
+
+namespace {
+
+template <int RANK, int W>
+struct WideGeo {
+  static constexpr int WR = (W + 3) / 4;   // 4-row groups of the lane-split dimension
+  static constexpr int T0 = RANK == 2 ? 32 : (W <= 12 ? 16 : 8);
+  static constexpr int T1 = RANK == 2 ? 32 : 8;
+  static constexpr int T2 = RANK == 2 ? 1 : 4;
+  static constexpr int L0 = T0 + W - 1, L1 = T1 + W - 1, L2 = RANK == 2 ? 1 : T2 + W - 1;
+  static constexpr int LS = RANK == 2 ? 48 : L0;
+  static constexpr int PS0 = LS * L1;
+  static constexpr int PS = RANK == 2 ? PS0 : PS0 + (48 - PS0 % 32) % 32;   // 3-D: 16 (mod 32)
+  static constexpr int SS = RANK == 2 ? LS : PS;                            // stride between the 4 lane rows
+  static constexpr int plane = RANK == 2 ? PS0 : PS * L2;
+  // lanes with dx >= W add 0 up to 15 cells past their row: behind the last row that is past the plane
+  static constexpr int pad = 16;
+};
+
+constexpr int kWideNW = 8;
+template <typename T, int RANK> constexpr int kWideCH = (sizeof(T) == 8 && RANK == 3) ? 8 : 16;   // staged points per wave
+// staging row pitch (16 values + pad): consecutive lanes' 16-byte stores then start 36 / 20 banks
+// apart and the 16 rows written by one ds_write_b128 cover the 64 banks once (pitch 16: 8- / 4-way conflicts)
+template <typename T> constexpr int kWideRP = sizeof(T) == 8 ? 18 : 20;
+
+// k = k z + t with the coefficient t taken straight from its scalar register: left to itself the
+// compiler builds each step as 3 moves + v_fmac (64 VALU instructions per 16-column row instead of
+// 16; measured 113 VALU instructions per point in the 2-D kernel, which made it VALU bound).
+__device__ __forceinline__ float fma_sgpr(float k, float z, float t) {
+  float r;
+  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(k), "v"(z), "s"(t));
+  return r;
+}
+__device__ __forceinline__ double fma_sgpr(double k, double z, double t) {
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(k), "v"(z), "s"(t));
+  return r;
+}
+template <typename T>
+__device__ __forceinline__ void horner16(const T* __restrict__ tab, int nc, T z, T (&k)[16]) {
+#pragma unroll
+  for (int q = 0; q < 16; ++q) k[q] = tab[(nc - 1) * kMaxW + q];
+  for (int t = nc - 2; t >= 0; --t) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) k[q] = fma_sgpr(k[q], z, tab[t * kMaxW + q]);
+  }
+}
+
+// COMP: 0 = both components (two planes), 1 / 2 = real / imaginary part only (one plane).
+template <typename T, int RANK, int W, int COMP>
+__global__ __launch_bounds__(kWideNW * 64) void spread_wide_kernel(
+    Geom g, SortedPoints<T> sp, const T* __restrict__ horner, const T* __restrict__ c,
+    T* __restrict__ fw, int64_t c_stride, int64_t fw_stride, T scale) {
+  using G = WideGeo<RANK, W>;
+  using T2 = typename Pair<T>::type;
+  constexpr int NW = kWideNW, CH = kWideCH<T, RANK>, WR = G::WR, RP = kWideRP<T>;
+  constexpr int LS = G::LS, PS = G::PS, SS = G::SS;
+  constexpr int NPL = COMP == 0 ? 2 : 1;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* plane_re = reinterpret_cast<double*>(smem_raw);
+  double* plane_im = plane_re + (NPL == 2 ? G::plane : 0);
+  T* stage_all = reinterpret_cast<T*>(plane_re + NPL * G::plane + G::pad);
+  int tb, p0, p1, slot;
+  if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1, &slot)) return;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  for (int i = tid; i < NPL * G::plane + G::pad; i += NW * 64) plane_re[i] = 0.0;
+  __syncthreads();
+
+  const int nc = g.ncoef;
+  T* kxs = stage_all + wave * (CH * 2 * RP);   // [CH][RP] x values
+  T* kss = kxs + CH * RP;                      // [CH][RP] values of the lane-split dimension
+  const int dx = lane & 15, r = lane >> 4;
+  const bool in_x = dx < W;
+  // Horner phase: lane = (point of the chunk, dimension)
+  const int hq = lane & (CH - 1), hd = lane / CH;
+  const T2* cc = reinterpret_cast<const T2*>(c) + (int64_t)slot * c_stride;
+  const int npt = p1 - p0;
+  const int share = (npt + NW - 1) / NW;
+  const int wbeg = p0 + wave * share;
+  const int wend = (wbeg + share < p1) ? wbeg + share : p1;
+
+  for (int base = wbeg; base < wend; base += CH) {
+    const int j = base + hq;
+    int off = 0;
+    T cre = (T)0, cim = (T)0;
+    T kmid[W];   // 3-D: y values, live in the lanes with hd == 1
+#pragma unroll
+    for (int q = 0; q < W; ++q) kmid[q] = (T)0;
+    if (hd < RANK) {
+      T kv[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) kv[q] = (T)0;
+      if (j < wend) {
+        const PointView<T> rec = unpack_rec<T, RANK>(sp.rec[j]);
+        const T z = hd == 0 ? rec.z0 : (hd == 1 ? rec.z1 : rec.z2);
+        horner16<T>(horner, nc, z, kv);
+        if (hd == 0) {
+          const T2 cv = cc[rec.idx];
+          cre = cv.x * scale;
+          cim = cv.y * scale;
+          off = (int)(rec.loc & 1023) + (int)((rec.loc >> 10) & 1023) * LS +
+                (RANK > 2 ? (int)((rec.loc >> 20) & 1023) * PS : 0);
+        }
+      }
+      if (hd == 0 || hd == RANK - 1) {
+        T* dst = (hd == 0 ? kxs : kss) + hq * RP;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) dst[q] = kv[q];
+      }
+      if (RANK > 2) {
+#pragma unroll
+        for (int q = 0; q < W; ++q) kmid[q] = kv[q];
+      }
+    }
+    int npts = wend - base;
+    if (npts > CH) npts = CH;
+    // staged values of the NEXT point are requested before this point's atomics
+    T a_n = kxs[dx];
+    T ks_n[WR];
+#pragma unroll
+    for (int gq = 0; gq < WR; ++gq) ks_n[gq] = kss[(4 * gq + r) & 15];
+    for (int q = 0; q < npts; ++q) {
+      const T a = in_x ? a_n : (T)0;
+      T ks[WR];
+#pragma unroll
+      for (int gq = 0; gq < WR; ++gq) ks[gq] = ks_n[gq];
+      const int qn = (q + 1 < npts) ? q + 1 : q;
+      a_n = kxs[qn * RP + dx];
+#pragma unroll
+      for (int gq = 0; gq < WR; ++gq) ks_n[gq] = kss[qn * RP + ((4 * gq + r) & 15)];
+      const int o = __builtin_amdgcn_readlane(off, q) + r * SS + dx;
+      const T c_re = bcast_lane(cre, q), c_im = bcast_lane(cim, q);
+      double* pr = plane_re + o;
+      double* pi = plane_im + o;
+      if (RANK == 2) {
+#pragma unroll
+        for (int gq = 0; gq < WR; ++gq) {
+          const T v = a * ks[gq];
+          // the last group is partial unless W is a multiple of 4: rows past the stencil are masked
+          if (4 * gq + 3 < W || 4 * gq + r < W) {
+            if (COMP != 2) lds_add(pr + 4 * gq * SS, (double)(v * c_re));
+            if (COMP != 1) lds_add(pi + 4 * gq * SS, (double)(v * c_im));
+          }
+        }
+      } else {
+        T are[WR], aim[WR];
+#pragma unroll
+        for (int gq = 0; gq < WR; ++gq) {
+          const T v = a * ks[gq];
+          are[gq] = v * c_re;
+          aim[gq] = v * c_im;
+        }
+#pragma unroll
+        for (int dy = 0; dy < W; ++dy) {
+          const T kyq = bcast_lane(kmid[dy], CH + q);
+#pragma unroll
+          for (int gq = 0; gq < WR; ++gq) {
+            if (4 * gq + 3 < W || 4 * gq + r < W) {
+              if (COMP != 2) lds_add(pr + dy * LS + 4 * gq * SS, (double)(are[gq] * kyq));
+              if (COMP != 1) lds_add(pi + dy * LS + 4 * gq * SS, (double)(aim[gq] * kyq));
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // write-out: add the tile to the periodic fine grid
+  const int t0 = tb % g.ntile[0];
+  const int t1 = (tb / g.ntile[0]) % g.ntile[1];
+  const int t2 = tb / (g.ntile[0] * g.ntile[1]);
+  const int o0 = t0 * G::T0, o1 = t1 * G::T1, o2 = t2 * G::T2;
+  T* out = fw + 2 * (int64_t)slot * fw_stride;
+  for (RowWalk rw(wave, G::L1); rw.a2 < G::L2; rw.advance(NW, G::L1)) {
+    const int g1 = wrap1(o1 + rw.a1, g.nf[1]);
+    const int g2 = RANK > 2 ? wrap1(o2 + rw.a2, g.nf[2]) : 0;
+    const int64_t rowbase = (int64_t)g.nf[0] * (g1 + (int64_t)g.nf[1] * g2);
+    const int lrow = rw.a2 * PS + rw.a1 * LS;
+    if (COMP == 0) {
+      for (int e = lane; e < 2 * G::L0; e += 64) {
+        const int a0 = e >> 1, comp = e & 1;
+        const T v = (T)(comp ? plane_im : plane_re)[lrow + a0];
+        if (v != (T)0) glb_add(&out[2 * (rowbase + wrap1(o0 + a0, g.nf[0])) + comp], v);
+      }
+    } else {
+      if (lane < G::L0) {
+        const T v = (T)plane_re[lrow + lane];
+        if (v != (T)0) glb_add(&out[2 * (rowbase + wrap1(o0 + lane, g.nf[0])) + (COMP - 1)], v);
+      }
+    }
+  }
+}
+
+template <typename K>
+hipError_t wide_ensure_lds(K kernel, size_t bytes) {
+  if (bytes <= 64 * 1024) return hipSuccess;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)bytes);
+}
+
+template <typename T, int RANK, int W, int COMP>
+hipError_t launch_one(const Geom& g, dim3 grid, const SortedPoints<T>& sp, const T* horner, const T* c, T* fw,
+                      int64_t c_stride, int64_t fw_stride, T scale, hipStream_t stream) {
+  using G = WideGeo<RANK, W>;
+  constexpr size_t lds = sizeof(double) * ((COMP == 0 ? 2 : 1) * G::plane + G::pad) +
+                         sizeof(T) * kWideNW * kWideCH<T, RANK> * 2 * kWideRP<T>;
+  hipError_t e = wide_ensure_lds(spread_wide_kernel<T, RANK, W, COMP>, lds);
+  if (e != hipSuccess) return e;
+  spread_wide_kernel<T, RANK, W, COMP><<<grid, kWideNW * 64, lds, stream>>>(g, sp, horner, c, fw, c_stride,
+                                                                            fw_stride, scale);
+  return hipGetLastError();
+}
+
+template <typename T, int W>
+hipError_t launch_w(const Geom& g, dim3 grid, const SortedPoints<T>& sp, const T* horner, const T* c, T* fw,
+                    int64_t c_stride, int64_t fw_stride, T scale, hipStream_t stream) {
+  if (g.rank == 2) return launch_one<T, 2, W, 0>(g, grid, sp, horner, c, fw, c_stride, fw_stride, scale, stream);
+  hipError_t e = launch_one<T, 3, W, 1>(g, grid, sp, horner, c, fw, c_stride, fw_stride, scale, stream);
+  if (e != hipSuccess) return e;
+  return launch_one<T, 3, W, 2>(g, grid, sp, horner, c, fw, c_stride, fw_stride, scale, stream);
+}
+
+}  // namespace
+
+// Host-side mirror of WideGeo: the tile the plan must sort by for these kernels.
+bool wide_spread_supported(int rank, int w) { return (rank == 2 || rank == 3) && w > 8 && w <= 16; }
+void wide_spread_tile(int rank, int w, int tile[3]) {
+  tile[0] = rank == 2 ? 32 : (w <= 12 ? 16 : 8);
+  tile[1] = rank == 2 ? 32 : 8;
+  tile[2] = rank == 2 ? 1 : 4;
+}
+int wide_spread_lstride(int rank, int w) { return rank == 2 ? 48 : (w <= 12 ? 16 : 8) + w - 1; }
+size_t wide_spread_lds_bytes(int rank, int w, int precision) {
+  int t[3];
+  wide_spread_tile(rank, w, t);
+  const int ls = wide_spread_lstride(rank, w), l1 = t[1] + w - 1;
+  size_t plane = (size_t)ls * l1;
+  if (rank == 3) {
+    plane += (48 - plane % 32) % 32;
+    plane *= (size_t)(t[2] + w - 1);
+  }
+  return sizeof(double) * ((rank == 2 ? 2 : 1) * plane + 16) + (size_t)precision * kWideNW * (precision == 8 ? (rank == 3 ? 8 : 16) * 2 * 18 : 16 * 2 * 20);
+}
+
+template <typename T>
+hipError_t launch_spread_wide(const Geom& g, const SortedPoints<T>& sp, int64_t M, const T* horner, const T* c,
+                              T* fw, int batch, int64_t c_stride, int64_t fw_stride, T scale,
+                              hipStream_t stream) {
+  if (M == 0) return hipSuccess;
+  dim3 grid((unsigned)((int64_t)g.ntiles + M / g.max_sub), (unsigned)batch);
+#define NUFFT_WIDE_CASE(WW) \
+  case WW: return launch_w<T, WW>(g, grid, sp, horner, c, fw, c_stride, fw_stride, scale, stream);
+  switch (g.w) {
+    NUFFT_WIDE_CASE(9) NUFFT_WIDE_CASE(10) NUFFT_WIDE_CASE(11) NUFFT_WIDE_CASE(12)
+    NUFFT_WIDE_CASE(13) NUFFT_WIDE_CASE(14) NUFFT_WIDE_CASE(15) NUFFT_WIDE_CASE(16)
+    default: return hipErrorInvalidValue;
+  }
+#undef NUFFT_WIDE_CASE
+}
+template hipError_t launch_spread_wide<float>(const Geom&, const SortedPoints<float>&, int64_t, const float*,
+                                              const float*, float*, int, int64_t, int64_t, float, hipStream_t);
+template hipError_t launch_spread_wide<double>(const Geom&, const SortedPoints<double>&, int64_t, const double*,
+                                               const double*, double*, int, int64_t, int64_t, double,
+                                               hipStream_t);
+
+}  // namespace nufft_hip

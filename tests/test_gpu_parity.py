@@ -120,6 +120,47 @@ def test_wave_kernels_all_widths_vs_generic_and_oracle(tfft, rank, grid, tol, dt
   assert rel_l2(outs[2], outs[1]) < max(1e-6, 1e-3 * tol)
 
 
+@pytest.mark.parametrize('rank,grid,tol,dtype,width', [
+    (2, [96, 80], 3e-8, 'c128', 9), (2, [50, 64], 3e-9, 'c128', 10), (2, [50, 64], 3e-10, 'c128', 11),
+    (2, [64, 64], 3e-11, 'c128', 12), (2, [40, 70], 3e-12, 'c128', 13), (2, [40, 70], 3e-13, 'c128', 14),
+    (2, [64, 48], 3e-14, 'c128', 15), (2, [64, 48], 3e-15, 'c128', 16), (2, [96, 80], 3e-8, 'c64', 9),
+    (3, [24, 20, 28], 3e-8, 'c128', 9), (3, [24, 20, 28], 3e-9, 'c128', 10), (3, [20, 28, 22], 3e-10, 'c128', 11),
+    (3, [20, 28, 22], 3e-11, 'c128', 12), (3, [20, 24, 18], 3e-12, 'c128', 13), (3, [20, 24, 18], 3e-13, 'c128', 14),
+    (3, [18, 18, 20], 3e-14, 'c128', 15), (3, [18, 18, 20], 3e-15, 'c128', 16), (3, [24, 20, 28], 3e-9, 'c64', 9),
+])
+@pytest.mark.parametrize('ttype', ['type_1', 'type_2'])
+def test_wide_kernels_vs_generic_and_oracle(tfft, rank, grid, tol, dtype, width, ttype):
+  # widths 9..16 (tol < 1e-7): the 16 x 4-lane spread kernels (nufft_wide.hip, method 2) against the
+  # thread-per-point tile kernels (method 1) and the fp64 oracle
+  import torch
+  from oracle import oracle
+  rng = np.random.default_rng(33)
+  M = 30000
+  cdt = np.complex64 if dtype == 'c64' else np.complex128
+  rdt = np.float32 if dtype == 'c64' else np.float64
+  pts = rng.uniform(-np.pi, np.pi, (M, rank)).astype(rdt)
+  pts[:64] = np.pi * rng.choice([-1.0, 1.0, 0.0], (64, rank))   # fold seams, tile corners
+  if ttype == 'type_1':
+    src = (rng.uniform(-.5, .5, M) + 1j * rng.uniform(-.5, .5, M)).astype(cdt)
+  else:
+    src = (rng.uniform(-.5, .5, grid) + 1j * rng.uniform(-.5, .5, grid)).astype(cdt)
+  truth = oracle.nufft(src.astype(np.complex128), pts, grid, ttype, 'forward', tol=1e-14)
+  outs = {}
+  for method in (1, 2):
+    plan = tfft.Plan(ttype, grid, 'forward', tol=tol, dtype=torch.complex64 if dtype == 'c64' else torch.complex128,
+                     spread_method=method)
+    assert plan.info().spread_method == method and plan.info().kernel_width == width
+    plan.set_points(_dev(pts))
+    outs[method] = plan.execute(_dev(src)).cpu().numpy()
+    plan.close()
+    assert rel_l2(outs[method], truth) < max(3 * tol, 6e-7 if dtype == 'c64' else 5e-13), (method, rel_l2(outs[method], truth))
+  assert rel_l2(outs[2], outs[1]) < (2e-6 if dtype == 'c64' else 1e-13)
+  # the automatic choice is the wide kernel
+  auto = tfft.Plan(ttype, grid, 'forward', tol=tol, dtype=torch.complex64 if dtype == 'c64' else torch.complex128)
+  assert auto.info().spread_method == 2
+  auto.close()
+
+
 def test_headline_shape_small_m_vs_oracle(tfft):
   # BASELINE config 2 geometry (1024^2 modes, 2048^2 fine grid) with M = 2e5 so
   # the oracle (fp64, sigma 2, tol 1e-12) finishes in seconds

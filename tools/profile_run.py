@@ -11,6 +11,7 @@ ap.add_argument('--M', type=float, default=1e7); ap.add_argument('--tol', type=f
 ap.add_argument('--method', type=int, default=0); ap.add_argument('--S', type=int, default=0)
 ap.add_argument('--steps', type=int, default=5); ap.add_argument('--ntransf', type=int, default=1)
 ap.add_argument('--acc', type=int, default=0)
+ap.add_argument('--double', action='store_true', help='complex128 / float64')
 ap.add_argument('--one-call', action='store_true', help='nufft_hip_execute_with_points instead of set_points + execute')
 a = ap.parse_args()
 grid = [int(g) for g in a.grid.split(',')]; M = int(a.M); rank = len(grid)
@@ -21,7 +22,8 @@ if a.type == 'type_1':
   src = torch.complex(torch.rand(lead + [M], generator=g, device='cuda') - .5, torch.rand(lead + [M], generator=g, device='cuda') - .5)
 else:
   src = torch.complex(torch.rand(lead + grid, generator=g, device='cuda') - .5, torch.rand(lead + grid, generator=g, device='cuda') - .5)
-plan = tfft.Plan(a.type, grid, 'forward', num_transforms=a.ntransf, tol=a.tol, spread_method=a.method, max_subproblem_size=a.S, lds_accumulate=a.acc)
+if a.double: pts = pts.double(); src = src.to(torch.complex128)
+plan = tfft.Plan(a.type, grid, 'forward', num_transforms=a.ntransf, tol=a.tol, dtype=torch.complex128 if a.double else torch.complex64, spread_method=a.method, max_subproblem_size=a.S, lds_accumulate=a.acc)
 for _ in range(a.steps):
   if a.one_call:
     out = plan.execute_with_points(pts, src)
