@@ -175,6 +175,11 @@ bool wide_spread_supported(int rank, int w);
 void wide_spread_tile(int rank, int w, int tile[3]);
 int wide_spread_lstride(int rank, int w);
 size_t wide_spread_lds_bytes(int rank, int w, int precision);
+size_t wide_interp_lds_bytes(int rank, int w, int precision);
+template <typename T>
+hipError_t launch_interp_wide(const Geom& g, const SortedPoints<T>& sp, int64_t M, const T* horner, T* c,
+                              const T* fw, int batch, int64_t c_stride, int64_t fw_stride, T scale,
+                              hipStream_t stream);
 template <typename T>
 hipError_t launch_spread_wide(const Geom& g, const SortedPoints<T>& sp, int64_t M, const T* horner, const T* c,
                               T* fw, int batch, int64_t c_stride, int64_t fw_stride, T scale,

@@ -2390,7 +2390,8 @@ size_t spread_lds_bytes(const Geom& g, int method, int precision) {
 }
 
 size_t interp_lds_bytes(const Geom& g, int method, int precision) {
-  if (method != NUFFT_HIP_METHOD_TILE_WAVE || g.wide) return 0;   // (wide: the gather kernel, no LDS tile)
+  if (method != NUFFT_HIP_METHOD_TILE_WAVE) return 0;
+  if (g.wide) return wide_interp_lds_bytes(g.rank, g.w, precision);
   size_t cells = (size_t)g.lstride;
   for (int d = 1; d < g.rank; ++d) cells *= (size_t)g.ldim[d];
   return cells * 2 * (size_t)precision;
@@ -2617,7 +2618,9 @@ hipError_t launch_interp(const Geom& g, int method, const SortedPoints<T>& sp, i
                          int64_t fw_stride, T scale, hipStream_t stream) {
   if (M == 0) return hipSuccess;
   dim3 grid(subproblem_grid(g, M), (unsigned)batch);
-  if (method == NUFFT_HIP_METHOD_TILE_WAVE && !g.wide) {
+  if (method == NUFFT_HIP_METHOD_TILE_WAVE && g.wide)
+    return launch_interp_wide<T>(g, sp, M, horner, c, fw, batch, c_stride, fw_stride, scale, stream);
+  if (method == NUFFT_HIP_METHOD_TILE_WAVE) {
     const size_t lds = interp_lds_bytes(g, method, (int)sizeof(T));
     hipError_t e = hipSuccess;
 #define NUFFT_LAUNCH_IP(RR, WW)                                                                       \

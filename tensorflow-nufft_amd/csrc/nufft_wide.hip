@@ -37,7 +37,7 @@ struct WideGeo {
   static constexpr int WR = (W + 3) / 4;   // 4-row groups of the lane-split dimension
   static constexpr int T0 = RANK == 2 ? 32 : (W <= 12 ? 16 : 8);
   static constexpr int T1 = RANK == 2 ? 32 : 8;
-  static constexpr int T2 = RANK == 2 ? 1 : 4;
+  static constexpr int T2 = RANK == 2 ? 1 : (W == 16 ? 2 : 4);   // (w = 16: the fp64 interp tile must fit 160 KB)
   static constexpr int L0 = T0 + W - 1, L1 = T1 + W - 1, L2 = RANK == 2 ? 1 : T2 + W - 1;
   static constexpr int LS = RANK == 2 ? 48 : L0;
   static constexpr int PS0 = LS * L1;
@@ -225,6 +225,172 @@ __global__ __launch_bounds__(kWideNW * 64) void spread_wide_kernel(
   }
 }
 
+// ------------------------------------------------------------ interp, widths 9..16
+//
+// Replaces, for these widths, the gather-from-global kernel (interp_tile_generic_kernel;
+// reference InterpSubproblem2D/3DKernel, nufft_plan.cu.cc:1041-1187, 1608-1804). The tile
+// (with its halo) is loaded into LDS as interleaved complex T; lanes are 16 (x) by 4 POINTS:
+// a ds_read_b128 / b64 wave-instruction fetches one 16-cell stencil row of four points, each
+// quarter-wave reading 256 (128) contiguous bytes -- conflict free whatever the four positions,
+// since a wide LDS read is served one quarter-wave at a time. Each lane keeps its point's y
+// (and z) kernel values in registers, multiplies and accumulates; the 16 lanes of a point are
+// summed with four row_shr DPP steps. 2-D: 16 points (4 quads) are staged per wave at a time,
+// 3-D: 4 (LDS is the tile's: 100-158 KB in fp64).
+template <int RANK> constexpr int kWideIQ = RANK == 2 ? 4 : 1;
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov0(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov0(double v) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+// lane 15 of every row of 16 lanes ends up with the row's sum (row_shr 1, 2, 4, 8; lanes shifted in are 0)
+template <typename T>
+__device__ __forceinline__ T row_sum16(T v) {
+  v += dpp_mov0<0x111>(v);
+  v += dpp_mov0<0x112>(v);
+  v += dpp_mov0<0x114>(v);
+  v += dpp_mov0<0x118>(v);
+  return v;
+}
+
+template <typename T, int RANK, int W>
+__global__ __launch_bounds__(kWideNW * 64) void interp_wide_kernel(
+    Geom g, SortedPoints<T> sp, const T* __restrict__ horner, T* __restrict__ c,
+    const T* __restrict__ fw, int64_t c_stride, int64_t fw_stride, T scale) {
+  using G = WideGeo<RANK, W>;
+  using T2 = typename Pair<T>::type;
+  constexpr int NW = kWideNW, NQ = kWideIQ<RANK>, CH = 4 * NQ, RP = kWideRP<T>;
+  constexpr int L0 = G::L0, L1 = G::L1, L2 = G::L2;
+  constexpr int LS = L0, PS = LS * L1, cells = PS * L2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T2* tile = reinterpret_cast<T2*>(smem_raw);
+  T* stage_all = reinterpret_cast<T*>(tile + cells + 16);
+  int tb, p0, p1, slot;
+  if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1, &slot)) return;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int t0 = tb % g.ntile[0];
+  const int t1 = (tb / g.ntile[0]) % g.ntile[1];
+  const int t2 = tb / (g.ntile[0] * g.ntile[1]);
+  const int o0 = t0 * G::T0, o1 = t1 * G::T1, o2 = t2 * G::T2;
+  const T2* in = reinterpret_cast<const T2*>(fw) + (int64_t)slot * fw_stride;
+  // tile + halo -> LDS: cells are dealt to threads in flat order (rows are only 24-47 cells long: a
+  // lane-per-column walk would leave half of every wavefront idle); kBatch loads in flight before
+  // the stores, so a workgroup pays two or three memory round trips for its 35-160 KB tile
+  {
+    constexpr int kBatch = 8;
+    for (int e0 = tid; e0 < cells; e0 += kBatch * NW * 64) {
+      T2 v[kBatch];
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) {
+        const int e = e0 + u * NW * 64;
+        const int ec = e < cells ? e : cells - 1;
+        const int rowi = ec / L0;          // (compile-time divisors)
+        const int a0 = ec - rowi * L0;
+        const int a2 = RANK > 2 ? rowi / L1 : 0;
+        const int a1 = rowi - a2 * L1;
+        const int64_t gx = wrap1(o0 + a0, g.nf[0]);
+        const int g1 = wrap1(o1 + a1, g.nf[1]);
+        const int g2 = RANK > 2 ? wrap1(o2 + a2, g.nf[2]) : 0;
+        v[u] = in[(int64_t)g.nf[0] * (g1 + (int64_t)g.nf[1] * g2) + gx];
+      }
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) {
+        const int e = e0 + u * NW * 64;
+        if (e < cells) tile[e] = v[u];
+      }
+    }
+    // lanes with dx >= W read (with weight 0) up to 15 cells past their row: keep those finite
+    if (tid < 16) { T2 z; z.x = (T)0; z.y = (T)0; tile[cells + tid] = z; }
+  }
+  __syncthreads();
+
+  const int nc = g.ncoef;
+  T* kst = stage_all + wave * (RANK * CH * RP);   // [RANK][CH][RP]
+  const int dx = lane & 15, pr = lane >> 4;
+  const bool in_x = dx < W;
+  const int hq = lane % CH, hd = lane / CH;       // Horner phase: lane = (point of the chunk, dimension)
+  T2* cc = reinterpret_cast<T2*>(c) + (int64_t)slot * c_stride;
+  const int npt = p1 - p0;
+  const int share = (npt + NW - 1) / NW;
+  const int wbeg = p0 + wave * share;
+  const int wend = (wbeg + share < p1) ? wbeg + share : p1;
+
+  for (int base = wbeg; base < wend; base += CH) {
+    int off = 0, idx = 0;
+    if (hd < RANK) {
+      T kv[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) kv[q] = (T)0;
+      const int j = base + hq;
+      if (j < wend) {
+        const PointView<T> rec = unpack_rec<T, RANK>(sp.rec[j]);
+        const T z = hd == 0 ? rec.z0 : (hd == 1 ? rec.z1 : rec.z2);
+        horner16<T>(horner, nc, z, kv);
+        idx = rec.idx;
+        off = (int)(rec.loc & 1023) + (int)((rec.loc >> 10) & 1023) * LS +
+              (RANK > 2 ? (int)((rec.loc >> 20) & 1023) * PS : 0);
+      }
+      T* dst = kst + (hd * CH + hq) * RP;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) dst[q] = kv[q];
+    }
+#pragma unroll 1
+    for (int qq = 0; qq < NQ; ++qq) {
+      const int p = 4 * qq + pr;   // this lane row's point of the chunk (lane p, dimension 0, holds off / idx)
+      if (base + 4 * qq >= wend) break;
+      const int offp = __shfl(off, p);
+      const int idxp = __shfl(idx, p);
+      const T a0 = kst[p * RP + dx];
+      const T a = in_x ? a0 : (T)0;
+      T ky[W];
+#pragma unroll
+      for (int q = 0; q < W; ++q) ky[q] = kst[(CH + p) * RP + q];
+      const T2* tp = tile + offp + dx;
+      T sre = (T)0, sim = (T)0;
+      if (RANK == 2) {
+#pragma unroll
+        for (int dy = 0; dy < W; ++dy) {
+          const T2 v = tp[dy * LS];
+          const T wgt = a * ky[dy];
+          sre = fma(wgt, v.x, sre);
+          sim = fma(wgt, v.y, sim);
+        }
+      } else {
+        T kz[W];
+#pragma unroll
+        for (int q = 0; q < W; ++q) kz[q] = kst[(2 * CH + p) * RP + q];
+#pragma unroll
+        for (int dz = 0; dz < W; ++dz) {
+          const T az = a * kz[dz];
+#pragma unroll
+          for (int dy = 0; dy < W; ++dy) {
+            const T2 v = tp[dz * PS + dy * LS];
+            const T wgt = az * ky[dy];
+            sre = fma(wgt, v.x, sre);
+            sim = fma(wgt, v.y, sim);
+          }
+        }
+      }
+      sre = row_sum16(sre);
+      sim = row_sum16(sim);
+      if (dx == 15 && base + p < wend) {
+        T2 out;
+        out.x = sre * scale;
+        out.y = sim * scale;
+        cc[idxp] = out;
+      }
+    }
+  }
+}
+
 template <typename K>
 hipError_t wide_ensure_lds(K kernel, size_t bytes) {
   if (bytes <= 64 * 1024) return hipSuccess;
@@ -261,7 +427,7 @@ bool wide_spread_supported(int rank, int w) { return (rank == 2 || rank == 3) &&
 void wide_spread_tile(int rank, int w, int tile[3]) {
   tile[0] = rank == 2 ? 32 : (w <= 12 ? 16 : 8);
   tile[1] = rank == 2 ? 32 : 8;
-  tile[2] = rank == 2 ? 1 : 4;
+  tile[2] = rank == 2 ? 1 : (w == 16 ? 2 : 4);
 }
 int wide_spread_lstride(int rank, int w) { return rank == 2 ? 48 : (w <= 12 ? 16 : 8) + w - 1; }
 size_t wide_spread_lds_bytes(int rank, int w, int precision) {
@@ -275,6 +441,46 @@ size_t wide_spread_lds_bytes(int rank, int w, int precision) {
   }
   return sizeof(double) * ((rank == 2 ? 2 : 1) * plane + 16) + (size_t)precision * kWideNW * (precision == 8 ? (rank == 3 ? 8 : 16) * 2 * 18 : 16 * 2 * 20);
 }
+
+size_t wide_interp_lds_bytes(int rank, int w, int precision) {
+  int t[3];
+  wide_spread_tile(rank, w, t);
+  size_t cells = 1;
+  for (int d = 0; d < rank; ++d) cells *= (size_t)(t[d] + w - 1);
+  return (cells + 16) * 2 * (size_t)precision +
+         (size_t)precision * kWideNW * rank * 4 * (rank == 2 ? 4 : 1) * (precision == 8 ? 18 : 20);
+}
+
+template <typename T>
+hipError_t launch_interp_wide(const Geom& g, const SortedPoints<T>& sp, int64_t M, const T* horner, T* c,
+                              const T* fw, int batch, int64_t c_stride, int64_t fw_stride, T scale,
+                              hipStream_t stream) {
+  if (M == 0) return hipSuccess;
+  dim3 grid((unsigned)((int64_t)g.ntiles + M / g.max_sub), (unsigned)batch);
+  const size_t lds = wide_interp_lds_bytes(g.rank, g.w, (int)sizeof(T));
+  hipError_t e = hipSuccess;
+#define NUFFT_WIDE_IP(RR, WW)                                                                        \
+  case RR * 100 + WW:                                                                                \
+    e = wide_ensure_lds(interp_wide_kernel<T, RR, WW>, lds);                                         \
+    if (e != hipSuccess) return e;                                                                   \
+    interp_wide_kernel<T, RR, WW><<<grid, kWideNW * 64, lds, stream>>>(g, sp, horner, c, fw, c_stride, \
+                                                                       fw_stride, scale);            \
+    break;
+  switch (g.rank * 100 + g.w) {
+    NUFFT_WIDE_IP(2, 9) NUFFT_WIDE_IP(2, 10) NUFFT_WIDE_IP(2, 11) NUFFT_WIDE_IP(2, 12)
+    NUFFT_WIDE_IP(2, 13) NUFFT_WIDE_IP(2, 14) NUFFT_WIDE_IP(2, 15) NUFFT_WIDE_IP(2, 16)
+    NUFFT_WIDE_IP(3, 9) NUFFT_WIDE_IP(3, 10) NUFFT_WIDE_IP(3, 11) NUFFT_WIDE_IP(3, 12)
+    NUFFT_WIDE_IP(3, 13) NUFFT_WIDE_IP(3, 14) NUFFT_WIDE_IP(3, 15) NUFFT_WIDE_IP(3, 16)
+    default: return hipErrorInvalidValue;
+  }
+#undef NUFFT_WIDE_IP
+  return hipGetLastError();
+}
+template hipError_t launch_interp_wide<float>(const Geom&, const SortedPoints<float>&, int64_t, const float*,
+                                              float*, const float*, int, int64_t, int64_t, float, hipStream_t);
+template hipError_t launch_interp_wide<double>(const Geom&, const SortedPoints<double>&, int64_t, const double*,
+                                               double*, const double*, int, int64_t, int64_t, double,
+                                               hipStream_t);
 
 template <typename T>
 hipError_t launch_spread_wide(const Geom& g, const SortedPoints<T>& sp, int64_t M, const T* horner, const T* c,
