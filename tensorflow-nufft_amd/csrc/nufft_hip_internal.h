@@ -39,6 +39,7 @@ struct Geom {
   int ntiles_item;  //   item * ntiles_item + tile, ntiles = nitems * ntiles_item
   int sparse_auto;  // spread_method AUTO: launch_spread may pick the LDS-free kernel for sparse point sets
   int fused;        // 2-D float records carry the strength instead of the point index (FusedRec)
+  int line;         // 1-D plan whose interpolation runs on interp_line_kernel (nufft_line.hip; spread_method AUTO)
   int wide;         // w = 9..16, rank 2 / 3: tiles and LDS strides of the 16 x 4-lane kernels (nufft_wide.hip)
   float fx_headroom;  // fixed-point accumulation: bound on prod_d max|P(z)| of the fitted kernel (>= 1)
 };
@@ -175,6 +176,13 @@ bool wide_spread_supported(int rank, int w);
 void wide_spread_tile(int rank, int w, int tile[3]);
 int wide_spread_lstride(int rank, int w);
 size_t wide_spread_lds_bytes(int rank, int w, int precision);
+// 1-D interpolation (nufft_line.hip)
+bool line_kernels_supported(const Geom& g);
+size_t line_interp_lds_bytes(const Geom& g, int precision);
+template <typename T>
+hipError_t launch_interp_line(const Geom& g, const SortedPoints<T>& sp, int64_t M, const T* horner, T* c,
+                              const T* fw, int batch, int64_t c_stride, int64_t fw_stride, T scale,
+                              hipStream_t stream);
 size_t wide_interp_lds_bytes(int rank, int w, int precision);
 template <typename T>
 hipError_t launch_interp_wide(const Geom& g, const SortedPoints<T>& sp, int64_t M, const T* horner, T* c,

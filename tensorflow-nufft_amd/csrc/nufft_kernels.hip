@@ -396,6 +396,15 @@ __device__ __forceinline__ uint32_t fused_pack(uint32_t l, float z) {
 __device__ __forceinline__ float fused_z(uint32_t p) { return (float)((int)(p & 0x7ffffffu) - (1 << 26)) * kFusedInv; }
 __device__ __forceinline__ uint32_t fused_loc(uint32_t px, uint32_t py) { return (px >> 27) | ((py >> 27) << 10); }
 
+__device__ __forceinline__ FusedRec fused_record(const Rec<float>& r, float2 cv) {
+  FusedRec fr;
+  fr.px = fused_pack(r.loc & 1023u, r.z0);
+  fr.py = fused_pack((r.loc >> 10) & 1023u, r.z1);
+  fr.re = cv.x;
+  fr.im = cv.y;
+  return fr;
+}
+
 template <typename T, int AOS, bool FUSED>
 __global__ __launch_bounds__(kSortBlock, NUFFT_SORT_MIN_WAVES) void scatter_lds_kernel(Geom g, PointsIn in, int64_t per_block,
                                                                  const int32_t* __restrict__ hist,
@@ -435,12 +444,7 @@ __global__ __launch_bounds__(kSortBlock, NUFFT_SORT_MIN_WAVES) void scatter_lds_
           const int tile = fold_coords<T>(g, in, x, &r, &bad) + br.tile_off;
           const float2 cv = slot >= 0 ? cs[slot] : ctail;
           const int pos = atomicAdd(&cur[tile], 1);
-          FusedRec fr;
-          fr.px = fused_pack(r.loc & 1023u, r.z0);
-          fr.py = fused_pack((r.loc >> 10) & 1023u, r.z1);
-          fr.re = cv.x;
-          fr.im = cv.y;
-          reinterpret_cast<FusedRec*>(out.rec)[pos] = fr;   // one 16-byte store
+          reinterpret_cast<FusedRec*>(out.rec)[pos] = fused_record(r, cv);   // one 16-byte store
         });
   } else {
     Walk::run(
@@ -515,12 +519,7 @@ __global__ __launch_bounds__(kSortBlock, 4) void scatter_staged_kernel(Geom g, P
       tr[u] = -1;
       if (i < ce) tr[u] = tile | (atomicAdd(&cnt[tile], 1) << 10);
       if constexpr (FUSED) {
-        FusedRec fr;
-        fr.px = fused_pack(r.loc & 1023u, r.z0);
-        fr.py = fused_pack((r.loc >> 10) & 1023u, r.z1);
-        fr.re = cs[u].x;
-        fr.im = cs[u].y;
-        rec[u] = fr;
+        rec[u] = fused_record(r, cs[u]);
       } else {
         rec[u] = pack_record<T>(g.rank, r, (int32_t)(i - br.base));
       }
@@ -2390,6 +2389,7 @@ size_t spread_lds_bytes(const Geom& g, int method, int precision) {
 }
 
 size_t interp_lds_bytes(const Geom& g, int method, int precision) {
+  if (g.line && method == NUFFT_HIP_METHOD_TILE_GENERIC) return line_interp_lds_bytes(g, precision);
   if (method != NUFFT_HIP_METHOD_TILE_WAVE) return 0;
   if (g.wide) return wide_interp_lds_bytes(g.rank, g.w, precision);
   size_t cells = (size_t)g.lstride;
@@ -2618,6 +2618,8 @@ hipError_t launch_interp(const Geom& g, int method, const SortedPoints<T>& sp, i
                          int64_t fw_stride, T scale, hipStream_t stream) {
   if (M == 0) return hipSuccess;
   dim3 grid(subproblem_grid(g, M), (unsigned)batch);
+  if (g.line && method == NUFFT_HIP_METHOD_TILE_GENERIC)
+    return launch_interp_line<T>(g, sp, M, horner, c, fw, batch, c_stride, fw_stride, scale, stream);
   if (method == NUFFT_HIP_METHOD_TILE_WAVE && g.wide)
     return launch_interp_wide<T>(g, sp, M, horner, c, fw, batch, c_stride, fw_stride, scale, stream);
   if (method == NUFFT_HIP_METHOD_TILE_WAVE) {

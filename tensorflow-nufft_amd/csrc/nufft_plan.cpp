@@ -1079,6 +1079,13 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
   if (method == NUFFT_HIP_METHOD_AUTO)
     method = (wide || t2_wave || wave_method_supported(g, precision)) ? NUFFT_HIP_METHOD_TILE_WAVE : NUFFT_HIP_METHOD_TILE_GENERIC;
   if (method != NUFFT_HIP_METHOD_TILE_WAVE) g.wide = 0;
+  // 1-D plans: interp_line_kernel (nufft_line.hip) behind the automatic choice (an explicit
+  // TILE_GENERIC keeps the gather-from-global kernel: the tests' second opinion)
+  static const bool no_line = getenv("NUFFT_HIP_NO_LINE") != nullptr;   // A/B knob
+  g.line = (!no_line && p->opts.spread_method == NUFFT_HIP_METHOD_AUTO && method == NUFFT_HIP_METHOD_TILE_GENERIC &&
+            line_kernels_supported(g)) ? 1 : 0;
+  // (type 2: one tile load per 4096 points; a spread_only plan serves both ops and keeps 1024)
+  if (g.line && auto_sub && type == NUFFT_HIP_TYPE_2 && !p->opts.spread_only) g.max_sub = 4096;
   if (method == NUFFT_HIP_METHOD_TILE_WAVE && !wide && !t2_wave && !wave_method_supported(g, precision)) {
     delete p;
     return fail(NUFFT_HIP_INVALID_ARGUMENT,

@@ -54,19 +54,6 @@ template <typename T, int RANK> constexpr int kWideCH = (sizeof(T) == 8 && RANK 
 // apart and the 16 rows written by one ds_write_b128 cover the 64 banks once (pitch 16: 8- / 4-way conflicts)
 template <typename T> constexpr int kWideRP = sizeof(T) == 8 ? 18 : 20;
 
-// k = k z + t with the coefficient t taken straight from its scalar register: left to itself the
-// compiler builds each step as 3 moves + v_fmac (64 VALU instructions per 16-column row instead of
-// 16; measured 113 VALU instructions per point in the 2-D kernel, which made it VALU bound).
-__device__ __forceinline__ float fma_sgpr(float k, float z, float t) {
-  float r;
-  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(k), "v"(z), "s"(t));
-  return r;
-}
-__device__ __forceinline__ double fma_sgpr(double k, double z, double t) {
-  double r;
-  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(k), "v"(z), "s"(t));
-  return r;
-}
 template <typename T>
 __device__ __forceinline__ void horner16(const T* __restrict__ tab, int nc, T z, T (&k)[16]) {
 #pragma unroll

@@ -161,6 +161,59 @@ def test_wide_kernels_vs_generic_and_oracle(tfft, rank, grid, tol, dtype, width,
   auto.close()
 
 
+@pytest.mark.parametrize('n,M,tol,dtype', [
+    (4096, 100000, 1e-6, 'c64'), (4096, 100000, 1e-9, 'c128'), (300, 70001, 1e-4, 'c64'), (300, 5000, 3e-13, 'c128'),
+    (20000, 3000, 1e-6, 'c64'), (1536, 400000, 1e-2, 'c64'), (2000, 60000, 1e-7, 'c128'),
+])
+@pytest.mark.parametrize('ttype', ['type_1', 'type_2'])
+def test_line_kernels_vs_generic_and_oracle(tfft, n, M, tol, dtype, ttype):
+  # 1-D plans: the automatic choice (LDS-tile interpolator of nufft_line.hip for type 2) against an
+  # explicit method 1 (gather from global memory) and the fp64 oracle; grids smaller than one tile,
+  # several tiles, dense (260 points per cell) and thin point sets, two transforms at once
+  import torch
+  from oracle import oracle
+  rng = np.random.default_rng(35)
+  cdt = np.complex64 if dtype == 'c64' else np.complex128
+  rdt = np.float32 if dtype == 'c64' else np.float64
+  pts = rng.uniform(-np.pi, np.pi, (M, 1)).astype(rdt)
+  pts[:16, 0] = np.pi * rng.choice([-1.0, 1.0, 0.0], 16)
+  if ttype == 'type_1':
+    src = (rng.uniform(-.5, .5, (2, M)) + 1j * rng.uniform(-.5, .5, (2, M))).astype(cdt)
+  else:
+    src = (rng.uniform(-.5, .5, (2, n)) + 1j * rng.uniform(-.5, .5, (2, n))).astype(cdt)
+  truth = np.stack([oracle.nufft(src[i].astype(np.complex128), pts, [n], ttype, 'forward', tol=1e-14) for i in range(2)])
+  outs = {}
+  for method in (0, 1):
+    plan = tfft.Plan(ttype, [n], 'forward', num_transforms=2, tol=tol,
+                     dtype=torch.complex64 if dtype == 'c64' else torch.complex128, spread_method=method)
+    plan.set_points(_dev(pts))
+    outs[method] = plan.execute(_dev(src)).cpu().numpy()
+    plan.close()
+    floor = 1e-6 if dtype == 'c64' else 5e-13
+    assert rel_l2(outs[method], truth) < max(3 * tol, floor), (method, rel_l2(outs[method], truth))
+  assert rel_l2(outs[0], outs[1]) < (3e-6 if dtype == 'c64' else 1e-13)
+
+
+def test_line_kernels_spread_and_interp_ops(tfft):
+  # the standalone ops on a 1-D grid (spread_only plans serve both directions)
+  import torch
+  rng = np.random.default_rng(36)
+  n, M = 3000, 50000
+  pts = rng.uniform(-np.pi, np.pi, (M, 1)).astype(np.float32)
+  c = (rng.uniform(-.5, .5, M) + 1j * rng.uniform(-.5, .5, M)).astype(np.complex64)
+  f = (rng.uniform(-.5, .5, n) + 1j * rng.uniform(-.5, .5, n)).astype(np.complex64)
+  s = tfft.spread(_dev(c), _dev(pts), [n], tol=1e-5).cpu().numpy()
+  i = tfft.interp(_dev(f), _dev(pts), tol=1e-5).cpu().numpy()
+  # adjointness: <spread(c), f> = <c, interp(f)>
+  lhs = np.vdot(f, s)
+  rhs = np.vdot(i, c)
+  assert abs(lhs - rhs) < 2e-5 * abs(lhs), (lhs, rhs)
+  # the reference's known answers: interp of ones is one; spread conserves the sum
+  ones = tfft.interp(_dev(np.ones(n, np.complex64)), _dev(pts), tol=1e-5).cpu().numpy()
+  assert np.allclose(ones, 1.0, atol=2e-4)
+  assert abs(s.sum() - c.sum()) < 2e-4 * M ** .5
+
+
 def test_headline_shape_small_m_vs_oracle(tfft):
   # BASELINE config 2 geometry (1024^2 modes, 2048^2 fine grid) with M = 2e5 so
   # the oracle (fp64, sigma 2, tol 1e-12) finishes in seconds
