@@ -467,31 +467,41 @@ __global__ __launch_bounds__(kSortBlock, NUFFT_SORT_MIN_WAVES) void scatter_lds_
 // CONSECUTIVE LANES: ~8 records = 128 bytes per store group at 1024 tiles.
 constexpr int kStagedMaxTiles = 1024;
 constexpr int kStagedBytes = 128 * 1024;   // LDS for the staged records
-template <typename T> constexpr int kStagedChunk = kStagedBytes / (int)sizeof(Rec<T>);   // 8192 float, 4096 double
+// records staged per pass: NTMAX = 1024: 8192 float / 4096 double; NTMAX = 4096 (three 16 KB counter
+// arrays instead of three 4 KB ones): 6144 / 3072
+template <typename T, int NTMAX> constexpr int kStagedChunkOf =
+    NTMAX == 1024 ? kStagedBytes / (int)sizeof(Rec<T>) : (sizeof(Rec<T>) == 16 ? 6144 : 3072);
+template <typename T> constexpr int kStagedChunk = kStagedChunkOf<T, 1024>;
+template <typename T, int NTMAX> constexpr size_t kStagedLds =
+    (size_t)kStagedChunkOf<T, NTMAX> * (sizeof(Rec<T>) + 2) + 3 * NTMAX * 4 + 64;
 
-template <typename T, int AOS, bool FUSED>
+template <typename T, int AOS, bool FUSED, int NTMAX = 1024>
 __global__ __launch_bounds__(kSortBlock, 4) void scatter_staged_kernel(Geom g, PointsIn in, int64_t per_block,
                                                                       const int32_t* __restrict__ hist,
                                                                       const int32_t* __restrict__ tile_start,
                                                                       SortedOut<T> out) {
   using RecT = std::conditional_t<FUSED, FusedRec, Rec<T>>;
   static_assert(sizeof(RecT) == sizeof(Rec<T>), "record sizes");
-  constexpr int CHUNK = kStagedChunk<T>;
+  constexpr int CHUNK = kStagedChunkOf<T, NTMAX>;
   constexpr int PER = CHUNK / kSortBlock;            // points per thread and chunk
+  constexpr int K = NTMAX / kSortBlock;              // tile counters per thread
+  constexpr int TB = NTMAX == 1024 ? 10 : 12;        // bits of the tile in the (tile, rank) word
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   RecT* stage = reinterpret_cast<RecT*>(smem_raw);                       // [CHUNK]
   uint16_t* tl = reinterpret_cast<uint16_t*>(stage + CHUNK);             // [CHUNK] tile of the staged record
-  int* cur = reinterpret_cast<int*>(tl + CHUNK);                         // [kStagedMaxTiles] global cursor
-  int* cnt = cur + kStagedMaxTiles;                                      // records of the chunk per tile
-  int* off = cnt + kStagedMaxTiles;                                      // their exclusive scan
-  int* wsum = off + kStagedMaxTiles;                                     // [16]
+  int* cur = reinterpret_cast<int*>(tl + CHUNK);                         // [NTMAX] global cursor
+  int* cnt = cur + NTMAX;                                                // records of the chunk per tile
+  int* off = cnt + NTMAX;                                                // their exclusive scan
+  int* wsum = off + NTMAX;                                               // [16]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ntl = g.ntiles_item;
   const BlockRange br(in, per_block, g);
   const int32_t* hb = hist + (int64_t)blockIdx.x * g.ntiles + br.tile_off;
-  if (tid < kStagedMaxTiles) {
-    cur[tid] = tid < ntl ? tile_start[br.tile_off + tid] + hb[tid] : 0;
-    cnt[tid] = 0;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int t = tid * K + k;
+    cur[t] = t < ntl ? tile_start[br.tile_off + t] + hb[t] : 0;
+    cnt[t] = 0;
   }
   __syncthreads();
   bool bad = false;
@@ -510,14 +520,14 @@ __global__ __launch_bounds__(kSortBlock, 4) void scatter_staged_kernel(Geom g, P
       if constexpr (FUSED) cs[u] = reinterpret_cast<const float2*>(in.strengths)[ic];
     }
     RecT rec[PER];
-    int tr[PER];     // tile | rank << 10, -1 past the end
+    int tr[PER];     // tile | rank << TB, -1 past the end
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
       const int64_t i = cb + (int64_t)u * kSortBlock + tid;
       Rec<T> r;
       const int tile = fold_coords<T>(g, in, x[u], &r, &bad);
       tr[u] = -1;
-      if (i < ce) tr[u] = tile | (atomicAdd(&cnt[tile], 1) << 10);
+      if (i < ce) tr[u] = tile | (atomicAdd(&cnt[tile], 1) << TB);
       if constexpr (FUSED) {
         rec[u] = fused_record(r, cs[u]);
       } else {
@@ -525,10 +535,12 @@ __global__ __launch_bounds__(kSortBlock, 4) void scatter_staged_kernel(Geom g, P
       }
     }
     __syncthreads();
-    // ---- phase 2: exclusive scan of the chunk's tile counts (one entry per thread)
+    // ---- phase 2: exclusive scan of the chunk's tile counts (K consecutive entries per thread)
     {
-      const int v = cnt[tid];
-      int incl = v;
+      int v[K], tot = 0;
+#pragma unroll
+      for (int k = 0; k < K; ++k) { v[k] = cnt[tid * K + k]; tot += v[k]; }
+      int incl = tot;
 #pragma unroll
       for (int d = 1; d < 64; d <<= 1) {
         const int t = __shfl_up(incl, d);
@@ -536,17 +548,18 @@ __global__ __launch_bounds__(kSortBlock, 4) void scatter_staged_kernel(Geom g, P
       }
       if (lane == 63) wsum[wave] = incl;
       __syncthreads();
-      int base = 0;
-      for (int k = 0; k < wave; ++k) base += wsum[k];
-      off[tid] = base + incl - v;
+      int run = incl - tot;
+      for (int k = 0; k < wave; ++k) run += wsum[k];
+#pragma unroll
+      for (int k = 0; k < K; ++k) { off[tid * K + k] = run; run += v[k]; }
     }
     __syncthreads();
     // ---- phase 3: records to their place in the chunk's tile order
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
       if (tr[u] >= 0) {
-        const int tile = tr[u] & 1023;
-        const int sidx = off[tile] + (tr[u] >> 10);
+        const int tile = tr[u] & ((1 << TB) - 1);
+        const int sidx = off[tile] + (tr[u] >> TB);
         stage[sidx] = rec[u];
         tl[sidx] = (uint16_t)tile;
       }
@@ -561,8 +574,11 @@ __global__ __launch_bounds__(kSortBlock, 4) void scatter_staged_kernel(Geom g, P
     }
     __syncthreads();
     // ---- phase 5: advance the cursors
-    cur[tid] += cnt[tid];
-    cnt[tid] = 0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      cur[tid * K + k] += cnt[tid * K + k];
+      cnt[tid * K + k] = 0;
+    }
     __syncthreads();
   }
 }
@@ -2130,11 +2146,17 @@ static hipError_t sort_lds_pass(const Geom& g, const PointsIn& in, const SortWor
   static const int staged_env = [] { const char* e2 = getenv("NUFFT_HIP_STAGED_SCATTER"); return e2 ? atoi(e2) : -1; }();
   const bool staged = g.ntiles_item <= kStagedMaxTiles && staged_env != 0 &&
                       (staged_env > 0 || in.M_item >= 4 * kStagedChunk<T>);
+  static const bool staged4k = getenv("NUFFT_HIP_STAGED_4K") != nullptr;   // experiment: up to 4096 tiles
   if (staged) {
-    const size_t slds = (size_t)kStagedBytes + (size_t)kStagedChunk<T> * 2 + 3 * kStagedMaxTiles * 4 + 64;
+    const size_t slds = kStagedLds<T, 1024>;
     e = ensure_lds(scatter_staged_kernel<T, AOS, FUSED>, slds);
     if (e != hipSuccess) return e;
     scatter_staged_kernel<T, AOS, FUSED><<<nblk, kSortBlock, slds, stream>>>(g, in, per_block, w.hist, w.tile_start, out);
+  } else if (staged4k && g.ntiles_item <= 4096 && in.M_item >= 4 * kStagedChunkOf<T, 4096>) {
+    const size_t slds = kStagedLds<T, 4096>;
+    e = ensure_lds(scatter_staged_kernel<T, AOS, FUSED, 4096>, slds);
+    if (e != hipSuccess) return e;
+    scatter_staged_kernel<T, AOS, FUSED, 4096><<<nblk, kSortBlock, slds, stream>>>(g, in, per_block, w.hist, w.tile_start, out);
   } else {
     scatter_lds_kernel<T, AOS, FUSED><<<nblk, kSortBlock, lds, stream>>>(g, in, per_block, w.hist, w.tile_start, out);
   }
