@@ -1351,6 +1351,8 @@ def test_bench_spawns_its_own_ranks():
     (3, [24, 32, 20], 30_000, 'c64', 1e-4, 1), # 3-D fixed point
     (2, [40, 48], 20_000, 'c128', 1e-9, 1),    # double
     (1, [256], 9_000, 'c128', 1e-9, 1),        # 1-D
+    (3, [20, 16, 24], 12_000, 'c128', 1e-9, 2),  # 3-D, w = 11: wide kernels, two transforms per set
+    (2, [40, 48], 9_000, 'c128', 1e-12, 2),      # 2-D, w = 14
 ])
 @pytest.mark.parametrize('ttype', ['type_1', 'type_2'])
 def test_plan_with_several_point_sets(tfft, rank, grid, M, dtype, tol, ntransf, ttype):
