@@ -194,6 +194,25 @@ def test_line_kernels_vs_generic_and_oracle(tfft, n, M, tol, dtype, ttype):
   assert rel_l2(outs[0], outs[1]) < (3e-6 if dtype == 'c64' else 1e-13)
 
 
+@pytest.mark.parametrize('grid', [[96, 80], [40, 36, 48]])
+def test_wide_kernels_spread_and_interp_ops(tfft, grid):
+  # the standalone ops at a width above 8 (no upsampling: the grid itself is tiled)
+  import torch
+  rng = np.random.default_rng(37)
+  M = 20000
+  rank = len(grid)
+  pts = rng.uniform(-np.pi, np.pi, (M, rank))
+  c = rng.uniform(-.5, .5, M) + 1j * rng.uniform(-.5, .5, M)
+  f = rng.uniform(-.5, .5, grid) + 1j * rng.uniform(-.5, .5, grid)
+  s = tfft.spread(_dev(c), _dev(pts), grid, tol=1e-10).cpu().numpy()
+  i = tfft.interp(_dev(f), _dev(pts), tol=1e-10).cpu().numpy()
+  lhs, rhs = np.vdot(f, s), np.vdot(i, c)          # adjointness
+  assert abs(lhs - rhs) < 1e-12 * abs(lhs), (lhs, rhs)
+  ones = tfft.interp(_dev(np.ones(grid, np.complex128)), _dev(pts), tol=1e-10).cpu().numpy()
+  assert np.allclose(ones, 1.0, atol=1e-8)        # the reference's known answer (nufft_ops_test.py: interp of ones)
+  assert abs(s.sum() - c.sum()) < 1e-8 * M ** .5
+
+
 def test_line_kernels_spread_and_interp_ops(tfft):
   # the standalone ops on a 1-D grid (spread_only plans serve both directions)
   import torch
