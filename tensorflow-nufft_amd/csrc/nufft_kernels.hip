@@ -2080,6 +2080,11 @@ hipError_t preload_device_code() {
   return hipSuccess;
 }
 
+// Below this many points (all sets together) the sort runs many small workgroups and the plain
+// scatter; from here on blocks of >= 4096 points and, tile count permitting, the staged scatter
+// (measured r02 on 512^2 grids: M = 2e6 0.141 -> 0.134 ms per transform in the small form, M = 4e6
+// 0.190 -> 0.201).
+constexpr int64_t kSmallSortPoints = (int64_t)1 << 21;
 int sort_blocks(const Geom& g, int64_t M, int64_t* per_block) {
   // at most ~512 workgroups (longer per-tile runs per workgroup => better write
   // combining in the scatter; measured r01), at least 4096 points each; a workgroup
@@ -2091,8 +2096,12 @@ int sort_blocks(const Geom& g, int64_t M, int64_t* per_block) {
   }();
   const int items = g.nitems > 1 ? g.nitems : 1;
   const int64_t m_item = M / items;
+  // (small point sets: 1024 per workgroup, so that a few hundred thousand points still spread over the
+  // chip -- the reference benchmark's M = 2e5 cases 62 -> 52 us per transform with the plain scatter)
+  static const int minpb_env = [] { const char* e = getenv("NUFFT_HIP_SORT_MINPB"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
+  const int minpb = minpb_env ? minpb_env : (M < kSmallSortPoints ? 1024 : 4096);
   int64_t pb = (M + maxblk - 1) / maxblk;
-  if (pb < 4096) pb = 4096;
+  if (pb < minpb) pb = minpb;
   pb += pb & 1;   // even: the paired 16-byte loads of interleaved 2-D float points start on a pair
   int64_t bpi = (m_item + pb - 1) / pb;
   if (bpi < 1) bpi = 1;
@@ -2145,7 +2154,7 @@ static hipError_t sort_lds_pass(const Geom& g, const PointsIn& in, const SortWor
   hook.begin(STAGE_SORT_SCATTER);
   static const int staged_env = [] { const char* e2 = getenv("NUFFT_HIP_STAGED_SCATTER"); return e2 ? atoi(e2) : -1; }();
   const bool staged = g.ntiles_item <= kStagedMaxTiles && staged_env != 0 &&
-                      (staged_env > 0 || in.M_item >= 4 * kStagedChunk<T>);
+                      (staged_env > 0 || (in.M_item >= 4 * kStagedChunk<T> && in.M >= kSmallSortPoints));
   static const bool staged4k = getenv("NUFFT_HIP_STAGED_4K") != nullptr;   // experiment: up to 4096 tiles
   if (staged) {
     const size_t slds = kStagedLds<T, 1024>;
@@ -2317,6 +2326,29 @@ int wave3_pad(int w) {   // = kWave3Pad<w>
   return over > 64 ? ((over + 7) & ~7) : 64;
 }
 
+// 3-D float w = 8 on depth-8 tiles: one launch with BOTH fp64 planes (132 KB: one workgroup of 16 waves
+// per CU) instead of one launch per component, for thin point sets. There the kernel is bound by the
+// write-out of the tile + halo, and a joint write-out adds (re, im) of consecutive cells with consecutive
+// lanes -- every 128-byte line of the fine grid is visited once, not once per component. Measured r02 on
+// 128^3 (256^3 fine cells), whole type-1 transform, split -> joint: M = 8e5 (0.05 points per cell) 1.07 ->
+// 0.72 ms, 2e6 1.13 -> 1.04, 4e6 1.57 -> 1.56, 8e6 2.67 -> 2.63, 1e7 3.25 -> 3.20, 3e7 level; M = 1e8 on
+// 256^3 32.0 -> 32.2. Taken below 0.5 points per cell. NUFFT_HIP_W8_JOINT = 0 / 1 forces the choice.
+static bool wave3_joint_wanted(const Geom& g, int64_t M) {
+  static const int mode = [] { const char* e = getenv("NUFFT_HIP_W8_JOINT"); return e ? atoi(e) : -1; }();
+  if (mode >= 0) return mode != 0;
+  return (double)M < 0.5 * (double)g.nf[0] * (double)g.nf[1] * (double)g.nf[2];
+}
+static size_t wave3_split8_lds(const Geom& g) {   // one plane, 12 waves, 16-point staging chunks
+  size_t cells = (size_t)g.lstride;
+  for (int d = 1; d < g.rank; ++d) cells *= (size_t)g.ldim[d];
+  return cells * sizeof(double) + (size_t)wave3_pad(g.w) * sizeof(double) + sizeof(float) * 12 * 16 * 2 * 8 + 256;
+}
+static size_t wave3_joint_lds(const Geom& g) {
+  size_t cells = (size_t)g.lstride;
+  for (int d = 1; d < g.rank; ++d) cells *= (size_t)g.ldim[d];
+  return cells * 2 * sizeof(double) + (size_t)wave3_pad(g.w) * sizeof(double) + sizeof(float) * 16 * 16 * 2 * 8 + 256;
+}
+
 // Waves per workgroup of the 3-D kernel. LDS decides how many workgroups share a CU and
 // 69 VGPRs allow 7 waves per SIMD: the float fixed-point form (one 52 KB plane) runs two
 // workgroups of 12 waves (3 per SIMD each; config 4: 11.8 ms against 15.6 ms with 16 waves
@@ -2404,6 +2436,7 @@ size_t spread_lds_bytes(const Geom& g, int method, int precision) {
       return group2d_geometry(g) ? std::max(wave2_lds(g, precision), group_lds(8, 64, false, precision)) : wave2_lds(g, precision);
     const int nw = g.split_reim ? 12 : wave3d_nw_rt(precision, g.fixed_point != 0);
     const int ch = (g.split_reim && g.tile[2] == 8) ? 16 : 32;   // (staging chunk: keeps two workgroups per CU)
+    if (g.split_reim && g.tile[2] == 8 && g.w == 8) return wave3_joint_lds(g);   // the larger of the two forms
     return cells * ((g.fixed_point || g.split_reim) ? 1 : 2) * sizeof(double) + (size_t)wave3_pad(g.w) * sizeof(double) +
            (size_t)precision * nw * ch * 2 * (g.w <= 6 ? 6 : 8) + 256;
   }
@@ -2577,7 +2610,16 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
       if constexpr (WW == 8) {                                                                   \
         if constexpr (sizeof(T) == 4) {                                                          \
           if (!g.split_reim) return hipErrorInvalidValue;                                        \
-          NUFFT_LAUNCH_W3S8(WW, 1) NUFFT_LAUNCH_W3S8(WW, 2)                                       \
+          if (wave3_joint_wanted(g, Md)) {   /* thin point sets: both planes, one write-out */   \
+            lds_bytes = wave3_joint_lds(g);                                                      \
+            e = ensure_lds(spread_wave3_kernel<T, WW, 8, 16, 16, false, 0>, lds_bytes);           \
+            if (e != hipSuccess) return e;                                                       \
+            spread_wave3_kernel<T, WW, 8, 16, 16, false, 0>                                       \
+                <<<grid, 16 * 64, lds_bytes, stream>>>(g, sp, horner, c, fw, c_stride, fw_stride, scale); \
+          } else {                                                                               \
+            lds_bytes = wave3_split8_lds(g);   /* (the plan's figure is the joint form's) */     \
+            NUFFT_LAUNCH_W3S8(WW, 1) NUFFT_LAUNCH_W3S8(WW, 2)                                     \
+          }                                                                                      \
         } else { return hipErrorInvalidValue; }                                                  \
       } else if constexpr (WW <= 6) {                                                            \
         if (g.fixed_point) {                                                                     \

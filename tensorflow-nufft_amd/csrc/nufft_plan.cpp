@@ -975,7 +975,10 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
   const bool t2_big = type == NUFFT_HIP_TYPE_2 && rank == 2 && precision == NUFFT_HIP_F32 && w <= 8 &&
                       p->opts.spread_method == NUFFT_HIP_METHOD_AUTO && p->opts.tile_dims[0] == 0 &&
                       p->opts.tile_dims[1] == 0 && p->opts.max_subproblem_size <= 0 && !no_t2_big &&
-                      g.nf[0] >= 64 && g.nf[1] >= 64;
+                      g.nf[0] >= 64 && g.nf[1] >= 64 &&
+                      // (enough of them to fill 256 CUs: a 512^2 fine grid has only 64 -- the reference
+                      // benchmark's 256^2 case ran its interp kernel in 30 us on 64 workgroups)
+                      ((int64_t)g.nf[0] * g.nf[1] >= ((int64_t)1 << 21) || getenv("NUFFT_HIP_BIG_T2_ALWAYS") != nullptr);
   const int t2d = t2_big ? 64 : 32;
   // 3-D float at w = 8 (fp64 planes, one component per launch): depth 8 as well -- the padded tile
   // (23 x 23 x 15 cells, 66 KB) still lets two workgroups share a CU with a 16-point staging chunk,
