@@ -128,9 +128,14 @@ __device__ __forceinline__ bool locate_subproblem(const Geom& g, const int32_t* 
     const int mid = (lo + hi) >> 1;
     if (sub_start[mid] <= s) lo = mid; else hi = mid;
   }
+  // the tile's k subproblems split its points EVENLY (ceil(n / k) each, the last one the rest): a
+  // tile just above the cap becomes two halves rather than a full and a nearly empty workgroup
   const int chunk = s - sub_start[lo];
-  const int a = tile_start[lo] + chunk * g.max_sub;
+  const int b = tile_start[lo];
   const int e = tile_start[lo + 1];
+  const int k = sub_start[lo + 1] - sub_start[lo];
+  const int sz = (e - b + k - 1) / k;
+  const int a = b + chunk * sz;
   if (g.nitems > 1) {
     const int item = lo / g.ntiles_item;
     *tile = lo - item * g.ntiles_item;
@@ -140,7 +145,7 @@ __device__ __forceinline__ bool locate_subproblem(const Geom& g, const int32_t* 
     *slot = (int)blockIdx.y;
   }
   *p0 = a;
-  *p1 = (a + g.max_sub < e) ? a + g.max_sub : e;
+  *p1 = (a + sz < e) ? a + sz : e;
   return true;
 }
 

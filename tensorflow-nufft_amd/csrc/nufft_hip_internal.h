@@ -41,6 +41,8 @@ struct Geom {
   int fused;        // 2-D float records carry the strength instead of the point index (FusedRec)
   int line;         // 1-D plan whose interpolation runs on interp_line_kernel (nufft_line.hip; spread_method AUTO)
   int wide;         // w = 9..16, rank 2 / 3: tiles and LDS strides of the 16 x 4-lane kernels (nufft_wide.hip)
+  int sub_small;    // > 0: scan_tiles_kernel caps the subproblems at this many points instead of max_sub when the
+                    // point set turns out clustered (a tile holds more than 1.5x the average): 2-D type-2 plans
   float fx_headroom;  // fixed-point accumulation: bound on prod_d max|P(z)| of the fitted kernel (>= 1)
 };
 

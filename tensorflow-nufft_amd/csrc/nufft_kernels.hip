@@ -723,9 +723,30 @@ __global__ __launch_bounds__(256) void scatter_global_kernel(Geom g, PointsIn in
 
 // Single-workgroup exclusive scans over the tiles: point offsets and
 // subproblem offsets (ceil(count / max_sub) per tile).
+// sub_small > 0 (2-D type-2 plans on 64 x 64 tiles): the cap on the points of a subproblem is chosen
+// HERE, from the tile counts. The interp kernel's workgroups are one subproblem long and the chip
+// holds ~1024 of them at a time: a uniform point set is served best by ONE subproblem per tile
+// (config 3: 1024 tiles of 9766 points, 262 us), but with a clustered one (radial trajectories:
+// 218000 points in the densest tile) the full-cap workgroups of the dense tiles decide when the
+// kernel ends (measured 430 us; a scheduling simulation of the measured tile counts reproduces
+// it), while caps of 2048-4096 pack well (296-333 us) and cost the uniform case 20 %.
 __global__ __launch_bounds__(1024) void scan_tiles_kernel(const int32_t* __restrict__ count, int n,
-                                                          int max_sub, int32_t* __restrict__ tile_start,
+                                                          int max_sub, int sub_small, int avg,
+                                                          int32_t* __restrict__ tile_start,
                                                           int32_t* __restrict__ sub_start) {
+  __shared__ int ws_m[16];
+  if (sub_small > 0) {
+    int m = 0;
+    for (int i = threadIdx.x; i < n; i += 1024) m = max(m, count[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_down(m, o));
+    if ((threadIdx.x & 63) == 0) ws_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) m = max(m, ws_m[k]);
+    if (2 * (long long)m > 3 * (long long)avg && sub_small < max_sub) max_sub = sub_small;
+  }
   // One workgroup walks the tiles in blocks of 4096 (4 consecutive tiles per thread, so the
   // loads and stores of a wave are contiguous), scanning each block with wave shuffles and
   // carrying the running totals. (A fixed contiguous range per thread made every access of
@@ -2149,7 +2170,7 @@ static hipError_t sort_lds_pass(const Geom& g, const PointsIn& in, const SortWor
   hook.end(STAGE_SORT_COUNT);
   hook.begin(STAGE_SORT_SCAN);
   colscan_kernel<<<(g.ntiles + kScanCols - 1) / kScanCols, 1024, 0, stream>>>(g.ntiles, nblk, w.hist, w.tile_count);
-  scan_tiles_kernel<<<1, 1024, 0, stream>>>(w.tile_count, g.ntiles, g.max_sub, w.tile_start, w.sub_start);
+  scan_tiles_kernel<<<1, 1024, 0, stream>>>(w.tile_count, g.ntiles, g.max_sub, g.sub_small, (int)(in.M_item / g.ntiles_item), w.tile_start, w.sub_start);
   hook.end(STAGE_SORT_SCAN);
   hook.begin(STAGE_SORT_SCATTER);
   static const int staged_env = [] { const char* e2 = getenv("NUFFT_HIP_STAGED_SCATTER"); return e2 ? atoi(e2) : -1; }();
@@ -2180,7 +2201,7 @@ hipError_t launch_sort(const Geom& g, const PointsIn& in_arg, const SortWork& w,
   if (in_arg.M == 0) {
     e = hipMemsetAsync(w.tile_count, 0, sizeof(int32_t) * (size_t)g.ntiles, stream);
     if (e != hipSuccess) return e;
-    scan_tiles_kernel<<<1, 1024, 0, stream>>>(w.tile_count, g.ntiles, g.max_sub, w.tile_start, w.sub_start);
+    scan_tiles_kernel<<<1, 1024, 0, stream>>>(w.tile_count, g.ntiles, g.max_sub, 0, 0, w.tile_start, w.sub_start);
     return hipGetLastError();
   }
   const int items = g.nitems > 1 ? g.nitems : 1;
@@ -2226,7 +2247,7 @@ hipError_t launch_sort(const Geom& g, const PointsIn& in_arg, const SortWork& w,
     hook.begin(STAGE_SORT_SCAN);
     colscan16_kernel<<<(g.ntiles + 63) / 64, 1024, 0, stream>>>(
         g.ntiles, nblk, reinterpret_cast<const uint16_t*>(hist16), pref, w.tile_count);
-    scan_tiles_kernel<<<1, 1024, 0, stream>>>(w.tile_count, g.ntiles, g.max_sub, w.tile_start, w.sub_start);
+    scan_tiles_kernel<<<1, 1024, 0, stream>>>(w.tile_count, g.ntiles, g.max_sub, g.sub_small, (int)(in.M_item / g.ntiles_item), w.tile_start, w.sub_start);
     hook.end(STAGE_SORT_SCAN);
     hook.begin(STAGE_SORT_SCATTER);
     scatter_ranked_kernel<T><<<dim3(blocks_for(in.M_item, 256), items), 256, 0, stream>>>(g, in, per_block, w.tile_of, rank16,
@@ -2242,7 +2263,7 @@ hipError_t launch_sort(const Geom& g, const PointsIn& in_arg, const SortWork& w,
                                                                     w.tile_count, w.bad_count);
   hook.end(STAGE_SORT_COUNT);
   hook.begin(STAGE_SORT_SCAN);
-  scan_tiles_kernel<<<1, 1024, 0, stream>>>(w.tile_count, g.ntiles, g.max_sub, w.tile_start, w.sub_start);
+  scan_tiles_kernel<<<1, 1024, 0, stream>>>(w.tile_count, g.ntiles, g.max_sub, g.sub_small, (int)(in.M_item / g.ntiles_item), w.tile_start, w.sub_start);
   hook.end(STAGE_SORT_SCAN);
   hook.begin(STAGE_SORT_SCATTER);
   scatter_global_kernel<T><<<dim3(blocks_for(in.M_item, 256), items), 256, 0, stream>>>(g, in, w.tile_of, w.rank_of,
@@ -2360,7 +2381,7 @@ static int wave3d_nw_rt(int precision, bool fx) { return precision == NUFFT_HIP_
 // Upper bound on the number of subproblems, known without reading the device:
 // sum_b ceil(n_b / S) <= ntiles + M / S.
 static inline unsigned subproblem_grid(const Geom& g, int64_t M) {
-  return (unsigned)((int64_t)g.ntiles + M / g.max_sub);
+  return (unsigned)((int64_t)g.ntiles + M / (g.sub_small > 0 && g.sub_small < g.max_sub ? g.sub_small : g.max_sub));
 }
 
 // LDS-free spreader for sparse point sets: below a few points per thousand fine cells the

@@ -1043,6 +1043,7 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
     g.tile[big] = (g.tile[big] + 1) / 2;
   }
   g.wide = wide ? 1 : 0;
+  g.sub_small = 0;
   if (!wide && spread_lds_bytes(g, NUFFT_HIP_METHOD_TILE_GENERIC, precision) > 160 * 1024) {
     delete p;
     return fail(NUFFT_HIP_RESOURCE_EXHAUSTED, "kernel too wide for an LDS tile");  // cf. nufft_plan.cu.cc:2458-2463
@@ -1121,7 +1122,11 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
     g.lstride = g.wide ? wide_spread_lstride(rank, w) : (t2_wave ? 72 : wave_lstride(rank));
   // wavefront kernels: one subproblem per typical tile measured fastest (r01 sweeps);
   // every extra subproblem of a tile repeats its zero-fill and write-out
-  if (method == NUFFT_HIP_METHOD_TILE_WAVE && auto_sub) g.max_sub = t2_wave ? 16384 : 4096;   // (interp: one tile load per subproblem)
+  static const int t2_sub = [] { const char* e = getenv("NUFFT_HIP_T2_SUB"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();   // A/B knob
+  if (method == NUFFT_HIP_METHOD_TILE_WAVE && auto_sub) g.max_sub = t2_wave ? (t2_sub ? t2_sub : 16384) : 4096;   // (interp: one tile load per subproblem)
+  // clustered point sets: scan_tiles_kernel falls back to 4096-point subproblems (NUFFT_HIP_T2_SMALL_SUB, 0 = never)
+  static const int t2_small = [] { const char* e = getenv("NUFFT_HIP_T2_SMALL_SUB"); return e ? atoi(e) : 4096; }();
+  if (method == NUFFT_HIP_METHOD_TILE_WAVE && auto_sub && t2_wave && !t2_sub) g.sub_small = t2_small;
   if (g.wide && auto_sub && rank == 3) g.max_sub = 1024;   // (hundreds of LDS atomics per point: keep workgroups short)
   if (g.fixed_point && w > 6) g.max_sub = std::min(g.max_sub, 512);
   p->lds_bytes = spread_lds_bytes(g, method, precision);

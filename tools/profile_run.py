@@ -12,11 +12,19 @@ ap.add_argument('--method', type=int, default=0); ap.add_argument('--S', type=in
 ap.add_argument('--steps', type=int, default=5); ap.add_argument('--ntransf', type=int, default=1)
 ap.add_argument('--acc', type=int, default=0)
 ap.add_argument('--double', action='store_true', help='complex128 / float64')
+ap.add_argument('--dist', default='uniform', help='uniform | radial | radial-ordered (2-D)')
 ap.add_argument('--one-call', action='store_true', help='nufft_hip_execute_with_points instead of set_points + execute')
 a = ap.parse_args()
 grid = [int(g) for g in a.grid.split(',')]; M = int(a.M); rank = len(grid)
 g = torch.Generator(device='cuda').manual_seed(2)
 pts = (torch.rand((M, rank), generator=g, device='cuda') * 2 - 1) * np.pi
+if a.dist == 'radial':
+  r = torch.rand(M, generator=g, device='cuda') * np.pi; th = torch.rand(M, generator=g, device='cuda') * 2 * np.pi
+  pts = torch.stack([r * torch.cos(th), r * torch.sin(th)], dim=1)
+elif a.dist == 'radial-ordered':   # spokes through the centre, stored spoke after spoke
+  ns = 1000; ang = torch.arange(M // ns, device='cuda') * (np.pi * 0.6180339887); s = torch.linspace(-np.pi, np.pi, ns + 1, device='cuda')[:ns]
+  pts = torch.stack([(s[None, :] * torch.cos(ang)[:, None]).reshape(-1), (s[None, :] * torch.sin(ang)[:, None]).reshape(-1)], dim=1)
+  M = pts.shape[0]
 lead = [a.ntransf] if a.ntransf > 1 else []
 if a.type == 'type_1':
   src = torch.complex(torch.rand(lead + [M], generator=g, device='cuda') - .5, torch.rand(lead + [M], generator=g, device='cuda') - .5)
