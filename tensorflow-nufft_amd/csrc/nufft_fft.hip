@@ -158,7 +158,7 @@ __device__ __forceinline__ void fft_load_line(const typename C2<T>::type* rowp, 
 }
 
 // One Stockham pass of radix RAD on the 8 values of a thread (8 / RAD butterflies).
-template <typename T, int RAD, bool CROP>
+template <typename T, int RAD, bool CROP, bool INPLACE = false>
 __device__ __forceinline__ void fft_pass(const typename C2<T>::type* twp, int n, const BinMap<T>& map,
                                          typename C2<T>::type (&v)[8], typename C2<T>::type* mybuf,
                                          typename C2<T>::type* trow, int lt, int TL, int Ns, bool first, bool last,
@@ -223,6 +223,8 @@ __device__ __forceinline__ void fft_pass(const typename C2<T>::type* twp, int n,
             V y; y.x = val.x * sc; y.y = val.y * sc;
             trow[idx] = y;
           }
+        } else if constexpr (INPLACE) {
+          trow[lpad(o + t * Ns)] = val;   // (the output row is the line buffer itself: padded layout)
         } else {
           trow[o + t * Ns] = val;
         }
@@ -239,7 +241,7 @@ template <int LOGN, int P> constexpr int fft_radix() {
 }
 template <int LOGN> constexpr int fft_npass() { return (LOGN + 2) / 3; }
 
-template <typename T, int LOGN, int P, bool CROP>
+template <typename T, int LOGN, int P, bool CROP, bool INPLACE = false>
 __device__ __forceinline__ void fft_all_passes(const typename C2<T>::type* twp, const BinMap<T>& map,
                                                typename C2<T>::type (&v)[8], typename C2<T>::type* mybuf,
                                                typename C2<T>::type* trow, int lt, bool row_ok, T sgn) {
@@ -247,15 +249,22 @@ __device__ __forceinline__ void fft_all_passes(const typename C2<T>::type* twp, 
   if constexpr (P < NP) {
     constexpr int RAD = fft_radix<LOGN, P>();
     constexpr int Ns = 1 << (3 * P);   // every earlier pass has radix 8
-    fft_pass<T, RAD, CROP>(twp, 1 << LOGN, map, v, mybuf, trow, lt, (1 << LOGN) / 8, Ns, P == 0, P == NP - 1, row_ok, sgn);
-    fft_all_passes<T, LOGN, P + 1, CROP>(twp, map, v, mybuf, trow, lt, row_ok, sgn);
+    fft_pass<T, RAD, CROP, INPLACE>(twp, 1 << LOGN, map, v, mybuf, trow, lt, (1 << LOGN) / 8, Ns, P == 0, P == NP - 1, row_ok, sgn);
+    fft_all_passes<T, LOGN, P + 1, CROP, INPLACE>(twp, map, v, mybuf, trow, lt, row_ok, sgn);
   }
 }
 
 // PAD = false: type-1 pass (plain input lines of n points, output cropped to kout modes);
 // PAD = true: type-2 pass (input lines of kin modes zero-padded to n, all n bins written).
-template <typename T, int LOGN, bool PAD>
+// GATHER (type 2): the mirror image of the data flow. The input holds the workgroup's R lines
+// INTERLEAVED (element m of line l at in[m nlines + l]: R x 8-byte runs, gathered into the LDS tile
+// by the whole workgroup) and every output line is written contiguously. A type-2 transform grows
+// from pass to pass (N -> nf per dimension), so its strided side should be the small input, not the
+// large output: with the scatter-out form the last 2-D pass wrote the 33.5 MB fine grid in 64-byte
+// pieces (39.6 us at 2048^2 against 21.5 us for the type-1 pass that READS those 33.5 MB).
+template <typename T, int LOGN, bool PAD, bool GATHER = false>
 __global__ __launch_bounds__(kFftMaxThreads, 4) void fft_rotate_kernel(FftPassArgs<T> a) {
+  static_assert(!GATHER || PAD, "the gather form is the type-2 pass");
   using V = typename C2<T>::type;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int n = 1 << LOGN;
@@ -265,9 +274,12 @@ __global__ __launch_bounds__(kFftMaxThreads, 4) void fft_rotate_kernel(FftPassAr
   constexpr int RADL = fft_radix<LOGN, NP - 1>();
   const int LW = a.LW;                    // lines in flight
   constexpr int LB = n + (n >> 5) + 1;
-  const int TS = a.kout + 1;              // tile row pitch (+1: the transposed read-out is conflict free)
+  // tile row pitch (+1: the transposed read-out is conflict free). GATHER: a line is transformed IN
+  // its tile row (padded line-buffer layout, pitch LB), so no separate line buffers exist and all
+  // the LDS goes to rows: 2048-point lines run four at a time (1024 threads) instead of one
+  const int TS = GATHER ? LB : a.kout + 1;
   V* lbuf = reinterpret_cast<V*>(smem_raw);               // [LW][LB]
-  V* tile = lbuf + (size_t)LW * LB;                        // [R][TS]
+  V* tile = GATHER ? lbuf : lbuf + (size_t)LW * LB;       // [R][TS]
   V* twl = tile + (size_t)a.R * TS;                        // [n / 2]: twiddles (a global table costs an L2 latency per pass)
   const int tid = threadIdx.x;
   for (int i = tid; i < n / 2; i += blockDim.x) twl[i] = a.tw[i];
@@ -277,7 +289,7 @@ __global__ __launch_bounds__(kFftMaxThreads, 4) void fft_rotate_kernel(FftPassAr
   V* __restrict__ out = a.out + (int64_t)blockIdx.y * a.out_batch;
   const V* twp = twl;
   const T sgn = (T)a.sgn;
-  V* mybuf = lbuf + (size_t)lw * LB;
+  V* mybuf = lbuf + (size_t)lw * LB;   // (GATHER: re-pointed at the line's tile row below)
   const int inlen = PAD ? a.kin : n;
 
   BinMap<T> map;
@@ -287,6 +299,7 @@ __global__ __launch_bounds__(kFftMaxThreads, 4) void fft_rotate_kernel(FftPassAr
       const int u = q / RAD0, t = q % RAD0;
       int ak = 0;
       map.idx[q] = bin_to_mode_index(lt + u * TL + t * (n / RAD0), n, a.kin, &ak);
+      if (GATHER && map.idx[q] >= 0) map.idx[q] = lpad(map.idx[q]);   // (position in the padded tile row)
       map.sc[q] = a.rf[ak];
     }
   } else {                      // last-pass output q of this thread -> mode index / factor
@@ -302,9 +315,21 @@ __global__ __launch_bounds__(kFftMaxThreads, 4) void fft_rotate_kernel(FftPassAr
     }
   }
 
-  __syncthreads();   // twiddle table
+  if constexpr (GATHER) {
+    // tile[r][m] = in[m nlines + line0 + r]: consecutive lanes take the R lines of one element
+    const int rs = __builtin_ctz(a.R);          // R is a power of two
+    const int nthr = blockDim.x;
+    for (int e = tid; e < (a.kin << rs); e += nthr) {
+      const int m = e >> rs, r = e & (a.R - 1);
+      const int64_t line = line0 + r;
+      V z; z.x = (T)0; z.y = (T)0;
+      if (line < a.nlines) z = in[(int64_t)m * a.nlines + line];
+      tile[r * TS + lpad(m)] = z;
+    }
+  }
+  __syncthreads();   // twiddle table (and the gathered lines)
   V v[8], vn[8];
-  {
+  if constexpr (!GATHER) {
     const int64_t line = line0 + lw;
     const bool live = lw < a.R && line < a.nlines;
     fft_load_line<T, RAD0, PAD>(in + (live ? line : 0) * inlen, live, lt, TL, n, map, v, a.zero_in != 0);
@@ -312,45 +337,63 @@ __global__ __launch_bounds__(kFftMaxThreads, 4) void fft_rotate_kernel(FftPassAr
   for (int g = 0; g < a.R; g += LW) {
     const int r = g + lw;                       // line inside the workgroup's block
     const bool more = g + LW < a.R;
-    if (more) {                                 // next group's loads are in flight during this group's passes
+    if constexpr (GATHER) {                     // first-pass inputs come from the tile row (modes, padded by the map)
+      const bool live = r < a.R && line0 + r < a.nlines;
+      fft_load_line<T, RAD0, PAD>(tile + (r < a.R ? r : 0) * TS, live, lt, TL, n, map, v);
+    } else if (more) {                          // next group's loads are in flight during this group's passes
       const int64_t line = line0 + r + LW;
       const bool live = r + LW < a.R && line < a.nlines;
       fft_load_line<T, RAD0, PAD>(in + (live ? line : 0) * inlen, live, lt, TL, n, map, vn, a.zero_in != 0);
     }
     V* trow = tile + (r < a.R ? r : 0) * TS;
+    if constexpr (GATHER) mybuf = trow;
     // (opaque copy of the lane's index: otherwise the compiler hoists the LDS and twiddle
     // addresses of every pass out of this loop and spills them: 70-280 bytes per lane)
     int ltv = lt;
     asm volatile("" : "+v"(ltv));
-    fft_all_passes<T, LOGN, 0, !PAD>(twp, map, v, mybuf, trow, ltv, r < a.R, sgn);
-    if (more) {
+    fft_all_passes<T, LOGN, 0, !PAD, GATHER>(twp, map, v, mybuf, trow, ltv, r < a.R, sgn);
+    if constexpr (!GATHER) {
+      if (more) {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] = vn[q];
+        for (int q = 0; q < 8; ++q) v[q] = vn[q];
+      }
     }
   }
   __syncthreads();
-  // ---- tile -> out[bin][line]: R consecutive lines per bin
   const int R = a.R;
   const int64_t nl = a.nlines;
   const int nthreads = blockDim.x;
-  for (int e = tid; e < a.kout * R; e += nthreads) {
-    const int bin = e / R, r = e - bin * R;
-    const int64_t line = line0 + r;
-    if (line < nl) out[(int64_t)bin * nl + line] = tile[r * TS + bin];
+  if constexpr (GATHER) {
+    // ---- tile -> out[line][bin]: whole lines, contiguous (kout = n here)
+    for (int e = tid; e < n * R; e += nthreads) {
+      const int r = e >> LOGN, bin = e & (n - 1);
+      const int64_t line = line0 + r;
+      if (line < nl) out[line * n + bin] = tile[r * TS + lpad(bin)];
+    }
+  } else {
+    // ---- tile -> out[bin][line]: R consecutive lines per bin
+    for (int e = tid; e < a.kout * R; e += nthreads) {
+      const int bin = e / R, r = e - bin * R;
+      const int64_t line = line0 + r;
+      if (line < nl) out[(int64_t)bin * nl + line] = tile[r * TS + bin];
+    }
   }
 }
 
 template <typename T, int LOGN>
-hipError_t launch_fft_pass(const FftPassArgs<T>& a, unsigned nblk, unsigned batch, size_t lds, hipStream_t stream) {
-  const bool pad = a.kin != a.n;
+hipError_t launch_fft_pass(const FftPassArgs<T>& a, bool pad, bool gather, unsigned nblk, unsigned batch, size_t lds,
+                           hipStream_t stream) {
   if (pad && a.kout != a.n) return hipErrorInvalidValue;   // a pass either pads or crops
-  const void* fn = pad ? reinterpret_cast<const void*>(fft_rotate_kernel<T, LOGN, true>)
-                       : reinterpret_cast<const void*>(fft_rotate_kernel<T, LOGN, false>);
+  if (gather && !pad) return hipErrorInvalidValue;
+  const void* fn = gather ? reinterpret_cast<const void*>(fft_rotate_kernel<T, LOGN, true, true>)
+                   : pad  ? reinterpret_cast<const void*>(fft_rotate_kernel<T, LOGN, true>)
+                          : reinterpret_cast<const void*>(fft_rotate_kernel<T, LOGN, false>);
   if (lds > 64 * 1024) {
     const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  if (pad) fft_rotate_kernel<T, LOGN, true><<<dim3(nblk, batch), a.LW * (a.n / 8), lds, stream>>>(a);
+  if (gather) fft_rotate_kernel<T, LOGN, true, true><<<dim3(nblk, batch), a.LW * (a.n / 8), lds, stream>>>(a);
+  else if (pad) fft_rotate_kernel<T, LOGN, true><<<dim3(nblk, batch), a.LW * (a.n / 8), lds, stream>>>(a);
   else fft_rotate_kernel<T, LOGN, false><<<dim3(nblk, batch), a.LW * (a.n / 8), lds, stream>>>(a);
   return hipGetLastError();
 }
@@ -358,7 +401,7 @@ hipError_t launch_fft_pass(const FftPassArgs<T>& a, unsigned nblk, unsigned batc
 // Lines per workgroup (R), lines in flight (LW) and dynamic LDS of one pass; R = 0: not
 // supported. Longer output segments (R consecutive lines per bin) write faster; more, smaller
 // workgroups fill the chip when a pass has few lines (2048 lines of 2048 points at config 2).
-int fft_pass_shape(int n, int kout, int csize, int64_t nlines, int* lw_out, size_t* lds) {
+int fft_pass_shape(int n, int kout, int csize, int64_t nlines, int* lw_out, size_t* lds, bool gather = false) {
   if (n < 16 || n > 2048 || (n & (n - 1))) return 0;
   const int TL = n / 8;
   int best = 0, best_lw = 0;
@@ -373,8 +416,10 @@ int fft_pass_shape(int n, int kout, int csize, int64_t nlines, int* lw_out, size
     // (2048-point lines with all 2048 bins written: 8 x 16 KB of tile + ONE 16 KB buffer)
     size_t bytes = 0;
     for (; LW >= 1; LW /= 2) {
-      bytes = ((size_t)LW * lpad_len(n) + (size_t)R * (kout + 1) + (size_t)n / 2) * csize;
+      bytes = gather ? ((size_t)R * lpad_len(n) + (size_t)n / 2) * csize   // lines are transformed in their tile rows
+                     : ((size_t)LW * lpad_len(n) + (size_t)R * (kout + 1) + (size_t)n / 2) * csize;
       if (bytes <= 160 * 1024) break;
+      if (gather) { LW = 0; break; }
     }
     if (LW < 1 || LW * TL < 64) continue;                          // at least one full wavefront
     const int64_t wgs = (nlines + R - 1) / R;
@@ -403,6 +448,7 @@ bool pruned_fft_supported(const Geom& g, int precision) {
     // type 1 crops to nmodes, type 2 writes all nf bins: both shapes must fit
     if (!fft_pass_shape(g.nf[d], g.nmodes[d], csize, 1 << 20, &lw, &lds)) return false;
     if (!fft_pass_shape(g.nf[d], g.nf[d], csize, 1 << 20, &lw, &lds)) return false;
+    if (!fft_pass_shape(g.nf[d], g.nf[d], csize, 1 << 20, &lw, &lds, true)) return false;
   }
   return true;
 }
@@ -436,7 +482,15 @@ hipError_t launch_pruned_fft(const Geom& g, int type, int iflag, T* fine, T* f, 
   // nmodes, type 2: expanded to nf), dims [d..rank) not yet
   const V* src = reinterpret_cast<const V*>(type == 1 ? fine : f);
   int64_t src_batch = type == 1 ? fine_elems : mode_elems;
-  for (int d = 0; d < rank; ++d) {
+  // Type 1 walks the dimensions fastest first: contiguous input lines, output transposed [bin][line]
+  // (the next dimension's lines are then contiguous) -- the strided side is the shrinking output.
+  // Type 2 (gather form) walks them SLOWEST first: the dimension's lines lie interleaved in the
+  // input ([element][line]: the strided, still small side) and leave contiguous ([line][bin]);
+  // after rank passes the layout is back to x fastest either way.
+  static const bool no_gather = getenv("NUFFT_HIP_FFT_NO_GATHER") != nullptr;   // A/B knob: type 2 in the scatter-out form
+  const bool gather = type == 2 && !no_gather;
+  for (int step = 0; step < rank; ++step) {
+    const int d = gather ? rank - 1 - step : step;
     FftPassArgs<T> a;
     a.n = g.nf[d];
     a.kin = type == 1 ? g.nf[d] : g.nmodes[d];
@@ -444,38 +498,38 @@ hipError_t launch_pruned_fft(const Geom& g, int type, int iflag, T* fine, T* f, 
     int64_t lines = 1;
     for (int e = 0; e < rank; ++e) {
       if (e == d) continue;
-      const bool done = e < d;
+      const bool done = gather ? e > d : e < d;
       lines *= (type == 1) ? (done ? g.nmodes[e] : g.nf[e]) : (done ? g.nf[e] : g.nmodes[e]);
     }
     a.nlines = lines;
     a.in = src;
     a.in_batch = src_batch;
-    const bool last = d == rank - 1;
-    V* dst = last ? reinterpret_cast<V*>(type == 1 ? f : fine) : reinterpret_cast<V*>((d & 1) ? tmp1 : tmp0);
+    const bool last = step == rank - 1;
+    V* dst = last ? reinterpret_cast<V*>(type == 1 ? f : fine) : reinterpret_cast<V*>((step & 1) ? tmp1 : tmp0);
     a.out = dst;
     a.out_batch = (int64_t)a.kout * lines;
     a.tw = reinterpret_cast<const V*>(tw[d]);
     a.rf = rf[d];
     a.sgn = iflag < 0 ? -1.0f : 1.0f;
-    a.zero_in = (zero_fine && type == 1 && d == 0) ? 1 : 0;
+    a.zero_in = (zero_fine && type == 1 && step == 0) ? 1 : 0;
     a.npass = 0;
     a.radpack = 0;
     size_t lds = 0;
     a.LW = 1;
-    a.R = fft_pass_shape(a.n, a.kout, csize, lines, &a.LW, &lds);
+    a.R = fft_pass_shape(a.n, a.kout, csize, lines, &a.LW, &lds, gather);
     if (a.R == 0) return hipErrorInvalidValue;
     const int64_t nblk = (lines + a.R - 1) / a.R;
     if (nblk > 2147483647LL || batch > 65535) return hipErrorInvalidValue;
     hipError_t e = hipErrorInvalidValue;
     switch (a.n) {
-      case 16: e = launch_fft_pass<T, 4>(a, (unsigned)nblk, (unsigned)batch, lds, stream); break;
-      case 32: e = launch_fft_pass<T, 5>(a, (unsigned)nblk, (unsigned)batch, lds, stream); break;
-      case 64: e = launch_fft_pass<T, 6>(a, (unsigned)nblk, (unsigned)batch, lds, stream); break;
-      case 128: e = launch_fft_pass<T, 7>(a, (unsigned)nblk, (unsigned)batch, lds, stream); break;
-      case 256: e = launch_fft_pass<T, 8>(a, (unsigned)nblk, (unsigned)batch, lds, stream); break;
-      case 512: e = launch_fft_pass<T, 9>(a, (unsigned)nblk, (unsigned)batch, lds, stream); break;
-      case 1024: e = launch_fft_pass<T, 10>(a, (unsigned)nblk, (unsigned)batch, lds, stream); break;
-      case 2048: e = launch_fft_pass<T, 11>(a, (unsigned)nblk, (unsigned)batch, lds, stream); break;
+      case 16: e = launch_fft_pass<T, 4>(a, type == 2, gather, (unsigned)nblk, (unsigned)batch, lds, stream); break;
+      case 32: e = launch_fft_pass<T, 5>(a, type == 2, gather, (unsigned)nblk, (unsigned)batch, lds, stream); break;
+      case 64: e = launch_fft_pass<T, 6>(a, type == 2, gather, (unsigned)nblk, (unsigned)batch, lds, stream); break;
+      case 128: e = launch_fft_pass<T, 7>(a, type == 2, gather, (unsigned)nblk, (unsigned)batch, lds, stream); break;
+      case 256: e = launch_fft_pass<T, 8>(a, type == 2, gather, (unsigned)nblk, (unsigned)batch, lds, stream); break;
+      case 512: e = launch_fft_pass<T, 9>(a, type == 2, gather, (unsigned)nblk, (unsigned)batch, lds, stream); break;
+      case 1024: e = launch_fft_pass<T, 10>(a, type == 2, gather, (unsigned)nblk, (unsigned)batch, lds, stream); break;
+      case 2048: e = launch_fft_pass<T, 11>(a, type == 2, gather, (unsigned)nblk, (unsigned)batch, lds, stream); break;
       default: break;
     }
     if (e != hipSuccess) return e;
