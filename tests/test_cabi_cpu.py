@@ -77,7 +77,12 @@ def test_kernel_width_rule_safe_side():
 
 
 def test_batch_size_rule():
-  assert _describe(2, [64, 64], 1e-6, 4, ntransf=20)[2].batch_size == 8   # nufft_plan.cu.cc:1923-1928
+  # the reference's rule is min(ntransf, 8) (nufft_plan.cu.cc:1923-1928); here the 8 grows for small fine
+  # grids (2^23 fine cells per batch), and stays for large ones
+  assert _describe(2, [64, 64], 1e-6, 4, ntransf=20)[2].batch_size == 20
+  assert _describe(2, [1024, 1024], 1e-6, 4, ntransf=20)[2].batch_size == 8
+  assert _describe(2, [512, 512], 1e-6, 4, ntransf=100)[2].batch_size == 8
+  assert _describe(2, [256, 256], 1e-6, 4, ntransf=100)[2].batch_size == 32
   assert _describe(2, [64, 64], 1e-6, 4, ntransf=3)[2].batch_size == 3
   assert _describe(2, [64, 64], 1e-6, 4, ntransf=20, max_batch_size=2)[2].batch_size == 2
 
