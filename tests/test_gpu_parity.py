@@ -1119,6 +1119,51 @@ def test_first_launch_in_fresh_processes():
   assert max(sums) - min(sums) <= 1e-4 * abs(sums[0]), sums
 
 
+_KNOB_CHILD = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+import tensorflow_nufft as tfft
+rng = np.random.default_rng(11)
+outs = {}
+for name, grid, M, ttype, tol in (('t1_3d_w8', [32, 32, 32], 150000, 'type_1', 1e-6), ('t1_3d_w8_thin', [64, 64, 64], 20000, 'type_1', 1e-6),
+                                  ('t2_2d_pow2', [64, 128], 50000, 'type_2', 1e-6), ('t2_3d_pow2', [16, 32, 16], 30000, 'type_2', 1e-5),
+                                  ('t1_2d_4096tiles', [1024, 1024], 300000, 'type_1', 1e-6), ('t2_1d', [2048], 70000, 'type_2', 1e-6)):
+  pts = torch.from_numpy(rng.uniform(-np.pi, np.pi, (M, len(grid))).astype(np.float32)).cuda()
+  shape = [M] if ttype == 'type_1' else grid
+  src = torch.from_numpy((rng.uniform(-.5, .5, shape) + 1j * rng.uniform(-.5, .5, shape)).astype(np.complex64)).cuda()
+  kw = dict(grid_shape=grid) if ttype == 'type_1' else {}
+  outs[name] = tfft.nufft(src, pts, transform_type=ttype, tol=tol, **kw).cpu().numpy()
+np.savez(sys.argv[3], **outs)
+print('CASES', len(outs))
+'''
+
+
+def test_ab_knobs_give_the_same_transforms(tmp_path):
+  # The environment knobs select alternative kernels for A/B runs (64-bit integer planes, the staged
+  # scatter for 4096 tiles, the scatter-out type-2 FFT passes, joint / split 3-D launches, the
+  # thread-per-point 1-D interp, 64 x 64 type-2 tiles on small grids): each must give the default
+  # path's transform.
+  import os
+  import subprocess
+  import sys
+  from conftest import PKG, ROOT
+  base = str(tmp_path / 'base.npz')
+  r = subprocess.run([sys.executable, '-c', _KNOB_CHILD, ROOT, PKG, base], capture_output=True, text=True, timeout=600)
+  assert r.returncode == 0, r.stderr[-1500:]
+  ref = np.load(base)
+  for knobs in ({'NUFFT_HIP_W8_I64': '1', 'NUFFT_HIP_STAGED_4K': '1', 'NUFFT_HIP_FFT_NO_GATHER': '1', 'NUFFT_HIP_NO_LINE': '1',
+                 'NUFFT_HIP_BIG_T2_ALWAYS': '1', 'NUFFT_HIP_SORT_MINPB': '4096'},
+                {'NUFFT_HIP_W8_JOINT': '1', 'NUFFT_HIP_T2_SUB': '2048', 'NUFFT_HIP_STAGED_SCATTER': '1'},
+                {'NUFFT_HIP_W8_JOINT': '0', 'NUFFT_HIP_W8_DEPTH4': '1', 'NUFFT_HIP_NO_FUSED': '1', 'NUFFT_HIP_NO_OWN_FFT': '1'}):
+    alt = str(tmp_path / 'alt.npz')
+    r = subprocess.run([sys.executable, '-c', _KNOB_CHILD, ROOT, PKG, alt], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, **knobs))
+    assert r.returncode == 0, (knobs, r.stderr[-1500:])
+    got = np.load(alt)
+    for k in ref.files:
+      assert rel_l2(got[k], ref[k]) < 2e-6, (knobs, k, rel_l2(got[k], ref[k]))
+
+
 _EFENCE_CHILD = r'''
 import sys, numpy as np, torch
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
