@@ -103,7 +103,7 @@ __device__ __forceinline__ void tile_to_grid(const Geom& g, const double* plane_
 // strengths of that pair start at c + slot * c_stride, its fine grid at fw + slot * fw_stride.
 __device__ __forceinline__ bool locate_subproblem(const Geom& g, const int32_t* __restrict__ tile_start,
                                                   const int32_t* __restrict__ sub_start, int s,
-                                                  int* tile, int* p0, int* p1, int* slot) {
+                                                  int* tile, int* p0, int* p1, int* slot, int* nsub = nullptr) {
   const int nt = g.ntiles;
   if (s >= sub_start[nt]) return false;
   // Invariant: sub_start[lo] <= s < sub_start[hi]. Most tiles own exactly one
@@ -136,6 +136,7 @@ __device__ __forceinline__ bool locate_subproblem(const Geom& g, const int32_t* 
   const int k = sub_start[lo + 1] - sub_start[lo];
   const int sz = (e - b + k - 1) / k;
   const int a = b + chunk * sz;
+  if (nsub) *nsub = k;   // subproblems of this tile
   if (g.nitems > 1) {
     const int item = lo / g.ntiles_item;
     *tile = lo - item * g.ntiles_item;

@@ -34,6 +34,8 @@ struct Geom {
   int nmodes[3];    // N, x fastest
   int fixed_point;  // 3-D float spread accumulates packed 32+32-bit fixed point in LDS
   int split_reim;   // 3-D float fp64-plane spread: real and imaginary parts in separate launches
+  int fx_max_subs;  // fixed_point: tiles with more subproblems than this are left to the fp64-plane kernels
+                    // (launched behind the fixed-point one; each kind exits on the other's tiles)
   int cell_sorted;  // records of each subproblem are ordered by stencil start cell (set per set_points)
   int nitems;       // point sets sorted together (batched per-item points); tiles are then composite:
   int ntiles_item;  //   item * ntiles_item + tile, ntiles = nitems * ntiles_item

@@ -754,6 +754,7 @@ __global__ __launch_bounds__(1024) void scan_tiles_kernel(const int32_t* __restr
   __shared__ int ws_a[16], ws_b[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int run_a = 0, run_b = 0;
+  int most = 0;   // most subproblems of any tile -> tile_start[n + 1] (fixed-point plans: is any tile crowded?)
   for (int base = 0; base < n; base += 4096) {
     const int i0 = base + 4 * tid;
     int c[4];
@@ -761,7 +762,12 @@ __global__ __launch_bounds__(1024) void scan_tiles_kernel(const int32_t* __restr
     for (int k = 0; k < 4; ++k) c[k] = (i0 + k < n) ? count[i0 + k] : 0;
     int sa = 0, sb = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { sa += c[k]; sb += (c[k] + max_sub - 1) / max_sub; }
+    for (int k = 0; k < 4; ++k) {
+      const int ns = (c[k] + max_sub - 1) / max_sub;
+      sa += c[k];
+      sb += ns;
+      most = max(most, ns);
+    }
     int ia = sa, ib = sb;   // inclusive scans inside the wave, then across the 16 waves
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -790,9 +796,16 @@ __global__ __launch_bounds__(1024) void scan_tiles_kernel(const int32_t* __restr
     run_a += tot_a;
     run_b += tot_b;
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) most = max(most, __shfl_down(most, o));
+  __syncthreads();
+  if (lane == 0) ws_a[wave] = most;
+  __syncthreads();
   if (tid == 0) {
     tile_start[n] = run_a;
     sub_start[n] = run_b;
+    for (int k = 0; k < 16; ++k) most = max(most, ws_a[k]);
+    tile_start[n + 1] = most;
   }
 }
 
@@ -1595,8 +1608,16 @@ __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
   T* stage_all = reinterpret_cast<T*>(pad + PAD);
   constexpr int SW = W <= 6 ? 6 : 8;                                  // staging row length
   float* red = reinterpret_cast<float*>(stage_all + NW * CH * 2 * SW);   // [NW] (FX bound reduction)
-  int tb, p0, p1, slot;
-  if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1, &slot)) return;
+  // (fp64-plane launch behind a fixed-point one: nothing to do unless some tile is crowded -- one scalar load)
+  if (!FX && g.fixed_point && sp.tile_start[g.ntiles + 1] <= g.fx_max_subs) return;
+  int tb, p0, p1, slot, nsub;
+  if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1, &slot, &nsub)) return;
+  // Fixed-point plans: crowded tiles go to the fp64-plane kernels. The quantisation noise of the
+  // packed fields is the same in every cell of a subproblem's tile, whatever the cell's kernel
+  // weight, and every further subproblem of the tile adds its share: with 600000 coincident points
+  // (1172 subproblems in one tile) the transform missed tol = 1e-5 by 9x (8.8e-5 against 1.4e-6 with
+  // fp64 planes; r02 soak, seed 45), while up to ~16 subproblems per tile it stays within a third of tol.
+  if (g.fixed_point && (FX ? nsub > g.fx_max_subs : nsub <= g.fx_max_subs)) return;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -2397,6 +2418,14 @@ static bool wave3_joint_wanted(const Geom& g, int64_t M) {
   if (mode >= 0) return mode != 0;
   return (double)M < 0.5 * (double)g.nf[0] * (double)g.nf[1] * (double)g.nf[2];
 }
+// one fp64 plane, 12 waves, 32-point staging chunks (the split launches of depth-4 tiles, and the
+// crowded-tile fallback of the fixed-point plans)
+static size_t wave3_split_lds(const Geom& g) {
+  size_t cells = (size_t)g.lstride;
+  for (int d = 1; d < g.rank; ++d) cells *= (size_t)g.ldim[d];
+  return cells * sizeof(double) + (size_t)wave3_pad(g.w) * sizeof(double) +
+         sizeof(float) * 12 * 32 * 2 * (g.w <= 6 ? 6 : 8) + 256;
+}
 static bool wave3_i64() {
   static const bool on = getenv("NUFFT_HIP_W8_I64") != nullptr;
   return on;
@@ -2694,12 +2723,24 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
         } else { return hipErrorInvalidValue; }                                                  \
       } else if constexpr (WW <= 6) {                                                            \
         if (g.fixed_point) {                                                                     \
-          if constexpr (sizeof(T) == 4) { NUFFT_LAUNCH_W3(WW, 8, true) } else { return hipErrorInvalidValue; } \
+          if constexpr (sizeof(T) == 4) {                                                        \
+            NUFFT_LAUNCH_W3(WW, 8, true)                                                         \
+            if (Md > (int64_t)g.fx_max_subs * g.max_sub) {   /* a tile may be crowded: fp64 planes for those */ \
+              lds_bytes = wave3_split_lds(g);                                                    \
+              NUFFT_LAUNCH_W3S(WW, 8, 1) NUFFT_LAUNCH_W3S(WW, 8, 2)                               \
+            }                                                                                    \
+          } else { return hipErrorInvalidValue; }                                                \
         } else { NUFFT_LAUNCH_W3(WW, 8, false) }                                                 \
       } else { return hipErrorInvalidValue; }                                                    \
     } else if (g.tile[2] == 4) {                                                                 \
       if (g.fixed_point) {                                                                       \
-        if constexpr (sizeof(T) == 4) { NUFFT_LAUNCH_W3(WW, 4, true) } else { return hipErrorInvalidValue; } \
+        if constexpr (sizeof(T) == 4) {                                                          \
+          NUFFT_LAUNCH_W3(WW, 4, true)                                                           \
+          if (Md > (int64_t)g.fx_max_subs * g.max_sub) {                                         \
+            lds_bytes = wave3_split_lds(g);                                                      \
+            NUFFT_LAUNCH_W3S(WW, 4, 1) NUFFT_LAUNCH_W3S(WW, 4, 2)                                 \
+          }                                                                                      \
+        } else { return hipErrorInvalidValue; }                                                  \
       } else if (g.split_reim) {                                                                 \
         if constexpr (sizeof(T) == 4) { NUFFT_LAUNCH_W3S(WW, 4, 1) NUFFT_LAUNCH_W3S(WW, 4, 2) }   \
         else { return hipErrorInvalidValue; }                                                    \

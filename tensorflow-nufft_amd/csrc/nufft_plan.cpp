@@ -418,7 +418,7 @@ int ensure_fixed_workspace(nufft_hip_plan p) {
   if (p->fixed_ws) return NUFFT_HIP_OK;
   const Geom& g = p->g;
   int rc = dev_alloc(p, (void**)&p->tile_count, sizeof(int32_t) * (size_t)g.ntiles);
-  if (!rc) rc = dev_alloc(p, (void**)&p->tile_start, sizeof(int32_t) * ((size_t)g.ntiles + 1));
+  if (!rc) rc = dev_alloc(p, (void**)&p->tile_start, sizeof(int32_t) * ((size_t)g.ntiles + 2));   // (+1: most subproblems of a tile)
   if (!rc) rc = dev_alloc(p, (void**)&p->sub_start, sizeof(int32_t) * ((size_t)g.ntiles + 1));
   if (!rc) rc = dev_alloc(p, (void**)&p->bad_count, sizeof(int32_t) * 4);
   if (!rc && !p->opts.spread_only)
@@ -1135,6 +1135,7 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
   if (method == NUFFT_HIP_METHOD_TILE_WAVE && auto_sub && t2_wave && !t2_sub) g.sub_small = t2_small;
   if (g.wide && auto_sub && rank == 3) g.max_sub = 1024;   // (hundreds of LDS atomics per point: keep workgroups short)
   if (g.fixed_point && w > 6) g.max_sub = std::min(g.max_sub, 512);
+  g.fx_max_subs = 16;
   p->lds_bytes = spread_lds_bytes(g, method, precision);
   if (p->lds_bytes > 160 * 1024 || interp_lds_bytes(g, method, precision) > 160 * 1024) {
     // does not fit (e.g. 3-D double at w = 8): fall back to the generic tile path
