@@ -1055,11 +1055,12 @@ def test_randomised_geometry_sweep_vs_oracle(tfft):
       # The width rule (w from tol, nufft_plan.h:762-777) promises "about tol", not a bound: on point sets
       # that do not average the kernel's pointwise error (all points at one spot, a single point) the
       # reference's own algorithm lands at 1.3-1.8x tol (seed 12: 3-D 12x6x12, points hugging +-pi, tol
-      # 1e-9: 1.8299e-9 for the fp64 restatement of the reference CPU path AND for this library). There
-      # the bar is the reference-rule oracle at the SAME tol, computed in fp64.
+      # 1e-9: 1.8299e-9 for the fp64 restatement of the reference CPU path AND for this library; a single
+      # point in 3-D at tol 1e-9: 3.1998e-9 and 3.1990e-9). There the bar is the reference-rule oracle at the
+      # SAME tol, computed in fp64 (+ 1e-6 for three float kernel factors of a lone point in fp32).
       same = oracle.nufft(src.astype(np.complex128), pts, gs, ttype, fd, tol=tol, sigma=2.0)
       ref_err = np.linalg.norm(same - truth) / nrm if nrm > 0 else np.linalg.norm(same)
-      assert err <= 1.05 * ref_err + (5e-7 if not f64 else 1e-13) and err <= 3 * tol, (worst[-1], ref_err)
+      assert err <= 1.05 * ref_err + (1e-6 if not f64 else 1e-13) and err <= 5 * tol, (worst[-1], ref_err)
   print('worst err/tol:', max(worst)[:2])
 
 
@@ -1587,4 +1588,4 @@ def test_randomised_power_of_two_grids_vs_oracle(tfft):
       if err >= tol:   # (see test_randomised_geometry_sweep_vs_oracle: the bar is the reference rule at the same tol)
         same = oracle.nufft(s1.astype(np.complex128), p1, gs, ttype, fd, tol=tol, sigma=2.0)
         ref_err = np.linalg.norm(same - truth) / den
-        assert err <= 1.05 * ref_err + (5e-7 if not f64 else 1e-13) and err <= 3 * tol, (case, rank, grid, f64, tol, M, ttype, fd, B, b, err, ref_err)
+        assert err <= 1.05 * ref_err + (1e-6 if not f64 else 1e-13) and err <= 5 * tol, (case, rank, grid, f64, tol, M, ttype, fd, B, b, err, ref_err)
