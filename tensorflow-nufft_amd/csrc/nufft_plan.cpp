@@ -281,7 +281,10 @@ namespace {
 // that mapping, so the first access past its end (and any access before its first page)
 // faults instead of silently touching a neighbour. GPU AddressSanitizer is not available
 // on this stack; tests/test_gpu_parity.py::test_plan_buffers_under_electric_fence runs a
-// mix of plans this way.
+// mix of plans this way (in a child process: when the same process also allocates and frees
+// large torch tensors between plan lifetimes -- e.g. the dense `nudft` of the test-suite -- the
+// map / unmap cycles of this allocator and torch's caching allocator have produced corrupted
+// torch tensors and spurious faults that no plan kernel is involved in; r02 investigation).
 struct FenceRec { void* va; size_t reserved; void* mapped_at; size_t mapped; hipMemGenericAllocationHandle_t handle; };
 static std::map<void*, FenceRec> g_fence;
 static std::mutex g_fence_mu;
