@@ -281,10 +281,9 @@ namespace {
 // that mapping, so the first access past its end (and any access before its first page)
 // faults instead of silently touching a neighbour. GPU AddressSanitizer is not available
 // on this stack; tests/test_gpu_parity.py::test_plan_buffers_under_electric_fence runs a
-// mix of plans this way (in a child process: when the same process also allocates and frees
-// large torch tensors between plan lifetimes -- e.g. the dense `nudft` of the test-suite -- the
-// map / unmap cycles of this allocator and torch's caching allocator have produced corrupted
-// torch tensors and spurious faults that no plan kernel is involved in; r02 investigation).
+// mix of plans this way. Freed ranges stay reserved (see fence_free): with recycled addresses
+// the r02 investigation saw corrupted results and spurious faults in long test processes that
+// no plan kernel was involved in.
 struct FenceRec { void* va; size_t reserved; void* mapped_at; size_t mapped; hipMemGenericAllocationHandle_t handle; };
 static std::map<void*, FenceRec> g_fence;
 static std::mutex g_fence_mu;
@@ -332,7 +331,9 @@ static bool fence_free(void* p) {
   (void)hipDeviceSynchronize();
   (void)hipMemUnmap(r.mapped_at, r.mapped);
   (void)hipMemRelease(r.handle);
-  (void)hipMemAddressFree(r.va, r.reserved);
+  // The address range is NOT given back: a later mapping at a recycled address was seen to go wrong
+  // intermittently (results of plans created right after differently-sized ones were freed; never with
+  // hipMalloc), and a range that stays reserved and unmapped also turns any use after free into a fault.
   return true;
 }
 

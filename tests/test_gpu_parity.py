@@ -1217,6 +1217,51 @@ print('PLANS', n)
 '''
 
 
+_EFENCE_CHILD_R02 = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+import tensorflow_nufft as tfft
+rng = np.random.default_rng(3)
+n = 0
+# r02 kernels: widths 11-14 (wide spread / interp, gather FFT passes on power-of-two grids), several point
+# sets per plan with sparse and dense sets, crowded tiles of a fixed-point plan, the one-call entry
+for rank, grid, M, cdt, rdt, tol, K in ((2, [64, 64], 40, torch.complex64, np.float32, 1e-6, 3), (2, [64, 32], 30000, torch.complex128, np.float64, 1e-12, 2),
+                                        (3, [16, 32, 16], 20000, torch.complex128, np.float64, 1e-9, 2), (3, [20, 24, 18], 300000, torch.complex64, np.float32, 1e-5, 1),
+                                        (1, [2048], 70000, torch.complex64, np.float32, 1e-6, 2)):
+  pts = torch.from_numpy(rng.uniform(-np.pi, np.pi, (K, M, rank)).astype(rdt)).cuda()
+  if rank == 3 and K == 1: pts[:, : M // 2] = 0.7 + 0.01 * pts[:, : M // 2]     # half of the points in one tile
+  for ttype in ('type_1', 'type_2'):
+    shape = [K, M] if ttype == 'type_1' else [K] + grid
+    src = torch.complex(torch.rand(shape, dtype=torch.float64), torch.rand(shape, dtype=torch.float64)).to(cdt).cuda()
+    plan = tfft.Plan(ttype, grid, 'forward', tol=tol, dtype=cdt, num_point_sets=K)
+    if K == 1: p_in, s_in = pts[0], src[0]
+    else: p_in, s_in = pts, src
+    plan.set_points(p_in)
+    outs = [plan.execute(s_in) for _ in range(4)]
+    outs.append(plan.execute_with_points(p_in, s_in))
+    torch.cuda.synchronize()
+    for o in outs[1:]:
+      assert float((o - outs[0]).abs().max()) <= 1e-4 * float(outs[0].abs().max()), (grid, ttype)
+    plan.close()
+    n += 1
+print('PLANS', n)
+'''
+
+
+def test_r02_kernels_under_electric_fence():
+  # The same allocator for the kernel families added in round 2: widths 11-14, gather FFT passes, several
+  # point sets (sparse and dense), crowded tiles of a fixed-point plan, 1-D, repeated executes and the
+  # one-call entry compared with each other.
+  import os
+  import subprocess
+  import sys
+  from conftest import PKG, ROOT
+  env = dict(os.environ, NUFFT_HIP_DEBUG_EFENCE='1')
+  r = subprocess.run([sys.executable, '-c', _EFENCE_CHILD_R02, ROOT, PKG], env=env, capture_output=True, text=True, timeout=900)
+  assert r.returncode == 0, r.stderr[-2000:]
+  assert r.stdout.strip().splitlines()[-1] == 'PLANS 10', r.stdout[-500:]
+
+
 def test_plan_buffers_under_electric_fence():
   # Every plan buffer allocated so that it ends at an unmapped page (NUFFT_HIP_DEBUG_EFENCE,
   # nufft_plan.cpp): any kernel reading or writing past the end of a plan buffer faults.
