@@ -84,7 +84,8 @@ typedef struct nufft_hip_options {
   int32_t tile_dims[3];        /* fine-grid cells per tile, x fastest; 0 = auto */
   int32_t lds_accumulate;      /* LDS tile accumulation: 0 auto, 1 double, 2 packed 32+32-bit fixed
                                   point (3-D float, kernel width <= 7 only; width 7 caps
-                                  max_subproblem_size at 512) */
+                                  max_subproblem_size at 512; tiles holding more than 16 subproblems
+                                  are accumulated in double all the same; DESIGN.md sections 4 and 6) */
   int32_t num_point_sets;      /* K > 1: the plan sorts and transforms K independent point sets at once
                                   (batched transforms with per-item points, nufft_kernels.cc:491-540 run as
                                   one pass): set_points takes K * num_points points, set k at
