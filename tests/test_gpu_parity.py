@@ -1021,7 +1021,7 @@ def test_randomised_geometry_sweep_vs_oracle(tfft):
     grid = [int(rng.integers(3, hi)) for _ in range(rank)]
     f64 = bool(rng.integers(0, 4) == 0)
     tol = float(rng.choice([1e-11, 1e-9, 1e-7, 1e-5]) if f64 else rng.choice([1e-6, 1e-5, 1e-4, 1e-3, 1e-2]))   # f64: w = 13, 11, 9, 7
-    M = int(rng.choice([1, 7, 64, 65, 1000, 20000, 60000]))
+    M = int(rng.choice([1, 7, 64, 65, 1000, 20000, 60000] + ([300000, 1000000] if os.environ.get('NUFFT_TEST_BIGM') else [])))   # (soak runs: bigger sets too)
     ttype = 'type_1' if rng.integers(0, 2) else 'type_2'
     fd = 'forward' if rng.integers(0, 2) else 'backward'
     dist = int(rng.integers(0, 4))
