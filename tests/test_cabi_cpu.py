@@ -87,6 +87,30 @@ def test_batch_size_rule():
   assert _describe(2, [64, 64], 1e-6, 4, ntransf=20, max_batch_size=2)[2].batch_size == 2
 
 
+def test_tile_rules_of_the_r02_kernels():
+  # widths 9..16 (nufft_wide.hip): 32 x 32 tiles in 2-D, 16 x 8 x 4 up to w = 12, 8 x 8 x 4 above, 8 x 8 x 2 at
+  # w = 16; grids smaller than a tile fall back to the thread-per-point kernels (method 1)
+  for rank, dims, tol, prec, tile, method in (
+      (2, [1024, 1024], 1e-9, 8, [32, 32, 1], 2), (2, [64, 64], 1e-12, 8, [32, 32, 1], 2),
+      (3, [128, 128, 128], 1e-9, 8, [16, 8, 4], 2), (3, [64, 64, 64], 1e-12, 8, [8, 8, 4], 2),
+      (3, [64, 64, 64], 1e-14, 8, [8, 8, 2], 2), (3, [128, 128, 128], 1e-12, 4, [16, 8, 4], 2)):   # float clamps to w = 9
+    rc, err, i = _describe(rank, dims, tol, prec)
+    assert rc == 0, err
+    assert list(i.tile_dims) == tile and i.spread_method == method, (dims, tol, list(i.tile_dims), i.spread_method)
+  rc, _, i = _describe(2, [8, 8], 1e-12, 8)            # fine grid 28 x 28 < 32: generic kernels
+  assert rc == 0 and i.spread_method == 1
+  # 3-D float w = 8: tiles of depth 8 (one fp64 plane per launch), double keeps depth 4
+  assert list(_describe(3, [128, 128, 128], 1e-6, 4)[2].tile_dims) == [16, 16, 8]
+  assert list(_describe(3, [128, 128, 128], 1e-6, 8)[2].tile_dims) == [16, 16, 4]
+  # 2-D float type 2: 64 x 64 tiles from 2^21 fine cells on, 32 x 32 below; type 1 always 32 x 32
+  assert list(_describe(2, [1024, 1024], 1e-6, 4, ttype=2)[2].tile_dims) == [64, 64, 1]
+  assert list(_describe(2, [256, 256], 1e-6, 4, ttype=2)[2].tile_dims) == [32, 32, 1]
+  assert list(_describe(2, [1024, 1024], 1e-6, 4, ttype=1)[2].tile_dims) == [32, 32, 1]
+  # explicit tile sizes switch the specialised geometries off
+  rc, _, i = _describe(2, [1024, 1024], 1e-9, 8, tile_dims=(ctypes.c_int32 * 3)(16, 16, 1))
+  assert rc == 0 and i.spread_method == 1 and list(i.tile_dims) == [16, 16, 1]
+
+
 def test_create_argument_errors():
   assert _describe(4, [8, 8, 8], 1e-6, 4)[0] == _lib.UNIMPLEMENTED
   rc, err, _ = _describe(2, [64, 64], 1e-6, 4, ttype=3)
