@@ -15,15 +15,19 @@
 // search in a scanned array, no host sync) and the wavefront-per-point
 // scatter are specific to this build. Wavefront = 64 lanes throughout.
 //
-// Map of this file (DESIGN.md sections 3-5 have the measurements):
-//   helpers            horner8 / hornerW, record packing, RowWalk, tile_to_grid, locate_subproblem
+// Map of this file (DESIGN.md sections 3-5 have the measurements). Kernels for widths 9-16 live in
+// nufft_wide.hip, the 1-D interpolation in nufft_line.hip, the pruned FFT passes in nufft_fft.hip; the
+// device helpers they share (record decoding, RowWalk, locate_subproblem, LDS / global adds) in
+// nufft_device.h.
+//   helpers            horner8 / hornerW, record packing, tile_to_grid
 //   sort               fold_coords; hist_lds / colscan / scan_tiles / scatter_lds (<= 16384 tiles),
 //                      hist16_lds / colscan16 / scatter_ranked (<= 73728 tiles), count_global /
 //                      scatter_global beyond; cellsort2d / cellsort3d (second level, by start cell)
 //   spread (type 1)    spread_2d_w8_group_kernel (2-D, w <= 8, dense: the config-2 kernel),
 //                      spread_2d_w8_wave_kernel (2-D float w = 8, sparse), spread_wave2_kernel
 //                      (2-D, sparse, other widths / double), spread_wave3_kernel (3-D, fp64 planes
-//                      or packed fixed point), spread_tile_generic_kernel (w 9-16, 1-D)
+//                      or packed fixed point; crowded tiles of fixed-point plans fall back to the fp64
+//                      planes), spread_tile_generic_kernel (1-D, explicit TILE_GENERIC, tiny grids)
 //   interp (type 2)    interp_point_kernel (LDS tile, thread per point), interp_tile_generic_kernel
 //   deconvolve_kernel, permute_kernel; launchers and the launch-shape / LDS-size rules at the end
 #include <algorithm>
