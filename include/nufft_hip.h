@@ -240,6 +240,30 @@ typedef struct nufft_hip_op_desc {
   int64_t grid_shape[3];   /* the `grid_shape` input (type 1; TF order) */
 } nufft_hip_op_desc;
 
+/* Decodes the op's `options` attr: the bytes of a serialized
+ * tensorflow.nufft.Options message (proto/nufft_options.proto:19-32), which the
+ * reference kernel parses with Options::ParseFromString (nufft_kernels.cc:582-585).
+ * proto3 rules: absent fields take their defaults (points_range absent = STRICT,
+ * the enum's zero; the Python wrapper always sends its own default EXTENDED),
+ * unknown fields are skipped, the last value of a repeated scalar wins. Fills
+ * the four user-visible fields of *out and sets every other field to its
+ * nufft_hip_default_options value. Returns NUFFT_HIP_INVALID_ARGUMENT for bytes
+ * the protobuf runtime would refuse (the reference then fails with
+ * InvalidArgument "Unable to parse options string."); *out is left untouched.
+ * Host only: no device is needed. */
+int nufft_hip_options_from_proto(const void* bytes, size_t n, nufft_hip_options* out);
+/* Fills *desc from the op's attrs exactly as the reference op constructors do
+ * (NUFFT: nufft_kernels.cc:559-585; Interp :590-604; Spread :607-621):
+ * transform_type 'type_1' / 'type_2', fft_direction 'forward' / 'backward'
+ * (both ignored for Interp and Spread, may be NULL), the `tol: float` attr, the
+ * serialized options (NUFFT only). Shapes are zeroed; the caller fills them per
+ * Compute call. Host only. */
+int nufft_hip_op_desc_from_attrs(nufft_hip_op_desc* desc, int op_type,
+                                 const char* transform_type, const char* fft_direction,
+                                 double tol, int precision,
+                                 const void* options, size_t options_len,
+                                 char* errbuf, size_t errbuf_len);
+
 int nufft_hip_op_shape(const nufft_hip_op_desc* desc, int32_t* target_ndim,
                        int64_t* target_shape /* >= 12 entries */,
                        char* errbuf, size_t errbuf_len);

@@ -2567,6 +2567,13 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
   }
   if (method == NUFFT_HIP_METHOD_TILE_WAVE && g.wide)
     return launch_spread_wide<T>(g, sp, M, horner, c, fw, batch, c_stride, fw_stride, scale, stream);
+  // 2-D type-2 plans on 64 x 64 tiles (the interp kernel's geometry): nufft_hip_spread on such a
+  // spread_only plan takes the thread-per-point tile kernel, which works on any tile; the wavefront
+  // spreaders are laid out for 32 x 32 tiles and row stride 40 only.
+  if (method == NUFFT_HIP_METHOD_TILE_WAVE && g.rank == 2 && (g.tile[0] != kWT || g.tile[1] != kWT || g.lstride != kWS)) {
+    method = NUFFT_HIP_METHOD_TILE_GENERIC;
+    lds_bytes = spread_lds_bytes(g, method, (int)sizeof(T));
+  }
   if (method == NUFFT_HIP_METHOD_TILE_WAVE) {
     if constexpr (sizeof(T) == 4) {
       if (wave8_supported(g, 4)) {

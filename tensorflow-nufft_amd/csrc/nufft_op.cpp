@@ -265,9 +265,169 @@ void scratch_give(void* stream, int device, void* ptr, size_t bytes) {
   g_scratch.push_front({stream, device, ptr, bytes});
 }
 
+// ----------------------------------------------------------- options attr
+// proto3 wire reader for the serialized `options` attr: the reference kernel calls
+// Options::ParseFromString on it (nufft_kernels.cc:582-585; schema
+// proto/nufft_options.proto:19-32). No generated code: four fields in three messages.
+struct WireReader {
+  const uint8_t* p;
+  const uint8_t* end;
+  bool varint(uint64_t* v) {   // at most 10 bytes, as the protobuf runtime accepts
+    *v = 0;
+    for (int i = 0; i < 10 && p < end; ++i) {
+      const uint8_t b = *p++;
+      *v |= (uint64_t)(b & 0x7F) << (7 * i);
+      if (!(b & 0x80)) return true;
+    }
+    return false;
+  }
+  bool skip(size_t n) {
+    if ((size_t)(end - p) < n) return false;
+    p += n;
+    return true;
+  }
+  // Skips the value of an unknown field (or of a known one sent with a foreign wire type,
+  // which the runtime files under unknown fields as well). Groups nest.
+  bool skip_value(uint32_t field, int wt, int depth) {
+    uint64_t v;
+    switch (wt) {
+      case 0: return varint(&v);
+      case 1: return skip(8);
+      case 2: return varint(&v) && v <= (uint64_t)(end - p) && skip((size_t)v);
+      case 5: return skip(4);
+      case 3:   // start group: read fields until the matching end group
+        if (depth > 64) return false;
+        while (p < end) {
+          uint64_t key;
+          if (!varint(&key) || (key >> 3) == 0 || (key >> 3) > 0x1FFFFFFF) return false;
+          if ((key & 7) == 4) return (uint32_t)(key >> 3) == field;
+          if (!skip_value((uint32_t)(key >> 3), (int)(key & 7), depth + 1)) return false;
+        }
+        return false;
+      default: return false;   // 4 (stray end group), 6, 7
+    }
+  }
+};
+
+// One message level: `on_field(field, wire_type, reader)` consumes the value of the
+// fields it knows and returns 1, returns 0 for the ones it leaves to skip_value, -1 on error.
+template <typename F>
+bool parse_message(WireReader r, F&& on_field) {
+  while (r.p < r.end) {
+    uint64_t key;
+    if (!r.varint(&key)) return false;
+    const uint64_t field = key >> 3;
+    const int wt = (int)(key & 7);
+    if (field == 0 || field > 0x1FFFFFFF) return false;
+    const int used = on_field((uint32_t)field, wt, &r);
+    if (used < 0) return false;
+    if (used == 0 && !r.skip_value((uint32_t)field, wt, 0)) return false;
+  }
+  return true;
+}
+
+// A length-delimited sub-message with one varint field number 1 (DebuggingOptions,
+// FftwOptions). Repeated occurrences merge, the last value wins (proto3 semantics).
+bool parse_single_varint_message(WireReader* r, uint64_t* value, bool* seen) {
+  uint64_t len;
+  if (!r->varint(&len) || len > (uint64_t)(r->end - r->p)) return false;
+  WireReader sub{r->p, r->p + len};
+  r->p += len;
+  return parse_message(sub, [&](uint32_t field, int wt, WireReader* s) -> int {
+    if (field != 1 || wt != 0) return 0;
+    if (!s->varint(value)) return -1;
+    *seen = true;
+    return 1;
+  });
+}
+
 }  // namespace
 
 extern "C" {
+
+int nufft_hip_options_from_proto(const void* bytes, size_t n, nufft_hip_options* out) {
+  if (!out || (!bytes && n)) return NUFFT_HIP_INVALID_ARGUMENT;
+  nufft_hip_options o;
+  nufft_hip_default_options(&o);
+  // proto3 leaves default-valued fields off the wire: an absent field 4 is
+  // PointsRange.STRICT (= 0), which is what the parsed message hands the reference kernel
+  // (nufft_kernels.cc:364-366). The Python wrapper's own default, EXTENDED (= 1), is
+  // always on the wire (python/ops/nufft_options.py:222-273).
+  o.points_range = NUFFT_HIP_RANGE_STRICT;
+  o.max_batch_size = 0;
+  o.check_points_range = 0;
+  o.fftw_planning_rigor = 0;
+  WireReader top{static_cast<const uint8_t*>(bytes), static_cast<const uint8_t*>(bytes) + n};
+  const bool ok = parse_message(top, [&](uint32_t field, int wt, WireReader* r) -> int {
+    uint64_t v = 0;
+    bool seen = false;
+    if (field == 1 && wt == 2) {          // DebuggingOptions debugging = 1 { bool check_points_range = 1 }
+      if (!parse_single_varint_message(r, &v, &seen)) return -1;
+      if (seen) o.check_points_range = v != 0;
+      return 1;
+    }
+    if (field == 2 && wt == 2) {          // FftwOptions fftw = 2 { FftwPlanningRigor planning_rigor = 1 }
+      if (!parse_single_varint_message(r, &v, &seen)) return -1;
+      if (seen) o.fftw_planning_rigor = (int32_t)(uint32_t)v;
+      return 1;
+    }
+    if (field == 3 && wt == 0) {          // int32 max_batch_size = 3 (low 32 bits of the varint)
+      if (!r->varint(&v)) return -1;
+      o.max_batch_size = (int32_t)(uint32_t)v;
+      return 1;
+    }
+    if (field == 4 && wt == 0) {          // PointsRange points_range = 4 (open enum)
+      if (!r->varint(&v)) return -1;
+      o.points_range = (int32_t)(uint32_t)v;
+      return 1;
+    }
+    return 0;
+  });
+  if (!ok) return NUFFT_HIP_INVALID_ARGUMENT;
+  *out = o;
+  return NUFFT_HIP_OK;
+}
+
+int nufft_hip_op_desc_from_attrs(nufft_hip_op_desc* desc, int op_type, const char* transform_type,
+                                 const char* fft_direction, double tol, int precision,
+                                 const void* options, size_t options_len,
+                                 char* errbuf, size_t errbuf_len) {
+  if (!desc) return fail(errbuf, errbuf_len, NUFFT_HIP_INVALID_ARGUMENT, "null desc");
+  memset(desc, 0, sizeof(*desc));
+  nufft_hip_default_options(&desc->options);
+  desc->op_type = op_type;
+  desc->precision = precision;
+  desc->tol = tol;
+  desc->fft_direction = NUFFT_HIP_FORWARD;
+  if (precision != NUFFT_HIP_F32 && precision != NUFFT_HIP_F64)
+    return fail(errbuf, errbuf_len, NUFFT_HIP_INVALID_ARGUMENT, "precision must be 4 (float) or 8 (double)");
+  switch (op_type) {
+    case NUFFT_HIP_OP_INTERP:   // nufft_kernels.cc:590-604
+      desc->transform_type = NUFFT_HIP_TYPE_2;
+      desc->fft_direction = NUFFT_HIP_BACKWARD;   // irrelevant, as upstream
+      return NUFFT_HIP_OK;
+    case NUFFT_HIP_OP_SPREAD:   // nufft_kernels.cc:607-621
+      desc->transform_type = NUFFT_HIP_TYPE_1;
+      return NUFFT_HIP_OK;
+    case NUFFT_HIP_OP_NUFFT: break;
+    default: return fail(errbuf, errbuf_len, NUFFT_HIP_INVALID_ARGUMENT, "unknown op type");
+  }
+  // nufft_kernels.cc:559-585. The op registration restricts both attrs to their two values
+  // (nufft_ops.cc:211-212); anything else cannot reach the reference kernel and is refused here.
+  const std::string tt = transform_type ? transform_type : "";
+  const std::string fd = fft_direction ? fft_direction : "";
+  if (tt == "type_1") desc->transform_type = NUFFT_HIP_TYPE_1;
+  else if (tt == "type_2") desc->transform_type = NUFFT_HIP_TYPE_2;
+  else return fail(errbuf, errbuf_len, NUFFT_HIP_INVALID_ARGUMENT,
+                   "transform_type attr must be 'type_1' or 'type_2', but is " + tt);
+  if (fd == "forward") desc->fft_direction = NUFFT_HIP_FORWARD;
+  else if (fd == "backward") desc->fft_direction = NUFFT_HIP_BACKWARD;
+  else return fail(errbuf, errbuf_len, NUFFT_HIP_INVALID_ARGUMENT,
+                   "fft_direction attr must be 'forward' or 'backward', but is " + fd);
+  if (nufft_hip_options_from_proto(options, options_len, &desc->options) != NUFFT_HIP_OK)
+    return fail(errbuf, errbuf_len, NUFFT_HIP_INVALID_ARGUMENT, "Unable to parse options string.");
+  return NUFFT_HIP_OK;
+}
 
 int nufft_hip_op_shape(const nufft_hip_op_desc* desc, int32_t* target_ndim, int64_t* target_shape,
                        char* errbuf, size_t errbuf_len) {
@@ -348,8 +508,9 @@ int nufft_hip_op_compute_ex(const nufft_hip_op_desc* desc, const void* source, c
       const double fine_bytes = (double)pi.fine_dims[0] * pi.fine_dims[1] * pi.fine_dims[2] * csize *
                                 (opts.spread_only ? 0.0 : (double)a.num_transforms);
       const int64_t ntiles = (int64_t)pi.num_tiles[0] * pi.num_tiles[1] * pi.num_tiles[2];
+      // (slots = transforms x sets ride in grid.y of the batched FFT / deconvolve launches: <= 65535)
       while (group > 1 && (fine_bytes * group > 1.5 * (1 << 30) || ntiles * group > 65536 ||
-                           a.num_points * group > 1500000000LL))
+                           a.num_points * group > 1500000000LL || a.num_transforms * group > 32768))
         group /= 2;
     } else {
       group = 1;

@@ -962,9 +962,10 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
   if (p->nitems > 1) {
     // every transform of every point set in ONE pass (the kernels index the fine grids by
     // item * ntransf + transform)
-    if (p->nitems > 4096 || ntransf > 32768) {
+    if (p->nitems > 4096 || ntransf > 32768 || (int64_t)p->nitems * ntransf > 65535) {
       delete p;
-      return fail(NUFFT_HIP_INVALID_ARGUMENT, "num_point_sets must be <= 4096 (and num_transforms <= 32768 with it)");
+      return fail(NUFFT_HIP_INVALID_ARGUMENT,
+                  "num_point_sets must be <= 4096, num_transforms <= 32768 and their product <= 65535");
     }
     p->batch_size = ntransf;
   }
@@ -1274,8 +1275,10 @@ int nufft_hip_set_points(nufft_hip_plan p, int64_t M, const void* x, const void*
     p->err = "this plan was created host-only (no device state)";
     return NUFFT_HIP_INVALID_ARGUMENT;
   }
-  if (M < 0 || M > kMaxArraySize) {
-    p->err = format("invalid number of points %lld", (long long)M);
+  // (tile_start / sub_start, the scatter cursors and the subproblem search are 32-bit over ALL sets)
+  if (M < 0 || M > kMaxArraySize || M * std::max(1, p->nitems) > kMaxArraySize) {
+    p->err = format("invalid number of points %lld (x %d point sets; at most %lld in total)", (long long)M,
+                    std::max(1, p->nitems), (long long)kMaxArraySize);
     return NUFFT_HIP_INVALID_ARGUMENT;
   }
   if (M > 0 && (!x || (p->rank > 1 && !y) || (p->rank > 2 && !z))) {
@@ -1299,8 +1302,10 @@ int nufft_hip_set_points(nufft_hip_plan p, int64_t M, const void* x, const void*
 int nufft_hip_execute_with_points(nufft_hip_plan p, int64_t M, const void* x, const void* y,
                                   const void* z, int64_t stride, void* c, void* f) {
   NUFFT_REQUIRE_DEVICE_PLAN(p);
-  if (M < 0 || M > kMaxArraySize) {
-    p->err = format("invalid number of points %lld", (long long)M);
+  // (tile_start / sub_start, the scatter cursors and the subproblem search are 32-bit over ALL sets)
+  if (M < 0 || M > kMaxArraySize || M * std::max(1, p->nitems) > kMaxArraySize) {
+    p->err = format("invalid number of points %lld (x %d point sets; at most %lld in total)", (long long)M,
+                    std::max(1, p->nitems), (long long)kMaxArraySize);
     return NUFFT_HIP_INVALID_ARGUMENT;
   }
   if (M > 0 && (!x || (p->rank > 1 && !y) || (p->rank > 2 && !z))) {
@@ -1337,7 +1342,8 @@ int nufft_hip_debug_stop_after(nufft_hip_plan p, int stage) {
     int rc = build_fft_plan(p, p->batch_size * p->nitems);
     if (!rc && p->nitems == 1) rc = build_fft_plan(p, p->ntransf % p->batch_size);
     if (rc) return rc;
-    if (p->fft_work_bytes && !p->fft_work) {
+    // (a plan whose fixed workspace is not allocated yet gets the buffer from ensure_fixed_workspace)
+    if (p->fft_work_bytes && !p->fft_work && p->fixed_ws) {
       if ((rc = dev_alloc(p, &p->fft_work, p->fft_work_bytes))) return rc;
       FFT_TRY(p, rocfft_execution_info_set_work_buffer(p->fft_info, p->fft_work, p->fft_work_bytes));
     }
@@ -1385,6 +1391,7 @@ int nufft_hip_plan_get_info(nufft_hip_plan p, nufft_hip_plan_info* info) {
 
 int nufft_hip_plan_set_stream(nufft_hip_plan p, void* stream) {
   if (!p || p->host_only) return NUFFT_HIP_INVALID_ARGUMENT;
+  if (p->stream != (hipStream_t)stream) p->fine_clear_slots = 0;   // the old stream may still be zeroing the fine grid
   p->stream = (hipStream_t)stream;
   if (p->fft_info) FFT_TRY(p, rocfft_execution_info_set_stream(p->fft_info, p->stream));
   return NUFFT_HIP_OK;

@@ -4,9 +4,13 @@
 // names, inputs, attrs and shape functions (reference
 // tensorflow_nufft/cc/ops/nufft_ops.cc:27-219) and GPU kernels with
 // HostMemory("grid_shape") (reference cc/kernels/nufft_kernels.cc:624-706).
-// All host logic (validation, batch broadcasting, the call loop) lives behind
-// the C ABI (include/nufft_hip.h, nufft_hip_op_shape / nufft_hip_op_compute),
-// so this file only translates TF tensors into shapes + device pointers.
+// All host logic lives behind the C ABI (include/nufft_hip.h): attr decoding incl. the
+// options proto (nufft_hip_op_desc_from_attrs / nufft_hip_options_from_proto), validation,
+// batch broadcasting and the call loop (nufft_hip_op_shape / nufft_hip_op_compute_ex); all
+// of it is tested through ctypes (tests/test_cabi_cpu.py, tests/test_options.py). This file
+// only moves attrs, shapes and device pointers between TF and those calls. The one piece
+// of logic that must live here is the graph-time shape function (TF's InferenceContext
+// works on symbolic shapes).
 //
 // NOT BUILT IN THIS REPOSITORY'S IMAGE: TensorFlow is not installed here
 // (SURVEY.md section 8c), so this translation unit has never been compiled;
@@ -100,85 +104,37 @@ REGISTER_OP("NUFFT")
     .Attr("options: string = ''")
     .SetShapeFn(NUFFTShapeFn);
 
-// Decodes the serialized Options proto (proto/nufft_options.proto:27-32):
-// 1: DebuggingOptions{1: bool check_points_range}, 2: FftwOptions{1: enum},
-// 3: int32 max_batch_size, 4: enum points_range. Hand-rolled varint reader so
-// the glue needs no generated protobuf code.
-static bool ReadVarint(const string& s, size_t* pos, uint64_t* v) {
-  *v = 0;
-  for (int shift = 0; *pos < s.size() && shift < 64; shift += 7) {
-    const uint8_t b = static_cast<uint8_t>(s[(*pos)++]);
-    *v |= static_cast<uint64_t>(b & 0x7F) << shift;
-    if (!(b & 0x80)) return true;
-  }
-  return false;
-}
-static void ParseOptions(const string& bytes, nufft_hip_options* o) {
-  nufft_hip_default_options(o);
-  // proto3 does not serialise default-valued fields: an absent field 4 means
-  // PointsRange.STRICT (= 0), exactly what options_.ParseFromString gives the
-  // reference kernel (nufft_kernels.cc:364-366). The Python wrapper always sends
-  // its own default, EXTENDED (= 1), explicitly.
-  o->points_range = NUFFT_HIP_RANGE_STRICT;
-  size_t pos = 0;
-  uint64_t key, v;
-  while (pos < bytes.size() && ReadVarint(bytes, &pos, &key)) {
-    const int field = static_cast<int>(key >> 3), wt = static_cast<int>(key & 7);
-    if (wt == 0) {
-      if (!ReadVarint(bytes, &pos, &v)) return;
-      if (field == 3) o->max_batch_size = static_cast<int32_t>(v);
-      if (field == 4) o->points_range = static_cast<int32_t>(v);
-    } else if (wt == 2) {
-      if (!ReadVarint(bytes, &pos, &v) || pos + v > bytes.size()) return;
-      const string sub = bytes.substr(pos, v);
-      pos += v;
-      size_t sp = 0;
-      uint64_t sk, sv;
-      while (sp < sub.size() && ReadVarint(sub, &sp, &sk) && (sk & 7) == 0 && ReadVarint(sub, &sp, &sv)) {
-        if (field == 1 && (sk >> 3) == 1) o->check_points_range = sv != 0;
-        if (field == 2 && (sk >> 3) == 1) o->fftw_planning_rigor = static_cast<int32_t>(sv);
-      }
-    } else {
-      return;
-    }
-  }
-}
-
 template <typename FloatType>
 class NufftHipOp : public OpKernel {
  public:
-  NufftHipOp(OpKernelConstruction* ctx, int op_type) : OpKernel(ctx), op_type_(op_type) {
-    nufft_hip_default_options(&options_);
-    transform_type_ = op_type == NUFFT_HIP_OP_SPREAD ? NUFFT_HIP_TYPE_1 : NUFFT_HIP_TYPE_2;
-    OP_REQUIRES_OK(ctx, ctx->GetAttr("tol", &tol_));
-    if (op_type == NUFFT_HIP_OP_NUFFT) {   // reference nufft_kernels.cc:559-585
-      string s;
-      OP_REQUIRES_OK(ctx, ctx->GetAttr("transform_type", &s));
-      transform_type_ = s == "type_1" ? NUFFT_HIP_TYPE_1 : NUFFT_HIP_TYPE_2;
-      OP_REQUIRES_OK(ctx, ctx->GetAttr("fft_direction", &s));
-      fft_direction_ = s == "backward" ? NUFFT_HIP_BACKWARD : NUFFT_HIP_FORWARD;
-      OP_REQUIRES_OK(ctx, ctx->GetAttr("options", &s));
-      ParseOptions(s, &options_);
+  // Attrs -> descriptor: nufft_hip_op_desc_from_attrs restates the reference constructors
+  // (nufft_kernels.cc:559-621), including Options::ParseFromString on the `options` attr.
+  NufftHipOp(OpKernelConstruction* ctx, int op_type) : OpKernel(ctx) {
+    float tol;
+    string transform_type, fft_direction, options;
+    OP_REQUIRES_OK(ctx, ctx->GetAttr("tol", &tol));
+    if (op_type == NUFFT_HIP_OP_NUFFT) {
+      OP_REQUIRES_OK(ctx, ctx->GetAttr("transform_type", &transform_type));
+      OP_REQUIRES_OK(ctx, ctx->GetAttr("fft_direction", &fft_direction));
+      OP_REQUIRES_OK(ctx, ctx->GetAttr("options", &options));
     }
+    char err[256] = {0};
+    const int rc = nufft_hip_op_desc_from_attrs(&desc_, op_type, transform_type.c_str(), fft_direction.c_str(),
+                                                tol, sizeof(FloatType), options.data(), options.size(),
+                                                err, sizeof(err));
+    OP_REQUIRES(ctx, rc == NUFFT_HIP_OK, ToStatus(rc, err));
   }
 
   void Compute(OpKernelContext* ctx) override {
     const Tensor& source = ctx->input(0);
     const Tensor& points = ctx->input(1);
-    nufft_hip_op_desc d;
-    memset(&d, 0, sizeof(d));
-    d.op_type = op_type_;
-    d.transform_type = transform_type_;
-    d.fft_direction = fft_direction_;
-    d.precision = sizeof(FloatType);
-    d.tol = tol_;
-    d.options = options_;
+    nufft_hip_op_desc d = desc_;   // attrs; shapes below
     OP_REQUIRES(ctx, source.dims() <= 12 && points.dims() <= 12, errors::InvalidArgument("too many dimensions"));
     d.source_ndim = source.dims();
     d.points_ndim = points.dims();
     for (int i = 0; i < source.dims(); ++i) d.source_shape[i] = source.dim_size(i);
     for (int i = 0; i < points.dims(); ++i) d.points_shape[i] = points.dim_size(i);
-    if (transform_type_ == NUFFT_HIP_TYPE_1) {
+    if (d.transform_type == NUFFT_HIP_TYPE_1) {
       const Tensor& gs = ctx->input(2);   // host memory
       OP_REQUIRES(ctx, TensorShapeUtils::IsVector(gs.shape()),
                   errors::InvalidArgument("grid_shape must be 1D, but got shape: ", gs.shape().DebugString()));
@@ -223,9 +179,7 @@ class NufftHipOp : public OpKernel {
       default: return errors::Internal(msg);
     }
   }
-  int op_type_, transform_type_, fft_direction_ = NUFFT_HIP_FORWARD;
-  float tol_ = 1e-6f;
-  nufft_hip_options options_;
+  nufft_hip_op_desc desc_;
 };
 
 template <typename F> struct NUFFT : NufftHipOp<F> { explicit NUFFT(OpKernelConstruction* c) : NufftHipOp<F>(c, NUFFT_HIP_OP_NUFFT) {} };

@@ -136,6 +136,11 @@ SYMBOLS = {
     'nufft_hip_debug_eval_kernel': (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
         ctypes.POINTER(ctypes.c_double)]),
+    'nufft_hip_options_from_proto': (ctypes.c_int, [
+        ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(OptionsStruct)]),
+    'nufft_hip_op_desc_from_attrs': (ctypes.c_int, [
+        ctypes.POINTER(OpDesc), ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_double,
+        ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]),
     'nufft_hip_op_shape': (ctypes.c_int, [
         ctypes.POINTER(OpDesc), ctypes.POINTER(ctypes.c_int32),
         ctypes.POINTER(ctypes.c_int64), ctypes.c_char_p, ctypes.c_size_t]),

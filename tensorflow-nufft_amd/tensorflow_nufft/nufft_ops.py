@@ -21,18 +21,16 @@ _FFT_DIRECTIONS = {'forward': _lib.FORWARD, 'backward': _lib.BACKWARD}
 _COMPLEX_TO_REAL = {torch.complex64: torch.float32, torch.complex128: torch.float64}
 
 
-def _options_struct(options):
-  o = _lib.OptionsStruct()
-  _lib.lib().nufft_hip_default_options(ctypes.byref(o))
-  if options is None:
-    return o
-  if isinstance(options, (bytes, bytearray)):   # serialized proto, like the op attr
-    options = nufft_options.Options.from_proto(bytes(options)) if options else nufft_options.Options()
-  o.max_batch_size = int(options.max_batch_size or 0)
-  o.points_range = int(options.points_range)
-  o.check_points_range = int(bool(options.debugging.check_points_range))
-  o.fftw_planning_rigor = int(options.fftw.planning_rigor)
-  # expert knobs (InternalOptions upstream, cc/kernels/nufft_options.h:92-162)
+def _options_bytes(options):
+  """The `options` attr: serialized Options proto, as the reference wrapper sends it
+  (python/ops/nufft_ops.py:118-123: `options or Options()`, always serialized)."""
+  if isinstance(options, (bytes, bytearray)):
+    return bytes(options)
+  return (options or nufft_options.Options()).to_proto().SerializeToString()
+
+
+def _apply_internal_options(o, options):
+  """Expert knobs (InternalOptions upstream, cc/kernels/nufft_options.h:92-162)."""
   extra = getattr(options, '_internal', None) or {}
   for k, v in extra.items():
     if k == 'tile_dims':
@@ -40,6 +38,15 @@ def _options_struct(options):
         o.tile_dims[i] = int(t)
     else:
       setattr(o, k, v)
+
+
+def _options_struct(options):
+  """Options -> proto bytes -> nufft_hip_options, decoded by the library like the op attr."""
+  o = _lib.OptionsStruct()
+  data = _options_bytes(options)
+  rc = _lib.lib().nufft_hip_options_from_proto(data, len(data), ctypes.byref(o))
+  _lib.raise_for_status(rc, 'Unable to parse options string.')
+  _apply_internal_options(o, options)
   return o
 
 
@@ -70,13 +77,15 @@ def _run_op(op_type, source, points, grid_shape, transform_type, fft_direction, 
   if points.dtype != _COMPLEX_TO_REAL[source.dtype]:
     raise _lib.InvalidArgumentError(
         f'Input `points` must have type {_COMPLEX_TO_REAL[source.dtype]} but got: {points.dtype}')
+  lib = _lib.lib()
+  err = ctypes.create_string_buffer(1024)
   desc = _lib.OpDesc()
-  desc.op_type = op_type
-  desc.transform_type = _TRANSFORM_TYPES[transform_type]
-  desc.fft_direction = _FFT_DIRECTIONS[fft_direction]
-  desc.precision = _lib.F32 if source.dtype == torch.complex64 else _lib.F64
-  desc.tol = float(tol)
-  desc.options = _options_struct(options)
+  data = _options_bytes(options) if op_type == _lib.OP_NUFFT else b''
+  rc = lib.nufft_hip_op_desc_from_attrs(
+      ctypes.byref(desc), op_type, transform_type.encode(), fft_direction.encode(), float(tol),
+      _lib.F32 if source.dtype == torch.complex64 else _lib.F64, data, len(data), err, len(err))
+  _lib.raise_for_status(rc, err.value)
+  _apply_internal_options(desc.options, options)
   if source.dim() > 12 or points.dim() > 12:
     raise _lib.InvalidArgumentError('too many dimensions')
   desc.source_ndim = source.dim()
@@ -95,8 +104,6 @@ def _run_op(op_type, source, points, grid_shape, transform_type, fft_direction, 
   desc.grid_shape_len = gs_len
   for i, g in enumerate(gs):
     desc.grid_shape[i] = g
-  lib = _lib.lib()
-  err = ctypes.create_string_buffer(1024)
   ndim = ctypes.c_int32(0)
   tshape = (ctypes.c_int64 * 12)()
   rc = lib.nufft_hip_op_shape(ctypes.byref(desc), ctypes.byref(ndim), tshape, err, len(err))

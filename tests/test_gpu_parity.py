@@ -500,6 +500,154 @@ def test_config3_full_size_direct(tfft):
   plan.close()
 
 
+def _note(line):
+  """Appends a measured figure to gpurun_out/full_size_parity.txt (best effort; copied to profiles/)."""
+  import os
+  from conftest import ROOT
+  try:
+    os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+    with open(os.path.join(ROOT, 'gpurun_out', 'full_size_parity.txt'), 'a') as fh:
+      fh.write(line + '\n')
+  except OSError:
+    pass
+  print(line)
+
+
+def _cpu_rule_distances(truth, src, pts, gs, ttype, fd, tol):
+  """SURVEY 8c acceptance (ii): the reference CPU rule (sigma = 1.25 on these grids, nufft_plan.h:742-752)
+  restated by the oracle, in the op's own precision (complex64) and in double: ||cpu - truth|| each."""
+  from oracle import oracle
+  cpu32 = oracle.nufft(src.astype(np.complex64), pts, gs, ttype, fd, tol=tol)
+  cpu64 = oracle.nufft(src.astype(np.complex128), pts, gs, ttype, fd, tol=tol)
+  return cpu32, rel_l2(cpu32, truth), rel_l2(cpu64, truth)
+
+
+def test_config2_total_parity_at_full_size(tfft):
+  # BASELINE config 2, SURVEY 8d inputs (numpy default_rng(2)): the WHOLE 1024^2 result of all 1e7
+  # points against the fp64 oracle at sigma 2, tol 1e-12 (reference CPU algorithm, nufft_plan.cc:166-351).
+  # Bar: rel-l2 <= tol = 1e-6, and ours - cpu_rule <= tol + ||cpu_rule - truth||.
+  import time
+  from oracle import oracle
+  rng = np.random.default_rng(2)
+  M, N = 10_000_000, 1024
+  pts = rng.uniform(-np.pi, np.pi, (M, 2)).astype(np.float32)
+  c = (rng.uniform(-.5, .5, M) + 1j * rng.uniform(-.5, .5, M)).astype(np.complex64)
+  out = tfft.nufft(_dev(c), _dev(pts), grid_shape=[N, N], transform_type='type_1', fft_direction='forward',
+                   tol=1e-6).cpu().numpy()
+  t0 = time.time()
+  truth = oracle.nufft(c.astype(np.complex128), pts, [N, N], 'type_1', 'forward', tol=1e-12, sigma=2.0)
+  t_truth = time.time() - t0
+  err = rel_l2(out, truth)
+  cpu32, e32, e64 = _cpu_rule_distances(truth, c, pts, [N, N], 'type_1', 'forward', 1e-6)
+  d32 = rel_l2(out, cpu32)
+  _note(f'config 2 (2D type 1, 1024^2, M=1e7, tol 1e-6, c64), all {N * N} outputs: ours-truth {err:.3e}; '
+        f'cpu-rule(sigma 1.25, c64)-truth {e32:.3e}; cpu-rule(c128)-truth {e64:.3e}; ours-cpu-rule(c64) {d32:.3e}; '
+        f'max |ours-truth| / max |truth| {np.abs(out - truth).max() / np.abs(truth).max():.3e}; oracle truth {t_truth:.1f} s')
+  assert err <= 1e-6, err
+  assert d32 <= 1e-6 + e32, (d32, e32)
+
+
+def test_config3_total_parity_at_full_size(tfft):
+  # BASELINE config 3 (default_rng(3)): all 1e7 outputs of the type-2 transform against the fp64 oracle.
+  from oracle import oracle
+  rng = np.random.default_rng(3)
+  M, N = 10_000_000, 1024
+  f = (rng.uniform(-.5, .5, (N, N)) + 1j * rng.uniform(-.5, .5, (N, N))).astype(np.complex64)
+  pts = rng.uniform(-np.pi, np.pi, (M, 2)).astype(np.float32)
+  out = tfft.nufft(_dev(f), _dev(pts), transform_type='type_2', fft_direction='forward', tol=1e-6).cpu().numpy()
+  truth = oracle.nufft(f.astype(np.complex128), pts, None, 'type_2', 'forward', tol=1e-12, sigma=2.0)
+  err = rel_l2(out, truth)
+  cpu32, e32, e64 = _cpu_rule_distances(truth, f, pts, None, 'type_2', 'forward', 1e-6)
+  d32 = rel_l2(out, cpu32)
+  _note(f'config 3 (2D type 2, 1024^2, M=1e7, tol 1e-6, c64), all {M} outputs: ours-truth {err:.3e}; '
+        f'cpu-rule(sigma 1.25, c64)-truth {e32:.3e}; cpu-rule(c128)-truth {e64:.3e}; ours-cpu-rule(c64) {d32:.3e}; '
+        f'max |ours-truth| / max |truth| {np.abs(out - truth).max() / np.abs(truth).max():.3e}')
+  assert err <= 1e-6, err
+  assert d32 <= 1e-6 + e32, (d32, e32)
+
+
+def test_config4_geometry_total_parity_at_1e7_points(tfft):
+  # BASELINE config 4's grid and tolerance (3D type 1, 256^3, tol 1e-4, default_rng(4)) with M = 1e7, where the
+  # fp64 oracle (sigma 2, tol 1e-8: 10^3 cells per point on a 512^3 double grid) still finishes in about a
+  # minute: the WHOLE 256^3 result. (At the full M = 1e8 the oracle would need ~10 minutes of host time:
+  # test_config4_full_size_properties keeps dense blocks + adjointness there.)
+  import time
+  from oracle import oracle
+  rng = np.random.default_rng(4)
+  M, N = 10_000_000, 256
+  pts = rng.uniform(-np.pi, np.pi, (M, 3)).astype(np.float32)
+  c = (rng.uniform(-.5, .5, M) + 1j * rng.uniform(-.5, .5, M)).astype(np.complex64)
+  out = tfft.nufft(_dev(c), _dev(pts), grid_shape=[N, N, N], transform_type='type_1', fft_direction='forward',
+                   tol=1e-4).cpu().numpy()
+  t0 = time.time()
+  truth = oracle.nufft(c.astype(np.complex128), pts, [N, N, N], 'type_1', 'forward', tol=1e-8, sigma=2.0)
+  t_truth = time.time() - t0
+  err = rel_l2(out, truth)
+  cpu32 = oracle.nufft(c, pts, [N, N, N], 'type_1', 'forward', tol=1e-4)
+  e32 = rel_l2(cpu32, truth)
+  d32 = rel_l2(out, cpu32)
+  _note(f'config 4 geometry (3D type 1, 256^3, tol 1e-4, c64) at M=1e7, all {N ** 3} outputs: ours-truth {err:.3e}; '
+        f'cpu-rule(sigma 1.25, c64)-truth {e32:.3e}; ours-cpu-rule {d32:.3e}; oracle truth {t_truth:.1f} s')
+  assert err <= 1e-4, err
+  assert d32 <= 1e-4 + e32, (d32, e32)
+
+
+def test_spread_on_a_type2_interp_geometry_plan(tfft):
+  # a spread_only type-2 float plan on a fine grid of >= 2^21 cells takes 64 x 64 tiles (the interp kernel's
+  # geometry); nufft_hip_spread on it must still be right (r02 advisor finding: it ran the 32 x 32 wave kernel)
+  import torch
+  from oracle import oracle
+  rng = np.random.default_rng(77)
+  grid = [2048, 1024]
+  M = 300000
+  pts = rng.uniform(-np.pi, np.pi, (M, 2)).astype(np.float32)
+  c = (rng.uniform(-.5, .5, M) + 1j * rng.uniform(-.5, .5, M)).astype(np.complex64)
+  f = (rng.uniform(-.5, .5, grid) + 1j * rng.uniform(-.5, .5, grid)).astype(np.complex64)
+  plan = tfft.Plan('type_2', grid, 'forward', tol=1e-6, dtype=torch.complex64, spread_only=True)
+  assert list(plan.info().tile_dims)[:2] == [64, 64]
+  plan.set_points(_dev(pts))
+  got_s = plan.spread(_dev(c)).cpu().numpy()
+  got_i = plan.interp(_dev(f)).cpu().numpy()
+  plan.close()
+  ref_s = oracle.nufft(c.astype(np.complex128), pts, grid, 'type_1', op='spread', tol=1e-6)
+  ref_i = oracle.nufft(f.astype(np.complex128), pts, None, 'type_2', op='interp', tol=1e-6)
+  assert rel_l2(got_s, ref_s) < 2e-6, rel_l2(got_s, ref_s)
+  assert rel_l2(got_i, ref_i) < 2e-6, rel_l2(got_i, ref_i)
+
+
+def test_many_transforms_times_many_point_sets(tfft):
+  # points batch [16] x source batch [16, 4500]: 16 point sets x 4500 transforms = 72000 fine grids, more
+  # than one batched FFT launch takes (grid.y <= 65535): the op must cut its groups (r02 advisor finding)
+  import torch
+  from oracle import oracle
+  rng = np.random.default_rng(78)
+  B, T, M, grid = 16, 4500, 40, [8, 8]
+  pts = rng.uniform(-np.pi, np.pi, (B, 1, M, 2)).astype(np.float32)
+  c = (rng.uniform(-.5, .5, (B, T, M)) + 1j * rng.uniform(-.5, .5, (B, T, M))).astype(np.complex64)
+  out = tfft.nufft(_dev(c), _dev(pts), grid_shape=grid, transform_type='type_1', tol=1e-6).cpu().numpy()
+  assert out.shape == (B, T, 8, 8)
+  for b in (0, 7, 15):
+    ref = oracle.nufft(c[b, ::500].astype(np.complex128), pts[b, 0], grid, 'type_1', 'forward', tol=1e-12)
+    assert rel_l2(out[b, ::500], ref) < 1e-6
+  # the plan itself refuses what it cannot launch
+  with pytest.raises(ValueError):
+    tfft.Plan('type_1', grid, 'forward', num_transforms=4500, tol=1e-6, num_point_sets=16)
+
+
+def test_total_points_over_all_sets_is_bounded(tfft):
+  # int32 tile tables span ALL point sets of a plan: M x sets > 2e9 is refused before anything is launched
+  import ctypes
+  import torch
+  from tensorflow_nufft import _lib
+  plan = tfft.Plan('type_1', [16, 16], 'forward', tol=1e-6, num_point_sets=16)
+  x = torch.zeros(8, device='cuda')
+  rc = plan.lib.nufft_hip_set_points(plan._handle, ctypes.c_int64(200_000_000), ctypes.c_void_p(x.data_ptr()),
+                                     ctypes.c_void_p(x.data_ptr()), None, 1)
+  assert rc == _lib.INVALID_ARGUMENT
+  assert b'point sets' in plan.lib.nufft_hip_last_error(plan._handle)
+  plan.close()
+
+
 @pytest.mark.parametrize('grid', [[8], [6, 8], [4, 8, 6]])
 @pytest.mark.parametrize('ttype', ['type_1', 'type_2'])
 @pytest.mark.parametrize('fd', ['forward', 'backward'])

@@ -5,6 +5,7 @@ cd $GRAFT_REPO_ROOT
 O=gpurun_out/r02m; mkdir -p $O
 python3 tools/sparse_crossover.py > $O/r02_sparse_crossover.txt 2>&1
 python3 tools/bench_configs.py 2 3 4 4t2 5 5s 5op 1 2d 3d6 2>&1 | grep -v amdgpu > $O/r02_configs.txt
+make -C tools/ubench -s all
 (cd tools/ubench && ./scatter_write_bench) > $O/r02_scatter_write_ubench.txt 2>&1
 (cd tools/ubench && ./lds_atomic_bench) > $O/r02_lds_atomic_ubench.txt 2>&1
 bash tools/sweep_group.sh > $O/r02_cfg5_group_sweep.txt 2>&1
