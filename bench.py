@@ -176,10 +176,114 @@ def lds_roofline(pts, info, spread_ms):
   }
 
 
+def _event_timed(fn, steps):
+  """ms per call of fn over `steps` calls, HIP events on the current stream (the stream the
+  plans and tfft.nufft launch on)."""
+  import torch
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  torch.cuda.synchronize()
+  e0.record()
+  for _ in range(steps):
+    fn()
+  e1.record()
+  e1.synchronize()
+  return e0.elapsed_time(e1) / steps
+
+
+def other_configs(args, dev):
+  """BASELINE configs 3, 4 and 5 on this one GPU, after the headline region: ms per step (HIP
+  events), whole-step rate, the dominant kernel's average duration (HIP events of the plan's
+  own stage timing around that kernel) and its HBM fraction on the SURVEY 8(d) algorithmic
+  bytes. `value` stays config 2; these are the driver-timed figures of the other configs."""
+  import numpy as np
+  import torch
+  import tensorflow_nufft as tfft
+  out = {}
+
+  def rnd_c(shape, g):
+    return torch.complex(torch.rand(shape, generator=g, device=dev) - .5, torch.rand(shape, generator=g, device=dev) - .5)
+
+  def plan_case(name, ttype, grid, m, tol, seed, steps, stage):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    rank = len(grid)
+    pts = (torch.rand((m, rank), generator=g, device=dev) * 2 - 1) * np.pi
+    src = rnd_c([m] if ttype == 'type_1' else grid, g)
+    plan = tfft.Plan(ttype, grid, 'forward', tol=tol, dtype=torch.complex64, device=dev)
+    info = plan.info()
+    res = torch.empty(grid if ttype == 'type_1' else [m], dtype=torch.complex64, device=dev)
+    step = lambda: plan.execute_with_points(pts, src, out=res)
+    for _ in range(2):
+      step()
+    ms = _event_timed(step, steps)
+    plan.set_timing(2)
+    plan.get_timing()
+    for _ in range(steps):
+      step()
+    tm = plan.get_timing()
+    plan.set_timing(False)
+    k_ms = tm[stage][0] / max(tm[stage][1], 1)
+    nf = [int(info.fine_dims[d]) for d in range(rank)]
+    algo = algorithmic_spread_bytes(m, nf, rank)   # (type 2: the fine grid is read, the results written: same count)
+    out[name] = {'ms_per_step': round(ms, 4), 'Gpts_s': round(m / ms / 1e6, 2), 'dominant_kernel': stage,
+                 'dominant_kernel_ms': round(k_ms, 4), 'algorithmic_bytes': algo,
+                 'hbm_frac': round(algo / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                 'kernel_width': int(info.kernel_width), 'fine_grid': nf[::-1], 'steps': steps}
+    plan.close()
+    del pts, src, res
+    torch.cuda.empty_cache()
+
+  plan_case('config3_2d_type2_1024_M1e7', 'type_2', GRID, M, TOL, 3, max(5, args.steps // 2), 'interp')
+  plan_case('config4_3d_type1_256_M1e8_tol1e-4', 'type_1', [256, 256, 256], 100_000_000, 1e-4, 4, 5, 'spread')
+
+  # config 5: one GPU's share at N = 8 (32 items), and the whole 256-item job on this GPU (the
+  # N = 1 anchor of the scaling curve), both through tfft.nufft with per-item points
+  g = torch.Generator(device=dev).manual_seed(5)
+  share = 32
+  pts = (torch.rand((share, C5_M, 2), generator=g, device=dev) * 2 - 1) * np.pi
+  c = rnd_c((share, C5_M), g)
+  call = lambda: tfft.nufft(c, pts, grid_shape=C5_GRID, transform_type='type_1', tol=TOL)
+  for _ in range(2):
+    call()
+  ms32 = _event_timed(call, max(5, args.steps // 5))
+  def whole():
+    for _ in range(C5_ITEMS // share):
+      call()
+  ms256 = _event_timed(whole, 3)
+  # dominant kernel of a group of 16 point sets, as the op runs them (one plan, num_point_sets = 16)
+  grp = 16
+  plan = tfft.Plan('type_1', C5_GRID, 'forward', tol=TOL, dtype=torch.complex64, device=dev, num_point_sets=grp)
+  info = plan.info()
+  pg, cg = pts[:grp].contiguous(), c[:grp].contiguous()
+  for _ in range(2):
+    plan.execute_with_points(pg, cg)
+  plan.set_timing(2)
+  plan.get_timing()
+  for _ in range(5):
+    plan.execute_with_points(pg, cg)
+  tm = plan.get_timing()
+  plan.close()
+  k_ms = tm['spread'][0] / max(tm['spread'][1], 1) / grp     # per item
+  nf = [int(info.fine_dims[d]) for d in range(2)]
+  algo = algorithmic_spread_bytes(C5_M, nf, 2)
+  c5 = {'dominant_kernel': 'spread', 'dominant_kernel_ms_per_item': round(k_ms, 4), 'algorithmic_bytes_per_item': algo,
+        'hbm_frac': round(algo / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), 'kernel_width': int(info.kernel_width),
+        'fine_grid': nf[::-1]}
+  out['config5_batched_2d_type1_512_32_items'] = dict(c5, ms_per_step=round(ms32, 4), Gpts_s=round(share * C5_M / ms32 / 1e6, 2))
+  out['config5_whole_job_256_items_one_gpu'] = dict(c5, ms_per_step=round(ms256, 4), Gpts_s=round(C5_ITEMS * C5_M / ms256 / 1e6, 2),
+                                                     note='the N = 1 anchor for the sharded runs (bench.py --gpus N reports this workload)')
+  return out
+
+
 def spawn_ranks(args, argv):
   """--gpus N > 1 without a launcher: one child process per rank, started before any GPU
   call in this process (a process that touched the GPU must not exec or fork workers)."""
-  port = int(os.environ.get('MASTER_PORT', '29533'))
+  if 'MASTER_PORT' in os.environ:
+    port = int(os.environ['MASTER_PORT'])
+  else:   # a free port picked by the kernel: two benches on one host do not collide
+    import socket
+    with socket.socket() as sk:
+      sk.bind(('127.0.0.1', 0))
+      port = sk.getsockname()[1]
   procs = []
   for r in range(args.gpus):
     env = dict(os.environ)
@@ -206,6 +310,7 @@ def main():
   ap.add_argument('--no-extras', action='store_true',
                   help='skip the informational legs (used under rocprofv3 so that its per-kernel '
                        'average covers the timed launches only)')
+  ap.add_argument('--no-other-configs', action='store_true', help='skip config.other_configs (configs 3, 4, 5 on this GPU)')
   ap.add_argument('--dist-backend', default='nccl', help='nccl (= RCCL, default) | gloo (testing)')
   ap.add_argument('--device', type=int, default=None, help='force a device index (testing)')
   ap.add_argument('--force-dist', action='store_true', help='initialise torch.distributed even at world size 1 (testing)')
@@ -230,7 +335,11 @@ def main():
   if world > 1 or args.force_dist:
     import torch.distributed as dist
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    os.environ.setdefault('MASTER_PORT', '29533')
+    if 'MASTER_PORT' not in os.environ:   # (--force-dist at world size 1: nobody else needs to know the port)
+      import socket
+      with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        os.environ['MASTER_PORT'] = str(sk.getsockname()[1])
     os.environ.setdefault('RANK', '0')
     os.environ.setdefault('WORLD_SIZE', '1')
     if args.dist_backend == 'nccl':
@@ -304,6 +413,7 @@ def run_config2(args, dev, dist, world, rank):
   stages = plan.get_timing()
   plan.set_timing(False)
 
+  lds_stats = lds_roofline(pts, info, stages['spread'][0] / max(stages['spread'][1], 1)) if rank == 0 else None
   extras = {}
   if not args.no_extras:
     # the two-call form (set_points, then execute with the strengths gathered through the
@@ -336,6 +446,9 @@ def run_config2(args, dev, dist, world, rank):
 
   if rank != 0:
     return None
+  if world == 1 and not args.no_extras and not args.no_other_configs:
+    plan.close()
+    extras['other_configs'] = other_configs(args, dev)
   ms_per_step = elapsed / args.steps * 1e3
   value = world * m / (elapsed / args.steps) / 1e6
   nf = [int(info.fine_dims[1]), int(info.fine_dims[0])]
@@ -362,7 +475,7 @@ def run_config2(args, dev, dist, world, rank):
           'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
           'traffic': traffic, 'traffic_source': 'offline: ' + traffic_src if traffic else None,
           'algorithmic_bytes': algo, 'kernel_ms': round(spread_ms, 4),
-          'lds': lds_roofline(pts, info, spread_ms),
+          'lds': lds_stats,
           'note': 'algorithmic bytes = M (4 d + 8) + 8 nf^d (SURVEY.md 8d). The kernel is bound by the LDS '
                   'pipe and its per-tile phases, not by HBM (DESIGN.md section 4): roofline.lds is the bound '
                   'that tracks it.',
@@ -427,13 +540,19 @@ def run_config5(args, dev, dist, world, rank):
       whole()
       torch.cuda.synchronize()
       t1 = time.perf_counter()
-      for _ in range(3):
+      for _ in range(args.steps):
         whole()
       torch.cuda.synchronize()
-      extras['one_gpu_whole_job_Mpts_s'] = round(items * m / ((time.perf_counter() - t1) / 3) / 1e6, 2)
+      extras['one_gpu_whole_job_Mpts_s'] = round(items * m / ((time.perf_counter() - t1) / args.steps) / 1e6, 2)
     if dist is not None:
       dist.barrier()
 
+  # ranks that actually took part, counted by the collective library itself
+  measured_world = 1
+  if dist is not None:
+    ones = torch.ones(1, dtype=torch.int32, device=dev if args.dist_backend == 'nccl' else 'cpu')
+    dist.all_reduce(ones)
+    measured_world = int(ones.item())
   if rank != 0:
     return None
   ms_per_step = elapsed / args.steps * 1e3
@@ -451,7 +570,7 @@ def run_config5(args, dev, dist, world, rank):
                       f'collective. The N=1 line of this script is configs[1] (a different workload); '
                       f'config.one_gpu_whole_job_Mpts_s is this workload on one GPU.',
           'items': items, 'items_per_rank': nloc, 'points_per_item': m, 'grid': C5_GRID,
-          'rccl_world_size': world if dist is not None else 1, 'backend': args.dist_backend if dist is not None else None,
+          'rccl_world_size': measured_world, 'backend': args.dist_backend if dist is not None else None,
           **extras,
       },
   }

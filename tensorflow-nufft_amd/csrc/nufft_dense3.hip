@@ -1,0 +1,419 @@
+// 3-D type-1 spreading for kernel widths 2..6 in single precision (tol >= 1e-4; BASELINE config 4),
+// packed fixed-point accumulation in LDS -- the kernel behind launch_spread for fixed-point plans.
+// Replaces the reference's SpreadSubproblem3D* kernels (nufft_plan.cu.cc:1295-1511: one thread per
+// point, w^3 pairs of shared-memory float atomics each).
+//
+// What the r02 kernel (spread_wave3_kernel<FX>) was bound by, measured (profiles/r03_pmc_cfg4.txt):
+// 65 VALU instructions per point -- the VALU busy for the whole 11.7 ms -- and 6 ds_add_u64 per point
+// with 36 of 64 lanes carrying a stencil cell. This kernel changes both:
+//
+//  * Lanes cover the stencil densely. A wave-instruction adds a W x YB x ZB block of cells (6 x 3 x 3
+//    = 54 lanes at W = 6; 4 x 4 x 4 = 64 at W = 4), and ceil(W / YB) * ceil(W / ZB) of them make a
+//    point: 4 ds_add_u64 at W = 6 (6 before), 1 at W <= 4 (W before). Which lane carries which cell
+//    is a compile-time table built so that the two 32-lane halves of the instruction each touch 32
+//    distinct 8-byte LDS columns (64 banks) whatever the point's position: row and plane strides are
+//    searched for, cells are dealt to the halves by their column, and the idle lanes (10 at W = 6)
+//    add 0 at the columns their half leaves free.
+//  * float -> packed fixed point costs two instructions per atomic instead of six: v_pk_fma_f32 onto
+//    1.5 * 2^23 leaves round-to-nearest(product) in the low mantissa bits of both halves of a register
+//    pair; read as one 64-bit integer that is (B + n_re) 2^32 + (B + n_im), B = 0x4B400000, and one
+//    v_lshl_add_u64 with the constant -B (2^32 + 1) turns it into n_re 2^32 + n_im: the sign extension
+//    of the low field folded into the high one, ready for ds_add_u64.
+//  * Kernel values reach the lanes through LDS as 16-byte reads that serve TWO points: per point the
+//    lane needs kx[x] (re c, im c), ky[y'], ky[y' + YB], kz[z'], kz[z' + ZB] -- three ds_read_b128 per
+//    point pair; no v_readlane broadcasts in the loop except the point's tile offset.
+//
+// LDS budget per point and CU at W = 6: 4 x 7.1 (ds_add_u64) + 1.5 x 6.1 (ds_read_b128) + staging
+// writes = ~39 cycles, against ~12 VALU instructions: the kernel is LDS-pipe bound by construction.
+//
+// Accumulation format (unchanged from r01/r02): one 64-bit integer per fine cell
+// holding (re, im) as two signed 32-bit fields in units of `step`, chosen per subproblem so that no
+// cell can overflow (sum of max(|re c|, |im c|) of the subproblem's strengths <= 2^31 steps) and no
+// single contribution leaves the exact range of the FMA conversion (|n| < 2^22). Tiles with more
+// subproblems than Geom::fx_max_subs are left to the fp64-plane kernels (nufft_kernels.hip).
+#include <hip/hip_runtime.h>
+
+#include "nufft_device.h"
+#include "nufft_hip_internal.h"
+
+namespace nufft_hip {
+
+namespace {
+
+constexpr int kDenseTile = 16;   // tile edge in x and y (the plan's 3-D tiles: 16 x 16 x {4, 8})
+constexpr int kDenseNW = 12;     // waves per workgroup (two workgroups per CU)
+
+// ---- compile-time lane layout -------------------------------------------------------------------
+
+constexpr int dense_yb(int W) { return W == 4 ? 4 : (W == 2 ? 2 : 3); }
+constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+struct DenseLayout {
+  int ls, ps;          // row / plane stride of the LDS tile in 8-byte elements
+  int rows, planes;    // allocated rows per plane and planes (incl. the rows / planes zero lanes spill into)
+  int cell[64];        // element offset of the lane's cell relative to the point's start cell
+  int sx[64], sy[64], sz[64];   // staging slots the lane reads: kx (W = the zero slot), ky, kz
+  bool ok;
+};
+
+// columns (8-byte elements mod 32 = bank pairs) hit by the W x YB x ZB block: at most two cells each
+constexpr bool dense_strides_ok(int W, int YB, int ZB, int ls, int ps) {
+  int cnt[32] = {};
+  for (int z = 0; z < ZB; ++z)
+    for (int y = 0; y < YB; ++y)
+      for (int x = 0; x < W; ++x) {
+        const int c = (x + y * ls + z * ps) & 31;
+        if (++cnt[c] > 2) return false;
+      }
+  return true;
+}
+
+constexpr DenseLayout make_dense_layout(int W, int TZ) {
+  DenseLayout L{};
+  const int YB = dense_yb(W), ZB = YB;
+  const int NYH = cdiv(W, YB), NZH = cdiv(W, ZB);
+  const int L0 = kDenseTile + W - 1;
+  L.rows = kDenseTile - 1 + YB * NYH;     // >= tile + W - 1
+  L.planes = TZ - 1 + ZB * NZH;
+  L.ok = false;
+  for (int ls = L0; ls < L0 + 12 && !L.ok; ++ls) {
+    for (int pad = 0; pad < 32 && !L.ok; ++pad) {
+      const int ps = ls * L.rows + pad;
+      if (dense_strides_ok(W, YB, ZB, ls, ps)) {
+        L.ls = ls;
+        L.ps = ps;
+        L.ok = true;
+      }
+    }
+  }
+  if (!L.ok) return L;
+  // deal the cells to the two 32-lane halves: one cell per column and half
+  bool used[2][32] = {};
+  int n[2] = {0, 0};
+  int half_of[64] = {};   // per cell index
+  int ncell = 0;
+  int cx[64] = {}, cy[64] = {}, cz[64] = {};
+  for (int z = 0; z < ZB; ++z)
+    for (int y = 0; y < YB; ++y)
+      for (int x = 0; x < W; ++x) {
+        const int col = (x + y * L.ls + z * L.ps) & 31;
+        int h = n[0] <= n[1] ? 0 : 1;
+        if (used[h][col]) h ^= 1;
+        used[h][col] = true;
+        ++n[h];
+        half_of[ncell] = h;
+        cx[ncell] = x; cy[ncell] = y; cz[ncell] = z;
+        ++ncell;
+      }
+  if (n[0] > 32 || n[1] > 32) { L.ok = false; return L; }
+  int next[2] = {0, 32};
+  for (int i = 0; i < ncell; ++i) {
+    const int lane = next[half_of[i]]++;
+    L.cell[lane] = cx[i] + cy[i] * L.ls + cz[i] * L.ps;
+    L.sx[lane] = cx[i]; L.sy[lane] = cy[i]; L.sz[lane] = cz[i];
+  }
+  // idle lanes: add 0 at a column their half leaves free
+  for (int h = 0; h < 2; ++h) {
+    int col = 0;
+    for (int lane = next[h]; lane < 32 * (h + 1); ++lane) {
+      while (used[h][col]) ++col;
+      used[h][col] = true;
+      L.cell[lane] = col;
+      L.sx[lane] = W;   // the zero slot
+      L.sy[lane] = 0; L.sz[lane] = 0;
+    }
+  }
+  return L;
+}
+
+template <int W, int TZ> struct DenseCfg {
+  static constexpr DenseLayout L = make_dense_layout(W, TZ);
+  static_assert(L.ok, "no conflict-free LDS strides found for this width");
+  static constexpr int YB = dense_yb(W), ZB = YB;
+  static constexpr int NYH = cdiv(W, YB), NZH = cdiv(W, ZB);
+  static constexpr int NW = kDenseNW;
+  static constexpr int SLOTS = W + 1 + YB + ZB;  // 16-byte staging slots per point pair
+  static constexpr int HALF = 16;               // points staged at a time per wave (64-point chunks stay in registers;
+                                                // 16 keep the workgroup at 66 KB of LDS at W = 6: two per CU)
+  static constexpr int plane_elems = L.ps * L.planes + 64;   // + room for the idle lanes' columns behind the last cell
+  static constexpr size_t stage_bytes = (size_t)NW * (HALF / 2) * SLOTS * 16;
+  static constexpr size_t lds_bytes = (size_t)plane_elems * 8 + stage_bytes + 2 * NW * sizeof(float) + 64;
+};
+
+// per-lane tables in constant memory (one 16-byte load per lane at kernel start)
+struct LaneTab { int cell[64]; int sx[64]; int sy[64]; int sz[64]; };
+template <int W, int TZ>
+constexpr LaneTab make_lane_tab() {
+  LaneTab t{};
+  constexpr DenseLayout L = DenseCfg<W, TZ>::L;
+  for (int i = 0; i < 64; ++i) { t.cell[i] = L.cell[i]; t.sx[i] = L.sx[i]; t.sy[i] = L.sy[i]; t.sz[i] = L.sz[i]; }
+  return t;
+}
+template <int W, int TZ> __constant__ const LaneTab kLaneTab = make_lane_tab<W, TZ>();
+
+// Piecewise-polynomial kernel values of the first W stencil cells in three dimensions (coefficient
+// loop outside: one wave-uniform row load feeds 3 W independent FMAs; cf. horner8, nufft_kernels.hip).
+constexpr int kDenseCoef = 10;
+template <int W>
+__device__ __forceinline__ void horner3(const float* __restrict__ tab, int nc, float z0, float z1, float z2,
+                                        float (&k0)[W], float (&k1)[W], float (&k2)[W]) {
+  if (nc <= kDenseCoef) {
+#pragma unroll
+    for (int q = 0; q < W; ++q) { const float t = tab[(kDenseCoef - 1) * kMaxW + q]; k0[q] = t; k1[q] = t; k2[q] = t; }
+#pragma unroll
+    for (int k = kDenseCoef - 2; k >= 0; --k) {
+#pragma unroll
+      for (int q = 0; q < W; ++q) {
+        const float t = tab[k * kMaxW + q];
+        k0[q] = fmaf(k0[q], z0, t); k1[q] = fmaf(k1[q], z1, t); k2[q] = fmaf(k2[q], z2, t);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < W; ++q) { const float t = tab[(nc - 1) * kMaxW + q]; k0[q] = t; k1[q] = t; k2[q] = t; }
+    for (int k = nc - 2; k >= 0; --k) {
+#pragma unroll
+      for (int q = 0; q < W; ++q) {
+        const float t = tab[k * kMaxW + q];
+        k0[q] = fmaf(k0[q], z0, t); k1[q] = fmaf(k1[q], z1, t); k2[q] = fmaf(k2[q], z2, t);
+      }
+    }
+  }
+}
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <int W, int TZ>
+__global__ __launch_bounds__(kDenseNW * 64) void spread_dense3_kernel(
+    Geom g, SortedPoints<float> sp, const float* __restrict__ horner, const float* __restrict__ c,
+    float* __restrict__ fw, int64_t c_stride, int64_t fw_stride, float scale) {
+  using C = DenseCfg<W, TZ>;
+  constexpr int LS = C::L.ls, PS = C::L.ps, NW = C::NW, YB = C::YB, ZB = C::ZB, NYH = C::NYH, NZH = C::NZH;
+  constexpr int L0 = kDenseTile + W - 1, L1 = kDenseTile + W - 1, L2 = TZ + W - 1;
+  constexpr int SLOTS = C::SLOTS, HALF = C::HALF;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned long long* plane = reinterpret_cast<unsigned long long*>(smem_raw);
+  unsigned char* stage_all = smem_raw + (size_t)C::plane_elems * 8;
+  float* red = reinterpret_cast<float*>(stage_all + C::stage_bytes);   // [2 NW]
+
+  int tb, p0, p1, slot, nsub;
+  if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1, &slot, &nsub)) return;
+  if (nsub > g.fx_max_subs) return;   // crowded tile: the fp64-plane launches behind this one take it
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: keeps the point loops' bounds in SGPRs)
+  for (int i = tid; i < C::plane_elems; i += NW * 64) plane[i] = 0ull;
+  const float2* cc = reinterpret_cast<const float2*>(c) + (int64_t)slot * c_stride;
+  const int npt = p1 - p0;
+
+  // step of the fixed-point grid (see the header comment): the subproblem's sum of max(|re c|, |im c|)
+  float part = 0.f;
+  for (int j = p0 + tid; j < p1; j += NW * 64) {
+    const float2 cv = cc[sp.rec[j].idx];
+    part += fmaxf(fabsf(cv.x), fabsf(cv.y));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o);
+  if (lane == 0) red[wave] = part;
+  // this wave's staging area: zero the kx slot the idle lanes read (never written again)
+  unsigned char* stage = stage_all + (size_t)wave * (HALF / 2) * SLOTS * 16;
+  if (lane < HALF / 2) *reinterpret_cast<v4f*>(stage + (lane * SLOTS + W) * 16) = (v4f){0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  float bound = 0.f;
+#pragma unroll
+  for (int k = 0; k < NW; ++k) bound += red[k];
+  const float amp = fabsf(scale) * g.fx_headroom;   // (the fitted polynomials overshoot 1 slightly)
+  // 2^31 minus the rounding of every contribution (npt of them + the <= 512 + npt / 2^22 extra parts below)
+  const float room = 2147482000.f - (float)npt;
+  const float step = bound * amp / room;
+  const float pre = step > 0.f ? scale / step : 0.f;
+  // A single contribution must stay below 2^22 steps (the exact range of the FMA conversion). A
+  // strength above 1 / 512 of the subproblem's sum -- few points, or one dominant strength -- is added
+  // in `rep` equal parts: the step, and with it the accuracy of every other point, stays what the sum asks for.
+  const float rep_scale = g.fx_headroom * (1.f / 4194000.f);
+
+  // lane constants
+  const int cell_b = kLaneTab<W, TZ>.cell[lane] * 8;
+  const int rd_x = kLaneTab<W, TZ>.sx[lane] * 16;
+  const int rd_y = (W + 1 + kLaneTab<W, TZ>.sy[lane]) * 16;
+  const int rd_z = (W + 1 + YB + kLaneTab<W, TZ>.sz[lane]) * 16;
+  const int nc = g.ncoef;
+  const int share = (npt + NW - 1) / NW;
+  const int wbeg = p0 + wave * share;
+  const int wend = (wbeg + share < p1) ? wbeg + share : p1;
+  const v2f magic = {12582912.f, 12582912.f};                 // 1.5 * 2^23
+  const unsigned long long unbias = 0ull - 0x4B4000004B400000ull;
+  unsigned char* plane_b = reinterpret_cast<unsigned char*>(plane);
+
+  for (int base = wbeg; base < wend; base += 64) {
+    // phase 1: one point per lane -- record, strength, 3 W kernel values
+    const int j = base + lane;
+    int off = 0, rep = 1;
+    float kx[W], ky[W], kz[W];
+    float cre = 0.f, cim = 0.f;
+#pragma unroll
+    for (int q = 0; q < W; ++q) { kx[q] = 0.f; ky[q] = 0.f; kz[q] = 0.f; }
+    if (j < wend) {
+      const PointView<float> rec = unpack_rec<float, 3>(sp.rec[j]);
+      const float2 cv = cc[rec.idx];
+      cre = cv.x * pre;
+      cim = cv.y * pre;
+      rep = (int)(fmaxf(fabsf(cre), fabsf(cim)) * rep_scale) + 1;
+      if (rep > 1) { cre /= (float)rep; cim /= (float)rep; }
+      off = ((int)(rec.loc & 1023) + (int)((rec.loc >> 10) & 1023) * LS + (int)((rec.loc >> 20) & 1023) * PS) * 8;
+      horner3<W>(horner, nc, rec.z0, rec.z1, rec.z2, kx, ky, kz);
+    }
+    int left = wend - base;
+    if (left > 64) left = 64;
+#pragma unroll
+    for (int h = 0; h < 64 / HALF; ++h) {
+      if (h * HALF >= left) break;
+      // stage HALF points: pair p holds points 2p, 2p + 1 of this round side by side in every 16-byte slot
+      if (lane / HALF == h) {
+        unsigned char* s = stage + (((lane % HALF) >> 1) * SLOTS) * 16 + (lane & 1) * 8;
+#pragma unroll
+        for (int x = 0; x < W; ++x) *reinterpret_cast<v2f*>(s + x * 16) = (v2f){kx[x] * cim, kx[x] * cre};
+#pragma unroll
+        for (int y = 0; y < YB; ++y)
+          *reinterpret_cast<v2f*>(s + (W + 1 + y) * 16) = (v2f){ky[y], (NYH > 1 && y + YB < W) ? ky[y + YB] : 0.f};
+#pragma unroll
+        for (int z = 0; z < ZB; ++z)
+          *reinterpret_cast<v2f*>(s + (W + 1 + YB + z) * 16) = (v2f){kz[z], (NZH > 1 && z + ZB < W) ? kz[z + ZB] : 0.f};
+      }
+      int npts = left - h * HALF;
+      if (npts > HALF) npts = HALF;
+      // phase 2: every lane adds its cell of every point; two points per staging read
+#pragma unroll 4
+      for (int p = 0; p < HALF / 2; ++p) {
+        if (2 * p >= npts) break;
+        const v4f rx = *reinterpret_cast<const v4f*>(stage + p * SLOTS * 16 + rd_x);
+        const v4f ry = *reinterpret_cast<const v4f*>(stage + p * SLOTS * 16 + rd_y);
+        const v4f rz = *reinterpret_cast<const v4f*>(stage + p * SLOTS * 16 + rd_z);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const v2f kxc = u ? (v2f){rx.z, rx.w} : (v2f){rx.x, rx.y};
+          const v2f kyv = u ? (v2f){ry.z, ry.w} : (v2f){ry.x, ry.y};
+          const v2f kzv = u ? (v2f){rz.z, rz.w} : (v2f){rz.x, rz.y};
+          const int o = __builtin_amdgcn_readlane(off, h * HALF + 2 * p + u) + cell_b;
+          unsigned char* dst = plane_b + o;
+#pragma unroll
+          for (int zh = 0; zh < NZH; ++zh) {
+            const float kzq = zh ? kzv.y : kzv.x;
+            const v2f yz = kyv * (v2f){kzq, kzq};
+#pragma unroll
+            for (int yh = 0; yh < NYH; ++yh) {
+              const float f = yh ? yz.y : yz.x;
+              const v2f fx = __builtin_elementwise_fma(kxc, (v2f){f, f}, magic);
+              const unsigned long long x = __builtin_bit_cast(unsigned long long, fx) + unbias;
+              atomicAdd(reinterpret_cast<unsigned long long*>(dst + (yh * YB * LS + zh * ZB * PS) * 8), x);
+            }
+          }
+        }
+      }
+    }
+    // the remaining rep - 1 parts of dominant strengths (rare: none for strengths of similar size)
+    unsigned long long pend = __ballot(rep > 1);
+    while (pend) {
+      const int src = __ffsll((long long)pend) - 1;
+      pend &= pend - 1;
+      if (lane == src) {   // staged alone as the first point of pair 0
+#pragma unroll
+        for (int x = 0; x < W; ++x) *reinterpret_cast<v2f*>(stage + x * 16) = (v2f){kx[x] * cim, kx[x] * cre};
+#pragma unroll
+        for (int y = 0; y < YB; ++y)
+          *reinterpret_cast<v2f*>(stage + (W + 1 + y) * 16) = (v2f){ky[y], (NYH > 1 && y + YB < W) ? ky[y + YB] : 0.f};
+#pragma unroll
+        for (int z = 0; z < ZB; ++z)
+          *reinterpret_cast<v2f*>(stage + (W + 1 + YB + z) * 16) = (v2f){kz[z], (NZH > 1 && z + ZB < W) ? kz[z + ZB] : 0.f};
+      }
+      const v4f rx = *reinterpret_cast<const v4f*>(stage + rd_x);
+      const v4f ry = *reinterpret_cast<const v4f*>(stage + rd_y);
+      const v4f rz = *reinterpret_cast<const v4f*>(stage + rd_z);
+      const v2f kxc = {rx.x, rx.y}, kyv = {ry.x, ry.y}, kzv = {rz.x, rz.y};
+      unsigned char* dst = plane_b + __builtin_amdgcn_readlane(off, src) + cell_b;
+      for (int r = __builtin_amdgcn_readlane(rep, src) - 1; r > 0; --r) {
+#pragma unroll
+        for (int zh = 0; zh < NZH; ++zh) {
+          const float kzq = zh ? kzv.y : kzv.x;
+          const v2f yz = kyv * (v2f){kzq, kzq};
+#pragma unroll
+          for (int yh = 0; yh < NYH; ++yh) {
+            const float f = yh ? yz.y : yz.x;
+            const v2f fx = __builtin_elementwise_fma(kxc, (v2f){f, f}, magic);
+            const unsigned long long x = __builtin_bit_cast(unsigned long long, fx) + unbias;
+            atomicAdd(reinterpret_cast<unsigned long long*>(dst + (yh * YB * LS + zh * ZB * PS) * 8), x);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // write-out: unpack, scale back, add to the periodic fine grid (consecutive lanes carry (re, im) of
+  // consecutive cells: contiguous bytes per wave-instruction)
+  const int t0 = tb % g.ntile[0];
+  const int t1 = (tb / g.ntile[0]) % g.ntile[1];
+  const int t2 = tb / (g.ntile[0] * g.ntile[1]);
+  const int o0 = t0 * kDenseTile, o1 = t1 * kDenseTile, o2 = t2 * TZ;
+  float* out = fw + 2 * (int64_t)slot * fw_stride;
+  for (RowWalk r(wave, L1); r.a2 < L2; r.advance(NW, L1)) {
+    const int g1 = wrap1(o1 + r.a1, g.nf[1]);
+    const int g2 = wrap1(o2 + r.a2, g.nf[2]);
+    const int64_t rowbase = (int64_t)g.nf[0] * (g1 + (int64_t)g.nf[1] * g2);
+    const int lrow = r.a2 * PS + r.a1 * LS;
+    for (int e = lane; e < 2 * L0; e += 64) {
+      const int a0 = e >> 1, comp = e & 1;
+      const long long t = (long long)plane[lrow + a0];
+      const int im_sum = (int)(unsigned)(t & 0xffffffffll);
+      const int re_sum = (int)((t - (long long)im_sum) >> 32);
+      const float v = (float)(comp ? im_sum : re_sum) * step;
+      if (v != 0.f) glb_add(&out[2 * (rowbase + wrap1(o0 + a0, g.nf[0])) + comp], v);
+    }
+  }
+}
+
+template <int W, int TZ>
+hipError_t launch_dense3(const Geom& g, const SortedPoints<float>& sp, const float* horner, const float* c, float* fw,
+                         dim3 grid, int64_t c_stride, int64_t fw_stride, float scale, hipStream_t stream) {
+  using C = DenseCfg<W, TZ>;
+  hipError_t e = hipSuccess;
+  if (C::lds_bytes > 64 * 1024)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(spread_dense3_kernel<W, TZ>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes);
+  if (e != hipSuccess) return e;
+  spread_dense3_kernel<W, TZ><<<grid, C::NW * 64, C::lds_bytes, stream>>>(g, sp, horner, c, fw, c_stride, fw_stride, scale);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+bool dense3_supported(const Geom& g, int precision) {
+  return precision == NUFFT_HIP_F32 && g.rank == 3 && g.fixed_point && g.w >= 2 && g.w <= 6 && g.tile[0] == kDenseTile &&
+         g.tile[1] == kDenseTile && (g.tile[2] == 4 || g.tile[2] == 8);
+}
+
+size_t dense3_lds_bytes(int w, int tz) {
+#define NUFFT_D3(WV) case WV: return tz == 8 ? DenseCfg<WV, 8>::lds_bytes : DenseCfg<WV, 4>::lds_bytes;
+  switch (w) {
+    NUFFT_D3(2) NUFFT_D3(3) NUFFT_D3(4) NUFFT_D3(5) NUFFT_D3(6)
+    default: return 0;
+  }
+#undef NUFFT_D3
+}
+
+hipError_t launch_spread_dense3(const Geom& g, const SortedPoints<float>& sp, unsigned nsub_bound, const float* horner,
+                                const float* c, float* fw, int batch, int64_t c_stride, int64_t fw_stride, float scale,
+                                hipStream_t stream) {
+  const dim3 grid(nsub_bound, (unsigned)batch);
+#define NUFFT_D3(WV)                                                                                                  \
+  case WV:                                                                                                            \
+    return g.tile[2] == 8 ? launch_dense3<WV, 8>(g, sp, horner, c, fw, grid, c_stride, fw_stride, scale, stream)      \
+                          : launch_dense3<WV, 4>(g, sp, horner, c, fw, grid, c_stride, fw_stride, scale, stream);
+  switch (g.w) {
+    NUFFT_D3(2) NUFFT_D3(3) NUFFT_D3(4) NUFFT_D3(5) NUFFT_D3(6)
+    default: return hipErrorInvalidValue;
+  }
+#undef NUFFT_D3
+}
+
+}  // namespace nufft_hip

@@ -196,6 +196,12 @@ template <typename T>
 hipError_t launch_spread_wide(const Geom& g, const SortedPoints<T>& sp, int64_t M, const T* horner, const T* c,
                               T* fw, int batch, int64_t c_stride, int64_t fw_stride, T scale,
                               hipStream_t stream);
+// 3-D float fixed-point spreading for w <= 6 (nufft_dense3.hip): lanes cover the stencil densely
+bool dense3_supported(const Geom& g, int precision);
+size_t dense3_lds_bytes(int w, int tile_depth);
+hipError_t launch_spread_dense3(const Geom& g, const SortedPoints<float>& sp, unsigned nsub_bound, const float* horner,
+                                const float* c, float* fw, int batch, int64_t c_stride, int64_t fw_stride, float scale,
+                                hipStream_t stream);
 int wave3_pad(int w);   // spill elements behind the LDS planes of the 3-D wavefront kernel
 bool sparse_wanted(const Geom& g, int64_t M);   // point set sparse enough for the LDS-free spreader
 bool wave_method_supported(const Geom& g, int precision);

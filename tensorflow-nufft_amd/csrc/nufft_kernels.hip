@@ -1648,8 +1648,14 @@ __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
     // slightly (w = 4: 1.00001 per dimension), which g.fx_headroom (>= 1, from the host fit) covers
     bound *= fabsf((float)scale) * g.fx_headroom;
     const float room = 2147483000.f - (float)npt;   // 2^31 minus the rounding of every contribution
-    pre = bound > 0.f ? (T)((float)scale * (room / bound)) : (T)0;
-    lsb = bound > 0.f ? (T)(bound / room) : (T)0;
+    // A single contribution must stay below 2^22 steps: the float -> fixed conversion is an FMA onto
+    // 1.5 * 2^23 (see the loop), exact for |n| < 2^22. A strength above 1 / 512 of the subproblem's
+    // sum (few points, or one dominant strength) is added in `rep` equal parts instead (<= 512 + 1
+    // extra passes per subproblem): the step, and with it the accuracy of every other point, stays
+    // what the sum alone asks for.
+    const float step = bound / (room - 1100.f);
+    pre = step > 0.f ? (T)((float)scale / step) : (T)0;
+    lsb = (T)step;
   }
   if (I64 && !FX) {
     float part = 0.f;
@@ -1683,7 +1689,7 @@ __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
 
   for (int base = wbeg; base < wend; base += CH) {
     const int j = base + lane;
-    int off = 0;
+    int off = 0, rep = 1;
     T kz[W];
     T cre = (T)0, cim = (T)0;
 #pragma unroll
@@ -1697,6 +1703,10 @@ __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
         const T2 cv = cc[rec.idx];
         cre = cv.x * pre;
         cim = cv.y * pre;
+        if (FX) {   // parts of at most 2^22 steps each (see the prelude)
+          rep = (int)(fmaxf(fabsf((float)cre), fabsf((float)cim)) * g.fx_headroom * (1.f / 4194000.f)) + 1;
+          if (rep > 1) { cre /= (T)rep; cim /= (T)rep; }
+        }
         off = (int)(rec.loc & 1023) + (int)((rec.loc >> 10) & 1023) * LS + (int)((rec.loc >> 20) & 1023) * PS;
         T h0[8], h1[8], h2[8];
         horner8<T, 3>(horner, nc, rec.z0, rec.z1, rec.z2, h0, h1, h2);
@@ -1729,18 +1739,23 @@ __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
       // component plane / the 64-element pad behind the planes.
       double* pr = plane_re + o;
       double* pi = plane_im + o;
+      int reps = FX ? __builtin_amdgcn_readlane(rep, q) : 1;   // (1 unless the strength dominates its subproblem)
+      do {
 #pragma unroll
       for (int dz = 0; dz < W; ++dz) {
         const T kzq = bcast_lane(kz[dz], q);
         if (FX) {
-          // v_cvt_rpi_i32_f32 = floor(x + 0.5) in ONE instruction (__float2int_rn is
-          // v_rndne + v_cvt); the loop is VALU-issue bound, every instruction counts
+          // float -> packed fixed point in TWO instructions: v_pk_fma_f32 onto the magic number
+          // 1.5 * 2^23 leaves round-to-nearest(product) in the low mantissa bits of either half,
+          // i.e. the register pair read as one 64-bit integer is (B + n_re) 2^32 + (B + n_im) with
+          // B = 0x4B400000 and B + n_im > 0; subtracting the constant B (2^32 + 1) (one v_lshl_add_u64)
+          // leaves n_re 2^32 + n_im, the sign extension of the low field folded into the high one.
+          // (r02: v_pk_mul + 2 v_cvt_rpi + shift + add + pack = 6 instructions per atomic; the loop
+          // was VALU-issue bound at 53 instructions per point.)
           typedef float v2f __attribute__((ext_vector_type(2)));
-          const v2f pr2 = (v2f){(float)ar, (float)ai} * (v2f){(float)kzq, (float)kzq};   // one v_pk_mul_f32
-          const int ir = cvt_rpi(pr2.x);
-          const int ii = cvt_rpi(pr2.y);
-          const unsigned hi = (unsigned)(ir + (ii >> 31));   // + sign extension of the low field
-          const unsigned long long x = ((unsigned long long)hi << 32) | (unsigned)ii;
+          const v2f fx = __builtin_elementwise_fma((v2f){(float)ai, (float)ar}, (v2f){(float)kzq, (float)kzq},
+                                                   (v2f){12582912.f, 12582912.f});
+          const unsigned long long x = __builtin_bit_cast(unsigned long long, fx) - 0x4B4000004B400000ull;
           atomicAdd(reinterpret_cast<unsigned long long*>(pr) + dz * PS, x);
         } else if (I64) {
           if (COMP != 2) {
@@ -1756,6 +1771,7 @@ __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
           if (COMP != 1) lds_add(pi + dz * PS, (double)(ai * kzq));
         }
       }
+      } while (FX && --reps > 0);
     }
   }
   __syncthreads();
@@ -2530,6 +2546,8 @@ size_t spread_lds_bytes(const Geom& g, int method, int precision) {
                       g.w == kWW ? wave8_lds(false) : wave2_lds(g, precision));
     if (g.rank == 2)
       return group2d_geometry(g) ? std::max(wave2_lds(g, precision), group_lds(8, 64, false, precision)) : wave2_lds(g, precision);
+    if (dense3_supported(g, precision))   // (and the fp64-plane launches behind it for crowded tiles)
+      return std::max(dense3_lds_bytes(g.w, g.tile[2]), wave3_split_lds(g));
     const int nw = g.split_reim ? 12 : wave3d_nw_rt(precision, g.fixed_point != 0);
     const int ch = (g.split_reim && g.tile[2] == 8) ? 16 : 32;   // (staging chunk: keeps two workgroups per CU)
     if (g.split_reim && g.tile[2] == 8 && g.w == 8) return wave3_joint_lds(g);   // the larger of the two forms
@@ -2735,7 +2753,8 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
       } else if constexpr (WW <= 6) {                                                            \
         if (g.fixed_point) {                                                                     \
           if constexpr (sizeof(T) == 4) {                                                        \
-            NUFFT_LAUNCH_W3(WW, 8, true)                                                         \
+            e = launch_spread_dense3(g, sp, grid.x, horner, c, fw, batch, c_stride, fw_stride, scale, stream); \
+            if (e != hipSuccess) return e;                                                       \
             if (Md > (int64_t)g.fx_max_subs * g.max_sub) {   /* a tile may be crowded: fp64 planes for those */ \
               lds_bytes = wave3_split_lds(g);                                                    \
               NUFFT_LAUNCH_W3S(WW, 8, 1) NUFFT_LAUNCH_W3S(WW, 8, 2)                               \
@@ -2746,7 +2765,10 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
     } else if (g.tile[2] == 4) {                                                                 \
       if (g.fixed_point) {                                                                       \
         if constexpr (sizeof(T) == 4) {                                                          \
-          NUFFT_LAUNCH_W3(WW, 4, true)                                                           \
+          if constexpr (WW <= 6) {   /* nufft_dense3.hip */                                      \
+            e = launch_spread_dense3(g, sp, grid.x, horner, c, fw, batch, c_stride, fw_stride, scale, stream); \
+            if (e != hipSuccess) return e;                                                       \
+          } else { NUFFT_LAUNCH_W3(WW, 4, true) }                                                \
           if (Md > (int64_t)g.fx_max_subs * g.max_sub) {                                         \
             lds_bytes = wave3_split_lds(g);                                                      \
             NUFFT_LAUNCH_W3S(WW, 4, 1) NUFFT_LAUNCH_W3S(WW, 4, 2)                                 \

@@ -592,6 +592,30 @@ def test_config4_geometry_total_parity_at_1e7_points(tfft):
   assert d32 <= 1e-4 + e32, (d32, e32)
 
 
+def test_config4_total_parity_at_full_size(tfft):
+  # BASELINE config 4 in full (default_rng(4), M = 1e8 points, 256^3 modes, tol 1e-4, complex64): the WHOLE result
+  # against the fp64 oracle at sigma 2, tol 1e-8 (about half a minute on the GPU box's host cores).
+  import time
+  import torch
+  from oracle import oracle
+  rng = np.random.default_rng(4)
+  M, N = 100_000_000, 256
+  pts = rng.uniform(-np.pi, np.pi, (M, 3)).astype(np.float32)
+  c = np.empty(M, np.complex64)
+  c.real = rng.uniform(-.5, .5, M)
+  c.imag = rng.uniform(-.5, .5, M)
+  out = tfft.nufft(_dev(c), _dev(pts), grid_shape=[N, N, N], transform_type='type_1', fft_direction='forward',
+                   tol=1e-4).cpu().numpy()
+  torch.cuda.empty_cache()
+  t0 = time.time()
+  truth = oracle.nufft(c.astype(np.complex128), pts, [N, N, N], 'type_1', 'forward', tol=1e-8, sigma=2.0)
+  t_truth = time.time() - t0
+  err = rel_l2(out, truth)
+  _note(f'config 4 (3D type 1, 256^3, M=1e8, tol 1e-4, c64), all {N ** 3} outputs: ours-truth {err:.3e}; '
+        f'max |ours-truth| / max |truth| {np.abs(out - truth).max() / np.abs(truth).max():.3e}; oracle truth {t_truth:.1f} s')
+  assert err <= 1e-4, err
+
+
 def test_spread_on_a_type2_interp_geometry_plan(tfft):
   # a spread_only type-2 float plan on a fine grid of >= 2^21 cells takes 64 x 64 tiles (the interp kernel's
   # geometry); nufft_hip_spread on it must still be right (r02 advisor finding: it ran the 32 x 32 wave kernel)
