@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define NUFFT_HIP_ABI_VERSION 2
+#define NUFFT_HIP_ABI_VERSION 3
 
 /* Status codes. They map onto the tensorflow::errors the reference returns. */
 enum {
@@ -91,8 +91,34 @@ typedef struct nufft_hip_options {
                                   one pass): set_points takes K * num_points points, set k at
                                   [k num_points, (k+1) num_points); c is [K][ntransf][M], f [K][ntransf][grid];
                                   every transform of every set is in flight together (one fine grid each) */
-  int32_t reserved[6];
+  int32_t tuning;              /* NUFFT_HIP_TUNE_* bits: forces one of the kernel families that the plan otherwise
+                                  chooses between by point density / geometry (second-opinion tests, A/B
+                                  measurements). Results do not depend on it beyond rounding. 0 = automatic */
+  int32_t op_group;            /* op-level entry: point sets handled per plan call; 0 = auto (16), 1 = one at a time */
+  int32_t op_lanes;            /* op-level entry: plans pipelined on private streams, 1..4; 0 = auto (2) */
+  int32_t reserved[3];
 } nufft_hip_options;
+
+/* nufft_hip_options.tuning (every OFF / ON pair: neither bit = by the plan's density / geometry rule) */
+enum {
+  NUFFT_HIP_TUNE_NO_FUSED = 1 << 0,        /* execute_with_points never sorts the strengths into the records */
+  NUFFT_HIP_TUNE_GROUP_OFF = 1 << 1,       /* 2-D cell-grouped spreader (spread_2d_w8_group_kernel): never / always */
+  NUFFT_HIP_TUNE_GROUP_ON = 1 << 2,
+  NUFFT_HIP_TUNE_SPARSE_OFF = 1 << 3,      /* LDS-free spreader under spread_method AUTO: never / always */
+  NUFFT_HIP_TUNE_SPARSE_ON = 1 << 4,
+  NUFFT_HIP_TUNE_CELLSORT_OFF = 1 << 5,    /* 2-D: records reordered by start cell on plan reuse: never / always */
+  NUFFT_HIP_TUNE_CELLSORT_ON = 1 << 6,
+  NUFFT_HIP_TUNE_CELLSORT3D_OFF = 1 << 7,  /* 3-D type 2: records ordered by start cell in set_points: never / always */
+  NUFFT_HIP_TUNE_CELLSORT3D_ON = 1 << 8,
+  NUFFT_HIP_TUNE_ROCFFT = 1 << 9,          /* rocFFT + deconvolve kernel instead of the pruned FFT passes */
+  NUFFT_HIP_TUNE_NO_WIDE = 1 << 10,        /* w = 9..16 on the thread-per-point tile kernels */
+  NUFFT_HIP_TUNE_NO_LINE = 1 << 11,        /* 1-D type 2 on the gather-from-global kernel */
+  NUFFT_HIP_TUNE_JOINT_OFF = 1 << 12,      /* 3-D float w = 8: both fp64 planes in one launch: never / always */
+  NUFFT_HIP_TUNE_JOINT_ON = 1 << 13,
+  NUFFT_HIP_TUNE_STAGED_OFF = 1 << 14,     /* staged scatter (<= 1024 tiles per point set): never / always */
+  NUFFT_HIP_TUNE_STAGED_ON = 1 << 15,
+  NUFFT_HIP_TUNE_T1_BIG_TILES = 1 << 16    /* experiment: 2-D float type-1 plans at w = 8 on 64 x 64 tiles */
+};
 
 typedef struct nufft_hip_plan_s* nufft_hip_plan;
 

@@ -10,10 +10,10 @@
 //  * Lanes cover the stencil densely. A wave-instruction adds a W x YB x ZB block of cells (6 x 3 x 3
 //    = 54 lanes at W = 6; 4 x 4 x 4 = 64 at W = 4), and ceil(W / YB) * ceil(W / ZB) of them make a
 //    point: 4 ds_add_u64 at W = 6 (6 before), 1 at W <= 4 (W before). Which lane carries which cell
-//    is a compile-time table built so that the two 32-lane halves of the instruction each touch 32
-//    distinct 8-byte LDS columns (64 banks) whatever the point's position: row and plane strides are
-//    searched for, cells are dealt to the halves by their column, and the idle lanes (10 at W = 6)
-//    add 0 at the columns their half leaves free.
+//    is a compile-time table built so that each of the four 16-lane groups an LDS atomic is served in
+//    touches 16 distinct 8-byte LDS columns (32 banks) whatever the point's position: row and plane
+//    strides are searched for, cells are dealt to the groups by their column, and the idle lanes (10 at
+//    W = 6) add 0 at the columns their group leaves free.
 //  * float -> packed fixed point costs two instructions per atomic instead of six: v_pk_fma_f32 onto
 //    1.5 * 2^23 leaves round-to-nearest(product) in the low mantissa bits of both halves of a register
 //    pair; read as one 64-bit integer that is (B + n_re) 2^32 + (B + n_im), B = 0x4B400000, and one
@@ -56,14 +56,17 @@ struct DenseLayout {
   bool ok;
 };
 
-// columns (8-byte elements mod 32 = bank pairs) hit by the W x YB x ZB block: at most two cells each
+// An LDS atomic of 8 bytes per lane is served in four groups of 16 consecutive lanes, each across 32 banks
+// (measured, tools/ubench/lds_pattern_bench.hip: 16-lane groups on the same 16 columns do not conflict, two
+// 8-lane groups on the same 8 columns do): a group is conflict free when its 16 cells lie in 16 distinct
+// columns, column = 8-byte element index mod 16. Strides: no column may hold more than 4 of the block's cells.
 constexpr bool dense_strides_ok(int W, int YB, int ZB, int ls, int ps) {
-  int cnt[32] = {};
+  int cnt[16] = {};
   for (int z = 0; z < ZB; ++z)
     for (int y = 0; y < YB; ++y)
       for (int x = 0; x < W; ++x) {
-        const int c = (x + y * ls + z * ps) & 31;
-        if (++cnt[c] > 2) return false;
+        const int c = (x + y * ls + z * ps) & 15;
+        if (++cnt[c] > 4) return false;
       }
   return true;
 }
@@ -77,7 +80,7 @@ constexpr DenseLayout make_dense_layout(int W, int TZ) {
   L.planes = TZ - 1 + ZB * NZH;
   L.ok = false;
   for (int ls = L0; ls < L0 + 12 && !L.ok; ++ls) {
-    for (int pad = 0; pad < 32 && !L.ok; ++pad) {
+    for (int pad = 0; pad < 16 && !L.ok; ++pad) {
       const int ps = ls * L.rows + pad;
       if (dense_strides_ok(W, YB, ZB, ls, ps)) {
         L.ls = ls;
@@ -87,37 +90,31 @@ constexpr DenseLayout make_dense_layout(int W, int TZ) {
     }
   }
   if (!L.ok) return L;
-  // deal the cells to the two 32-lane halves: one cell per column and half
-  bool used[2][32] = {};
-  int n[2] = {0, 0};
-  int half_of[64] = {};   // per cell index
-  int ncell = 0;
-  int cx[64] = {}, cy[64] = {}, cz[64] = {};
+  // deal the cells to the four 16-lane groups: one cell per column and group
+  bool used[4][16] = {};
+  int n[4] = {0, 0, 0, 0};
+  int lane_of_next[4] = {0, 16, 32, 48};
   for (int z = 0; z < ZB; ++z)
     for (int y = 0; y < YB; ++y)
       for (int x = 0; x < W; ++x) {
-        const int col = (x + y * L.ls + z * L.ps) & 31;
-        int h = n[0] <= n[1] ? 0 : 1;
-        if (used[h][col]) h ^= 1;
-        used[h][col] = true;
-        ++n[h];
-        half_of[ncell] = h;
-        cx[ncell] = x; cy[ncell] = y; cz[ncell] = z;
-        ++ncell;
+        const int cell = x + y * L.ls + z * L.ps;
+        const int col = cell & 15;
+        int best = -1;
+        for (int grp = 0; grp < 4; ++grp)
+          if (!used[grp][col] && (best < 0 || n[grp] < n[best])) best = grp;
+        if (best < 0) { L.ok = false; return L; }
+        used[best][col] = true;
+        ++n[best];
+        const int lane = lane_of_next[best]++;
+        L.cell[lane] = cell;
+        L.sx[lane] = x; L.sy[lane] = y; L.sz[lane] = z;
       }
-  if (n[0] > 32 || n[1] > 32) { L.ok = false; return L; }
-  int next[2] = {0, 32};
-  for (int i = 0; i < ncell; ++i) {
-    const int lane = next[half_of[i]]++;
-    L.cell[lane] = cx[i] + cy[i] * L.ls + cz[i] * L.ps;
-    L.sx[lane] = cx[i]; L.sy[lane] = cy[i]; L.sz[lane] = cz[i];
-  }
-  // idle lanes: add 0 at a column their half leaves free
-  for (int h = 0; h < 2; ++h) {
+  // idle lanes: add 0 at a column their group leaves free
+  for (int grp = 0; grp < 4; ++grp) {
     int col = 0;
-    for (int lane = next[h]; lane < 32 * (h + 1); ++lane) {
-      while (used[h][col]) ++col;
-      used[h][col] = true;
+    for (int lane = lane_of_next[grp]; lane < 16 * (grp + 1); ++lane) {
+      while (used[grp][col]) ++col;
+      used[grp][col] = true;
       L.cell[lane] = col;
       L.sx[lane] = W;   // the zero slot
       L.sy[lane] = 0; L.sz[lane] = 0;
@@ -135,7 +132,9 @@ template <int W, int TZ> struct DenseCfg {
   static constexpr int SLOTS = W + 1 + YB + ZB;  // 16-byte staging slots per point pair
   static constexpr int HALF = 16;               // points staged at a time per wave (64-point chunks stay in registers;
                                                 // 16 keep the workgroup at 66 KB of LDS at W = 6: two per CU)
-  static constexpr int plane_elems = L.ps * L.planes + 64;   // + room for the idle lanes' columns behind the last cell
+  // (+ room for the idle lanes' columns behind the last cell; even: the staging area behind it is read 16 bytes at
+  // a time, and a ds_read_b128 at an address that is not a multiple of 16 costs ~60 stall cycles)
+  static constexpr int plane_elems = (L.ps * L.planes + 64 + 1) & ~1;
   static constexpr size_t stage_bytes = (size_t)NW * (HALF / 2) * SLOTS * 16;
   static constexpr size_t lds_bytes = (size_t)plane_elems * 8 + stage_bytes + 2 * NW * sizeof(float) + 64;
 };
@@ -184,7 +183,8 @@ __device__ __forceinline__ void horner3(const float* __restrict__ tab, int nc, f
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-template <int W, int TZ>
+// FUSED: the records are FusedRec3 (strength behind the 16-byte record): nothing is gathered.
+template <int W, int TZ, bool FUSED>
 __global__ __launch_bounds__(kDenseNW * 64) void spread_dense3_kernel(
     Geom g, SortedPoints<float> sp, const float* __restrict__ horner, const float* __restrict__ c,
     float* __restrict__ fw, int64_t c_stride, int64_t fw_stride, float scale) {
@@ -204,12 +204,15 @@ __global__ __launch_bounds__(kDenseNW * 64) void spread_dense3_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: keeps the point loops' bounds in SGPRs)
   for (int i = tid; i < C::plane_elems; i += NW * 64) plane[i] = 0ull;
   const float2* cc = reinterpret_cast<const float2*>(c) + (int64_t)slot * c_stride;
+  const FusedRec3* rec3 = reinterpret_cast<const FusedRec3*>(sp.rec);
   const int npt = p1 - p0;
 
   // step of the fixed-point grid (see the header comment): the subproblem's sum of max(|re c|, |im c|)
   float part = 0.f;
   for (int j = p0 + tid; j < p1; j += NW * 64) {
-    const float2 cv = cc[sp.rec[j].idx];
+    float2 cv;
+    if constexpr (FUSED) cv = *reinterpret_cast<const float2*>(&rec3[j].re);
+    else cv = cc[sp.rec[j].idx];
     part += fmaxf(fabsf(cv.x), fabsf(cv.y));
   }
 #pragma unroll
@@ -254,8 +257,16 @@ __global__ __launch_bounds__(kDenseNW * 64) void spread_dense3_kernel(
 #pragma unroll
     for (int q = 0; q < W; ++q) { kx[q] = 0.f; ky[q] = 0.f; kz[q] = 0.f; }
     if (j < wend) {
-      const PointView<float> rec = unpack_rec<float, 3>(sp.rec[j]);
-      const float2 cv = cc[rec.idx];
+      float2 cv;
+      PointView<float> rec;
+      if constexpr (FUSED) {
+        const FusedRec3 f = rec3[j];   // two 16-byte loads
+        rec = unpack_rec<float, 3>(f.r);
+        cv = make_float2(f.re, f.im);
+      } else {
+        rec = unpack_rec<float, 3>(sp.rec[j]);
+        cv = cc[rec.idx];
+      }
       cre = cv.x * pre;
       cim = cv.y * pre;
       rep = (int)(fmaxf(fabsf(cre), fabsf(cim)) * rep_scale) + 1;
@@ -372,16 +383,16 @@ __global__ __launch_bounds__(kDenseNW * 64) void spread_dense3_kernel(
   }
 }
 
-template <int W, int TZ>
+template <int W, int TZ, bool FUSED>
 hipError_t launch_dense3(const Geom& g, const SortedPoints<float>& sp, const float* horner, const float* c, float* fw,
                          dim3 grid, int64_t c_stride, int64_t fw_stride, float scale, hipStream_t stream) {
   using C = DenseCfg<W, TZ>;
   hipError_t e = hipSuccess;
   if (C::lds_bytes > 64 * 1024)
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(spread_dense3_kernel<W, TZ>),
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(spread_dense3_kernel<W, TZ, FUSED>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes);
   if (e != hipSuccess) return e;
-  spread_dense3_kernel<W, TZ><<<grid, C::NW * 64, C::lds_bytes, stream>>>(g, sp, horner, c, fw, c_stride, fw_stride, scale);
+  spread_dense3_kernel<W, TZ, FUSED><<<grid, C::NW * 64, C::lds_bytes, stream>>>(g, sp, horner, c, fw, c_stride, fw_stride, scale);
   return hipGetLastError();
 }
 
@@ -407,8 +418,11 @@ hipError_t launch_spread_dense3(const Geom& g, const SortedPoints<float>& sp, un
   const dim3 grid(nsub_bound, (unsigned)batch);
 #define NUFFT_D3(WV)                                                                                                  \
   case WV:                                                                                                            \
-    return g.tile[2] == 8 ? launch_dense3<WV, 8>(g, sp, horner, c, fw, grid, c_stride, fw_stride, scale, stream)      \
-                          : launch_dense3<WV, 4>(g, sp, horner, c, fw, grid, c_stride, fw_stride, scale, stream);
+    if (g.fused)                                                                                                      \
+      return g.tile[2] == 8 ? launch_dense3<WV, 8, true>(g, sp, horner, c, fw, grid, c_stride, fw_stride, scale, stream)  \
+                            : launch_dense3<WV, 4, true>(g, sp, horner, c, fw, grid, c_stride, fw_stride, scale, stream); \
+    return g.tile[2] == 8 ? launch_dense3<WV, 8, false>(g, sp, horner, c, fw, grid, c_stride, fw_stride, scale, stream)   \
+                          : launch_dense3<WV, 4, false>(g, sp, horner, c, fw, grid, c_stride, fw_stride, scale, stream);
   switch (g.w) {
     NUFFT_D3(2) NUFFT_D3(3) NUFFT_D3(4) NUFFT_D3(5) NUFFT_D3(6)
     default: return hipErrorInvalidValue;

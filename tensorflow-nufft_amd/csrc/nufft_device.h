@@ -9,12 +9,6 @@ namespace nufft_hip {
 namespace {
 
 __device__ __forceinline__ void lds_add(double* p, double v) { unsafeAtomicAdd(p, v); }
-// float -> int, rounding half up, as one VALU instruction
-__device__ __forceinline__ int cvt_rpi(float x) {
-  int r;
-  asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
-  return r;
-}
 __device__ __forceinline__ void glb_add(float* p, float v) { unsafeAtomicAdd(p, v); }
 __device__ __forceinline__ void glb_add(double* p, double v) { unsafeAtomicAdd(p, v); }
 
@@ -46,6 +40,12 @@ __device__ __forceinline__ PointView<float> unpack_rec<float, 3>(const Rec<float
 template <> __device__ __forceinline__ PointView<double> unpack_rec<double, 1>(const Rec<double>& r) { return {r.loc, r.z0, r.z1, r.z2, r.idx}; }
 template <> __device__ __forceinline__ PointView<double> unpack_rec<double, 2>(const Rec<double>& r) { return {r.loc, r.z0, r.z1, r.z2, r.idx}; }
 template <> __device__ __forceinline__ PointView<double> unpack_rec<double, 3>(const Rec<double>& r) { return {r.loc, r.z0, r.z1, r.z2, r.idx}; }
+
+// Record j of an array whose records lie `stride` bytes apart (16 / 32 for float, see FusedRec3)
+template <typename T>
+__device__ __forceinline__ const Rec<T>& rec_at(const Rec<T>* base, int j, int stride) {
+  return *reinterpret_cast<const Rec<T>*>(reinterpret_cast<const unsigned char*>(base) + (size_t)j * (size_t)stride);
+}
 
 // Rows (a1, a2) of an LDS tile are dealt to waves; lanes run along x. No
 // integer division or 64-bit modulo per cell (a generic `i % L0`, `% nf` walk

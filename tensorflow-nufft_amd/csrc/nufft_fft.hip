@@ -384,16 +384,14 @@ template <typename T, int LOGN>
 hipError_t launch_fft_pass(const FftPassArgs<T>& a, bool pad, bool gather, unsigned nblk, unsigned batch, size_t lds,
                            hipStream_t stream) {
   if (pad && a.kout != a.n) return hipErrorInvalidValue;   // a pass either pads or crops
-  if (gather && !pad) return hipErrorInvalidValue;
+  if (gather != pad) return hipErrorInvalidValue;          // (type 2 = padding passes in gather form, type 1 = cropping scatter-out passes)
   const void* fn = gather ? reinterpret_cast<const void*>(fft_rotate_kernel<T, LOGN, true, true>)
-                   : pad  ? reinterpret_cast<const void*>(fft_rotate_kernel<T, LOGN, true>)
                           : reinterpret_cast<const void*>(fft_rotate_kernel<T, LOGN, false>);
   if (lds > 64 * 1024) {
     const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
   if (gather) fft_rotate_kernel<T, LOGN, true, true><<<dim3(nblk, batch), a.LW * (a.n / 8), lds, stream>>>(a);
-  else if (pad) fft_rotate_kernel<T, LOGN, true><<<dim3(nblk, batch), a.LW * (a.n / 8), lds, stream>>>(a);
   else fft_rotate_kernel<T, LOGN, false><<<dim3(nblk, batch), a.LW * (a.n / 8), lds, stream>>>(a);
   return hipGetLastError();
 }
@@ -438,8 +436,7 @@ int fft_pass_shape(int n, int kout, int csize, int64_t nlines, int* lw_out, size
 }  // namespace
 
 bool pruned_fft_supported(const Geom& g, int precision) {
-  static const bool off = getenv("NUFFT_HIP_NO_OWN_FFT") != nullptr;   // A/B against rocFFT + deconvolve
-  if (off) return false;
+  if (g.tuning & NUFFT_HIP_TUNE_ROCFFT) return false;   // second opinion / A/B: rocFFT + deconvolve kernel
   const int csize = 2 * precision;
   for (int d = 0; d < g.rank; ++d) {
     size_t lds;
@@ -487,8 +484,7 @@ hipError_t launch_pruned_fft(const Geom& g, int type, int iflag, T* fine, T* f, 
   // Type 2 (gather form) walks them SLOWEST first: the dimension's lines lie interleaved in the
   // input ([element][line]: the strided, still small side) and leave contiguous ([line][bin]);
   // after rank passes the layout is back to x fastest either way.
-  static const bool no_gather = getenv("NUFFT_HIP_FFT_NO_GATHER") != nullptr;   // A/B knob: type 2 in the scatter-out form
-  const bool gather = type == 2 && !no_gather;
+  const bool gather = type == 2;   // (r02: 2048^2 type 2 59 -> 43 us against the scatter-out form)
   for (int step = 0; step < rank; ++step) {
     const int d = gather ? rank - 1 - step : step;
     FftPassArgs<T> a;

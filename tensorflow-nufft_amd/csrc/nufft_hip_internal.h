@@ -40,13 +40,16 @@ struct Geom {
   int nitems;       // point sets sorted together (batched per-item points); tiles are then composite:
   int ntiles_item;  //   item * ntiles_item + tile, ntiles = nitems * ntiles_item
   int sparse_auto;  // spread_method AUTO: launch_spread may pick the LDS-free kernel for sparse point sets
-  int fused;        // 2-D float records carry the strength instead of the point index (FusedRec)
+  int fused;        // float records carry the strength: 2-D FusedRec (instead of the point index), 3-D FusedRec3 (32 bytes)
   int line;         // 1-D plan whose interpolation runs on interp_line_kernel (nufft_line.hip; spread_method AUTO)
   int wide;         // w = 9..16, rank 2 / 3: tiles and LDS strides of the 16 x 4-lane kernels (nufft_wide.hip)
   int sub_small;    // > 0: scan_tiles_kernel caps the subproblems at this many points instead of max_sub when the
                     // point set turns out clustered (a tile holds more than 1.5x the average): 2-D type-2 plans
   float fx_headroom;  // fixed-point accumulation: bound on prod_d max|P(z)| of the fitted kernel (>= 1)
+  int tuning;       // nufft_hip_options.tuning (NUFFT_HIP_TUNE_* bits; read by the host-side launchers only)
 };
+// OFF / ON pair of nufft_hip_options.tuning: -1 = by the plan's own rule, 0 = never, 1 = always
+inline int tune_mode(const Geom& g, int off_bit, int on_bit) { return (g.tuning & on_bit) ? 1 : ((g.tuning & off_bit) ? 0 : -1); }
 
 // Per-point record in tile-sorted order. float: 16 bytes, one dwordx4 access;
 // the original point index shares the slot of the unused third coordinate in
@@ -69,6 +72,16 @@ template <> struct alignas(16) Rec<double> {
 struct alignas(16) FusedRec {
   uint32_t px, py;           // l << 27 | round((z + 1) 2^26)
   float re, im;
+};
+// 3-D float counterpart (fixed-point plans on the ranked-scatter sort path, nufft_dense3.hip): the 16-byte
+// record (index kept: the fp64-plane launches for crowded tiles still gather through it) followed by the
+// strength, padded to 32 bytes -- ONE scattered 32-byte store per point in the sort (scattered stores are bound
+// by transactions, not bytes: DESIGN.md section 5), and the spread kernel gathers nothing (the gather of 8-byte
+// strengths through the sort permutation cost a 64-byte sector per point, twice: profiles/r03_pmc_cfg4.txt).
+struct alignas(32) FusedRec3 {
+  Rec<float> r;
+  float re, im;
+  uint32_t pad[2];
 };
 constexpr float kFusedScale = 67108864.0f;            // 2^26
 constexpr float kFusedInv = 1.4901161193847656e-08f;  // 2^-26

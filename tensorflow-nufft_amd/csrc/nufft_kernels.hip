@@ -671,7 +671,7 @@ __global__ __launch_bounds__(1024) void colscan16_kernel(int nt, int nblk, const
 
 // Streaming scatter for path A16: position = tile_start + prefix of the point's
 // workgroup + its 16-bit rank; no LDS, full occupancy.
-template <typename T>
+template <typename T, bool FUSED3 = false>
 __global__ __launch_bounds__(256) void scatter_ranked_kernel(Geom g, PointsIn in, int64_t per_block,
                                                              const int32_t* __restrict__ tile_of,
                                                              const uint16_t* __restrict__ rank16,
@@ -679,6 +679,40 @@ __global__ __launch_bounds__(256) void scatter_ranked_kernel(Geom g, PointsIn in
                                                              const int32_t* __restrict__ tile_start,
                                                              SortedOut<T> out) {
   const int64_t il = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // index inside the point set blockIdx.y
+  if constexpr (FUSED3) {
+    // record + strength = 32 bytes per point. A lane stores at most 16 bytes per instruction, and two 16-byte
+    // stores per lane are two write transactions per point (measured r03: scatter 3.1 -> 4.2 ms at M = 1e8).
+    // So lane PAIRS store: instruction 1 writes the even lane's record (even lane the first half, odd lane the
+    // second), instruction 2 the odd lane's -- every instruction then touches 32 whole 32-byte blocks.
+    const bool live = il < in.M_item;
+    const int64_t ic = live ? il : in.M_item - 1;                        // (clamped: every lane takes part in the exchange)
+    const int64_t i = (int64_t)blockIdx.y * in.M_item + ic;
+    Rec<T> r;
+    bool bad = false;
+    fold_point<T>(g, in, i, &r, &bad);
+    const int tile = tile_of[i];
+    const int64_t blk = (int64_t)blockIdx.y * in.blocks_per_item + ic / per_block;
+    const int pos = live ? tile_start[tile] + pref[blk * g.ntiles + tile] + (int)rank16[i] : -1;
+    const float2 cv = reinterpret_cast<const float2*>(in.strengths)[i];
+    const Rec<float> pr = pack_record<float>(3, r, (int32_t)ic);
+    const uint4 lo = {pr.loc, __float_as_uint(pr.z0), __float_as_uint(pr.z1), (uint32_t)pr.idx};
+    const uint4 hi = {__float_as_uint(cv.x), __float_as_uint(cv.y), 0u, 0u};
+    const int lane = threadIdx.x & 63, odd = lane & 1;
+    uint4* dst = reinterpret_cast<uint4*>(out.rec);
+    // what the partner lane (lane ^ 1) holds
+    const int ppos = __shfl_xor(pos, 1);
+    uint4 plo, phi;
+    plo.x = __shfl_xor(lo.x, 1); plo.y = __shfl_xor(lo.y, 1); plo.z = __shfl_xor(lo.z, 1); plo.w = __shfl_xor(lo.w, 1);
+    phi.x = __shfl_xor(hi.x, 1); phi.y = __shfl_xor(hi.y, 1); phi.z = __shfl_xor(hi.z, 1); phi.w = __shfl_xor(hi.w, 1);
+    // instruction 1: the even lane's record; instruction 2: the odd lane's
+    const int pa = odd ? ppos : pos;
+    const uint4 va = odd ? phi : lo;
+    if (pa >= 0) dst[2 * (int64_t)pa + odd] = va;
+    const int pb = odd ? pos : ppos;
+    const uint4 vb = odd ? hi : plo;
+    if (pb >= 0) dst[2 * (int64_t)pb + odd] = vb;
+    return;
+  }
   if (il >= in.M_item) return;
   const int64_t i = (int64_t)blockIdx.y * in.M_item + il;
   Rec<T> r;
@@ -1248,6 +1282,7 @@ __global__ __launch_bounds__(kCellSortThreads) void cellsort3d_kernel(
 // points per cell) that removes ~60 % of the LDS atomics that bound the
 // ungrouped kernel.
 constexpr int kGroupMaxSub = 4096;
+constexpr int kBig2NW = 16, kBig2SC = 16;   // the 64 x 64-tile variant (experiment): 16 waves, 16 staged points
 constexpr double kGroupMinDensity = 0.5;   // points per fine cell
 constexpr double kInterpSortMinDensity = 0.3;   // 3-D interp cell sort pays from here (r01: 0.075 loses, 0.75 and 1.8 win)
 constexpr int kGroupStage = 32; // points whose kernel values are in LDS at a time (per wave; 16 measured 12 % slower, r02)
@@ -1255,7 +1290,9 @@ template <typename T> constexpr int kGroupStageOf = sizeof(T) == 8 ? 16 : kGroup
 constexpr int kGroupBlk = 36;   // staging words per block of 4 points (8 x 4 + 4 pad)
 template <int CH> constexpr int kGroupStageWave = 3 * (CH / 4) * kGroupBlk;   // words per wave (kx, ky re, ky im)
 // FUSED: the records are FusedRec (strength inside, no index): no gather at all.
-template <typename T, int W, int NW, int CH, bool PRE, bool FUSED = false>
+// TILE = 64 (experiment, options.tuning T1_BIG_TILES): 64 x 64 tiles, 71 x 72 planes (82 KB), 4096 start cells,
+// subproblems of up to 16384 points, one workgroup per CU -- the tile size at which the sort becomes ONE staged pass.
+template <typename T, int W, int NW, int CH, bool PRE, bool FUSED = false, int TILE = 32>
 __global__ __launch_bounds__(NW * 64) void spread_2d_w8_group_kernel(
     Geom g, SortedPoints<T> sp, const T* __restrict__ horner, const T* __restrict__ c,
     T* __restrict__ fw, int64_t c_stride, int64_t fw_stride, T scale) {
@@ -1264,16 +1301,21 @@ __global__ __launch_bounds__(NW * 64) void spread_2d_w8_group_kernel(
   using RecT = std::conditional_t<FUSED, FusedRec, Rec<T>>;
   const RecT* __restrict__ recs = reinterpret_cast<const RecT*>(sp.rec);
   constexpr int NT = NW * 64;
-  constexpr int IT = (kGroupMaxSub + NT - 1) / NT;   // records per thread in the LDS sort
-  constexpr int SC = CH < kGroupStageOf<T> ? CH : kGroupStageOf<T>;   // points staged through LDS at a time
+  constexpr int kWT = TILE, kWL = TILE + kWW - 1, kWS = TILE + 8, kWPlane = kWS * kWL;   // (shadow the 32 x 32 constants)
+  constexpr int NKEY = TILE * TILE, KB = TILE == 64 ? 6 : 5, RB = 2 * KB;
+  constexpr int kMaxSub = TILE == 64 ? 16384 : kGroupMaxSub;
+  static_assert(!(FUSED && TILE != 32), "FusedRec holds 5-bit tile-local starts");
+  constexpr int IT = (kMaxSub + NT - 1) / NT;   // records per thread in the LDS sort
+  constexpr int SC0 = TILE == 64 ? kBig2SC : kGroupStageOf<T>;
+  constexpr int SC = CH < SC0 ? CH : SC0;   // points staged through LDS at a time
   static_assert(NT <= 1024, "at most 16 waves");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* plane_re = reinterpret_cast<double*>(smem_raw);
   double* plane_im = plane_re + kWPlane;
   T* stage_all = reinterpret_cast<T*>(plane_im + kWPlane);
   uint32_t* cnt = reinterpret_cast<uint32_t*>(stage_all + NW * kGroupStageWave<SC>);   // [1024]
-  uint16_t* perm = reinterpret_cast<uint16_t*>(cnt + 1024);                     // [4096]
-  uint32_t* wsum = reinterpret_cast<uint32_t*>(perm + kGroupMaxSub);            // [16]
+  uint16_t* perm = reinterpret_cast<uint16_t*>(cnt + NKEY);                     // [kMaxSub]
+  uint32_t* wsum = reinterpret_cast<uint32_t*>(perm + kMaxSub);                 // [16]
   int tb, p0, p1, slot;
   if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1, &slot)) return;
   const int n = p1 - p0;
@@ -1282,14 +1324,14 @@ __global__ __launch_bounds__(NW * 64) void spread_2d_w8_group_kernel(
   const int wave = tid >> 6;
   for (int i = tid; i < 2 * kWPlane; i += NT) plane_re[i] = 0.0;
   if constexpr (!PRE) {
-    for (int i = tid; i < 1024; i += NT) cnt[i] = 0u;
+    for (int i = tid; i < NKEY; i += NT) cnt[i] = 0u;
     __syncthreads();
 
     // ---- LDS counting sort of the subproblem by start cell (plans whose records are
     // not already cell-ordered by cellsort2d_kernel)
     // (all loads are unconditional on clamped indices: a load under a divergent
     // branch makes the compiler wait for it before the next one is issued)
-    uint32_t kr[IT];   // key | rank-in-cell << 10
+    uint32_t kr[IT];   // key | rank-in-cell << RB
 #pragma unroll
     for (int u = 0; u < IT; ++u) {
       const int i = tid + u * NT;
@@ -1306,15 +1348,15 @@ __global__ __launch_bounds__(NW * 64) void spread_2d_w8_group_kernel(
 #pragma unroll
     for (int u = 0; u < IT; ++u) {
       const int i = tid + u * NT;
-      const uint32_t key = (((kr[u] >> 10) & 31u) << 5) | (kr[u] & 31u);
-      if (i < n) kr[u] = key | (atomicAdd(&cnt[key], 1u) << 10);
+      const uint32_t key = (((kr[u] >> 10) & (uint32_t)(TILE - 1)) << KB) | (kr[u] & (uint32_t)(TILE - 1));
+      if (i < n) kr[u] = key | (atomicAdd(&cnt[key], 1u) << RB);
     }
     __syncthreads();
-    scan1024<NT>(cnt, wsum, tid);
+    scan_counts<NT, NKEY>(cnt, wsum, tid);
 #pragma unroll
     for (int u = 0; u < IT; ++u) {
       const int i = tid + u * NT;
-      if (i < n) perm[cnt[kr[u] & 1023u] + (kr[u] >> 10)] = (uint16_t)i;
+      if (i < n) perm[cnt[kr[u] & (uint32_t)(NKEY - 1)] + (kr[u] >> RB)] = (uint16_t)i;
     }
   }
   __syncthreads();
@@ -1585,14 +1627,7 @@ __global__ __launch_bounds__(NW * 64) void spread_wave2_kernel(
 // COMP (fp64 planes only): 0 = both components in one launch (two planes); 1 / 2 = only
 // the real / imaginary part (ONE plane, so two workgroups fit a CU; the host launches both).
 template <int W> constexpr int kWave3Pad = (551 - 24 * (15 + W) + 1) > 64 ? ((551 - 24 * (15 + W) + 1 + 7) & ~7) : 64;
-// I64 (float, fp64-plane layout; NUFFT_HIP_W8_I64=1, w = 8 on depth-8 tiles): every plane cell is a
-// signed 64-bit integer; a contribution is rounded to 31 bits against the LARGEST strength of the
-// subproblem (a single contribution must fit, the 64-bit sum cannot overflow) and added with
-// ds_add_u64 (7.1 cycles per wave-instruction against 8.6 for ds_add_f64). Measured r02 (the r01
-// verdict's "2 x ds_add_u64" suggestion): 256^3, M = 1e8: 32.1 -> 30.7 ms, 128^3, M = 3e7: 8.65 ->
-// 8.12 ms at unchanged error (2.35e-7 -> 2.37e-7; 2.49e-7 with every 1000th strength 1000x larger).
-// Left opt-in: 5 % for a fixed-point grid whose step follows the largest strength of a subproblem.
-template <typename T, int W, int TZ, int NW, int CH, bool FX, int COMP = 0, bool I64 = false>
+template <typename T, int W, int TZ, int NW, int CH, bool FX, int COMP = 0>
 __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
     Geom g, SortedPoints<T> sp, const T* __restrict__ horner, const T* __restrict__ c,
     T* __restrict__ fw, int64_t c_stride, int64_t fw_stride, T scale) {
@@ -1614,6 +1649,8 @@ __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
   float* red = reinterpret_cast<float*>(stage_all + NW * CH * 2 * SW);   // [NW] (FX bound reduction)
   // (fp64-plane launch behind a fixed-point one: nothing to do unless some tile is crowded -- one scalar load)
   if (!FX && g.fixed_point && sp.tile_start[g.ntiles + 1] <= g.fx_max_subs) return;
+  // (behind a fused 3-D sort the records are 32-byte FusedRec3: the 16-byte record comes first)
+  const int rstride = g.fused ? (int)sizeof(FusedRec3) : (int)sizeof(Rec<T>);
   int tb, p0, p1, slot, nsub;
   if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1, &slot, &nsub)) return;
   // Fixed-point plans: crowded tiles go to the fp64-plane kernels. The quantisation noise of the
@@ -1634,7 +1671,7 @@ __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
   if (FX) {
     float part = 0.f;
     for (int j = p0 + tid; j < p1; j += NW * 64) {
-      const T2 cv = cc[unpack_rec<T, 3>(sp.rec[j]).idx];
+      const T2 cv = cc[unpack_rec<T, 3>(rec_at(sp.rec, j, rstride)).idx];
       part += fmaxf(fabsf((float)cv.x), fabsf((float)cv.y));
     }
 #pragma unroll
@@ -1656,24 +1693,6 @@ __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
     const float step = bound / (room - 1100.f);
     pre = step > 0.f ? (T)((float)scale / step) : (T)0;
     lsb = (T)step;
-  }
-  if (I64 && !FX) {
-    float part = 0.f;
-    for (int j = p0 + tid; j < p1; j += NW * 64) {
-      const T2 cv = cc[unpack_rec<T, 3>(sp.rec[j]).idx];
-      part = fmaxf(part, fmaxf(fabsf((float)cv.x), fabsf((float)cv.y)));
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) part = fmaxf(part, __shfl_down(part, o));
-    if (lane == 0) red[wave] = part;
-    __syncthreads();
-    float bound = 0.f;
-#pragma unroll
-    for (int k = 0; k < NW; ++k) bound = fmaxf(bound, red[k]);
-    bound *= fabsf((float)scale) * g.fx_headroom;     // no single contribution exceeds this
-    const float room = 1073741824.f;                  // 2^30
-    pre = bound > 0.f ? (T)((float)scale * (room / bound)) : (T)0;
-    lsb = bound > 0.f ? (T)(bound / room) : (T)0;
   }
   __syncthreads();
 
@@ -1699,7 +1718,7 @@ __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
 #pragma unroll
       for (int q = 0; q < W; ++q) { kx[q] = (T)0; ky[q] = (T)0; }
       if (j < wend) {
-        const PointView<T> rec = unpack_rec<T, 3>(sp.rec[j]);
+        const PointView<T> rec = unpack_rec<T, 3>(rec_at(sp.rec, j, rstride));
         const T2 cv = cc[rec.idx];
         cre = cv.x * pre;
         cim = cv.y * pre;
@@ -1739,8 +1758,6 @@ __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
       // component plane / the 64-element pad behind the planes.
       double* pr = plane_re + o;
       double* pi = plane_im + o;
-      int reps = FX ? __builtin_amdgcn_readlane(rep, q) : 1;   // (1 unless the strength dominates its subproblem)
-      do {
 #pragma unroll
       for (int dz = 0; dz < W; ++dz) {
         const T kzq = bcast_lane(kz[dz], q);
@@ -1757,21 +1774,32 @@ __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
                                                    (v2f){12582912.f, 12582912.f});
           const unsigned long long x = __builtin_bit_cast(unsigned long long, fx) - 0x4B4000004B400000ull;
           atomicAdd(reinterpret_cast<unsigned long long*>(pr) + dz * PS, x);
-        } else if (I64) {
-          if (COMP != 2) {
-            const int ir = cvt_rpi((float)(ar * kzq));
-            atomicAdd(reinterpret_cast<unsigned long long*>(pr) + dz * PS, (unsigned long long)(long long)ir);
-          }
-          if (COMP != 1) {
-            const int ii = cvt_rpi((float)(ai * kzq));
-            atomicAdd(reinterpret_cast<unsigned long long*>(pi) + dz * PS, (unsigned long long)(long long)ii);
-          }
         } else {
           if (COMP != 2) lds_add(pr + dz * PS, (double)(ar * kzq));
           if (COMP != 1) lds_add(pi + dz * PS, (double)(ai * kzq));
         }
       }
-      } while (FX && --reps > 0);
+    }
+    if constexpr (FX) {
+      // the remaining rep - 1 parts of dominant strengths (rare: none for strengths of similar size). Kept out of the
+      // loop above: a per-point repeat count around its body cost 55 % at w = 7 (r03: 5.7 -> 8.9 ms at M = 3e7).
+      unsigned long long pend = __ballot(rep > 1);
+      while (pend) {
+        const int src = __ffsll((long long)pend) - 1;
+        pend &= pend - 1;
+        const T a = active ? kxs[src * SW + dx] * kys[src * SW + dy] : (T)0;
+        const float ar = (float)(a * bcast_lane(cre, src)), ai = (float)(a * bcast_lane(cim, src));
+        unsigned long long* pr = reinterpret_cast<unsigned long long*>(plane_re + __builtin_amdgcn_readlane(off, src) + cell);
+        for (int r = __builtin_amdgcn_readlane(rep, src) - 1; r > 0; --r) {
+#pragma unroll
+          for (int dz = 0; dz < W; ++dz) {
+            typedef float v2f __attribute__((ext_vector_type(2)));
+            const float kzq = (float)bcast_lane(kz[dz], src);
+            const v2f fx = __builtin_elementwise_fma((v2f){ai, ar}, (v2f){kzq, kzq}, (v2f){12582912.f, 12582912.f});
+            atomicAdd(pr + dz * PS, __builtin_bit_cast(unsigned long long, fx) - 0x4B4000004B400000ull);
+          }
+        }
+      }
     }
   }
   __syncthreads();
@@ -1795,10 +1823,6 @@ __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
         const int im_sum = (int)(unsigned)(t & 0xffffffffll);
         const int re_sum = (int)((t - (long long)im_sum) >> 32);
         v = (T)(comp ? im_sum : re_sum) * lsb;
-      } else if (I64) {
-        if (COMP != 0 && comp != COMP - 1) continue;
-        const long long t = reinterpret_cast<const long long*>(comp ? plane_im : plane_re)[lrow + a0];
-        v = (T)((double)t * (double)lsb);
       } else {
         if (COMP != 0 && comp != COMP - 1) continue;
         v = (T)(comp ? plane_im : plane_re)[lrow + a0];
@@ -2164,6 +2188,9 @@ static hipError_t ensure_lds(K kernel, size_t bytes) {
 // runtime build the module for the device -- and waits for the device before anything of
 // ours is launched.
 hipError_t preload_device_code() {
+#ifdef NUFFT_HIP_NO_PRELOAD   // build macro of tools/first_launch_experiment.sh: does the fault still reproduce?
+  return hipSuccess;
+#endif
   static std::mutex mu;
   static bool done[64] = {};
   int dev = 0;
@@ -2189,17 +2216,12 @@ int sort_blocks(const Geom& g, int64_t M, int64_t* per_block) {
   // at most ~512 workgroups (longer per-tile runs per workgroup => better write
   // combining in the scatter; measured r01), at least 4096 points each; a workgroup
   // stays inside one point set, so the count is per set
-  static const int maxblk = [] {
-    const char* e = getenv("NUFFT_HIP_SORT_BLOCKS");   // tuning knob (tools/sweep_sort.py)
-    const int v = e ? atoi(e) : 0;
-    return v > 0 ? (v < kScanGroups * kScanRowsMax ? v : kScanGroups * kScanRowsMax) : 512;   // colscan_kernel's capacity
-  }();
+  const int maxblk = 512;   // (tools/sweep_sort.py, r01: 256 and 1024 measured slower)
   const int items = g.nitems > 1 ? g.nitems : 1;
   const int64_t m_item = M / items;
   // (small point sets: 1024 per workgroup, so that a few hundred thousand points still spread over the
   // chip -- the reference benchmark's M = 2e5 cases 62 -> 52 us per transform with the plain scatter)
-  static const int minpb_env = [] { const char* e = getenv("NUFFT_HIP_SORT_MINPB"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
-  const int minpb = minpb_env ? minpb_env : (M < kSmallSortPoints ? 1024 : 4096);
+  const int minpb = M < kSmallSortPoints ? 1024 : 4096;
   int64_t pb = (M + maxblk - 1) / maxblk;
   if (pb < minpb) pb = minpb;
   pb += pb & 1;   // even: the paired 16-byte loads of interleaved 2-D float points start on a pair
@@ -2252,20 +2274,14 @@ static hipError_t sort_lds_pass(const Geom& g, const PointsIn& in, const SortWor
   scan_tiles_kernel<<<1, 1024, 0, stream>>>(w.tile_count, g.ntiles, g.max_sub, g.sub_small, (int)(in.M_item / g.ntiles_item), w.tile_start, w.sub_start);
   hook.end(STAGE_SORT_SCAN);
   hook.begin(STAGE_SORT_SCATTER);
-  static const int staged_env = [] { const char* e2 = getenv("NUFFT_HIP_STAGED_SCATTER"); return e2 ? atoi(e2) : -1; }();
-  const bool staged = g.ntiles_item <= kStagedMaxTiles && staged_env != 0 &&
-                      (staged_env > 0 || (in.M_item >= 4 * kStagedChunk<T> && in.M >= kSmallSortPoints));
-  static const bool staged4k = getenv("NUFFT_HIP_STAGED_4K") != nullptr;   // experiment: up to 4096 tiles
+  const int staged_mode = tune_mode(g, NUFFT_HIP_TUNE_STAGED_OFF, NUFFT_HIP_TUNE_STAGED_ON);
+  const bool staged = g.ntiles_item <= kStagedMaxTiles && staged_mode != 0 &&
+                      (staged_mode > 0 || (in.M_item >= 4 * kStagedChunk<T> && in.M >= kSmallSortPoints));
   if (staged) {
     const size_t slds = kStagedLds<T, 1024>;
     e = ensure_lds(scatter_staged_kernel<T, AOS, FUSED>, slds);
     if (e != hipSuccess) return e;
     scatter_staged_kernel<T, AOS, FUSED><<<nblk, kSortBlock, slds, stream>>>(g, in, per_block, w.hist, w.tile_start, out);
-  } else if (staged4k && g.ntiles_item <= 4096 && in.M_item >= 4 * kStagedChunkOf<T, 4096>) {
-    const size_t slds = kStagedLds<T, 4096>;
-    e = ensure_lds(scatter_staged_kernel<T, AOS, FUSED, 4096>, slds);
-    if (e != hipSuccess) return e;
-    scatter_staged_kernel<T, AOS, FUSED, 4096><<<nblk, kSortBlock, slds, stream>>>(g, in, per_block, w.hist, w.tile_start, out);
   } else {
     scatter_lds_kernel<T, AOS, FUSED><<<nblk, kSortBlock, lds, stream>>>(g, in, per_block, w.hist, w.tile_start, out);
   }
@@ -2288,7 +2304,8 @@ hipError_t launch_sort(const Geom& g, const PointsIn& in_arg, const SortWork& w,
   in.M_item = in.M / items;
   in.blocks_per_item = 1;
   const int mode = sort_mode(g, in.M);
-  if (in.strengths && (mode != 0 || sizeof(T) != 4 || g.rank != 2)) return hipErrorInvalidValue;   // see fused_sort_supported
+  if (in.strengths && !(sizeof(T) == 4 && ((mode == 0 && g.rank == 2) || (mode == 1 && g.rank == 3))))
+    return hipErrorInvalidValue;   // see fused_sort_supported
   if (mode == 0) {
     int64_t per_block;
     in.blocks_per_item = sort_blocks(g, in.M, &per_block);
@@ -2329,8 +2346,17 @@ hipError_t launch_sort(const Geom& g, const PointsIn& in_arg, const SortWork& w,
     scan_tiles_kernel<<<1, 1024, 0, stream>>>(w.tile_count, g.ntiles, g.max_sub, g.sub_small, (int)(in.M_item / g.ntiles_item), w.tile_start, w.sub_start);
     hook.end(STAGE_SORT_SCAN);
     hook.begin(STAGE_SORT_SCATTER);
-    scatter_ranked_kernel<T><<<dim3(blocks_for(in.M_item, 256), items), 256, 0, stream>>>(g, in, per_block, w.tile_of, rank16,
-                                                                        pref, w.tile_start, out);
+    if constexpr (sizeof(T) == 4) {
+      if (in.strengths)
+        scatter_ranked_kernel<T, true><<<dim3(blocks_for(in.M_item, 256), items), 256, 0, stream>>>(g, in, per_block, w.tile_of,
+                                                                                  rank16, pref, w.tile_start, out);
+      else
+        scatter_ranked_kernel<T><<<dim3(blocks_for(in.M_item, 256), items), 256, 0, stream>>>(g, in, per_block, w.tile_of, rank16,
+                                                                            pref, w.tile_start, out);
+    } else {
+      scatter_ranked_kernel<T><<<dim3(blocks_for(in.M_item, 256), items), 256, 0, stream>>>(g, in, per_block, w.tile_of, rank16,
+                                                                          pref, w.tile_start, out);
+    }
     hook.end(STAGE_SORT_SCATTER);
     return hipGetLastError();
   }
@@ -2355,12 +2381,10 @@ template hipError_t launch_sort<float>(const Geom&, const PointsIn&, const SortW
 template hipError_t launch_sort<double>(const Geom&, const PointsIn&, const SortWork&,
                                         const SortedOut<double>&, hipStream_t, const StageHook&);
 
-// Launch shape of the specialised kernel (waves per workgroup, points per
-// staging chunk); NUFFT_HIP_W8_SHAPE = "NWxCH" overrides for experiments.
-// Cell-grouped kernel: NUFFT_HIP_W8_GROUP = 0 never, 1 always; unset: by point density
-// (the in-LDS sort only pays when start cells are shared often enough).
+// Cell-grouped kernel: by point density (the in-LDS sort only pays when start cells are shared
+// often enough); options.tuning GROUP_OFF / GROUP_ON force the choice.
 static bool wave8_use_group(const Geom& g, int64_t M) {
-  static const int mode = [] { const char* e = getenv("NUFFT_HIP_W8_GROUP"); return e ? atoi(e) : -1; }();
+  const int mode = tune_mode(g, NUFFT_HIP_TUNE_GROUP_OFF, NUFFT_HIP_TUNE_GROUP_ON);
   if (g.max_sub > kGroupMaxSub) return false;
   if (mode >= 0) return mode != 0;
   return (double)M >= kGroupMinDensity * (double)g.nf[0] * (double)g.nf[1];
@@ -2369,22 +2393,17 @@ static bool wave8_use_group(const Geom& g, int64_t M) {
 // Defaults from the r01 sweeps (tools/sweep_w8.py, tools/sweep_w8_group.py): 4 x 64
 // for the per-point kernel, 12 x 64 for the cell-grouped one (79 KB of LDS: two
 // workgroups = 24 waves per CU, 3 per SIMD each; 8 x 64 = 16 waves per CU was 8 % slower).
-struct W8Shape { int nw = -1, ch = -1; };
-static const W8Shape& wave8_shape_env() {   // NUFFT_HIP_W8_SHAPE = "NWxCH" (tuning knob), read once
-  static const W8Shape s = [] {
-    W8Shape v;
-    if (const char* e = getenv("NUFFT_HIP_W8_SHAPE")) sscanf(e, "%dx%d", &v.nw, &v.ch);
-    return v;
-  }();
-  return s;
-}
-static int wave8_nw(bool grouped) { const int v = wave8_shape_env().nw; return v > 0 ? v : (grouped ? 12 : 4); }
-static int wave8_ch(bool grouped) { const int v = wave8_shape_env().ch; return v > 0 ? v : 64; }
+static int wave8_nw(bool grouped) { return grouped ? 12 : 4; }
+static int wave8_ch(bool) { return 64; }
 constexpr int kW2NW = 4, kW2CH = 64;   // launch shape of spread_wave2_kernel (others measured no better)
 static size_t group_lds(int nw, int ch, bool presorted, int precision = NUFFT_HIP_F32) {
   const int stage = precision == NUFFT_HIP_F32 ? kGroupStage : kGroupStage / 2;   // kGroupStageOf<T>
   return sizeof(double) * 2 * kWPlane + (size_t)precision * nw * 3 * ((ch < stage ? ch : stage) / 4) * kGroupBlk +
          (presorted ? 0 : 1024 * 4 + kGroupMaxSub * 2 + 64);   // + counters, permutation, wave sums
+}
+// (launch shape of the 64 x 64-tile variant: kBig2NW waves, kBig2SC staged points, in-kernel sort only)
+static size_t group64_lds() {
+  return sizeof(double) * 2 * 72 * 71 + sizeof(float) * kBig2NW * 3 * (kBig2SC / 4) * kGroupBlk + 4096 * 4 + 16384 * 2 + 64;
 }
 static size_t wave8_lds(bool grouped, bool presorted = false) {
   const int nw = wave8_nw(grouped), ch = wave8_ch(grouped);
@@ -2399,8 +2418,7 @@ static size_t wave2_lds(const Geom& g, int precision) {
 
 // Geometry the cell-grouped 2-D kernels need (either precision)
 static bool group2d_geometry(const Geom& g) {
-  static const bool off = getenv("NUFFT_HIP_NO_W8") != nullptr;   // A/B against spread_wave2_kernel
-  if (off || g.wide) return false;
+  if (g.wide) return false;
   return g.rank == 2 && g.w <= kWW && g.ncoef <= kWaveCoef && g.tile[0] == kWT && g.tile[1] == kWT &&
          g.lstride == kWS;
 }
@@ -2432,9 +2450,9 @@ int wave3_pad(int w) {   // = kWave3Pad<w>
 // lanes -- every 128-byte line of the fine grid is visited once, not once per component. Measured r02 on
 // 128^3 (256^3 fine cells), whole type-1 transform, split -> joint: M = 8e5 (0.05 points per cell) 1.07 ->
 // 0.72 ms, 2e6 1.13 -> 1.04, 4e6 1.57 -> 1.56, 8e6 2.67 -> 2.63, 1e7 3.25 -> 3.20, 3e7 level; M = 1e8 on
-// 256^3 32.0 -> 32.2. Taken below 0.5 points per cell. NUFFT_HIP_W8_JOINT = 0 / 1 forces the choice.
+// 256^3 32.0 -> 32.2. Taken below 0.5 points per cell. options.tuning JOINT_OFF / JOINT_ON force the choice.
 static bool wave3_joint_wanted(const Geom& g, int64_t M) {
-  static const int mode = [] { const char* e = getenv("NUFFT_HIP_W8_JOINT"); return e ? atoi(e) : -1; }();
+  const int mode = tune_mode(g, NUFFT_HIP_TUNE_JOINT_OFF, NUFFT_HIP_TUNE_JOINT_ON);
   if (mode >= 0) return mode != 0;
   return (double)M < 0.5 * (double)g.nf[0] * (double)g.nf[1] * (double)g.nf[2];
 }
@@ -2445,10 +2463,6 @@ static size_t wave3_split_lds(const Geom& g) {
   for (int d = 1; d < g.rank; ++d) cells *= (size_t)g.ldim[d];
   return cells * sizeof(double) + (size_t)wave3_pad(g.w) * sizeof(double) +
          sizeof(float) * 12 * 32 * 2 * (g.w <= 6 ? 6 : 8) + 256;
-}
-static bool wave3_i64() {
-  static const bool on = getenv("NUFFT_HIP_W8_I64") != nullptr;
-  return on;
 }
 static size_t wave3_split8_lds(const Geom& g) {   // one plane, 12 waves, 16-point staging chunks
   size_t cells = (size_t)g.lstride;
@@ -2480,9 +2494,9 @@ static inline unsigned subproblem_grid(const Geom& g, int64_t M) {
 // Crossover measured r02 (profiles/r02_sparse_crossover.txt, spread stage): 3-D 512^3 w = 6
 // between 7.5e-4 (LDS-free 0.80 ms vs 0.99 ms) and 2.2e-3 points per cell (1.94 vs 1.34 ms);
 // 2-D 2048^2 w = 8 between 2.4e-3 (25 vs 31 us) and 7.2e-3 (47 vs 34 us).
-// NUFFT_HIP_SPARSE = 0 / 1 forces it off / on.
+// options.tuning SPARSE_OFF / SPARSE_ON force it off / on.
 bool sparse_wanted(const Geom& g, int64_t M) {
-  static const int mode = [] { const char* e = getenv("NUFFT_HIP_SPARSE"); return e ? atoi(e) : -1; }();
+  const int mode = tune_mode(g, NUFFT_HIP_TUNE_SPARSE_OFF, NUFFT_HIP_TUNE_SPARSE_ON);
   if (mode >= 0) return mode != 0;
   const double density = g.rank == 3 ? 1.2e-3 : 4e-3;
   return (double)M < density * (double)g.nf[0] * (double)g.nf[1] * (double)g.nf[2];
@@ -2492,15 +2506,18 @@ bool sparse_wanted(const Geom& g, int64_t M) {
 // wavefront spreaders (grouped, per-point w = 8, per-point narrower), LDS-histogram sort, and
 // a point set that does not go to the LDS-free kernel.
 bool fused_sort_supported(const Geom& g, int method, int precision, int64_t M) {
-  static const bool off = getenv("NUFFT_HIP_NO_FUSED") != nullptr;   // A/B knob
-  if (off || method != NUFFT_HIP_METHOD_TILE_WAVE || !wave8_supported(g, precision)) return false;
+  if ((g.tuning & NUFFT_HIP_TUNE_NO_FUSED) || method != NUFFT_HIP_METHOD_TILE_WAVE || M <= 0) return false;
+  // 3-D float fixed-point plans (nufft_dense3.hip) on the ranked-scatter sort path: 32-byte FusedRec3 records
+  if (dense3_supported(g, precision))
+    return g.nitems <= 1 && sort_mode(g, M) == 1 && !(g.sparse_auto && sparse_wanted(g, M));
+  if (!wave8_supported(g, precision)) return false;
   if (M <= 0 || sort_mode(g, M * (g.nitems > 1 ? g.nitems : 1)) != 0 || g.max_sub > kGroupMaxSub) return false;   // M: per set
   return !(g.sparse_auto && sparse_wanted(g, M));   // every LDS-tile 2-D float spreader reads fused records
 }
 
-// NUFFT_HIP_CELLSORT = 0 never, 1 whenever the geometry allows; unset: by point density.
+// By point density; options.tuning CELLSORT_OFF never, CELLSORT_ON whenever the geometry allows.
 bool cellsort_wanted(const Geom& g, int method, int precision, int64_t M) {
-  static const int mode = [] { const char* e = getenv("NUFFT_HIP_CELLSORT"); return e ? atoi(e) : -1; }();
+  const int mode = tune_mode(g, NUFFT_HIP_TUNE_CELLSORT_OFF, NUFFT_HIP_TUNE_CELLSORT_ON);
   // only the 2-D w = 8 float spreader has a kernel that exploits the order
   if (method != NUFFT_HIP_METHOD_TILE_WAVE || !wave8_supported(g, precision)) return false;
   if (g.max_sub > kCellSortMaxSub || M == 0 || mode == 0) return false;
@@ -2510,10 +2527,10 @@ bool cellsort_wanted(const Geom& g, int method, int precision, int64_t M) {
 
 // The same ordering for the 3-D interp kernel (type 2 / interp op), applied eagerly in
 // set_points: it costs ~1 ms per 1e8 points and removes the LDS bank conflicts of the
-// stencil loop. NUFFT_HIP_CELLSORT3D = 0 / 1 forces it off / on.
+// stencil loop. options.tuning CELLSORT3D_OFF / CELLSORT3D_ON force it off / on.
 bool cellsort_wanted_interp(const Geom& g, int method, int precision, int64_t M) {
   (void)precision;
-  static const int mode = [] { const char* e = getenv("NUFFT_HIP_CELLSORT3D"); return e ? atoi(e) : -1; }();
+  const int mode = tune_mode(g, NUFFT_HIP_TUNE_CELLSORT3D_OFF, NUFFT_HIP_TUNE_CELLSORT3D_ON);
   if (method != NUFFT_HIP_METHOD_TILE_WAVE || g.wide || g.rank != 3 || g.tile[0] != 16 || g.tile[1] != 16 || g.tile[2] > 8) return false;
   if (g.max_sub > kCellSortMaxSub || M == 0 || mode == 0) return false;
   if (mode > 0) return true;
@@ -2588,6 +2605,19 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
   // 2-D type-2 plans on 64 x 64 tiles (the interp kernel's geometry): nufft_hip_spread on such a
   // spread_only plan takes the thread-per-point tile kernel, which works on any tile; the wavefront
   // spreaders are laid out for 32 x 32 tiles and row stride 40 only.
+  if constexpr (sizeof(T) == 4) {
+    // experiment (options.tuning T1_BIG_TILES): type 1 on 64 x 64 tiles -- one staged scatter pass
+    // into <= 1024 tiles per point set, then the cell-grouped spreader on 82 KB of planes, one workgroup per CU
+    if (method == NUFFT_HIP_METHOD_TILE_WAVE && g.rank == 2 && !g.wide && (g.tuning & NUFFT_HIP_TUNE_T1_BIG_TILES) && !g.fused &&
+        g.w == kWW && g.tile[0] == 64 && g.tile[1] == 64 && g.lstride == 72 && g.max_sub <= 16384 && g.ncoef <= kWaveCoef) {
+      lds_bytes = group64_lds();
+      e = ensure_lds(spread_2d_w8_group_kernel<float, 8, kBig2NW, 64, false, false, 64>, lds_bytes);
+      if (e != hipSuccess) return e;
+      spread_2d_w8_group_kernel<float, 8, kBig2NW, 64, false, false, 64><<<grid, kBig2NW * 64, lds_bytes, stream>>>(
+          g, sp, horner, c, fw, c_stride, fw_stride, scale);
+      return hipGetLastError();
+    }
+  }
   if (method == NUFFT_HIP_METHOD_TILE_WAVE && g.rank == 2 && (g.tile[0] != kWT || g.tile[1] != kWT || g.lstride != kWS)) {
     method = NUFFT_HIP_METHOD_TILE_GENERIC;
     lds_bytes = spread_lds_bytes(g, method, (int)sizeof(T));
@@ -2630,7 +2660,7 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
             NUFFT_CASE_W8G(6) NUFFT_CASE_W8G(7)
             case 8:
               switch (shape) {
-                NUFFT_LAUNCH_W8G(8, 8, 64) NUFFT_LAUNCH_W8G(8, 12, 64) NUFFT_LAUNCH_W8G(8, 16, 64)
+                NUFFT_LAUNCH_W8G(8, 12, 64)
                 default: return hipErrorInvalidValue;
               }
               break;
@@ -2656,7 +2686,7 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
     }                                                                                          \
     break;
         switch (shape) {
-          NUFFT_LAUNCH_W8(4, 64) NUFFT_LAUNCH_W8(4, 32) NUFFT_LAUNCH_W8(8, 64) NUFFT_LAUNCH_W8(8, 32)
+          NUFFT_LAUNCH_W8(4, 64)
           default: return hipErrorInvalidValue;
         }
 #undef NUFFT_LAUNCH_W8
@@ -2731,15 +2761,7 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
       if constexpr (WW == 8) {                                                                   \
         if constexpr (sizeof(T) == 4) {                                                          \
           if (!g.split_reim) return hipErrorInvalidValue;                                        \
-          if (wave3_i64()) {   /* experiment: 64-bit integer planes (NUFFT_HIP_W8_I64) */        \
-            lds_bytes = wave3_split8_lds(g);                                                     \
-            e = ensure_lds(spread_wave3_kernel<T, WW, 8, 12, 16, false, 1, true>, lds_bytes);     \
-            if (e != hipSuccess) return e;                                                       \
-            spread_wave3_kernel<T, WW, 8, 12, 16, false, 1, true>                                 \
-                <<<grid, 12 * 64, lds_bytes, stream>>>(g, sp, horner, c, fw, c_stride, fw_stride, scale); \
-            spread_wave3_kernel<T, WW, 8, 12, 16, false, 2, true>                                 \
-                <<<grid, 12 * 64, lds_bytes, stream>>>(g, sp, horner, c, fw, c_stride, fw_stride, scale); \
-          } else if (wave3_joint_wanted(g, Md)) {   /* thin point sets: both planes, one write-out */   \
+          if (wave3_joint_wanted(g, Md)) {   /* thin point sets: both planes, one write-out */   \
             lds_bytes = wave3_joint_lds(g);                                                      \
             e = ensure_lds(spread_wave3_kernel<T, WW, 8, 16, 16, false, 0>, lds_bytes);           \
             if (e != hipSuccess) return e;                                                       \

@@ -486,13 +486,12 @@ int nufft_hip_op_compute_ex(const nufft_hip_op_desc* desc, const void* source, c
   // launches per set -- a 512^2 / M = 1e6 item keeps the GPU busy for only ~60 us of the
   // ~90 us its own launches take. Needs the source to carry the same batch dims as the
   // points (otherwise the strengths of consecutive calls are not consecutive in memory).
-  // NUFFT_HIP_OP_GROUP overrides K (1 = the r01 behaviour, one call at a time).
+  // options.op_group overrides K (1 = the r01 behaviour, one call at a time).
   // Groups alternate between two plans on private streams, so that the memory-bound sort of
   // one overlaps the LDS-bound spread of the other (r01: 0.126 -> 0.092 ms per item);
-  // NUFFT_HIP_OP_LANES overrides the lane count (1..kMaxLanes). With a framework allocator
+  // options.op_lanes overrides the lane count (1..kMaxLanes). With a framework allocator
   // everything stays on the caller's stream (its memory is ordered against that stream only).
-  static const int lanes_env = [] { const char* e = getenv("NUFFT_HIP_OP_LANES"); return e ? atoi(e) : 0; }();
-  static const int group_env = [] { const char* e = getenv("NUFFT_HIP_OP_GROUP"); return e ? atoi(e) : 0; }();
+  const int lanes_opt = desc->options.op_lanes, group_opt = desc->options.op_group;
   std::vector<int64_t> src_outer, pts_outer;
   for (int i : a.outer) { src_outer.push_back(a.source_batch[i]); pts_outer.push_back(a.points_batch[i]); }
   bool groupable = a.num_calls > 1 && !a.transpose;
@@ -500,7 +499,7 @@ int nufft_hip_op_compute_ex(const nufft_hip_op_desc* desc, const void* source, c
     if (src_outer[i] != pts_outer[i]) groupable = false;
   int64_t group = 1;
   if (groupable) {
-    group = group_env > 0 ? group_env : 16;
+    group = group_opt > 0 ? group_opt : 16;
     nufft_hip_plan_info pi;
     char pe[256];
     if (nufft_hip_plan_describe(desc->transform_type, rank, dims, desc->fft_direction, (int)a.num_transforms, tol,
@@ -521,7 +520,7 @@ int nufft_hip_op_compute_ex(const nufft_hip_op_desc* desc, const void* source, c
   const int64_t ngroups = (a.num_calls + group - 1) / group;
   const int64_t tail = a.num_calls - (ngroups - 1) * group;   // sets in the last group
   int want_lanes = 2;
-  if (lanes_env > 0) want_lanes = lanes_env < kMaxLanes ? lanes_env : kMaxLanes;
+  if (lanes_opt > 0) want_lanes = lanes_opt < kMaxLanes ? lanes_opt : kMaxLanes;
   if (fw_alloc) want_lanes = 1;
   const int64_t nfull = tail != group ? ngroups - 1 : ngroups;   // groups of the full size (>= 1)
   const int nlanes = (int)std::min<int64_t>(nfull, want_lanes);

@@ -525,7 +525,8 @@ StageHook make_hook(nufft_hip_plan p) {
   return h;
 }
 
-int ensure_point_capacity(nufft_hip_plan p, int64_t M) {
+// rec_mult: record slots per point (2 for the 32-byte fused records of 3-D float plans)
+int ensure_point_capacity(nufft_hip_plan p, int64_t M, int rec_mult = 1) {
   int rc = ensure_fixed_workspace(p);
   if (rc) return rc;
   const int mode = sort_mode(p->g, M);
@@ -553,14 +554,15 @@ int ensure_point_capacity(nufft_hip_plan p, int64_t M) {
     if ((rc = dev_alloc(p, (void**)&p->rank_of, (size_t)M * 4))) return rc;
     p->cap_global = M;
   }
-  if (M <= p->cap) return NUFFT_HIP_OK;
+  const int64_t slots = M * rec_mult;
+  if (slots <= p->cap) return NUFFT_HIP_OK;
   if ((rc = sync_before_regrow(p))) return rc;
   dev_free(p, p->rec);
   p->rec = nullptr;
   p->cap = 0;
   const size_t rec_bytes = p->precision == NUFFT_HIP_F32 ? sizeof(Rec<float>) : sizeof(Rec<double>);
-  if ((rc = dev_alloc(p, &p->rec, (size_t)M * rec_bytes))) return rc;
-  p->cap = M;
+  if ((rc = dev_alloc(p, &p->rec, (size_t)slots * rec_bytes))) return rc;
+  p->cap = slots;
   return NUFFT_HIP_OK;
 }
 
@@ -570,7 +572,7 @@ template <typename T>
 int set_points_impl(nufft_hip_plan p, int64_t M, const void* x, const void* y, const void* z,
                     int64_t stride, const void* strengths = nullptr) {
   const int64_t Mtot = M * p->nitems;   // M points in each of the nitems sets
-  int rc = ensure_point_capacity(p, Mtot);
+  int rc = ensure_point_capacity(p, Mtot, (strengths && p->rank == 3) ? (int)(sizeof(FusedRec3) / sizeof(Rec<float>)) : 1);
   if (rc) return rc;
   p->M = M;
   p->points_set = false;
@@ -982,25 +984,23 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
   // 2-D float type-2 (and interp-only) plans: 64 x 64. Their LDS tile is single-precision
   // complex (71^2 x 8 B = 40 KB), and four times fewer tiles make the (workgroup, tile) runs
   // of the scatter four times longer (the scatter is transaction bound).
-  static const bool no_t2_big = getenv("NUFFT_HIP_NO_BIG_T2_TILES") != nullptr;   // A/B knob
-  const bool t2_big = type == NUFFT_HIP_TYPE_2 && rank == 2 && precision == NUFFT_HIP_F32 && w <= 8 &&
+  const bool t1_big_exp = type == NUFFT_HIP_TYPE_1 && (p->opts.tuning & NUFFT_HIP_TUNE_T1_BIG_TILES) && w == 8 && !p->opts.spread_only;
+  const bool t2_big = (type == NUFFT_HIP_TYPE_2 || t1_big_exp) && rank == 2 && precision == NUFFT_HIP_F32 && w <= 8 &&
                       p->opts.spread_method == NUFFT_HIP_METHOD_AUTO && p->opts.tile_dims[0] == 0 &&
-                      p->opts.tile_dims[1] == 0 && p->opts.max_subproblem_size <= 0 && !no_t2_big &&
+                      p->opts.tile_dims[1] == 0 && p->opts.max_subproblem_size <= 0 &&
                       g.nf[0] >= 64 && g.nf[1] >= 64 &&
                       // (enough of them to fill 256 CUs: a 512^2 fine grid has only 64 -- the reference
                       // benchmark's 256^2 case ran its interp kernel in 30 us on 64 workgroups)
-                      ((int64_t)g.nf[0] * g.nf[1] >= ((int64_t)1 << 21) || getenv("NUFFT_HIP_BIG_T2_ALWAYS") != nullptr);
+                      (int64_t)g.nf[0] * g.nf[1] >= ((int64_t)1 << 21);
   const int t2d = t2_big ? 64 : 32;
   // 3-D float at w = 8 (fp64 planes, one component per launch): depth 8 as well -- the padded tile
   // (23 x 23 x 15 cells, 66 KB) still lets two workgroups share a CU with a 16-point staging chunk,
   // and the halo written out per fine cell falls from 5.7x to 3.9x.
-  static const bool w8_flat = getenv("NUFFT_HIP_W8_DEPTH4") != nullptr;   // A/B knob
-  const bool deep8 = w <= 6 || (w == 8 && precision == NUFFT_HIP_F32 && p->opts.lds_accumulate != 2 && !w8_flat);
+  const bool deep8 = w <= 6 || (w == 8 && precision == NUFFT_HIP_F32 && p->opts.lds_accumulate != 2);
   int def_tile[3][3] = {{1024, 1, 1}, {t2d, t2d, 1}, {16, 16, deep8 ? 8 : 4}};
   // w = 9..16 (tol < 1e-7): the 16 x 4-lane spread kernels of nufft_wide.hip and their tiles
   // (2-D 32 x 32; 3-D 16 x 8 x 4 up to w = 12, 8 x 8 x 4 above: one fp64 plane of LDS per launch)
-  static const bool no_wide = getenv("NUFFT_HIP_NO_WIDE") != nullptr;   // A/B knob
-  bool wide = !no_wide && wide_spread_supported(rank, w) &&
+  bool wide = !(p->opts.tuning & NUFFT_HIP_TUNE_NO_WIDE) && wide_spread_supported(rank, w) &&
               (p->opts.spread_method == NUFFT_HIP_METHOD_AUTO || p->opts.spread_method == NUFFT_HIP_METHOD_TILE_WAVE) &&
               p->opts.tile_dims[0] == 0 && p->opts.tile_dims[1] == 0 && p->opts.tile_dims[2] == 0;
   int wide_tile[3] = {1, 1, 1};
@@ -1090,14 +1090,14 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
   // AUTO also lets launch_spread take the LDS-free kernel when the point set turns out sparse
   g.sparse_auto = method == NUFFT_HIP_METHOD_AUTO ? 1 : 0;
   g.fused = 0;
+  g.tuning = p->opts.tuning;
   const bool t2_wave = t2_big && g.tile[0] == 64 && g.tile[1] == 64;   // (not shrunk by a tiny grid)
   if (method == NUFFT_HIP_METHOD_AUTO)
     method = (wide || t2_wave || wave_method_supported(g, precision)) ? NUFFT_HIP_METHOD_TILE_WAVE : NUFFT_HIP_METHOD_TILE_GENERIC;
   if (method != NUFFT_HIP_METHOD_TILE_WAVE) g.wide = 0;
   // 1-D plans: interp_line_kernel (nufft_line.hip) behind the automatic choice (an explicit
   // TILE_GENERIC keeps the gather-from-global kernel: the tests' second opinion)
-  static const bool no_line = getenv("NUFFT_HIP_NO_LINE") != nullptr;   // A/B knob
-  g.line = (!no_line && p->opts.spread_method == NUFFT_HIP_METHOD_AUTO && method == NUFFT_HIP_METHOD_TILE_GENERIC &&
+  g.line = (!(p->opts.tuning & NUFFT_HIP_TUNE_NO_LINE) && p->opts.spread_method == NUFFT_HIP_METHOD_AUTO && method == NUFFT_HIP_METHOD_TILE_GENERIC &&
             line_kernels_supported(g)) ? 1 : 0;
   // (type 2: one tile load per 4096 points; a spread_only plan serves both ops and keeps 1024)
   if (g.line && auto_sub && type == NUFFT_HIP_TYPE_2 && !p->opts.spread_only) g.max_sub = 4096;
@@ -1127,17 +1127,14 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
   // fp64 planes in 3-D float at tile depth 4 (w = 8, or w <= 7 with lds_accumulate = 1):
   // one plane per launch, so that two workgroups share a CU
   g.split_reim = (method == NUFFT_HIP_METHOD_TILE_WAVE && rank == 3 && precision == NUFFT_HIP_F32 &&
-                  !g.fixed_point && (g.tile[2] == 4 || (g.tile[2] == 8 && w == 8)) &&
-                  (getenv("NUFFT_HIP_NO_SPLIT") == nullptr || g.tile[2] == 8)) ? 1 : 0;
+                  !g.fixed_point && (g.tile[2] == 4 || (g.tile[2] == 8 && w == 8))) ? 1 : 0;
   if (method == NUFFT_HIP_METHOD_TILE_WAVE)
     g.lstride = g.wide ? wide_spread_lstride(rank, w) : (t2_wave ? 72 : wave_lstride(rank));
   // wavefront kernels: one subproblem per typical tile measured fastest (r01 sweeps);
   // every extra subproblem of a tile repeats its zero-fill and write-out
-  static const int t2_sub = [] { const char* e = getenv("NUFFT_HIP_T2_SUB"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();   // A/B knob
-  if (method == NUFFT_HIP_METHOD_TILE_WAVE && auto_sub) g.max_sub = t2_wave ? (t2_sub ? t2_sub : 16384) : 4096;   // (interp: one tile load per subproblem)
-  // clustered point sets: scan_tiles_kernel falls back to 4096-point subproblems (NUFFT_HIP_T2_SMALL_SUB, 0 = never)
-  static const int t2_small = [] { const char* e = getenv("NUFFT_HIP_T2_SMALL_SUB"); return e ? atoi(e) : 4096; }();
-  if (method == NUFFT_HIP_METHOD_TILE_WAVE && auto_sub && t2_wave && !t2_sub) g.sub_small = t2_small;
+  if (method == NUFFT_HIP_METHOD_TILE_WAVE && auto_sub) g.max_sub = t2_wave ? 16384 : 4096;   // (interp: one tile load per subproblem)
+  // clustered point sets: scan_tiles_kernel falls back to 4096-point subproblems
+  if (method == NUFFT_HIP_METHOD_TILE_WAVE && auto_sub && t2_wave && type == NUFFT_HIP_TYPE_2) g.sub_small = 4096;
   if (g.wide && auto_sub && rank == 3) g.max_sub = 1024;   // (hundreds of LDS atomics per point: keep workgroups short)
   if (g.fixed_point && w > 6) g.max_sub = std::min(g.max_sub, 512);
   g.fx_max_subs = 16;

@@ -20,6 +20,10 @@ FORWARD, BACKWARD = -1, 1
 F32, F64 = 4, 8
 OP_NUFFT, OP_INTERP, OP_SPREAD = 0, 1, 2
 METHOD_AUTO, METHOD_TILE_GENERIC, METHOD_TILE_WAVE, METHOD_POINT_GLOBAL = 0, 1, 2, 3
+# nufft_hip_options.tuning bits (include/nufft_hip.h)
+TUNE = {name: 1 << bit for bit, name in enumerate((
+    'NO_FUSED', 'GROUP_OFF', 'GROUP_ON', 'SPARSE_OFF', 'SPARSE_ON', 'CELLSORT_OFF', 'CELLSORT_ON', 'CELLSORT3D_OFF',
+    'CELLSORT3D_ON', 'ROCFFT', 'NO_WIDE', 'NO_LINE', 'JOINT_OFF', 'JOINT_ON', 'STAGED_OFF', 'STAGED_ON', 'T1_BIG_TILES'))}
 STAGES = ('sort_count', 'sort_scan', 'sort_scatter', 'zero', 'spread', 'fft', 'deconvolve', 'interp', 'sort_cell')
 
 
@@ -52,7 +56,10 @@ class OptionsStruct(ctypes.Structure):
               ('tile_dims', ctypes.c_int32 * 3),
               ('lds_accumulate', ctypes.c_int32),
               ('num_point_sets', ctypes.c_int32),
-              ('reserved', ctypes.c_int32 * 6)]
+              ('tuning', ctypes.c_int32),
+              ('op_group', ctypes.c_int32),
+              ('op_lanes', ctypes.c_int32),
+              ('reserved', ctypes.c_int32 * 3)]
 
 
 class PlanInfo(ctypes.Structure):

@@ -97,6 +97,9 @@ class Options(_Model):
   fftw: FftwOptions = pydantic.Field(default_factory=FftwOptions)
   max_batch_size: typing.Optional[int] = None
   points_range: PointsRange = PointsRange.EXTENDED
+  # expert knobs outside the reference's schema (InternalOptions upstream, cc/kernels/nufft_options.h:92-162):
+  # fields of nufft_hip_options by name, e.g. {'tuning': TUNE['ROCFFT'], 'spread_method': 1}; never serialized
+  _internal: dict = pydantic.PrivateAttr(default_factory=dict)
 
   def to_proto(self):
     pb = _proto.OptionsProto()

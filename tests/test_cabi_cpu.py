@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
   missing = [n for n in sorted(declared) if not hasattr(handle, n)]
   assert not missing, missing
   assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
-  assert _lib.lib().nufft_hip_abi_version() == 2
+  assert _lib.lib().nufft_hip_abi_version() == 3
 
 
 def test_default_options_and_struct_layout():

@@ -616,6 +616,35 @@ def test_config4_total_parity_at_full_size(tfft):
   assert err <= 1e-4, err
 
 
+def test_3d_one_call_sorts_the_strengths_into_32_byte_records(tfft):
+  # 3-D float fixed-point plans with more than 16384 tiles (ranked-scatter sort path): the one-call entry writes
+  # FusedRec3 records (strength inside) and the dense-lane spreader gathers nothing; a tile holding more than
+  # 16 subproblems goes to the fp64-plane kernels, which read the same records with a 32-byte stride.
+  import torch
+  from oracle import oracle
+  rng = np.random.default_rng(123)
+  grid = [128, 256, 256]
+  for name, n_uniform, n_spot in (('uniform', 500000, 0), ('crowded', 300000, 150000)):
+    pts = rng.uniform(-np.pi, np.pi, (n_uniform + n_spot, 3)).astype(np.float32)
+    if n_spot:
+      pts[n_uniform:] = (np.array([0.4, -1.1, 2.0]) + 1e-3 * rng.standard_normal((n_spot, 3))).astype(np.float32)
+    M = pts.shape[0]
+    c = (rng.uniform(-.5, .5, M) + 1j * rng.uniform(-.5, .5, M)).astype(np.complex64)
+    truth = oracle.nufft(c.astype(np.complex128), pts, grid, 'type_1', 'forward', tol=1e-9, sigma=2.0)
+    plan = tfft.Plan('type_1', grid, 'forward', tol=1e-4)
+    i = plan.info()
+    assert i.kernel_width == 6 and int(np.prod(list(i.num_tiles))) > 16384
+    one = plan.execute_with_points(_dev(pts), _dev(c)).cpu().numpy()
+    plan.set_points(_dev(pts))
+    two = plan.execute(_dev(c)).cpu().numpy()
+    plan.close()
+    unfused = tfft.Plan('type_1', grid, 'forward', tol=1e-4, tuning=1)   # TUNE_NO_FUSED
+    ref = unfused.execute_with_points(_dev(pts), _dev(c)).cpu().numpy()
+    unfused.close()
+    assert rel_l2(one, truth) < 1e-4 and rel_l2(two, truth) < 1e-4, (name, rel_l2(one, truth), rel_l2(two, truth))
+    assert rel_l2(one, two) < 2e-6 and rel_l2(one, ref) < 2e-6, (name, rel_l2(one, two), rel_l2(one, ref))
+
+
 def test_spread_on_a_type2_interp_geometry_plan(tfft):
   # a spread_only type-2 float plan on a fine grid of >= 2^21 cells takes 64 x 64 tiles (the interp kernel's
   # geometry); nufft_hip_spread on it must still be right (r02 advisor finding: it ran the 32 x 32 wave kernel)
@@ -1092,6 +1121,8 @@ import tensorflow_nufft as tfft
 from oracle import oracle
 rng = np.random.default_rng(5)
 worst = 0.0
+opts = tfft.Options()
+opts._internal = {'tuning': int(sys.argv[3])}
 for name, grid, M in (('uniform', [96, 80], 120000), ('one_cell', [64, 64], 5000), ('ragged', [40, 136], 64 * 37 + 1)):
   pts = rng.uniform(-np.pi, np.pi, (M, 2)).astype(np.float32)
   if name == 'one_cell':   # every point inside one fine cell: a single group per 64-point chunk
@@ -1099,7 +1130,7 @@ for name, grid, M in (('uniform', [96, 80], 120000), ('one_cell', [64, 64], 5000
   c = (rng.uniform(-.5, .5, M) + 1j * rng.uniform(-.5, .5, M)).astype(np.complex64)
   truth = oracle.nufft(c.astype(np.complex128), pts, grid, 'type_1', 'backward', tol=1e-12, sigma=2.0)
   out = tfft.nufft(torch.from_numpy(c).cuda(), torch.from_numpy(pts).cuda(), grid_shape=grid,
-                   transform_type='type_1', fft_direction='backward', tol=1e-6).cpu().numpy()
+                   transform_type='type_1', fft_direction='backward', tol=1e-6, options=opts).cpu().numpy()
   err = np.linalg.norm(out - truth) / np.linalg.norm(truth)
   worst = max(worst, err)
   print(name, err)
@@ -1110,7 +1141,7 @@ c = (rng.uniform(-.5, .5, M) + 1j * rng.uniform(-.5, .5, M)).astype(np.complex64
 truth = oracle.nufft(c.astype(np.complex128), pts, grid, 'type_1', 'forward', tol=1e-12, sigma=2.0)
 for tol in (1e-5, 1e-4, 1e-3, 1e-2, 1e-1):
   out = tfft.nufft(torch.from_numpy(c).cuda(), torch.from_numpy(pts).cuda(), grid_shape=grid,
-                   transform_type='type_1', tol=tol).cpu().numpy()
+                   transform_type='type_1', tol=tol, options=opts).cpu().numpy()
   err = np.linalg.norm(out - truth) / np.linalg.norm(truth)
   worst = max(worst, err / tol * 1e-6)    # normalised so that the 1e-6 threshold below means err <= tol
   print('tol', tol, err)
@@ -1118,17 +1149,17 @@ print('WORST', worst)
 '''
 
 
-@pytest.mark.parametrize('group', ['0', '1'])
+@pytest.mark.parametrize('group', ['GROUP_OFF', 'GROUP_ON'])
 def test_w8_spread_variants_forced(group):
   # The 2-D w = 8 float spreader has a per-point and a cell-grouped kernel, picked by point
-  # density; NUFFT_HIP_W8_GROUP forces one (read once per process, hence the child process).
+  # density; options.tuning GROUP_OFF / GROUP_ON forces one (in a child process: a fresh plan cache).
   # Both must meet tol = 1e-6 against the fp64 oracle on dense, degenerate and ragged inputs.
-  import os
   import subprocess
   import sys
   from conftest import PKG, ROOT
-  env = dict(os.environ, NUFFT_HIP_W8_GROUP=group)
-  r = subprocess.run([sys.executable, '-c', _W8_CHILD, ROOT, PKG], env=env, capture_output=True, text=True, timeout=600)
+  from tensorflow_nufft import _lib
+  r = subprocess.run([sys.executable, '-c', _W8_CHILD, ROOT, PKG, str(_lib.TUNE[group])], capture_output=True, text=True,
+                     timeout=600)
   assert r.returncode == 0, r.stderr[-2000:]
   worst = float(r.stdout.strip().splitlines()[-1].split()[1])
   assert worst < 1e-6, r.stdout
@@ -1325,43 +1356,53 @@ sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
 import tensorflow_nufft as tfft
 rng = np.random.default_rng(11)
 outs = {}
+opts = tfft.Options()
+opts._internal = {'tuning': int(sys.argv[4])}
 for name, grid, M, ttype, tol in (('t1_3d_w8', [32, 32, 32], 150000, 'type_1', 1e-6), ('t1_3d_w8_thin', [64, 64, 64], 20000, 'type_1', 1e-6),
                                   ('t2_2d_pow2', [64, 128], 50000, 'type_2', 1e-6), ('t2_3d_pow2', [16, 32, 16], 30000, 'type_2', 1e-5),
-                                  ('t1_2d_4096tiles', [1024, 1024], 300000, 'type_1', 1e-6), ('t2_1d', [2048], 70000, 'type_2', 1e-6)):
+                                  ('t1_2d_4096tiles', [1024, 1024], 300000, 'type_1', 1e-6), ('t2_1d', [2048], 70000, 'type_2', 1e-6),
+                                  ('t1_2d_dense', [128, 128], 200000, 'type_1', 1e-6), ('t1_2d_w11', [64, 64], 30000, 'type_1', 1e-9),
+                                  ('t1_3d_sparse', [64, 64, 64], 800, 'type_1', 1e-4), ('t2_3d_dense', [24, 24, 24], 200000, 'type_2', 1e-4)):
   pts = torch.from_numpy(rng.uniform(-np.pi, np.pi, (M, len(grid))).astype(np.float32)).cuda()
   shape = [M] if ttype == 'type_1' else grid
   src = torch.from_numpy((rng.uniform(-.5, .5, shape) + 1j * rng.uniform(-.5, .5, shape)).astype(np.complex64)).cuda()
   kw = dict(grid_shape=grid) if ttype == 'type_1' else {}
-  outs[name] = tfft.nufft(src, pts, transform_type=ttype, tol=tol, **kw).cpu().numpy()
+  if name == 't1_2d_w11':
+    pts, src = pts.double(), src.to(torch.complex128)
+  outs[name] = tfft.nufft(src, pts, transform_type=ttype, tol=tol, options=opts, **kw).cpu().numpy()
 np.savez(sys.argv[3], **outs)
 print('CASES', len(outs))
 '''
 
 
-def test_ab_knobs_give_the_same_transforms(tmp_path):
-  # The environment knobs select alternative kernels for A/B runs (64-bit integer planes, the staged
-  # scatter for 4096 tiles, the scatter-out type-2 FFT passes, joint / split 3-D launches, the
-  # thread-per-point 1-D interp, 64 x 64 type-2 tiles on small grids): each must give the default
-  # path's transform.
-  import os
+def test_tuning_bits_give_the_same_transforms(tmp_path):
+  # options.tuning forces one of the kernel families the plan otherwise picks by density / geometry (staged or
+  # plain scatter, fused records or not, grouped or per-point 2-D spreader, joint or split 3-D w = 8 launches,
+  # LDS-free spreader, cell-sorted records, rocFFT + deconvolve instead of the pruned passes, thread-per-point
+  # kernels instead of the wide / line ones): each must give the default path's transform.
   import subprocess
   import sys
   from conftest import PKG, ROOT
-  base = str(tmp_path / 'base.npz')
-  r = subprocess.run([sys.executable, '-c', _KNOB_CHILD, ROOT, PKG, base], capture_output=True, text=True, timeout=600)
-  assert r.returncode == 0, r.stderr[-1500:]
-  ref = np.load(base)
-  for knobs in ({'NUFFT_HIP_W8_I64': '1', 'NUFFT_HIP_STAGED_4K': '1', 'NUFFT_HIP_FFT_NO_GATHER': '1', 'NUFFT_HIP_NO_LINE': '1',
-                 'NUFFT_HIP_BIG_T2_ALWAYS': '1', 'NUFFT_HIP_SORT_MINPB': '4096'},
-                {'NUFFT_HIP_W8_JOINT': '1', 'NUFFT_HIP_T2_SUB': '2048', 'NUFFT_HIP_STAGED_SCATTER': '1'},
-                {'NUFFT_HIP_W8_JOINT': '0', 'NUFFT_HIP_W8_DEPTH4': '1', 'NUFFT_HIP_NO_FUSED': '1', 'NUFFT_HIP_NO_OWN_FFT': '1'}):
-    alt = str(tmp_path / 'alt.npz')
-    r = subprocess.run([sys.executable, '-c', _KNOB_CHILD, ROOT, PKG, alt], capture_output=True, text=True, timeout=600,
-                       env=dict(os.environ, **knobs))
-    assert r.returncode == 0, (knobs, r.stderr[-1500:])
-    got = np.load(alt)
+  from tensorflow_nufft import _lib
+  T = _lib.TUNE
+
+  def run(path, tuning):
+    r = subprocess.run([sys.executable, '-c', _KNOB_CHILD, ROOT, PKG, path, str(tuning)], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, (tuning, r.stderr[-1500:])
+    return np.load(path)
+
+  ref = run(str(tmp_path / 'base.npz'), 0)
+  for bits in (('NO_FUSED', 'GROUP_OFF', 'SPARSE_OFF', 'CELLSORT_OFF', 'CELLSORT3D_OFF', 'ROCFFT', 'NO_WIDE', 'NO_LINE',
+                'JOINT_OFF', 'STAGED_OFF'),
+               ('GROUP_ON', 'SPARSE_OFF', 'CELLSORT_ON', 'CELLSORT3D_ON', 'JOINT_ON', 'STAGED_ON'),
+               ('SPARSE_ON', 'NO_FUSED')):
+    tuning = 0
+    for b in bits:
+      tuning |= T[b]
+    got = run(str(tmp_path / 'alt.npz'), tuning)
     for k in ref.files:
-      assert rel_l2(got[k], ref[k]) < 2e-6, (knobs, k, rel_l2(got[k], ref[k]))
+      assert rel_l2(got[k], ref[k]) < (2e-6 if k != 't1_3d_sparse' and k != 't2_3d_dense' else 2e-5), (bits, k, rel_l2(got[k], ref[k]))
 
 
 _EFENCE_CHILD = r'''

@@ -51,9 +51,11 @@ if '5op' in which:
   B, M = 32, 1_000_000
   pts = (torch.rand((B, M, 2), generator=g, device='cuda') * 2 - 1) * np.pi
   c = rnd_c([B, M], g)
-  for _ in range(3): out = tfft.nufft(c, pts, grid_shape=[512, 512], transform_type='type_1')
+  opts = tfft.Options()   # BENCH_OP_GROUP / BENCH_OP_LANES: options.op_group / op_lanes (tools/sweep_group.sh)
+  opts._internal = {'op_group': int(os.environ.get('BENCH_OP_GROUP', '0')), 'op_lanes': int(os.environ.get('BENCH_OP_LANES', '0'))}
+  for _ in range(3): out = tfft.nufft(c, pts, grid_shape=[512, 512], transform_type='type_1', options=opts)
   torch.cuda.synchronize(); t0 = time.perf_counter()
-  for _ in range(5): out = tfft.nufft(c, pts, grid_shape=[512, 512], transform_type='type_1')
+  for _ in range(5): out = tfft.nufft(c, pts, grid_shape=[512, 512], transform_type='type_1', options=opts)
   torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
   print(f'cfg5 via tfft.nufft (op level, per-item points, 32 items): {dt*1e3:.3f} ms  {B*M/dt/1e6:.1f} Mpts/s')
 if '1dbig' in which:

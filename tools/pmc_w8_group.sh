@@ -1,12 +1,11 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-export NUFFT_HIP_W8_SHAPE=${W8SHAPE:-8x64}
 for grp in ${W8GROUPS:-1}; do
-export NUFFT_HIP_W8_GROUP=$grp
+TUNE=$([ $grp = 1 ] && echo GROUP_ON || echo GROUP_OFF)
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS" "SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" "SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $set --kernel-trace -d gpurun_out/pmcg_${grp}_$i -o p --output-format csv -- python3 tools/profile_run.py --steps 2 > gpurun_out/pmcg_${grp}_$i.log 2>&1
+  timeout 300 rocprofv3 --pmc $set --kernel-trace -d gpurun_out/pmcg_${grp}_$i -o p --output-format csv -- python3 tools/profile_run.py --steps 2 --tuning $TUNE > gpurun_out/pmcg_${grp}_$i.log 2>&1
 done
 done
 python3 - <<'PY'

@@ -11,6 +11,7 @@ ap.add_argument('--M', type=float, default=1e7); ap.add_argument('--tol', type=f
 ap.add_argument('--method', type=int, default=0); ap.add_argument('--S', type=int, default=0)
 ap.add_argument('--steps', type=int, default=5); ap.add_argument('--ntransf', type=int, default=1)
 ap.add_argument('--acc', type=int, default=0)
+ap.add_argument('--tuning', default='', help='comma-separated nufft_hip_options.tuning bits, e.g. GROUP_OFF,ROCFFT')
 ap.add_argument('--double', action='store_true', help='complex128 / float64')
 ap.add_argument('--dist', default='uniform', help='uniform | radial | radial-ordered (2-D)')
 ap.add_argument('--one-call', action='store_true', help='nufft_hip_execute_with_points instead of set_points + execute')
@@ -31,7 +32,10 @@ if a.type == 'type_1':
 else:
   src = torch.complex(torch.rand(lead + grid, generator=g, device='cuda') - .5, torch.rand(lead + grid, generator=g, device='cuda') - .5)
 if a.double: pts = pts.double(); src = src.to(torch.complex128)
-plan = tfft.Plan(a.type, grid, 'forward', num_transforms=a.ntransf, tol=a.tol, dtype=torch.complex128 if a.double else torch.complex64, spread_method=a.method, max_subproblem_size=a.S, lds_accumulate=a.acc)
+from tensorflow_nufft import _lib
+tuning = 0
+for b in filter(None, a.tuning.split(',')): tuning |= _lib.TUNE[b]
+plan = tfft.Plan(a.type, grid, 'forward', num_transforms=a.ntransf, tol=a.tol, dtype=torch.complex128 if a.double else torch.complex64, spread_method=a.method, max_subproblem_size=a.S, lds_accumulate=a.acc, tuning=tuning)
 for _ in range(a.steps):
   if a.one_call:
     out = plan.execute_with_points(pts, src)

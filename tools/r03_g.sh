@@ -1,0 +1,28 @@
+#!/bin/bash
+cd /tmp && export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r03g; mkdir -p $O
+timeout 600 python -m pytest tests -m gpu -x -q -k "32_byte_records or config4_total or fixed_point_lds" > $O/pytest.txt 2>&1; tail -3 $O/pytest.txt
+python3 - <<'PY' 2>&1 | grep -v amdgpu
+import sys, os, time
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), 'tensorflow-nufft_amd'))
+import numpy as np, torch, tensorflow_nufft as tfft
+g = torch.Generator(device='cuda').manual_seed(4)
+M = 100_000_000
+pts = (torch.rand((M, 3), generator=g, device='cuda') * 2 - 1) * np.pi
+c = torch.complex(torch.rand(M, generator=g, device='cuda') - .5, torch.rand(M, generator=g, device='cuda') - .5)
+for rep in range(2):
+ for name, tuning in (('fused (one call)', 0), ('unfused (one call, TUNE_NO_FUSED)', 1)):
+  plan = tfft.Plan('type_1', [256, 256, 256], 'forward', tol=1e-4, tuning=tuning)
+  for _ in range(2): out = plan.execute_with_points(pts, c)
+  torch.cuda.synchronize(); t0 = time.perf_counter()
+  for _ in range(5): out = plan.execute_with_points(pts, c)
+  torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
+  plan.set_timing(True); plan.get_timing()
+  for _ in range(3): plan.execute_with_points(pts, c)
+  tm = plan.get_timing()
+  print(f'cfg4 {name}: {dt*1e3:.3f} ms/step ', ' '.join(f'{k}={v[0]/max(v[1],1)*1e3:.0f}us' for k, v in tm.items() if v[1]))
+  plan.close()
+PY
+python3 tools/ab_t1_big_tiles.py 2>&1 | grep -v amdgpu | tee $O/ab_t1_big_tiles.txt
+bash tools/first_launch_experiment.sh 40 2>&1 | tail -8 | tee $O/first_launch.txt

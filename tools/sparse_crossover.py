@@ -1,6 +1,6 @@
 """Crossover between the LDS-tile spreaders and the LDS-free (global atomic) spreader:
-spread-stage time by point count, both forced (NUFFT_HIP_SPARSE = 0 / 1 is read once per
-process, so each measurement runs in a child process)."""
+spread-stage time by point count, both forced (options.tuning SPARSE_OFF / SPARSE_ON; each
+measurement in a child process)."""
 import os, subprocess, sys
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
 CHILD = r'''
@@ -12,7 +12,8 @@ grid = [int(g) for g in sys.argv[2].split(',')]; M = int(float(sys.argv[3])); to
 g = torch.Generator(device='cuda').manual_seed(1)
 pts = (torch.rand((M, len(grid)), generator=g, device='cuda') * 2 - 1) * np.pi
 c = torch.complex(torch.rand(M, generator=g, device='cuda') - .5, torch.rand(M, generator=g, device='cuda') - .5)
-plan = tfft.Plan('type_1', grid, tol=tol)
+from tensorflow_nufft import _lib
+plan = tfft.Plan('type_1', grid, tol=tol, tuning=_lib.TUNE[sys.argv[5]])
 plan.set_points(pts)
 for _ in range(3): plan.execute(c)
 plan.set_timing(2); plan.get_timing()
@@ -27,8 +28,7 @@ for grid, tol, Ms in (('256,256,256', 1e-4, ['1e3', '1e4', '1e5', '3e5', '1e6', 
   for gdim in grid.split(','): cells *= 2 * int(gdim)
   for M in Ms:
     res = []
-    for mode in ('0', '1'):
-      env = dict(os.environ, NUFFT_HIP_SPARSE=mode)
-      r = subprocess.run([sys.executable, '-c', CHILD, ROOT, grid, M, str(tol)], env=env, capture_output=True, text=True)
+    for mode in ('SPARSE_OFF', 'SPARSE_ON'):
+      r = subprocess.run([sys.executable, '-c', CHILD, ROOT, grid, M, str(tol), mode], capture_output=True, text=True)
       res.append(float(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else float('nan'))
     print(f'{M:>6} | {float(M)/cells:9.2e} | {res[0]:10.1f} | {res[1]:10.1f}')

@@ -52,6 +52,18 @@ int main() {
   mk("8x8 patch, row stride 40 (2-D kernels)", [](int l) { return (l & 7) + 40 * (l >> 3); });
   // 6 x 3 x 3 cells, LS = 21, PS = 21 * 21 + 6 = 447 (== 31 mod 32): natural lane order
   mk("6x3x3 natural order, LS 21, PS 447", [](int l) { return l < 54 ? (l % 6) + 21 * ((l / 6) % 3) + 447 * (l / 18) : l; });
+  mk("16-lane groups: lanes j, j+8 sixteen elements apart (2-way only if columns are mod 16)", [](int l) { const int j = l % 16; return (j % 8) + 16 * (j / 8) + 64 * (l / 16); });
+  {   // the lane table of spread_dense3_kernel<6, 8>: 6 x 3 x 3 cells dealt to four 16-lane groups by column mod 16
+    P p; p.name = "6x3x3 dealt to 4 groups of 16 by column (nufft_dense3.hip), LS 21, PS 441"; p.pat.assign(64, 0);
+    bool used[4][16] = {}; int n[4] = {0, 0, 0, 0}, next[4] = {0, 16, 32, 48};
+    for (int z = 0; z < 3; ++z) for (int y = 0; y < 3; ++y) for (int x = 0; x < 6; ++x) {
+      const int cell = x + 21 * y + 441 * z, col = cell & 15; int best = -1;
+      for (int g = 0; g < 4; ++g) if (!used[g][col] && (best < 0 || n[g] < n[best])) best = g;
+      used[best][col] = true; ++n[best]; p.pat[next[best]++] = cell;
+    }
+    for (int g = 0; g < 4; ++g) { int col = 0; for (int l = next[g]; l < 16 * (g + 1); ++l) { while (used[g][col]) ++col; used[g][col] = true; p.pat[l] = col; } }
+    ps.push_back(p);
+  }
   for (auto& p : ps) {
     hipMemcpy(dpat, p.pat.data(), 64 * 4, hipMemcpyHostToDevice);
     float ms[2];
