@@ -116,8 +116,7 @@ enum {
   NUFFT_HIP_TUNE_JOINT_OFF = 1 << 12,      /* 3-D float w = 8: both fp64 planes in one launch: never / always */
   NUFFT_HIP_TUNE_JOINT_ON = 1 << 13,
   NUFFT_HIP_TUNE_STAGED_OFF = 1 << 14,     /* staged scatter (<= 1024 tiles per point set): never / always */
-  NUFFT_HIP_TUNE_STAGED_ON = 1 << 15,
-  NUFFT_HIP_TUNE_T1_BIG_TILES = 1 << 16    /* experiment: 2-D float type-1 plans at w = 8 on 64 x 64 tiles */
+  NUFFT_HIP_TUNE_STAGED_ON = 1 << 15
 };
 
 typedef struct nufft_hip_plan_s* nufft_hip_plan;

@@ -1282,7 +1282,6 @@ __global__ __launch_bounds__(kCellSortThreads) void cellsort3d_kernel(
 // points per cell) that removes ~60 % of the LDS atomics that bound the
 // ungrouped kernel.
 constexpr int kGroupMaxSub = 4096;
-constexpr int kBig2NW = 16, kBig2SC = 16;   // the 64 x 64-tile variant (experiment): 16 waves, 16 staged points
 constexpr double kGroupMinDensity = 0.5;   // points per fine cell
 constexpr double kInterpSortMinDensity = 0.3;   // 3-D interp cell sort pays from here (r01: 0.075 loses, 0.75 and 1.8 win)
 constexpr int kGroupStage = 32; // points whose kernel values are in LDS at a time (per wave; 16 measured 12 % slower, r02)
@@ -1290,9 +1289,9 @@ template <typename T> constexpr int kGroupStageOf = sizeof(T) == 8 ? 16 : kGroup
 constexpr int kGroupBlk = 36;   // staging words per block of 4 points (8 x 4 + 4 pad)
 template <int CH> constexpr int kGroupStageWave = 3 * (CH / 4) * kGroupBlk;   // words per wave (kx, ky re, ky im)
 // FUSED: the records are FusedRec (strength inside, no index): no gather at all.
-// TILE = 64 (experiment, options.tuning T1_BIG_TILES): 64 x 64 tiles, 71 x 72 planes (82 KB), 4096 start cells,
-// subproblems of up to 16384 points, one workgroup per CU -- the tile size at which the sort becomes ONE staged pass.
-template <typename T, int W, int NW, int CH, bool PRE, bool FUSED = false, int TILE = 32>
+// (r03 measured this kernel on 64 x 64 tiles -- 82 KB of planes, 4096 start cells, one workgroup per CU -- so that the
+// sort becomes ONE staged pass: scatter 161 -> 97 us, spread 283 -> 397 us at config 2, a net loss)
+template <typename T, int W, int NW, int CH, bool PRE, bool FUSED = false>
 __global__ __launch_bounds__(NW * 64) void spread_2d_w8_group_kernel(
     Geom g, SortedPoints<T> sp, const T* __restrict__ horner, const T* __restrict__ c,
     T* __restrict__ fw, int64_t c_stride, int64_t fw_stride, T scale) {
@@ -1301,21 +1300,16 @@ __global__ __launch_bounds__(NW * 64) void spread_2d_w8_group_kernel(
   using RecT = std::conditional_t<FUSED, FusedRec, Rec<T>>;
   const RecT* __restrict__ recs = reinterpret_cast<const RecT*>(sp.rec);
   constexpr int NT = NW * 64;
-  constexpr int kWT = TILE, kWL = TILE + kWW - 1, kWS = TILE + 8, kWPlane = kWS * kWL;   // (shadow the 32 x 32 constants)
-  constexpr int NKEY = TILE * TILE, KB = TILE == 64 ? 6 : 5, RB = 2 * KB;
-  constexpr int kMaxSub = TILE == 64 ? 16384 : kGroupMaxSub;
-  static_assert(!(FUSED && TILE != 32), "FusedRec holds 5-bit tile-local starts");
-  constexpr int IT = (kMaxSub + NT - 1) / NT;   // records per thread in the LDS sort
-  constexpr int SC0 = TILE == 64 ? kBig2SC : kGroupStageOf<T>;
-  constexpr int SC = CH < SC0 ? CH : SC0;   // points staged through LDS at a time
+  constexpr int IT = (kGroupMaxSub + NT - 1) / NT;   // records per thread in the LDS sort
+  constexpr int SC = CH < kGroupStageOf<T> ? CH : kGroupStageOf<T>;   // points staged through LDS at a time
   static_assert(NT <= 1024, "at most 16 waves");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* plane_re = reinterpret_cast<double*>(smem_raw);
   double* plane_im = plane_re + kWPlane;
   T* stage_all = reinterpret_cast<T*>(plane_im + kWPlane);
   uint32_t* cnt = reinterpret_cast<uint32_t*>(stage_all + NW * kGroupStageWave<SC>);   // [1024]
-  uint16_t* perm = reinterpret_cast<uint16_t*>(cnt + NKEY);                     // [kMaxSub]
-  uint32_t* wsum = reinterpret_cast<uint32_t*>(perm + kMaxSub);                 // [16]
+  uint16_t* perm = reinterpret_cast<uint16_t*>(cnt + 1024);                     // [4096]
+  uint32_t* wsum = reinterpret_cast<uint32_t*>(perm + kGroupMaxSub);            // [16]
   int tb, p0, p1, slot;
   if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1, &slot)) return;
   const int n = p1 - p0;
@@ -1324,14 +1318,14 @@ __global__ __launch_bounds__(NW * 64) void spread_2d_w8_group_kernel(
   const int wave = tid >> 6;
   for (int i = tid; i < 2 * kWPlane; i += NT) plane_re[i] = 0.0;
   if constexpr (!PRE) {
-    for (int i = tid; i < NKEY; i += NT) cnt[i] = 0u;
+    for (int i = tid; i < 1024; i += NT) cnt[i] = 0u;
     __syncthreads();
 
     // ---- LDS counting sort of the subproblem by start cell (plans whose records are
     // not already cell-ordered by cellsort2d_kernel)
     // (all loads are unconditional on clamped indices: a load under a divergent
     // branch makes the compiler wait for it before the next one is issued)
-    uint32_t kr[IT];   // key | rank-in-cell << RB
+    uint32_t kr[IT];   // key | rank-in-cell << 10
 #pragma unroll
     for (int u = 0; u < IT; ++u) {
       const int i = tid + u * NT;
@@ -1348,15 +1342,15 @@ __global__ __launch_bounds__(NW * 64) void spread_2d_w8_group_kernel(
 #pragma unroll
     for (int u = 0; u < IT; ++u) {
       const int i = tid + u * NT;
-      const uint32_t key = (((kr[u] >> 10) & (uint32_t)(TILE - 1)) << KB) | (kr[u] & (uint32_t)(TILE - 1));
-      if (i < n) kr[u] = key | (atomicAdd(&cnt[key], 1u) << RB);
+      const uint32_t key = (((kr[u] >> 10) & 31u) << 5) | (kr[u] & 31u);
+      if (i < n) kr[u] = key | (atomicAdd(&cnt[key], 1u) << 10);
     }
     __syncthreads();
-    scan_counts<NT, NKEY>(cnt, wsum, tid);
+    scan1024<NT>(cnt, wsum, tid);
 #pragma unroll
     for (int u = 0; u < IT; ++u) {
       const int i = tid + u * NT;
-      if (i < n) perm[cnt[kr[u] & (uint32_t)(NKEY - 1)] + (kr[u] >> RB)] = (uint16_t)i;
+      if (i < n) perm[cnt[kr[u] & 1023u] + (kr[u] >> 10)] = (uint16_t)i;
     }
   }
   __syncthreads();
@@ -2401,10 +2395,6 @@ static size_t group_lds(int nw, int ch, bool presorted, int precision = NUFFT_HI
   return sizeof(double) * 2 * kWPlane + (size_t)precision * nw * 3 * ((ch < stage ? ch : stage) / 4) * kGroupBlk +
          (presorted ? 0 : 1024 * 4 + kGroupMaxSub * 2 + 64);   // + counters, permutation, wave sums
 }
-// (launch shape of the 64 x 64-tile variant: kBig2NW waves, kBig2SC staged points, in-kernel sort only)
-static size_t group64_lds() {
-  return sizeof(double) * 2 * 72 * 71 + sizeof(float) * kBig2NW * 3 * (kBig2SC / 4) * kGroupBlk + 4096 * 4 + 16384 * 2 + 64;
-}
 static size_t wave8_lds(bool grouped, bool presorted = false) {
   const int nw = wave8_nw(grouped), ch = wave8_ch(grouped);
   if (!grouped) return sizeof(double) * 2 * kWPlane + sizeof(float) * nw * ch * kWW * 3;
@@ -2605,19 +2595,6 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
   // 2-D type-2 plans on 64 x 64 tiles (the interp kernel's geometry): nufft_hip_spread on such a
   // spread_only plan takes the thread-per-point tile kernel, which works on any tile; the wavefront
   // spreaders are laid out for 32 x 32 tiles and row stride 40 only.
-  if constexpr (sizeof(T) == 4) {
-    // experiment (options.tuning T1_BIG_TILES): type 1 on 64 x 64 tiles -- one staged scatter pass
-    // into <= 1024 tiles per point set, then the cell-grouped spreader on 82 KB of planes, one workgroup per CU
-    if (method == NUFFT_HIP_METHOD_TILE_WAVE && g.rank == 2 && !g.wide && (g.tuning & NUFFT_HIP_TUNE_T1_BIG_TILES) && !g.fused &&
-        g.w == kWW && g.tile[0] == 64 && g.tile[1] == 64 && g.lstride == 72 && g.max_sub <= 16384 && g.ncoef <= kWaveCoef) {
-      lds_bytes = group64_lds();
-      e = ensure_lds(spread_2d_w8_group_kernel<float, 8, kBig2NW, 64, false, false, 64>, lds_bytes);
-      if (e != hipSuccess) return e;
-      spread_2d_w8_group_kernel<float, 8, kBig2NW, 64, false, false, 64><<<grid, kBig2NW * 64, lds_bytes, stream>>>(
-          g, sp, horner, c, fw, c_stride, fw_stride, scale);
-      return hipGetLastError();
-    }
-  }
   if (method == NUFFT_HIP_METHOD_TILE_WAVE && g.rank == 2 && (g.tile[0] != kWT || g.tile[1] != kWT || g.lstride != kWS)) {
     method = NUFFT_HIP_METHOD_TILE_GENERIC;
     lds_bytes = spread_lds_bytes(g, method, (int)sizeof(T));

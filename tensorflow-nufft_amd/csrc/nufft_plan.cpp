@@ -984,8 +984,7 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
   // 2-D float type-2 (and interp-only) plans: 64 x 64. Their LDS tile is single-precision
   // complex (71^2 x 8 B = 40 KB), and four times fewer tiles make the (workgroup, tile) runs
   // of the scatter four times longer (the scatter is transaction bound).
-  const bool t1_big_exp = type == NUFFT_HIP_TYPE_1 && (p->opts.tuning & NUFFT_HIP_TUNE_T1_BIG_TILES) && w == 8 && !p->opts.spread_only;
-  const bool t2_big = (type == NUFFT_HIP_TYPE_2 || t1_big_exp) && rank == 2 && precision == NUFFT_HIP_F32 && w <= 8 &&
+  const bool t2_big = type == NUFFT_HIP_TYPE_2 && rank == 2 && precision == NUFFT_HIP_F32 && w <= 8 &&
                       p->opts.spread_method == NUFFT_HIP_METHOD_AUTO && p->opts.tile_dims[0] == 0 &&
                       p->opts.tile_dims[1] == 0 && p->opts.max_subproblem_size <= 0 &&
                       g.nf[0] >= 64 && g.nf[1] >= 64 &&
@@ -1134,7 +1133,7 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
   // every extra subproblem of a tile repeats its zero-fill and write-out
   if (method == NUFFT_HIP_METHOD_TILE_WAVE && auto_sub) g.max_sub = t2_wave ? 16384 : 4096;   // (interp: one tile load per subproblem)
   // clustered point sets: scan_tiles_kernel falls back to 4096-point subproblems
-  if (method == NUFFT_HIP_METHOD_TILE_WAVE && auto_sub && t2_wave && type == NUFFT_HIP_TYPE_2) g.sub_small = 4096;
+  if (method == NUFFT_HIP_METHOD_TILE_WAVE && auto_sub && t2_wave) g.sub_small = 4096;
   if (g.wide && auto_sub && rank == 3) g.max_sub = 1024;   // (hundreds of LDS atomics per point: keep workgroups short)
   if (g.fixed_point && w > 6) g.max_sub = std::min(g.max_sub, 512);
   g.fx_max_subs = 16;

@@ -12,14 +12,12 @@
 // of logic that must live here is the graph-time shape function (TF's InferenceContext
 // works on symbolic shapes).
 //
-// NOT BUILT IN THIS REPOSITORY'S IMAGE: TensorFlow is not installed here
-// (SURVEY.md section 8c), so this translation unit has never been compiled;
-// it is the binding a maintainer adds on a TensorFlow-ROCm machine:
-//
-//   hipcc -std=c++17 -shared -fPIC nufft_tf_ops.cc -o _nufft_ops.so \
-//     $(python -c 'import tensorflow as tf; print(" ".join(tf.sysconfig.get_compile_flags()))') \
-//     -I<repo>/include -L<repo>/tensorflow-nufft_amd/tensorflow_nufft -lnufft_hip \
-//     $(python -c 'import tensorflow as tf; print(" ".join(tf.sysconfig.get_link_flags()))')
+// NOT BUILT IN THIS REPOSITORY'S IMAGE: TensorFlow is not installed here. What IS
+// checked here: this file type-checks (g++ -fsyntax-only) against tests/tf_api_stub/, a set of declarations
+// with the names and signatures of TensorFlow's public C++ op API and no behaviour
+// (tests/test_cabi_cpu.py::test_tf_glue_type_checks_against_the_api_stub) -- syntax, types and the use of the
+// C ABI, nothing about the real headers or about loading. The build line for a TensorFlow-ROCm machine is in
+// INTEGRATION.md section 1.
 #define EIGEN_USE_GPU
 #include <string>
 #include <vector>

@@ -231,3 +231,22 @@ def test_stage_list_matches_the_header():
   n = int(re.search(r'#define NUFFT_HIP_NUM_STAGES (\d+)', hdr).group(1))
   assert n == len(_lib.STAGES)
   assert _lib.STAGES[-1] == 'sort_cell' and _lib.STAGES[4] == 'spread'
+
+
+def test_tf_glue_type_checks_against_the_api_stub():
+  # TensorFlow is absent from this image, so the TF glue cannot be built; it can be TYPE-CHECKED against
+  # tests/tf_api_stub (declarations only, NOT TensorFlow): syntax, types, and every call into the C ABI.
+  import subprocess
+  src = os.path.join(ROOT, 'tensorflow-nufft_amd', 'csrc', 'tf_glue', 'nufft_tf_ops.cc')
+  cmd = ['g++', '-std=c++17', '-fsyntax-only', '-Wall', '-Werror', '-Wno-unused-function',
+         '-I', os.path.join(ROOT, 'tests', 'tf_api_stub'), '-I', os.path.join(ROOT, 'include'), src]
+  r = subprocess.run(cmd, capture_output=True, text=True)
+  assert r.returncode == 0, r.stderr[-3000:]
+  # the check has teeth: a wrong argument to the C ABI is refused
+  bad = open(src).read().replace('nufft_hip_op_shape(&d, &ndim, shape, err, sizeof(err))', 'nufft_hip_op_shape(&d, shape, &ndim, err, sizeof(err))')
+  assert bad != open(src).read()
+  r = subprocess.run(cmd[:-1] + ['-x', 'c++', '-'], input=bad, capture_output=True, text=True)
+  assert r.returncode != 0
+  # and the glue stays plumbing: no arithmetic on tensor contents, no parsing
+  text = open(src).read()
+  assert len(text.splitlines()) <= 210 and 'ReadVarint' not in text and 'ParseOptions' not in text
