@@ -29,7 +29,8 @@
 // Accumulation format (unchanged from r01/r02): one 64-bit integer per fine cell
 // holding (re, im) as two signed 32-bit fields in units of `step`, chosen per subproblem so that no
 // cell can overflow (sum of max(|re c|, |im c|) of the subproblem's strengths <= 2^31 steps) and no
-// single contribution leaves the exact range of the FMA conversion (|n| < 2^22). Tiles with more
+// single contribution leaves the exact range of the FMA conversion (|n| < 2^22; a dominant strength is converted
+// with v_cvt behind the loop instead of coarsening the step for the others). Tiles with more
 // subproblems than Geom::fx_max_subs are left to the fp64-plane kernels (nufft_kernels.hip).
 #include <hip/hip_runtime.h>
 
@@ -137,6 +138,11 @@ template <int W, int TZ> struct DenseCfg {
   static constexpr int plane_elems = (L.ps * L.planes + 64 + 1) & ~1;
   static constexpr size_t stage_bytes = (size_t)NW * (HALF / 2) * SLOTS * 16;
   static constexpr size_t lds_bytes = (size_t)plane_elems * 8 + stage_bytes + 2 * NW * sizeof(float) + 64;
+  // GROUP: + the permutation of the in-LDS sort by start cell (its counters borrow the plane before it is zeroed)
+  static constexpr int NKEY = kDenseTile * kDenseTile * TZ;       // start cells of a tile
+  static constexpr int kMaxSub = 4096;                            // points per subproblem (the plan's cap)
+  static constexpr size_t lds_bytes_group = lds_bytes + kMaxSub * 2 + 64;
+  static_assert(NKEY * 4 <= plane_elems * 8, "sort counters must fit in the plane");
 };
 
 // per-lane tables in constant memory (one 16-byte load per lane at kernel start)
@@ -184,7 +190,11 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 // FUSED: the records are FusedRec3 (strength behind the 16-byte record): nothing is gathered.
-template <int W, int TZ, bool FUSED>
+// GROUP (dense point sets): the subproblem's points are counting-sorted by stencil start cell in LDS first (as
+// spread_2d_w8_group_kernel does), and consecutive points that share a start cell add their packed contributions
+// in registers (one v_lshl_add_u64 per atomic saved; the bias of the FMA conversion is taken out once per run)
+// before ONE set of ds_add_u64. Pays above ~1.2 points per fine cell (dense3_grouped below has the measurements).
+template <int W, int TZ, bool FUSED, bool GROUP>
 __global__ __launch_bounds__(kDenseNW * 64) void spread_dense3_kernel(
     Geom g, SortedPoints<float> sp, const float* __restrict__ horner, const float* __restrict__ c,
     float* __restrict__ fw, int64_t c_stride, int64_t fw_stride, float scale) {
@@ -202,38 +212,79 @@ __global__ __launch_bounds__(kDenseNW * 64) void spread_dense3_kernel(
   if (nsub > g.fx_max_subs) return;   // crowded tile: the fp64-plane launches behind this one take it
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: keeps the point loops' bounds in SGPRs)
-  for (int i = tid; i < C::plane_elems; i += NW * 64) plane[i] = 0ull;
   const float2* cc = reinterpret_cast<const float2*>(c) + (int64_t)slot * c_stride;
   const FusedRec3* rec3 = reinterpret_cast<const FusedRec3*>(sp.rec);
   const int npt = p1 - p0;
+  uint16_t* perm = reinterpret_cast<uint16_t*>(red + 2 * NW + 8);   // [kMaxSub] (GROUP)
+  if constexpr (GROUP) {
+    // counting sort of the subproblem by start cell: keys 4 + 4 + 3 bits (tile 16 x 16 x 8), counters in the
+    // (not yet zeroed) plane, 16-bit permutation; records stay where the global sort put them
+    constexpr int NT = NW * 64, NKEY = C::NKEY, KBITS = TZ == 8 ? 11 : 10, IT = (C::kMaxSub + NT - 1) / NT;
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(plane);
+    uint32_t* wsum = reinterpret_cast<uint32_t*>(perm + C::kMaxSub);
+    for (int i = tid; i < NKEY; i += NT) cnt[i] = 0u;
+    __syncthreads();
+    uint32_t kr[IT];
+#pragma unroll
+    for (int u = 0; u < IT; ++u) {   // (loads unconditional on clamped indices: issued back to back)
+      const int i = tid + u * NT;
+      const int ic = p0 + (i < npt ? i : npt - 1);
+      uint4 w;
+      if constexpr (FUSED) w = *reinterpret_cast<const uint4*>(&rec3[ic].r);
+      else w = *reinterpret_cast<const uint4*>(&sp.rec[ic]);
+      kr[u] = (w.x >> 28) | ((w.y >> 28) << 4) | ((w.z >> 28) << 8);
+    }
+#pragma unroll
+    for (int u = 0; u < IT; ++u) {
+      const int i = tid + u * NT;
+      if (i < npt) kr[u] |= atomicAdd(&cnt[kr[u]], 1u) << KBITS;
+    }
+    __syncthreads();
+    scan_counts<NT, NKEY>(cnt, wsum, tid);
+#pragma unroll
+    for (int u = 0; u < IT; ++u) {
+      const int i = tid + u * NT;
+      if (i < npt) perm[cnt[kr[u] & (uint32_t)(NKEY - 1)] + (kr[u] >> KBITS)] = (uint16_t)i;
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < C::plane_elems; i += NW * 64) plane[i] = 0ull;
 
   // step of the fixed-point grid (see the header comment): the subproblem's sum of max(|re c|, |im c|)
-  float part = 0.f;
+  float part = 0.f, big = 0.f;
   for (int j = p0 + tid; j < p1; j += NW * 64) {
     float2 cv;
     if constexpr (FUSED) cv = *reinterpret_cast<const float2*>(&rec3[j].re);
     else cv = cc[sp.rec[j].idx];
-    part += fmaxf(fabsf(cv.x), fabsf(cv.y));
+    const float m = fmaxf(fabsf(cv.x), fabsf(cv.y));
+    part += m;
+    big = fmaxf(big, m);
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o);
-  if (lane == 0) red[wave] = part;
+  for (int o = 32; o > 0; o >>= 1) {
+    part += __shfl_down(part, o);
+    big = fmaxf(big, __shfl_down(big, o));
+  }
+  if (lane == 0) { red[wave] = part; red[NW + wave] = big; }
   // this wave's staging area: zero the kx slot the idle lanes read (never written again)
   unsigned char* stage = stage_all + (size_t)wave * (HALF / 2) * SLOTS * 16;
   if (lane < HALF / 2) *reinterpret_cast<v4f*>(stage + (lane * SLOTS + W) * 16) = (v4f){0.f, 0.f, 0.f, 0.f};
   __syncthreads();
-  float bound = 0.f;
+  float bound = 0.f, top = 0.f;
 #pragma unroll
-  for (int k = 0; k < NW; ++k) bound += red[k];
+  for (int k = 0; k < NW; ++k) { bound += red[k]; top = fmaxf(top, red[NW + k]); }
   const float amp = fabsf(scale) * g.fx_headroom;   // (the fitted polynomials overshoot 1 slightly)
-  // 2^31 minus the rounding of every contribution (npt of them + the <= 512 + npt / 2^22 extra parts below)
-  const float room = 2147482000.f - (float)npt;
-  const float step = bound * amp / room;
+  const float room = 2147483000.f - (float)npt;     // 2^31 minus the rounding of every contribution
+  // Two constraints on the step: no cell may overflow 32 bits (sum rule), and the FMA conversion is exact only
+  // for |n| < 2^22 per contribution (top rule). Strengths of similar size (largest <= 8 x the mean): the larger
+  // of the two -- the top rule binds for subproblems of fewer than ~512 points and is still 2^-22 of the largest
+  // strength. One dominant strength: that step would drown the others, so it follows the mean instead, and the
+  // few strengths above 2^22 steps are added behind the loop with the exact conversion (v_cvt, any |n| < 2^31).
+  const float s_sum = bound * amp / room;
+  const bool skewed = top * (float)npt > 8.f * bound;
+  const float step = fmaxf(s_sum, (skewed ? 2.f * bound / (float)npt : top) * amp * (1.f / 4194000.f));
   const float pre = step > 0.f ? scale / step : 0.f;
-  // A single contribution must stay below 2^22 steps (the exact range of the FMA conversion). A
-  // strength above 1 / 512 of the subproblem's sum -- few points, or one dominant strength -- is added
-  // in `rep` equal parts: the step, and with it the accuracy of every other point, stays what the sum asks for.
-  const float rep_scale = g.fx_headroom * (1.f / 4194000.f);
+  const float big_limit = 4194000.f / g.fx_headroom;   // |c| in steps above which a point waits for the exact pass
 
   // lane constants
   const int cell_b = kLaneTab<W, TZ>.cell[lane] * 8;
@@ -241,22 +292,28 @@ __global__ __launch_bounds__(kDenseNW * 64) void spread_dense3_kernel(
   const int rd_y = (W + 1 + kLaneTab<W, TZ>.sy[lane]) * 16;
   const int rd_z = (W + 1 + YB + kLaneTab<W, TZ>.sz[lane]) * 16;
   const int nc = g.ncoef;
+  // (indices into the subproblem, in sorted order when GROUP)
   const int share = (npt + NW - 1) / NW;
-  const int wbeg = p0 + wave * share;
-  const int wend = (wbeg + share < p1) ? wbeg + share : p1;
+  const int wbeg = wave * share;
+  const int wend = (wbeg + share < npt) ? wbeg + share : npt;
   const v2f magic = {12582912.f, 12582912.f};                 // 1.5 * 2^23
   const unsigned long long unbias = 0ull - 0x4B4000004B400000ull;
   unsigned char* plane_b = reinterpret_cast<unsigned char*>(plane);
 
+  // (Loading chunk i + 1's records and strengths before chunk i's atomics was measured, r03: no gain at config 4 --
+  // 7.75 ms either way, the other 23 waves of the CU already cover a wave's load latency -- and 10 % slower on a
+  // sparse set, 256^3 with M = 1e7. Not kept.)
   for (int base = wbeg; base < wend; base += 64) {
     // phase 1: one point per lane -- record, strength, 3 W kernel values
-    const int j = base + lane;
-    int off = 0, rep = 1;
+    const int js = base + lane;
+    int j = p0 + (js < wend ? js : wend - 1);
+    if constexpr (GROUP) j = p0 + (int)perm[js < wend ? js : wend - 1];
+    int off = 0;
     float kx[W], ky[W], kz[W];
-    float cre = 0.f, cim = 0.f;
+    float cre = 0.f, cim = 0.f, bre = 0.f, bim = 0.f;   // (bre, bim): a strength too large for the FMA conversion
 #pragma unroll
     for (int q = 0; q < W; ++q) { kx[q] = 0.f; ky[q] = 0.f; kz[q] = 0.f; }
-    if (j < wend) {
+    if (js < wend) {
       float2 cv;
       PointView<float> rec;
       if constexpr (FUSED) {
@@ -269,13 +326,22 @@ __global__ __launch_bounds__(kDenseNW * 64) void spread_dense3_kernel(
       }
       cre = cv.x * pre;
       cim = cv.y * pre;
-      rep = (int)(fmaxf(fabsf(cre), fabsf(cim)) * rep_scale) + 1;
-      if (rep > 1) { cre /= (float)rep; cim /= (float)rep; }
+      if (fmaxf(fabsf(cre), fabsf(cim)) > big_limit) { bre = cre; bim = cim; cre = 0.f; cim = 0.f; }
       off = ((int)(rec.loc & 1023) + (int)((rec.loc >> 10) & 1023) * LS + (int)((rec.loc >> 20) & 1023) * PS) * 8;
       horner3<W>(horner, nc, rec.z0, rec.z1, rec.z2, kx, ky, kz);
     }
     int left = wend - base;
     if (left > 64) left = 64;
+    // GROUP: a point ends a run when the next one starts in another cell (or the chunk / the wave's share ends)
+    unsigned long long tailm = 0ull;
+    if constexpr (GROUP) {
+      const int off_next = __shfl_down(off, 1);
+      tailm = __ballot(js < wend && (lane == 63 || js == wend - 1 || off_next != off));
+    }
+    unsigned long long acc[NZH * NYH];
+#pragma unroll
+    for (int k = 0; k < NZH * NYH; ++k) acc[k] = 0ull;
+    int nrun = 0;
 #pragma unroll
     for (int h = 0; h < 64 / HALF; ++h) {
       if (h * HALF >= left) break;
@@ -305,31 +371,59 @@ __global__ __launch_bounds__(kDenseNW * 64) void spread_dense3_kernel(
           const v2f kxc = u ? (v2f){rx.z, rx.w} : (v2f){rx.x, rx.y};
           const v2f kyv = u ? (v2f){ry.z, ry.w} : (v2f){ry.x, ry.y};
           const v2f kzv = u ? (v2f){rz.z, rz.w} : (v2f){rz.x, rz.y};
-          const int o = __builtin_amdgcn_readlane(off, h * HALF + 2 * p + u) + cell_b;
-          unsigned char* dst = plane_b + o;
+          const int q = h * HALF + 2 * p + u;
+          if constexpr (!GROUP) {
+            unsigned char* dst = plane_b + __builtin_amdgcn_readlane(off, q) + cell_b;
 #pragma unroll
-          for (int zh = 0; zh < NZH; ++zh) {
-            const float kzq = zh ? kzv.y : kzv.x;
-            const v2f yz = kyv * (v2f){kzq, kzq};
+            for (int zh = 0; zh < NZH; ++zh) {
+              const float kzq = zh ? kzv.y : kzv.x;
+              const v2f yz = kyv * (v2f){kzq, kzq};
 #pragma unroll
-            for (int yh = 0; yh < NYH; ++yh) {
-              const float f = yh ? yz.y : yz.x;
-              const v2f fx = __builtin_elementwise_fma(kxc, (v2f){f, f}, magic);
-              const unsigned long long x = __builtin_bit_cast(unsigned long long, fx) + unbias;
-              atomicAdd(reinterpret_cast<unsigned long long*>(dst + (yh * YB * LS + zh * ZB * PS) * 8), x);
+              for (int yh = 0; yh < NYH; ++yh) {
+                const float f = yh ? yz.y : yz.x;
+                const v2f fx = __builtin_elementwise_fma(kxc, (v2f){f, f}, magic);
+                const unsigned long long x = __builtin_bit_cast(unsigned long long, fx) + unbias;
+                atomicAdd(reinterpret_cast<unsigned long long*>(dst + (yh * YB * LS + zh * ZB * PS) * 8), x);
+              }
+            }
+          } else {
+#pragma unroll
+            for (int zh = 0; zh < NZH; ++zh) {
+              const float kzq = zh ? kzv.y : kzv.x;
+              const v2f yz = kyv * (v2f){kzq, kzq};
+#pragma unroll
+              for (int yh = 0; yh < NYH; ++yh) {
+                const float f = yh ? yz.y : yz.x;
+                const v2f fx = __builtin_elementwise_fma(kxc, (v2f){f, f}, magic);
+                acc[zh * NYH + yh] += __builtin_bit_cast(unsigned long long, fx);   // (mod 2^64; the biases go at the flush)
+              }
+            }
+            ++nrun;
+            if ((tailm >> q) & 1ull) {   // wave-uniform
+              unsigned char* dst = plane_b + __builtin_amdgcn_readlane(off, q) + cell_b;
+              const unsigned long long unb = (unsigned long long)nrun * unbias;
+#pragma unroll
+              for (int zh = 0; zh < NZH; ++zh)
+#pragma unroll
+                for (int yh = 0; yh < NYH; ++yh) {
+                  atomicAdd(reinterpret_cast<unsigned long long*>(dst + (yh * YB * LS + zh * ZB * PS) * 8), acc[zh * NYH + yh] + unb);
+                  acc[zh * NYH + yh] = 0ull;
+                }
+              nrun = 0;
             }
           }
         }
       }
     }
-    // the remaining rep - 1 parts of dominant strengths (rare: none for strengths of similar size)
-    unsigned long long pend = __ballot(rep > 1);
+    // strengths above 2^22 steps (only where one strength dominates its subproblem): one at a time, staged alone as
+    // the first point of pair 0, converted with v_cvt (exact for the whole 32-bit field)
+    unsigned long long pend = __ballot(bre != 0.f || bim != 0.f);
     while (pend) {
       const int src = __ffsll((long long)pend) - 1;
       pend &= pend - 1;
-      if (lane == src) {   // staged alone as the first point of pair 0
+      if (lane == src) {
 #pragma unroll
-        for (int x = 0; x < W; ++x) *reinterpret_cast<v2f*>(stage + x * 16) = (v2f){kx[x] * cim, kx[x] * cre};
+        for (int x = 0; x < W; ++x) *reinterpret_cast<v2f*>(stage + x * 16) = (v2f){kx[x] * bim, kx[x] * bre};
 #pragma unroll
         for (int y = 0; y < YB; ++y)
           *reinterpret_cast<v2f*>(stage + (W + 1 + y) * 16) = (v2f){ky[y], (NYH > 1 && y + YB < W) ? ky[y + YB] : 0.f};
@@ -342,18 +436,17 @@ __global__ __launch_bounds__(kDenseNW * 64) void spread_dense3_kernel(
       const v4f rz = *reinterpret_cast<const v4f*>(stage + rd_z);
       const v2f kxc = {rx.x, rx.y}, kyv = {ry.x, ry.y}, kzv = {rz.x, rz.y};
       unsigned char* dst = plane_b + __builtin_amdgcn_readlane(off, src) + cell_b;
-      for (int r = __builtin_amdgcn_readlane(rep, src) - 1; r > 0; --r) {
 #pragma unroll
-        for (int zh = 0; zh < NZH; ++zh) {
-          const float kzq = zh ? kzv.y : kzv.x;
-          const v2f yz = kyv * (v2f){kzq, kzq};
+      for (int zh = 0; zh < NZH; ++zh) {
+        const float kzq = zh ? kzv.y : kzv.x;
+        const v2f yz = kyv * (v2f){kzq, kzq};
 #pragma unroll
-          for (int yh = 0; yh < NYH; ++yh) {
-            const float f = yh ? yz.y : yz.x;
-            const v2f fx = __builtin_elementwise_fma(kxc, (v2f){f, f}, magic);
-            const unsigned long long x = __builtin_bit_cast(unsigned long long, fx) + unbias;
-            atomicAdd(reinterpret_cast<unsigned long long*>(dst + (yh * YB * LS + zh * ZB * PS) * 8), x);
-          }
+        for (int yh = 0; yh < NYH; ++yh) {
+          const float f = yh ? yz.y : yz.x;
+          const v2f pr = kxc * (v2f){f, f};
+          const int ii = __float2int_rn(pr.x), ir = __float2int_rn(pr.y);
+          const unsigned long long x = ((unsigned long long)(unsigned)(ir + (ii >> 31)) << 32) | (unsigned)ii;
+          atomicAdd(reinterpret_cast<unsigned long long*>(dst + (yh * YB * LS + zh * ZB * PS) * 8), x);
         }
       }
     }
@@ -383,28 +476,30 @@ __global__ __launch_bounds__(kDenseNW * 64) void spread_dense3_kernel(
   }
 }
 
-template <int W, int TZ, bool FUSED>
+template <int W, int TZ, bool FUSED, bool GROUP>
 hipError_t launch_dense3(const Geom& g, const SortedPoints<float>& sp, const float* horner, const float* c, float* fw,
                          dim3 grid, int64_t c_stride, int64_t fw_stride, float scale, hipStream_t stream) {
   using C = DenseCfg<W, TZ>;
   hipError_t e = hipSuccess;
-  if (C::lds_bytes > 64 * 1024)
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(spread_dense3_kernel<W, TZ, FUSED>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes);
+  constexpr size_t lds = GROUP ? C::lds_bytes_group : C::lds_bytes;
+  if (lds > 64 * 1024)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(spread_dense3_kernel<W, TZ, FUSED, GROUP>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  spread_dense3_kernel<W, TZ, FUSED><<<grid, C::NW * 64, C::lds_bytes, stream>>>(g, sp, horner, c, fw, c_stride, fw_stride, scale);
+  spread_dense3_kernel<W, TZ, FUSED, GROUP><<<grid, C::NW * 64, lds, stream>>>(g, sp, horner, c, fw, c_stride, fw_stride, scale);
   return hipGetLastError();
 }
 
 }  // namespace
 
 bool dense3_supported(const Geom& g, int precision) {
+  // (tiles of depth 4 -- only on request, options.tile_dims -- stay on spread_wave3_kernel)
   return precision == NUFFT_HIP_F32 && g.rank == 3 && g.fixed_point && g.w >= 2 && g.w <= 6 && g.tile[0] == kDenseTile &&
-         g.tile[1] == kDenseTile && (g.tile[2] == 4 || g.tile[2] == 8);
+         g.tile[1] == kDenseTile && g.tile[2] == 8;
 }
 
-size_t dense3_lds_bytes(int w, int tz) {
-#define NUFFT_D3(WV) case WV: return tz == 8 ? DenseCfg<WV, 8>::lds_bytes : DenseCfg<WV, 4>::lds_bytes;
+size_t dense3_lds_bytes(int w) {
+#define NUFFT_D3(WV) case WV: return DenseCfg<WV, 8>::lds_bytes_group;
   switch (w) {
     NUFFT_D3(2) NUFFT_D3(3) NUFFT_D3(4) NUFFT_D3(5) NUFFT_D3(6)
     default: return 0;
@@ -412,17 +507,33 @@ size_t dense3_lds_bytes(int w, int tz) {
 #undef NUFFT_D3
 }
 
-hipError_t launch_spread_dense3(const Geom& g, const SortedPoints<float>& sp, unsigned nsub_bound, const float* horner,
+// When the cell-grouped form pays (r03, w = 6, spread stage, grouped against not): runs per point are
+// (1 - exp(-d)) / d at d points per fine cell -- 0.70 at config 4's 0.75, where the in-LDS sort and the register adds
+// cost what the saved atomics gain (fused records 7.63-7.77 against 7.73-7.81 ms; unfused 8.69 against 8.14: the
+// records AND the strengths are then gathered through the permutation); 0.46 at 1.8 points per cell: 1.95 against
+// 2.23 ms (128^3, M = 3e7). At w <= 4 a point is ONE atomic and there is nothing to save (5.6 against 5.0 ms): not
+// instantiated. Taken from 1.2 points per cell; options.tuning GROUP_OFF / GROUP_ON force the choice (w >= 5).
+bool dense3_grouped(const Geom& g, int64_t M) {
+  if (g.w < 5 || g.max_sub > DenseCfg<6, 8>::kMaxSub) return false;
+  const int mode = tune_mode(g, NUFFT_HIP_TUNE_GROUP_OFF, NUFFT_HIP_TUNE_GROUP_ON);
+  if (mode >= 0) return mode != 0;
+  return (double)M >= 1.2 * (double)g.nf[0] * (double)g.nf[1] * (double)g.nf[2];
+}
+
+hipError_t launch_spread_dense3(const Geom& g, const SortedPoints<float>& sp, unsigned nsub_bound, int64_t M, const float* horner,
                                 const float* c, float* fw, int batch, int64_t c_stride, int64_t fw_stride, float scale,
                                 hipStream_t stream) {
   const dim3 grid(nsub_bound, (unsigned)batch);
+  const bool grouped = dense3_grouped(g, M);
 #define NUFFT_D3(WV)                                                                                                  \
   case WV:                                                                                                            \
-    if (g.fused)                                                                                                      \
-      return g.tile[2] == 8 ? launch_dense3<WV, 8, true>(g, sp, horner, c, fw, grid, c_stride, fw_stride, scale, stream)  \
-                            : launch_dense3<WV, 4, true>(g, sp, horner, c, fw, grid, c_stride, fw_stride, scale, stream); \
-    return g.tile[2] == 8 ? launch_dense3<WV, 8, false>(g, sp, horner, c, fw, grid, c_stride, fw_stride, scale, stream)   \
-                          : launch_dense3<WV, 4, false>(g, sp, horner, c, fw, grid, c_stride, fw_stride, scale, stream);
+    if constexpr (WV >= 5) {                                                                                          \
+      if (grouped)                                                                                                    \
+        return g.fused ? launch_dense3<WV, 8, true, true>(g, sp, horner, c, fw, grid, c_stride, fw_stride, scale, stream)   \
+                       : launch_dense3<WV, 8, false, true>(g, sp, horner, c, fw, grid, c_stride, fw_stride, scale, stream); \
+    }                                                                                                                 \
+    return g.fused ? launch_dense3<WV, 8, true, false>(g, sp, horner, c, fw, grid, c_stride, fw_stride, scale, stream)    \
+                   : launch_dense3<WV, 8, false, false>(g, sp, horner, c, fw, grid, c_stride, fw_stride, scale, stream);
   switch (g.w) {
     NUFFT_D3(2) NUFFT_D3(3) NUFFT_D3(4) NUFFT_D3(5) NUFFT_D3(6)
     default: return hipErrorInvalidValue;

@@ -160,6 +160,34 @@ __device__ __forceinline__ double bcast_lane(double v, int lane) {
   return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 
+// Exclusive scan of NK LDS counters by NT threads (NK a multiple of the scanning thread count); wsum: [16] scratch.
+// Ends with a barrier.
+template <int NT, int NK>
+__device__ __forceinline__ void scan_counts(uint32_t* cnt, uint32_t* wsum, int tid) {
+  constexpr int NS = NT >= 1024 ? 1024 : NT >= 512 ? 512 : NT >= 256 ? 256 : NT >= 128 ? 128 : 64;
+  constexpr int PER = NK / NS;
+  const int lane = tid & 63, wave = tid >> 6;
+  const bool on = tid < NS;
+  uint32_t v[PER], tot = 0u;
+#pragma unroll
+  for (int u = 0; u < PER; ++u) { v[u] = on ? cnt[tid * PER + u] : 0u; tot += v[u]; }
+  uint32_t incl = tot;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t t = __shfl_up(incl, d);
+    if (lane >= d) incl += t;
+  }
+  if (on && lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  if (on) {
+    uint32_t run = incl - tot;
+    for (int w2 = 0; w2 < wave; ++w2) run += wsum[w2];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) { cnt[tid * PER + u] = run; run += v[u]; }
+  }
+  __syncthreads();
+}
+
 template <typename T> struct Pair;
 template <> struct Pair<float> { using type = float2; };
 template <> struct Pair<double> { using type = double2; };

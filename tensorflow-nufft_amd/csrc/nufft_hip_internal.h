@@ -211,8 +211,8 @@ hipError_t launch_spread_wide(const Geom& g, const SortedPoints<T>& sp, int64_t 
                               hipStream_t stream);
 // 3-D float fixed-point spreading for w <= 6 (nufft_dense3.hip): lanes cover the stencil densely
 bool dense3_supported(const Geom& g, int precision);
-size_t dense3_lds_bytes(int w, int tile_depth);
-hipError_t launch_spread_dense3(const Geom& g, const SortedPoints<float>& sp, unsigned nsub_bound, const float* horner,
+size_t dense3_lds_bytes(int w);
+hipError_t launch_spread_dense3(const Geom& g, const SortedPoints<float>& sp, unsigned nsub_bound, int64_t M, const float* horner,
                                 const float* c, float* fw, int batch, int64_t c_stride, int64_t fw_stride, float scale,
                                 hipStream_t stream);
 int wave3_pad(int w);   // spill elements behind the LDS planes of the 3-D wavefront kernel

@@ -1154,31 +1154,6 @@ __global__ __launch_bounds__(NW * 64) void spread_2d_w8_wave_kernel(
 // Exclusive scan of cnt[NK] (NK = 1024 or 2048) in place by a workgroup of NT threads; the
 // first NS = largest power of two <= NT threads do the work. wsum: >= NS/64 words of LDS
 // scratch. Ends with a barrier.
-template <int NT, int NK>
-__device__ __forceinline__ void scan_counts(uint32_t* cnt, uint32_t* wsum, int tid) {
-  constexpr int NS = NT >= 1024 ? 1024 : NT >= 512 ? 512 : NT >= 256 ? 256 : NT >= 128 ? 128 : 64;
-  constexpr int PER = NK / NS;
-  const int lane = tid & 63, wave = tid >> 6;
-  const bool on = tid < NS;
-  uint32_t v[PER], tot = 0u;
-#pragma unroll
-  for (int u = 0; u < PER; ++u) { v[u] = on ? cnt[tid * PER + u] : 0u; tot += v[u]; }
-  uint32_t incl = tot;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t t = __shfl_up(incl, d);
-    if (lane >= d) incl += t;
-  }
-  if (on && lane == 63) wsum[wave] = incl;
-  __syncthreads();
-  if (on) {
-    uint32_t run = incl - tot;
-    for (int w2 = 0; w2 < wave; ++w2) run += wsum[w2];
-#pragma unroll
-    for (int u = 0; u < PER; ++u) { cnt[tid * PER + u] = run; run += v[u]; }
-  }
-  __syncthreads();
-}
 template <int NT>
 __device__ __forceinline__ void scan1024(uint32_t* cnt, uint32_t* wsum, int tid) { scan_counts<NT, 1024>(cnt, wsum, tid); }
 
@@ -1663,28 +1638,34 @@ __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
   T pre = scale;     // multiplies the strengths (FX: also converts to LSB units)
   T lsb = (T)1;
   if (FX) {
-    float part = 0.f;
+    float part = 0.f, big = 0.f;
     for (int j = p0 + tid; j < p1; j += NW * 64) {
       const T2 cv = cc[unpack_rec<T, 3>(rec_at(sp.rec, j, rstride)).idx];
-      part += fmaxf(fabsf((float)cv.x), fabsf((float)cv.y));
+      const float m = fmaxf(fabsf((float)cv.x), fabsf((float)cv.y));
+      part += m;
+      big = fmaxf(big, m);
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o);
-    if (lane == 0) red[wave] = part;
+    for (int o = 32; o > 0; o >>= 1) {
+      part += __shfl_down(part, o);
+      big = fmaxf(big, __shfl_down(big, o));
+    }
+    if (lane == 0) { red[wave] = part; red[NW + wave] = big; }
     __syncthreads();
-    float bound = 0.f;
+    float bound = 0.f, top = 0.f;
 #pragma unroll
-    for (int k = 0; k < NW; ++k) bound += red[k];
+    for (int k = 0; k < NW; ++k) { bound += red[k]; top = fmaxf(top, red[NW + k]); }
     // every cell sum is bounded by sum_j |c_j| prod_d max|P_d|; the fitted polynomials overshoot 1
     // slightly (w = 4: 1.00001 per dimension), which g.fx_headroom (>= 1, from the host fit) covers
-    bound *= fabsf((float)scale) * g.fx_headroom;
+    const float amp = fabsf((float)scale) * g.fx_headroom;
     const float room = 2147483000.f - (float)npt;   // 2^31 minus the rounding of every contribution
-    // A single contribution must stay below 2^22 steps: the float -> fixed conversion is an FMA onto
-    // 1.5 * 2^23 (see the loop), exact for |n| < 2^22. A strength above 1 / 512 of the subproblem's
-    // sum (few points, or one dominant strength) is added in `rep` equal parts instead (<= 512 + 1
-    // extra passes per subproblem): the step, and with it the accuracy of every other point, stays
-    // what the sum alone asks for.
-    const float step = bound / (room - 1100.f);
+    // The step obeys the sum rule (no cell overflows 32 bits) and, for strengths of similar size (largest <= 8 x the
+    // mean), the top rule (every contribution below 2^22 steps: the exact range of the FMA conversion in the loop).
+    // With one dominant strength it follows the mean instead, and the strengths above 2^22 steps are added behind
+    // the loop with the exact conversion (nufft_dense3.hip has the same rule and the reasoning).
+    const float s_sum = bound * amp / room;
+    const bool skewed = top * (float)npt > 8.f * bound;
+    const float step = fmaxf(s_sum, (skewed ? 2.f * bound / (float)npt : top) * amp * (1.f / 4194000.f));
     pre = step > 0.f ? (T)((float)scale / step) : (T)0;
     lsb = (T)step;
   }
@@ -1702,9 +1683,9 @@ __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
 
   for (int base = wbeg; base < wend; base += CH) {
     const int j = base + lane;
-    int off = 0, rep = 1;
+    int off = 0;
     T kz[W];
-    T cre = (T)0, cim = (T)0;
+    T cre = (T)0, cim = (T)0, bre = (T)0, bim = (T)0;
 #pragma unroll
     for (int q = 0; q < W; ++q) kz[q] = (T)0;
     if (lane < CH) {
@@ -1716,9 +1697,8 @@ __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
         const T2 cv = cc[rec.idx];
         cre = cv.x * pre;
         cim = cv.y * pre;
-        if (FX) {   // parts of at most 2^22 steps each (see the prelude)
-          rep = (int)(fmaxf(fabsf((float)cre), fabsf((float)cim)) * g.fx_headroom * (1.f / 4194000.f)) + 1;
-          if (rep > 1) { cre /= (T)rep; cim /= (T)rep; }
+        if (FX) {   // too large for the FMA conversion (see the prelude): waits for the exact pass behind the loop
+          if (fmaxf(fabsf((float)cre), fabsf((float)cim)) * g.fx_headroom > 4194000.f) { bre = cre; bim = cim; cre = (T)0; cim = (T)0; }
         }
         off = (int)(rec.loc & 1023) + (int)((rec.loc >> 10) & 1023) * LS + (int)((rec.loc >> 20) & 1023) * PS;
         T h0[8], h1[8], h2[8];
@@ -1775,23 +1755,20 @@ __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
       }
     }
     if constexpr (FX) {
-      // the remaining rep - 1 parts of dominant strengths (rare: none for strengths of similar size). Kept out of the
-      // loop above: a per-point repeat count around its body cost 55 % at w = 7 (r03: 5.7 -> 8.9 ms at M = 3e7).
-      unsigned long long pend = __ballot(rep > 1);
+      // strengths above 2^22 steps (only where one strength dominates its subproblem), one at a time with the exact
+      // conversion. Kept out of the loop above: a per-point repeat count around its body cost 55 % at w = 7.
+      unsigned long long pend = __ballot(bre != (T)0 || bim != (T)0);
       while (pend) {
         const int src = __ffsll((long long)pend) - 1;
         pend &= pend - 1;
         const T a = active ? kxs[src * SW + dx] * kys[src * SW + dy] : (T)0;
-        const float ar = (float)(a * bcast_lane(cre, src)), ai = (float)(a * bcast_lane(cim, src));
+        const float ar = (float)(a * bcast_lane(bre, src)), ai = (float)(a * bcast_lane(bim, src));
         unsigned long long* pr = reinterpret_cast<unsigned long long*>(plane_re + __builtin_amdgcn_readlane(off, src) + cell);
-        for (int r = __builtin_amdgcn_readlane(rep, src) - 1; r > 0; --r) {
 #pragma unroll
-          for (int dz = 0; dz < W; ++dz) {
-            typedef float v2f __attribute__((ext_vector_type(2)));
-            const float kzq = (float)bcast_lane(kz[dz], src);
-            const v2f fx = __builtin_elementwise_fma((v2f){ai, ar}, (v2f){kzq, kzq}, (v2f){12582912.f, 12582912.f});
-            atomicAdd(pr + dz * PS, __builtin_bit_cast(unsigned long long, fx) - 0x4B4000004B400000ull);
-          }
+        for (int dz = 0; dz < W; ++dz) {
+          const float kzq = (float)bcast_lane(kz[dz], src);
+          const int ir = __float2int_rn(ar * kzq), ii = __float2int_rn(ai * kzq);
+          atomicAdd(pr + dz * PS, ((unsigned long long)(unsigned)(ir + (ii >> 31)) << 32) | (unsigned)ii);
         }
       }
     }
@@ -2554,7 +2531,7 @@ size_t spread_lds_bytes(const Geom& g, int method, int precision) {
     if (g.rank == 2)
       return group2d_geometry(g) ? std::max(wave2_lds(g, precision), group_lds(8, 64, false, precision)) : wave2_lds(g, precision);
     if (dense3_supported(g, precision))   // (and the fp64-plane launches behind it for crowded tiles)
-      return std::max(dense3_lds_bytes(g.w, g.tile[2]), wave3_split_lds(g));
+      return std::max(dense3_lds_bytes(g.w), wave3_split_lds(g));
     const int nw = g.split_reim ? 12 : wave3d_nw_rt(precision, g.fixed_point != 0);
     const int ch = (g.split_reim && g.tile[2] == 8) ? 16 : 32;   // (staging chunk: keeps two workgroups per CU)
     if (g.split_reim && g.tile[2] == 8 && g.w == 8) return wave3_joint_lds(g);   // the larger of the two forms
@@ -2752,7 +2729,7 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
       } else if constexpr (WW <= 6) {                                                            \
         if (g.fixed_point) {                                                                     \
           if constexpr (sizeof(T) == 4) {                                                        \
-            e = launch_spread_dense3(g, sp, grid.x, horner, c, fw, batch, c_stride, fw_stride, scale, stream); \
+            e = launch_spread_dense3(g, sp, grid.x, Md, horner, c, fw, batch, c_stride, fw_stride, scale, stream); \
             if (e != hipSuccess) return e;                                                       \
             if (Md > (int64_t)g.fx_max_subs * g.max_sub) {   /* a tile may be crowded: fp64 planes for those */ \
               lds_bytes = wave3_split_lds(g);                                                    \
@@ -2764,10 +2741,7 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
     } else if (g.tile[2] == 4) {                                                                 \
       if (g.fixed_point) {                                                                       \
         if constexpr (sizeof(T) == 4) {                                                          \
-          if constexpr (WW <= 6) {   /* nufft_dense3.hip */                                      \
-            e = launch_spread_dense3(g, sp, grid.x, horner, c, fw, batch, c_stride, fw_stride, scale, stream); \
-            if (e != hipSuccess) return e;                                                       \
-          } else { NUFFT_LAUNCH_W3(WW, 4, true) }                                                \
+          NUFFT_LAUNCH_W3(WW, 4, true)                                                           \
           if (Md > (int64_t)g.fx_max_subs * g.max_sub) {                                         \
             lds_bytes = wave3_split_lds(g);                                                      \
             NUFFT_LAUNCH_W3S(WW, 4, 1) NUFFT_LAUNCH_W3S(WW, 4, 2)                                 \
