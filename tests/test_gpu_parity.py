@@ -1294,6 +1294,63 @@ def test_3d_fixed_point_plans_on_crowded_tiles(tfft, grid, M, tol):
     assert err <= max(0.5 * tol, 1.3 * ref_err + 5e-7), (kind, err, ref_err)
 
 
+def test_randomised_3d_fixed_point_strengths_vs_oracle(tfft):
+  # The packed fixed-point accumulation of 3-D float plans (tol >= 1e-5) picks its step per subproblem from the sum
+  # and the largest of the strengths, and converts dominant strengths separately (nufft_dense3.hip): seeded random
+  # cases over grid, point count and distribution, width, strength distribution (uniform, six decades of dynamic
+  # range, one or a few huge ones, all equal, mostly zero) and entry point (one call = fused records where the sort
+  # path has them / set_points + execute). Bars: tol against the fp64 oracle, and the fp64-plane accumulation
+  # (lds_accumulate = 1) + 0.2 tol.
+  from oracle import oracle
+  import os
+  rng = np.random.default_rng(int(os.environ.get('NUFFT_TEST_SEED', '20261005')))
+  for case in range(14):
+    grid = [int(rng.integers(6, 44)) for _ in range(3)]
+    tol = float(rng.choice([1e-5, 1e-4, 1e-4, 1e-3, 1e-2]))
+    M = int(rng.choice([50, 3000, 40000, 250000]))
+    dist = int(rng.integers(0, 3))
+    if dist == 0:
+      pts = rng.uniform(-np.pi, np.pi, (M, 3))
+    elif dist == 1:   # half of the points in a blob of a few cells
+      pts = rng.uniform(-np.pi, np.pi, (M, 3))
+      pts[: M // 2] = rng.uniform(-2.5, 2.5, (1, 3)) + 0.05 * rng.standard_normal((M // 2, 3))
+    else:             # everything in one tile
+      pts = rng.uniform(-2.5, 2.5, (1, 3)) + 0.01 * rng.standard_normal((M, 3))
+    pts = pts.astype(np.float32)
+    kind = int(rng.integers(0, 6))
+    c = rng.standard_normal(M) + 1j * rng.standard_normal(M)
+    if kind == 1:
+      c = c * 10.0 ** rng.uniform(-3, 3, M)
+    elif kind == 2:
+      c[int(rng.integers(0, M))] *= 10.0 ** rng.uniform(3, 7)
+    elif kind == 3:
+      c[rng.integers(0, M, max(1, M // 100))] *= 1e3
+    elif kind == 4:
+      c = np.full(M, 0.7 - 0.2j)
+    elif kind == 5:
+      c[rng.uniform(0, 1, M) < 0.95] = 0.0
+    c = c.astype(np.complex64)
+    truth = oracle.nufft(c.astype(np.complex128), pts, grid, 'type_1', 'forward', tol=1e-12, sigma=2.0)
+    den = np.linalg.norm(truth)
+    if den == 0:
+      continue
+    errs = {}
+    for mode in (1, 0):
+      plan = tfft.Plan('type_1', grid, 'forward', tol=tol, lds_accumulate=mode)
+      if rng.integers(0, 2):
+        out = plan.execute_with_points(_dev(pts), _dev(c)).cpu().numpy()
+      else:
+        plan.set_points(_dev(pts))
+        out = plan.execute(_dev(c)).cpu().numpy()
+      plan.close()
+      errs[mode] = np.linalg.norm(out - truth) / den
+    same = oracle.nufft(c.astype(np.complex128), pts, grid, 'type_1', 'forward', tol=tol, sigma=2.0)
+    ref_err = np.linalg.norm(same - truth) / den
+    info = (case, grid, tol, M, dist, kind, errs, ref_err)
+    assert errs[0] <= max(tol, 1.05 * ref_err + 1e-6), info
+    assert errs[0] <= errs[1] + 0.2 * tol, info
+
+
 def test_3d_interp_on_cell_sorted_records(tfft):
   # Dense 3-D type-2 plans reorder every subproblem by stencil start cell in set_points
   # (removes the LDS bank conflicts of the interp stencil loop). Same answer as the fp64
