@@ -1257,6 +1257,15 @@ __global__ __launch_bounds__(kCellSortThreads) void cellsort3d_kernel(
 // points per cell) that removes ~60 % of the LDS atomics that bound the
 // ungrouped kernel.
 constexpr int kGroupMaxSub = 4096;
+// Phase timestamps of the grouped kernel's workgroups (experiment build -DNUFFT_HIP_PHASE_LOG, tools/phase_log_experiment.sh):
+// thread 0 of every workgroup stores s_memtime at the phase boundaries; the product build compiles none of it.
+#ifdef NUFFT_HIP_PHASE_LOG
+constexpr int kPhaseSlots = 8, kPhaseLogWgs = 16384;
+__device__ unsigned long long g_phase_log[kPhaseLogWgs * kPhaseSlots];
+#define NUFFT_PHASE(k) do { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < kPhaseLogWgs) g_phase_log[blockIdx.x * kPhaseSlots + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define NUFFT_PHASE(k) do { } while (0)
+#endif
 constexpr double kGroupMinDensity = 0.5;   // points per fine cell
 constexpr double kInterpSortMinDensity = 0.3;   // 3-D interp cell sort pays from here (r01: 0.075 loses, 0.75 and 1.8 win)
 constexpr int kGroupStage = 32; // points whose kernel values are in LDS at a time (per wave; 16 measured 12 % slower, r02)
@@ -1286,7 +1295,9 @@ __global__ __launch_bounds__(NW * 64) void spread_2d_w8_group_kernel(
   uint16_t* perm = reinterpret_cast<uint16_t*>(cnt + 1024);                     // [4096]
   uint32_t* wsum = reinterpret_cast<uint32_t*>(perm + kGroupMaxSub);            // [16]
   int tb, p0, p1, slot;
+  NUFFT_PHASE(0);
   if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1, &slot)) return;
+  NUFFT_PHASE(1);
   const int n = p1 - p0;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1295,11 +1306,14 @@ __global__ __launch_bounds__(NW * 64) void spread_2d_w8_group_kernel(
   if constexpr (!PRE) {
     for (int i = tid; i < 1024; i += NT) cnt[i] = 0u;
     __syncthreads();
+    NUFFT_PHASE(2);
 
     // ---- LDS counting sort of the subproblem by start cell (plans whose records are
     // not already cell-ordered by cellsort2d_kernel)
     // (all loads are unconditional on clamped indices: a load under a divergent
-    // branch makes the compiler wait for it before the next one is issued)
+    // branch makes the compiler wait for it before the next one is issued. Issuing them
+    // before the zero-fill was measured, r03: the wait moves into the zero-fill phase, the
+    // workgroup takes the same 66.7 k cycles.)
     uint32_t kr[IT];   // key | rank-in-cell << 10
 #pragma unroll
     for (int u = 0; u < IT; ++u) {
@@ -1321,7 +1335,9 @@ __global__ __launch_bounds__(NW * 64) void spread_2d_w8_group_kernel(
       if (i < n) kr[u] = key | (atomicAdd(&cnt[key], 1u) << 10);
     }
     __syncthreads();
+    NUFFT_PHASE(3);
     scan1024<NT>(cnt, wsum, tid);
+    NUFFT_PHASE(4);
 #pragma unroll
     for (int u = 0; u < IT; ++u) {
       const int i = tid + u * NT;
@@ -1329,6 +1345,7 @@ __global__ __launch_bounds__(NW * 64) void spread_2d_w8_group_kernel(
     }
   }
   __syncthreads();
+  NUFFT_PHASE(5);
 
   // Staging holds kernel values of 4 consecutive points side by side, so one
   // ds_read_b128 fetches a lane's kx (or ky) for 4 passes (6 cycles instead of
@@ -1461,6 +1478,7 @@ __global__ __launch_bounds__(NW * 64) void spread_2d_w8_group_kernel(
     }
   }
   __syncthreads();
+  NUFFT_PHASE(6);
 
   const int t0 = tb % g.ntile[0];
   const int t1 = tb / g.ntile[0];
@@ -1477,6 +1495,7 @@ __global__ __launch_bounds__(NW * 64) void spread_2d_w8_group_kernel(
       glb_add(&out[2 * (g0 + (int64_t)g.nf[0] * g1) + comp], v);
     }
   }
+  NUFFT_PHASE(7);
 }
 
 
@@ -2158,6 +2177,12 @@ static hipError_t ensure_lds(K kernel, size_t bytes) {
 // first kernel). So the plan forces the load here -- a function-attribute query makes the
 // runtime build the module for the device -- and waits for the device before anything of
 // ours is launched.
+#ifdef NUFFT_HIP_PHASE_LOG
+extern "C" int nufft_hip_debug_phase_log(unsigned long long* dst, int n) {   // experiment build only
+  if (n > kPhaseLogWgs * kPhaseSlots) n = kPhaseLogWgs * kPhaseSlots;
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_phase_log), sizeof(unsigned long long) * (size_t)n);
+}
+#endif
 hipError_t preload_device_code() {
 #ifdef NUFFT_HIP_NO_PRELOAD   // build macro of tools/first_launch_experiment.sh: does the fault still reproduce?
   return hipSuccess;
