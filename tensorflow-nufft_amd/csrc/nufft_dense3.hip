@@ -189,6 +189,15 @@ __device__ __forceinline__ void horner3(const float* __restrict__ tab, int nc, f
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+// Phase timestamps (experiment build -DNUFFT_HIP_PHASE_LOG, tools/phase_log_experiment.sh; compiled out otherwise)
+#ifdef NUFFT_HIP_PHASE_LOG
+constexpr int kPhaseSlots3 = 8, kPhaseLogWgs3 = 65536;
+__device__ unsigned long long g_phase_log3[kPhaseLogWgs3 * kPhaseSlots3];
+#define NUFFT_PHASE3(k) do { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < kPhaseLogWgs3) g_phase_log3[blockIdx.x * kPhaseSlots3 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define NUFFT_PHASE3(k) do { } while (0)
+#endif
+
 // FUSED: the records are FusedRec3 (strength behind the 16-byte record): nothing is gathered.
 // GROUP (dense point sets): the subproblem's points are counting-sorted by stencil start cell in LDS first (as
 // spread_2d_w8_group_kernel does), and consecutive points that share a start cell add their packed contributions
@@ -208,8 +217,10 @@ __global__ __launch_bounds__(kDenseNW * 64) void spread_dense3_kernel(
   float* red = reinterpret_cast<float*>(stage_all + C::stage_bytes);   // [2 NW]
 
   int tb, p0, p1, slot, nsub;
+  NUFFT_PHASE3(0);
   if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1, &slot, &nsub)) return;
   if (nsub > g.fx_max_subs) return;   // crowded tile: the fp64-plane launches behind this one take it
+  NUFFT_PHASE3(1);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: keeps the point loops' bounds in SGPRs)
   const float2* cc = reinterpret_cast<const float2*>(c) + (int64_t)slot * c_stride;
@@ -248,6 +259,7 @@ __global__ __launch_bounds__(kDenseNW * 64) void spread_dense3_kernel(
     }
     __syncthreads();
   }
+  NUFFT_PHASE3(2);
   for (int i = tid; i < C::plane_elems; i += NW * 64) plane[i] = 0ull;
 
   // step of the fixed-point grid (see the header comment): the subproblem's sum of max(|re c|, |im c|)
@@ -270,6 +282,7 @@ __global__ __launch_bounds__(kDenseNW * 64) void spread_dense3_kernel(
   unsigned char* stage = stage_all + (size_t)wave * (HALF / 2) * SLOTS * 16;
   if (lane < HALF / 2) *reinterpret_cast<v4f*>(stage + (lane * SLOTS + W) * 16) = (v4f){0.f, 0.f, 0.f, 0.f};
   __syncthreads();
+  NUFFT_PHASE3(3);
   float bound = 0.f, top = 0.f;
 #pragma unroll
   for (int k = 0; k < NW; ++k) { bound += red[k]; top = fmaxf(top, red[NW + k]); }
@@ -452,6 +465,7 @@ __global__ __launch_bounds__(kDenseNW * 64) void spread_dense3_kernel(
     }
   }
   __syncthreads();
+  NUFFT_PHASE3(4);
 
   // write-out: unpack, scale back, add to the periodic fine grid (consecutive lanes carry (re, im) of
   // consecutive cells: contiguous bytes per wave-instruction)
@@ -474,6 +488,7 @@ __global__ __launch_bounds__(kDenseNW * 64) void spread_dense3_kernel(
       if (v != 0.f) glb_add(&out[2 * (rowbase + wrap1(o0 + a0, g.nf[0])) + comp], v);
     }
   }
+  NUFFT_PHASE3(5);
 }
 
 template <int W, int TZ, bool FUSED, bool GROUP>
@@ -491,6 +506,13 @@ hipError_t launch_dense3(const Geom& g, const SortedPoints<float>& sp, const flo
 }
 
 }  // namespace
+
+#ifdef NUFFT_HIP_PHASE_LOG
+extern "C" int nufft_hip_debug_phase_log3(unsigned long long* dst, int n) {   // experiment build only
+  if (n > kPhaseLogWgs3 * kPhaseSlots3) n = kPhaseLogWgs3 * kPhaseSlots3;
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_phase_log3), sizeof(unsigned long long) * (size_t)n);
+}
+#endif
 
 bool dense3_supported(const Geom& g, int precision) {
   // (tiles of depth 4 -- only on request, options.tile_dims -- stay on spread_wave3_kernel)
