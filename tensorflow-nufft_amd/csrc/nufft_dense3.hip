@@ -23,8 +23,9 @@
 //    lane needs kx[x] (re c, im c), ky[y'], ky[y' + YB], kz[z'], kz[z' + ZB] -- three ds_read_b128 per
 //    point pair; no v_readlane broadcasts in the loop except the point's tile offset.
 //
-// LDS budget per point and CU at W = 6: 4 x 7.1 (ds_add_u64) + 1.5 x 6.1 (ds_read_b128) + staging
-// writes = ~39 cycles, against ~12 VALU instructions: the kernel is LDS-pipe bound by construction.
+// What bounds it (profiles/r03_pmc_cfg4*.txt): the VGPR -> LDS data path, 2 cycles per source
+// dword of an LDS write or atomic: 4 x 7.0 (ds_add_u64) + 4.5 (12 ds_write_b64 per 16 staged points) = 33 cycles per
+// point and CU at W = 6 (measured main loop: 30 with two workgroups per CU), against ~12 VALU instructions.
 //
 // Accumulation format (unchanged from r01/r02): one 64-bit integer per fine cell
 // holding (re, im) as two signed 32-bit fields in units of `step`, chosen per subproblem so that no
@@ -41,7 +42,7 @@ namespace nufft_hip {
 
 namespace {
 
-constexpr int kDenseTile = 16;   // tile edge in x and y (the plan's 3-D tiles: 16 x 16 x {4, 8})
+constexpr int kDenseTile = 16;   // tile edge in x and y (the plan's 3-D tiles: 16 x 16 x 8)
 constexpr int kDenseNW = 12;     // waves per workgroup (two workgroups per CU)
 
 // ---- compile-time lane layout -------------------------------------------------------------------
