@@ -316,7 +316,9 @@ __global__ __launch_bounds__(kDenseNW * 64) void spread_dense3_kernel(
 
   // (Loading chunk i + 1's records and strengths before chunk i's atomics was measured, r03: no gain at config 4 --
   // 7.75 ms either way, the other 23 waves of the CU already cover a wave's load latency -- and 10 % slower on a
-  // sparse set, 256^3 with M = 1e7. Not kept.)
+  // sparse set, 256^3 with M = 1e7. Running the first chunk's phase 1 before the barrier the step waits behind moved
+  // 2 k cycles from the main loop into that phase and left the workgroup at 122 k. Neither kept: the LDS data path,
+  // shared by the CU's two workgroups, is busy either way.)
   for (int base = wbeg; base < wend; base += 64) {
     // phase 1: one point per lane -- record, strength, 3 W kernel values
     const int js = base + lane;
