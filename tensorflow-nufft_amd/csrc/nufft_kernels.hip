@@ -600,7 +600,6 @@ __global__ __launch_bounds__(kSortBlock, 4) void scatter_staged_kernel(Geom g, P
 template <typename T>
 __global__ __launch_bounds__(kSortBlock) void hist16_lds_kernel(Geom g, PointsIn in, int64_t per_block,
                                                                 int span, uint32_t* __restrict__ hist16,
-                                                                int32_t* __restrict__ tile_of,
                                                                 uint16_t* __restrict__ rank16,
                                                                 int32_t* __restrict__ bad_count) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -630,7 +629,8 @@ __global__ __launch_bounds__(kSortBlock) void hist16_lds_kernel(Geom g, PointsIn
         const int tl = tile - t_lo;
         const int sh = 16 * (tl & 1);
         const unsigned old = atomicAdd(&h2[tl >> 1], 1u << sh);
-        tile_of[i] = tile;
+        // (the scatter pass folds the point again and gets the same tile: no per-point tile array on this path --
+        // 0.4 GB less written here and read there at M = 1e8)
         rank16[i] = (uint16_t)((old >> sh) & 0xffffu);   // rank inside (workgroup, tile)
       }
     }
@@ -673,7 +673,6 @@ __global__ __launch_bounds__(1024) void colscan16_kernel(int nt, int nblk, const
 // workgroup + its 16-bit rank; no LDS, full occupancy.
 template <typename T, bool FUSED3 = false>
 __global__ __launch_bounds__(256) void scatter_ranked_kernel(Geom g, PointsIn in, int64_t per_block,
-                                                             const int32_t* __restrict__ tile_of,
                                                              const uint16_t* __restrict__ rank16,
                                                              const int32_t* __restrict__ pref,
                                                              const int32_t* __restrict__ tile_start,
@@ -689,8 +688,7 @@ __global__ __launch_bounds__(256) void scatter_ranked_kernel(Geom g, PointsIn in
     const int64_t i = (int64_t)blockIdx.y * in.M_item + ic;
     Rec<T> r;
     bool bad = false;
-    fold_point<T>(g, in, i, &r, &bad);
-    const int tile = tile_of[i];
+    const int tile = fold_point<T>(g, in, i, &r, &bad) + (int)blockIdx.y * g.ntiles_item;
     const int64_t blk = (int64_t)blockIdx.y * in.blocks_per_item + ic / per_block;
     const int pos = live ? tile_start[tile] + pref[blk * g.ntiles + tile] + (int)rank16[i] : -1;
     const float2 cv = reinterpret_cast<const float2*>(in.strengths)[i];
@@ -717,8 +715,7 @@ __global__ __launch_bounds__(256) void scatter_ranked_kernel(Geom g, PointsIn in
   const int64_t i = (int64_t)blockIdx.y * in.M_item + il;
   Rec<T> r;
   bool bad = false;
-  fold_point<T>(g, in, i, &r, &bad);
-  const int tile = tile_of[i];
+  const int tile = fold_point<T>(g, in, i, &r, &bad) + (int)blockIdx.y * g.ntiles_item;
   const int64_t blk = (int64_t)blockIdx.y * in.blocks_per_item + il / per_block;
   const int pos = tile_start[tile] + pref[blk * g.ntiles + tile] + (int)rank16[i];
   store_record<T>(out, g.rank, pos, r, (int32_t)il);
@@ -2334,7 +2331,7 @@ hipError_t launch_sort(const Geom& g, const PointsIn& in_arg, const SortWork& w,
     uint16_t* rank16 = reinterpret_cast<uint16_t*>(w.rank_of);
     hook.begin(STAGE_SORT_COUNT);
     hist16_lds_kernel<T><<<dim3(nblk, ranges), kSortBlock, lds, stream>>>(g, in, per_block, span, hist16,
-                                                                          w.tile_of, rank16, w.bad_count);
+                                                                          rank16, w.bad_count);
     hook.end(STAGE_SORT_COUNT);
     hook.begin(STAGE_SORT_SCAN);
     colscan16_kernel<<<(g.ntiles + 63) / 64, 1024, 0, stream>>>(
@@ -2344,13 +2341,13 @@ hipError_t launch_sort(const Geom& g, const PointsIn& in_arg, const SortWork& w,
     hook.begin(STAGE_SORT_SCATTER);
     if constexpr (sizeof(T) == 4) {
       if (in.strengths)
-        scatter_ranked_kernel<T, true><<<dim3(blocks_for(in.M_item, 256), items), 256, 0, stream>>>(g, in, per_block, w.tile_of,
+        scatter_ranked_kernel<T, true><<<dim3(blocks_for(in.M_item, 256), items), 256, 0, stream>>>(g, in, per_block,
                                                                                   rank16, pref, w.tile_start, out);
       else
-        scatter_ranked_kernel<T><<<dim3(blocks_for(in.M_item, 256), items), 256, 0, stream>>>(g, in, per_block, w.tile_of, rank16,
+        scatter_ranked_kernel<T><<<dim3(blocks_for(in.M_item, 256), items), 256, 0, stream>>>(g, in, per_block, rank16,
                                                                             pref, w.tile_start, out);
     } else {
-      scatter_ranked_kernel<T><<<dim3(blocks_for(in.M_item, 256), items), 256, 0, stream>>>(g, in, per_block, w.tile_of, rank16,
+      scatter_ranked_kernel<T><<<dim3(blocks_for(in.M_item, 256), items), 256, 0, stream>>>(g, in, per_block, rank16,
                                                                           pref, w.tile_start, out);
     }
     hook.end(STAGE_SORT_SCATTER);

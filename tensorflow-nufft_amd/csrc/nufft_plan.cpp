@@ -227,7 +227,7 @@ struct nufft_hip_plan_s {
   void* fft_tmp[2] = {nullptr, nullptr};              // intermediates of the pruned passes
 
   int nitems = 1;                // point sets handled together (options.num_point_sets)
-  int64_t M = 0, cap = 0, cap_global = 0;   // M: points per set
+  int64_t M = 0, cap = 0, cap_global = 0, cap_tile_of = 0;   // M: points per set
   void* rec = nullptr;           // Rec<T>[cap], tile-sorted
   void* rec2 = nullptr;          // Rec<T>[cap2]: target of the lazy cell-sort pass (then swapped with rec)
   int64_t cap2 = 0;
@@ -449,7 +449,7 @@ void release_workspace(nufft_hip_plan p) {
     dev_free(p, *b);
     *b = nullptr;
   }
-  p->cap = p->cap2 = p->cap_global = 0;
+  p->cap = p->cap2 = p->cap_global = p->cap_tile_of = 0;
   p->hist_elems = 0;
   p->workspace_bytes = 0;
   p->fixed_ws = false;
@@ -545,14 +545,21 @@ int ensure_point_capacity(nufft_hip_plan p, int64_t M, int rec_mult = 1) {
     if ((rc = dev_alloc(p, (void**)&p->hist, sizeof(int32_t) * (size_t)need))) return rc;
     p->hist_elems = need;
   }
-  if (mode != 0 && M > p->cap_global) {   // per-point tile / rank arrays (modes 1 and 2)
+  if (mode != 0 && M > p->cap_global) {   // per-point rank array (modes 1 and 2; 16-bit ranks in mode 1)
     if ((rc = sync_before_regrow(p))) return rc;
-    dev_free(p, p->tile_of); dev_free(p, p->rank_of);
-    p->tile_of = p->rank_of = nullptr;
+    dev_free(p, p->rank_of);
+    p->rank_of = nullptr;
     p->cap_global = 0;
-    if ((rc = dev_alloc(p, (void**)&p->tile_of, (size_t)M * 4))) return rc;
     if ((rc = dev_alloc(p, (void**)&p->rank_of, (size_t)M * 4))) return rc;
     p->cap_global = M;
+  }
+  if (mode == 2 && M > p->cap_tile_of) {   // per-point tile array: the global-counter path only
+    if ((rc = sync_before_regrow(p))) return rc;
+    dev_free(p, p->tile_of);
+    p->tile_of = nullptr;
+    p->cap_tile_of = 0;
+    if ((rc = dev_alloc(p, (void**)&p->tile_of, (size_t)M * 4))) return rc;
+    p->cap_tile_of = M;
   }
   const int64_t slots = M * rec_mult;
   if (slots <= p->cap) return NUFFT_HIP_OK;
