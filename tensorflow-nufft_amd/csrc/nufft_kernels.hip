@@ -1871,9 +1871,11 @@ __device__ __forceinline__ void hornerW(const T* __restrict__ tab, int nc, T z0,
 
 // Threads per workgroup: 256 in 2-D (12.5 KB tiles, the thread limit of the CU binds), 512
 // in 3-D, where a 46 KB tile lets only three workgroups share a CU.
+// The 64 x 64 tiles of 2-D float type-2 plans (41 KB: three workgroups per CU) take 512 as well: 12 -> 24 waves per CU,
+// config 3 interp 256 -> 241 us (r03; 1024 threads: 260).
 template <int RANK> constexpr int kInterpThreads = RANK > 2 ? 512 : 256;
-template <typename T, int RANK, int W>
-__global__ __launch_bounds__(kInterpThreads<RANK>) void interp_point_kernel(
+template <typename T, int RANK, int W, int NTHREADS = kInterpThreads<RANK>>
+__global__ __launch_bounds__(NTHREADS) void interp_point_kernel(
     Geom g, SortedPoints<T> sp, const T* __restrict__ horner, T* __restrict__ c,
     const T* __restrict__ fw, int64_t c_stride, int64_t fw_stride, T scale) {
   using T2 = typename Pair<T>::type;
@@ -1893,7 +1895,7 @@ __global__ __launch_bounds__(kInterpThreads<RANK>) void interp_point_kernel(
   const int t2 = tb / (g.ntile[0] * g.ntile[1]);
   const int o0 = t0 * g.tile[0], o1 = t1 * g.tile[1], o2 = t2 * g.tile[2];
   const T2* in = reinterpret_cast<const T2*>(fw) + (int64_t)slot * fw_stride;
-  constexpr int NT = kInterpThreads<RANK>;
+  constexpr int NT = NTHREADS;
   // Tile rows (L0 <= 39 cells: one lane per cell) are fetched kRowBatch at a time: the
   // loads of a batch are issued back to back on clamped addresses and only then stored
   // to LDS. One load - wait - store per row exposed an L2 latency per row (10 rows per
@@ -2832,6 +2834,15 @@ hipError_t launch_interp(const Geom& g, int method, const SortedPoints<T>& sp, i
     hipError_t e = hipSuccess;
 #define NUFFT_LAUNCH_IP(RR, WW)                                                                       \
   case RR * 100 + WW:                                                                                 \
+    if constexpr (RR == 2 && sizeof(T) == 4) {                                                        \
+      if (g.tile[0] == 64 && g.tile[1] == 64) {   /* big type-2 tiles: 512 threads */                 \
+        e = ensure_lds(interp_point_kernel<T, RR, WW, 512>, lds);                                     \
+        if (e != hipSuccess) return e;                                                                \
+        interp_point_kernel<T, RR, WW, 512><<<grid, 512, lds, stream>>>(g, sp, horner, c, fw,         \
+                                                                        c_stride, fw_stride, scale);  \
+        break;                                                                                        \
+      }                                                                                               \
+    }                                                                                                 \
     e = ensure_lds(interp_point_kernel<T, RR, WW>, lds);                                              \
     if (e != hipSuccess) return e;                                                                    \
     interp_point_kernel<T, RR, WW><<<grid, kInterpThreads<RR>, lds, stream>>>(g, sp, horner, c, fw,   \
