@@ -682,6 +682,30 @@ def test_radial_trajectories_total_parity_at_scale(tfft):
   assert e2 < 1e-6 and e2b < 1e-6 and e3 < 1e-4, (e2, e2b, e3)
 
 
+def test_double_precision_total_parity_at_scale(tfft):
+  # complex128 at scale, whole outputs against the fp64 oracle run two decades tighter: the headline geometry at
+  # tol 1e-9 (w = 11: the 16 x 4-lane "wide" kernels, nufft_wide.hip) both types, and 3-D 128^3 with M = 1e7 at
+  # tol 1e-12 (w = 14).
+  from oracle import oracle
+  rng = np.random.default_rng(88)
+  M, N = 10_000_000, 1024
+  pts = rng.uniform(-np.pi, np.pi, (M, 2))
+  c = rng.uniform(-.5, .5, M) + 1j * rng.uniform(-.5, .5, M)
+  out = tfft.nufft(_dev(c), _dev(pts), grid_shape=[N, N], transform_type='type_1', tol=1e-9).cpu().numpy()
+  truth = oracle.nufft(c, pts, [N, N], 'type_1', 'forward', tol=1e-13, sigma=2.0)
+  e1 = rel_l2(out, truth)
+  f = rng.uniform(-.5, .5, (N, N)) + 1j * rng.uniform(-.5, .5, (N, N))
+  out = tfft.nufft(_dev(f), _dev(pts), transform_type='type_2', tol=1e-9).cpu().numpy()
+  truth = oracle.nufft(f, pts, None, 'type_2', 'forward', tol=1e-13, sigma=2.0)
+  e2 = rel_l2(out, truth)
+  pts3 = rng.uniform(-np.pi, np.pi, (M, 3))
+  out = tfft.nufft(_dev(c), _dev(pts3), grid_shape=[128, 128, 128], transform_type='type_1', tol=1e-12).cpu().numpy()
+  truth = oracle.nufft(c, pts3, [128, 128, 128], 'type_1', 'forward', tol=1e-15, sigma=2.0)
+  e3 = rel_l2(out, truth)
+  _note(f'complex128, whole outputs: 2D 1024^2 M=1e7 tol 1e-9 type 1 {e1:.3e}, type 2 {e2:.3e}; 3D 128^3 M=1e7 tol 1e-12 type 1 {e3:.3e}')
+  assert e1 < 1e-9 and e2 < 1e-9 and e3 < 1e-12, (e1, e2, e3)
+
+
 def test_spread_on_a_type2_interp_geometry_plan(tfft):
   # a spread_only type-2 float plan on a fine grid of >= 2^21 cells takes 64 x 64 tiles (the interp kernel's
   # geometry); nufft_hip_spread on it must still be right (r02 advisor finding: it ran the 32 x 32 wave kernel)
