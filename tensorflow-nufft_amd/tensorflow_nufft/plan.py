@@ -142,6 +142,12 @@ class Plan:
           base + (r - 3) * es if r > 2 else None, r, c.data_ptr(), f.data_ptr()))
     return out
 
+  def set_stream(self, stream):
+    """Moves the plan to another stream (a torch.cuda.Stream or a raw hipStream_t value); the caller orders the
+    streams against each other, as with any buffer used on two streams."""
+    raw = stream.cuda_stream if hasattr(stream, 'cuda_stream') else int(stream)
+    self._check(self.lib.nufft_hip_plan_set_stream(self._handle, ctypes.c_void_p(raw)))
+
   def stop_after(self, stage):
     """Debug: execute returns after the named stage ('spread', 'fft', 'deconvolve'); None = run all."""
     self._check(self.lib.nufft_hip_debug_stop_after(

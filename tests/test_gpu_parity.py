@@ -706,6 +706,36 @@ def test_double_precision_total_parity_at_scale(tfft):
   assert e1 < 1e-9 and e2 < 1e-9 and e3 < 1e-12, (e1, e2, e3)
 
 
+def test_plan_moves_between_streams(tfft):
+  # nufft_hip_plan_set_stream: a type-1 plan on a power-of-two fine grid skips its memset when the previous FFT pass
+  # left the grid zeroed -- bookkeeping that must not survive a change of stream (r02 advisor finding). Executes
+  # alternate between two streams, ordered by events, and must all equal the first.
+  import torch
+  rng = np.random.default_rng(12)
+  grid, M = [64, 64], 50000
+  pts = _dev(rng.uniform(-np.pi, np.pi, (M, 2)).astype(np.float32))
+  c = _dev((rng.uniform(-.5, .5, M) + 1j * rng.uniform(-.5, .5, M)).astype(np.complex64))
+  plan = tfft.Plan('type_1', grid, 'forward', tol=1e-6)
+  plan.set_points(pts)
+  ref = plan.execute(c).clone()
+  torch.cuda.synchronize()
+  streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+  outs = []
+  prev = None
+  for k in range(6):
+    s = streams[k % 2]
+    if prev is not None:
+      s.wait_event(prev)
+    plan.set_stream(s)
+    with torch.cuda.stream(s):
+      outs.append(plan.execute(c).clone())
+      prev = s.record_event()
+  torch.cuda.synchronize()
+  for o in outs:
+    assert torch.equal(o, ref) or float((o - ref).abs().max() / ref.abs().max()) < 1e-6
+  plan.close()
+
+
 def test_spread_on_a_type2_interp_geometry_plan(tfft):
   # a spread_only type-2 float plan on a fine grid of >= 2^21 cells takes 64 x 64 tiles (the interp kernel's
   # geometry); nufft_hip_spread on it must still be right (r02 advisor finding: it ran the 32 x 32 wave kernel)
