@@ -116,7 +116,9 @@ enum {
   NUFFT_HIP_TUNE_JOINT_OFF = 1 << 12,      /* 3-D float w = 8: both fp64 planes in one launch: never / always */
   NUFFT_HIP_TUNE_JOINT_ON = 1 << 13,
   NUFFT_HIP_TUNE_STAGED_OFF = 1 << 14,     /* staged scatter (<= 1024 tiles per point set): never / always */
-  NUFFT_HIP_TUNE_STAGED_ON = 1 << 15
+  NUFFT_HIP_TUNE_STAGED_ON = 1 << 15,
+  NUFFT_HIP_TUNE_SORT2_OFF = 1 << 16,      /* 3-D float: two-level sort (64^3-cell super-tiles first): never / wherever it exists */
+  NUFFT_HIP_TUNE_SORT2_ON = 1 << 17
 };
 
 typedef struct nufft_hip_plan_s* nufft_hip_plan;
@@ -242,6 +244,9 @@ int nufft_hip_debug_eval_kernel(nufft_hip_plan plan, int n, const double* x1, do
  * nufft_hip_plan_get_timing: 4 = spread, 5 = fft, 6 = deconvolve/amplify), so
  * that tests can compare the fine grid stage by stage; -1 = run everything. */
 int nufft_hip_debug_stop_after(nufft_hip_plan plan, int stage);
+/* Which sort the plan ran at its last set_points: 0 = LDS histogram, 1 = 16-bit LDS histogram + ranked scatter,
+ * 2 = global counters, 3 = two levels (super-tiles, then tiles); -1 = no points set. */
+int nufft_hip_debug_sort_path(nufft_hip_plan plan);
 
 /* ---- Op-level entry: the host logic of NUFFTBaseOp::Compute/Execute --------
  * (nufft_kernels.cc:54-542): validation with the reference's error messages,

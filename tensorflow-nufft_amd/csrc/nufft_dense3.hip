@@ -472,9 +472,8 @@ __global__ __launch_bounds__(kDenseNW * 64) void spread_dense3_kernel(
 
   // write-out: unpack, scale back, add to the periodic fine grid (consecutive lanes carry (re, im) of
   // consecutive cells: contiguous bytes per wave-instruction)
-  const int t0 = tb % g.ntile[0];
-  const int t1 = (tb / g.ntile[0]) % g.ntile[1];
-  const int t2 = tb / (g.ntile[0] * g.ntile[1]);
+  int t0, t1, t2;
+  tile_coords(g, tb, &t0, &t1, &t2);
   const int o0 = t0 * kDenseTile, o1 = t1 * kDenseTile, o2 = t2 * TZ;
   float* out = fw + 2 * (int64_t)slot * fw_stride;
   for (RowWalk r(wave, L1); r.a2 < L2; r.advance(NW, L1)) {

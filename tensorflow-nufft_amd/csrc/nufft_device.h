@@ -41,6 +41,23 @@ template <> __device__ __forceinline__ PointView<double> unpack_rec<double, 1>(c
 template <> __device__ __forceinline__ PointView<double> unpack_rec<double, 2>(const Rec<double>& r) { return {r.loc, r.z0, r.z1, r.z2, r.idx}; }
 template <> __device__ __forceinline__ PointView<double> unpack_rec<double, 3>(const Rec<double>& r) { return {r.loc, r.z0, r.z1, r.z2, r.idx}; }
 
+// Tile id <-> tile coordinates (Geom::sup_shift)
+__device__ __forceinline__ int tile_id(const Geom& g, const int tc[3]) {
+  const int sh0 = g.sup_shift[0], sh1 = g.sup_shift[1], sh2 = g.sup_shift[2];
+  const int s = (tc[0] >> sh0) + g.nsup[0] * ((tc[1] >> sh1) + g.nsup[1] * (tc[2] >> sh2));
+  const int key = (tc[0] & ((1 << sh0) - 1)) | ((tc[1] & ((1 << sh1) - 1)) << sh0) | ((tc[2] & ((1 << sh2) - 1)) << (sh0 + sh1));
+  return (s << (sh0 + sh1 + sh2)) | key;
+}
+__device__ __forceinline__ void tile_coords(const Geom& g, int tb, int* t0, int* t1, int* t2) {
+  const int sh0 = g.sup_shift[0], sh1 = g.sup_shift[1], sh2 = g.sup_shift[2];
+  const int key = tb & ((1 << (sh0 + sh1 + sh2)) - 1);
+  const int s = tb >> (sh0 + sh1 + sh2);
+  const int s0 = s % g.nsup[0], s1 = (s / g.nsup[0]) % g.nsup[1], s2 = s / (g.nsup[0] * g.nsup[1]);
+  *t0 = (s0 << sh0) | (key & ((1 << sh0) - 1));
+  *t1 = (s1 << sh1) | ((key >> sh0) & ((1 << sh1) - 1));
+  *t2 = (s2 << sh2) | (key >> (sh0 + sh1));
+}
+
 // Record j of an array whose records lie `stride` bytes apart (16 / 32 for float, see FusedRec3)
 template <typename T>
 __device__ __forceinline__ const Rec<T>& rec_at(const Rec<T>* base, int j, int stride) {
@@ -78,9 +95,8 @@ __device__ __forceinline__ void tile_to_grid(const Geom& g, const double* plane_
                                              int nwaves, int lane) {
   const int L0 = g.ldim[0], L1 = g.ldim[1];
   const int L2 = RANK > 2 ? g.ldim[2] : 1;
-  const int t0 = tb % g.ntile[0];
-  const int t1 = (tb / g.ntile[0]) % g.ntile[1];
-  const int t2 = tb / (g.ntile[0] * g.ntile[1]);
+  int t0, t1, t2;
+  tile_coords(g, tb, &t0, &t1, &t2);
   const int o0 = t0 * g.tile[0], o1 = t1 * g.tile[1], o2 = t2 * g.tile[2];
   for (RowWalk r(wave, L1); r.a2 < L2; r.advance(nwaves, L1)) {
     const int g1 = wrap1(o1 + r.a1, g.nf[1]);

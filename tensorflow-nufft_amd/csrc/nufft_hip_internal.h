@@ -47,6 +47,12 @@ struct Geom {
                     // point set turns out clustered (a tile holds more than 1.5x the average): 2-D type-2 plans
   float fx_headroom;  // fixed-point accumulation: bound on prod_d max|P(z)| of the fitted kernel (>= 1)
   int tuning;       // nufft_hip_options.tuning (NUFFT_HIP_TUNE_* bits; read by the host-side launchers only)
+  // Tile numbering: tiles are numbered super-tile by super-tile (2^sup_shift[d] tiles per dimension each, nsup[d]
+  // super-tiles per dimension; id = super-tile << sum(sup_shift) | tile inside it, x fastest in both parts), which
+  // is what the two-level sort of large 3-D tile sets sorts by. sup_shift = {0, 0, 0}, nsup = ntile: the plain
+  // x-fastest numbering.
+  int sup_shift[3];
+  int nsup[3];
 };
 // OFF / ON pair of nufft_hip_options.tuning: -1 = by the plan's own rule, 0 = never, 1 = always
 inline int tune_mode(const Geom& g, int off_bit, int on_bit) { return (g.tuning & on_bit) ? 1 : ((g.tuning & off_bit) ? 0 : -1); }
@@ -117,7 +123,10 @@ struct SortWork {
   int32_t* tile_start;  // [ntiles + 1]
   int32_t* sub_start;   // [ntiles + 1]
   int32_t* bad_count;
+  void* tmp;            // two-level sort: [M] 16-byte level-1 records
 };
+struct Sort2Layout { int64_t table, pieces, words; };
+Sort2Layout sort2_layout(const Geom& g, int64_t M);
 
 constexpr int kMaxLdsTiles = 16384;     // 64 KiB of 32-bit LDS counters
 constexpr int kMaxLds16Tiles = 73728;   // 144 KiB of packed 16-bit LDS counters

@@ -193,7 +193,7 @@ __device__ __forceinline__ int fold_coords(const Geom& g, const PointsIn& in, co
   r->z0 = zz3[0];
   r->z1 = zz3[1];
   r->z2 = zz3[2];
-  return tc[0] + g.ntile[0] * (tc[1] + g.ntile[1] * tc[2]);
+  return tile_id(g, tc);
 }
 
 template <typename T>
@@ -469,6 +469,14 @@ __global__ __launch_bounds__(kSortBlock, NUFFT_SORT_MIN_WAVES) void scatter_lds_
 // points kStagedChunk at a time, orders the chunk by tile in LDS (counting sort: returning LDS
 // atomics for the ranks, a 1024-entry scan) and writes every tile's records of the chunk with
 // CONSECUTIVE LANES: ~8 records = 128 bytes per store group at 1024 tiles.
+// Level-1 record: (6-bit super-tile-local start | 26-bit Horner argument) x 3 + the point index.
+__device__ __forceinline__ uint32_t coarse_pack(uint32_t l, float z) {
+  float q = (z + 1.0f) * 33554432.0f;   // 2^25
+  q = fminf(fmaxf(q, 0.0f), 67108863.0f);
+  uint32_t w = (uint32_t)__float2uint_rn(q);
+  if (w > 67108863u) w = 67108863u;
+  return (l << 26) | w;
+}
 constexpr int kStagedMaxTiles = 1024;
 // (r03: 64 KB of staging, i.e. two workgroups per CU with 4-record runs, measured 100 -> 158 us at config 3)
 constexpr int kStagedBytes = 128 * 1024;   // LDS for the staged records
@@ -480,7 +488,9 @@ template <typename T> constexpr int kStagedChunk = kStagedChunkOf<T, 1024>;
 template <typename T, int NTMAX> constexpr size_t kStagedLds =
     (size_t)kStagedChunkOf<T, NTMAX> * (sizeof(Rec<T>) + 2) + 3 * NTMAX * 4 + 64;
 
-template <typename T, int AOS, bool FUSED, int NTMAX = 1024>
+// COARSE (3-D float, level 1 of the two-level sort below): g is the coarse geometry (tiles = super-tiles) and the
+// records take the level-1 form (coarse_pack).
+template <typename T, int AOS, bool FUSED, int NTMAX = 1024, bool COARSE = false>
 __global__ __launch_bounds__(kSortBlock, 4) void scatter_staged_kernel(Geom g, PointsIn in, int64_t per_block,
                                                                       const int32_t* __restrict__ hist,
                                                                       const int32_t* __restrict__ tile_start,
@@ -535,6 +545,11 @@ __global__ __launch_bounds__(kSortBlock, 4) void scatter_staged_kernel(Geom g, P
       if (i < ce) tr[u] = tile | (atomicAdd(&cnt[tile], 1) << TB);
       if constexpr (FUSED) {
         rec[u] = fused_record(r, cs[u]);
+      } else if constexpr (COARSE) {
+        rec[u].loc = coarse_pack(r.loc & 1023u, r.z0);
+        rec[u].z0 = __uint_as_float(coarse_pack((r.loc >> 10) & 1023u, r.z1));
+        rec[u].z1 = __uint_as_float(coarse_pack((r.loc >> 20) & 1023u, r.z2));
+        rec[u].idx = (int32_t)(i - br.base);
       } else {
         rec[u] = pack_record<T>(g.rank, r, (int32_t)(i - br.base));
       }
@@ -720,6 +735,172 @@ __global__ __launch_bounds__(256) void scatter_ranked_kernel(Geom g, PointsIn in
   const int64_t blk = (int64_t)blockIdx.y * in.blocks_per_item + il / per_block;
   const int pos = tile_start[tile] + pref[blk * g.ntiles + tile] + (int)rank16[i];
   store_record<T>(out, g.rank, pos, r, (int32_t)il);
+}
+
+// --- path S (two levels; 3-D float plans whose tiles are numbered by super-tiles, Geom::sup_shift).
+// The one-pass scatters above write every record to a random place: one 32-byte write transaction per
+// record, ~3e10 per second whatever the record size, and the 16-bit path adds a random 4-byte read of its
+// [workgroup][tile] prefix table per point (a 64-byte sector each). Here the points go
+// to their super-tile first (64^3 fine cells; <= 1024 destinations, so a workgroup's 8192-point pass writes
+// ~16 records = 256 bytes per destination with consecutive lanes), and then every <= 4096-record piece of a
+// super-tile is ordered by tile inside it (<= 256 keys: segments of ~32-64 records). Neither level stages
+// records in LDS: a workgroup computes the permutation of its piece (LDS counters, 16-bit indices) and then
+// walks the OUTPUT positions, re-reading its input through the permutation (it was read a moment ago: L2).
+constexpr int kSort2Chunk = 8192;       // points per pass of the level-1 scatter
+constexpr int kSort2Sub = 4096;         // records per level-2 workgroup (a piece of a super-tile): 64 KB staged
+constexpr size_t kSort2Lds = (size_t)kSort2Sub * 17 + 2 * 256 * 4 + 16;
+constexpr int kSort2Threads = 512;      // threads of a level-2 count workgroup
+constexpr int kSort2MaxKeys = 256;      // tiles per super-tile
+constexpr int kSort2MaxSuper = 1024;
+
+// tile of a level-1 record inside its super-tile (fine geometry g), and the record's final form
+__device__ __forceinline__ int coarse_key(const Geom& g, const uint4& r) {
+  const int k0 = (int)(r.x >> 26) >> g.tile_shift[0], k1 = (int)(r.y >> 26) >> g.tile_shift[1],
+            k2 = (int)(r.z >> 26) >> g.tile_shift[2];
+  return k0 | (k1 << g.sup_shift[0]) | (k2 << (g.sup_shift[0] + g.sup_shift[1]));
+}
+__device__ __forceinline__ uint4 coarse_to_final(const Geom& g, const uint4& r) {
+  uint4 o;
+  o.x = (((r.x >> 26) & (uint32_t)(g.tile[0] - 1)) << 28) | ((r.x & 0x3ffffffu) << 2);
+  o.y = (((r.y >> 26) & (uint32_t)(g.tile[1] - 1)) << 28) | ((r.y & 0x3ffffffu) << 2);
+  o.z = (((r.z >> 26) & (uint32_t)(g.tile[2] - 1)) << 28) | ((r.z & 0x3ffffffu) << 2);
+  o.w = r.w;
+  return o;
+}
+
+// Level 2, count: workgroup = one piece (<= kSort2Sub records) of a super-tile; hist2[piece][key].
+__global__ __launch_bounds__(kSort2Threads) void count2_kernel(Geom g, Geom g1, const int32_t* __restrict__ c_start,
+                                                               const int32_t* __restrict__ c_sub,
+                                                               const uint4* __restrict__ tmp_rec,
+                                                               int32_t* __restrict__ hist2, int nkeys) {
+  __shared__ int cnt[kSort2MaxKeys];
+  int st, p0, p1, slot;
+  if (!locate_subproblem(g1, c_start, c_sub, blockIdx.x, &st, &p0, &p1, &slot)) return;
+  const int tid = threadIdx.x;
+  if (tid < kSort2MaxKeys) cnt[tid] = 0;
+  __syncthreads();
+  constexpr int PER = kSort2Sub / kSort2Threads;
+  const int n = p1 - p0;
+  uint4 r[PER];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int i = tid + u * kSort2Threads;
+    if (u * kSort2Threads < n) r[u] = tmp_rec[p0 + (i < n ? i : n - 1)];
+  }
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int i = tid + u * kSort2Threads;
+    if (i < n) atomicAdd(&cnt[coarse_key(g, r[u])], 1);
+  }
+  __syncthreads();
+  if (tid < nkeys) hist2[(int64_t)blockIdx.x * nkeys + tid] = cnt[tid];
+}
+
+// Level 2, scan: workgroup = super-tile. hist2[piece][key] -> exclusive prefix over the super-tile's pieces,
+// totals -> tile_count[super-tile << bits | key].
+__global__ __launch_bounds__(1024) void scan2_kernel(const int32_t* __restrict__ c_sub, int32_t* __restrict__ hist2,
+                                                     int nkeys, int key_bits, int32_t* __restrict__ tile_count) {
+  __shared__ int part[1024];
+  const int st = blockIdx.x;
+  const int r_lo = c_sub[st], r_hi = c_sub[st + 1];
+  const int ngrp = 1024 / nkeys;
+  const int key = threadIdx.x & (nkeys - 1), grp = threadIdx.x / nkeys;
+  const int rpg = (r_hi - r_lo + ngrp - 1) / ngrp;
+  const int r0 = r_lo + grp * rpg < r_hi ? r_lo + grp * rpg : r_hi;
+  const int r1 = r0 + rpg < r_hi ? r0 + rpg : r_hi;
+  int sum = 0;
+  for (int r = r0; r < r1; ++r) sum += hist2[(int64_t)r * nkeys + key];
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  int run = 0, total = 0;
+  for (int k = 0; k < ngrp; ++k) {
+    const int v = part[k * nkeys + key];
+    if (k < grp) run += v;
+    total += v;
+  }
+  for (int r = r0; r < r1; ++r) {
+    const int64_t at = (int64_t)r * nkeys + key;
+    const int v = hist2[at];
+    hist2[at] = run;
+    run += v;
+  }
+  if (grp == 0) tile_count[(st << key_bits) | key] = total;
+}
+
+// Level 2, scatter: the piece's records to their tiles, in the final record form. The piece is ordered in LDS (a
+// first version re-read its records from memory through a 16-bit permutation: the pieces in flight are twice
+// the L2, every 16-byte gather then pulled a whole line back in -- 1.17 ms at M = 1e8 against 0.9 for this form).
+__global__ __launch_bounds__(kSortBlock) void scatter2_kernel(Geom g, Geom g1, const int32_t* __restrict__ c_start,
+                                                              const int32_t* __restrict__ c_sub,
+                                                              const uint4* __restrict__ tmp_rec,
+                                                              const int32_t* __restrict__ hist2, int nkeys, int key_bits,
+                                                              const int32_t* __restrict__ tile_start,
+                                                              uint4* __restrict__ out) {
+  constexpr int NT = kSortBlock;
+  constexpr int SUB = kSort2Sub;
+  constexpr int PER = SUB / NT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint4* stage = reinterpret_cast<uint4*>(smem_raw);                 // [SUB]
+  int* cnt = reinterpret_cast<int*>(stage + SUB);                   // [256]
+  int* base = cnt + kSort2MaxKeys;                                  // [256]
+  int* wsum = base + kSort2MaxKeys;                                 // [4]
+  uint8_t* keyof = reinterpret_cast<uint8_t*>(wsum + 4);            // [SUB] key of the staged record
+  int st, p0, p1, slot;
+  if (!locate_subproblem(g1, c_start, c_sub, blockIdx.x, &st, &p0, &p1, &slot)) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = p1 - p0;
+  if (tid < kSort2MaxKeys) cnt[tid] = 0;
+  __syncthreads();
+  uint4 r[PER];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int i = tid + u * NT;
+    if (u * NT < n) r[u] = tmp_rec[p0 + (i < n ? i : n - 1)];
+  }
+  int kr[PER];   // key | rank << 8
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int i = tid + u * NT;
+    kr[u] = -1;
+    if (i < n) {
+      const int key = coarse_key(g, r[u]);
+      kr[u] = key | (atomicAdd(&cnt[key], 1) << 8);
+    }
+  }
+  __syncthreads();
+  if (tid < kSort2MaxKeys) {   // exclusive scan of the 256 counters by the first four waves
+    const int v = cnt[tid];
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(incl, d);
+      if (lane >= d) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    cnt[tid] = incl - v;   // (completed below)
+  }
+  __syncthreads();
+  if (tid < kSort2MaxKeys) {
+    int run = cnt[tid];
+    for (int k = 0; k < wave; ++k) run += wsum[k];
+    cnt[tid] = run;
+    // output slot of the key's first record of this piece, minus its slot in the piece's key order
+    base[tid] = tid < nkeys ? tile_start[(st << key_bits) | tid] + hist2[(int64_t)blockIdx.x * nkeys + tid] - run : 0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    if (kr[u] >= 0) {
+      const int at = cnt[kr[u] & 255] + (kr[u] >> 8);
+      stage[at] = coarse_to_final(g, r[u]);
+      keyof[at] = (uint8_t)(kr[u] & 255);
+    }
+  }
+  __syncthreads();
+  for (int sidx = tid; sidx < n; sidx += NT) {
+    const int dst = base[keyof[sidx]] + sidx;
+    out[dst] = stage[sidx];
+  }
 }
 
 // --- path B (many tiles): per-point rank from a global counter (the
@@ -932,9 +1113,8 @@ __global__ __launch_bounds__(kBlock) void spread_tile_generic_kernel(
   __syncthreads();
 
   // tile -> periodic fine grid
-  const int t0 = tb % g.ntile[0];
-  const int t1 = (tb / g.ntile[0]) % g.ntile[1];
-  const int t2 = tb / (g.ntile[0] * g.ntile[1]);
+  int t0, t1, t2;
+  tile_coords(g, tb, &t0, &t1, &t2);
   const int o0 = t0 * g.tile[0], o1 = t1 * g.tile[1], o2 = t2 * g.tile[2];
   T* out = fw + 2 * (int64_t)slot * fw_stride;
   const int ncell = L0 * L1 * L2;
@@ -982,9 +1162,8 @@ __global__ __launch_bounds__(kBlock) void spread_sparse_kernel(
   const int dx = e >> 1, comp = e & 1;
   const bool lane_on = e < 2 * w;
   const int nrows = RANK == 1 ? 1 : RANK == 2 ? w : w * w;
-  const int t0 = tb % g.ntile[0];
-  const int t1 = (tb / g.ntile[0]) % g.ntile[1];
-  const int t2 = tb / (g.ntile[0] * g.ntile[1]);
+  int t0, t1, t2;
+  tile_coords(g, tb, &t0, &t1, &t2);
   const int o0 = t0 * g.tile[0], o1 = t1 * g.tile[1], o2 = t2 * g.tile[2];
   const T* cc = c + 2 * (int64_t)slot * c_stride;
   T* out = fw + 2 * (int64_t)slot * fw_stride;
@@ -1793,9 +1972,8 @@ __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
   __syncthreads();
 
   // write-out: (FX: unpack, scale back,) add to the periodic fine grid
-  const int t0 = tb % g.ntile[0];
-  const int t1 = (tb / g.ntile[0]) % g.ntile[1];
-  const int t2 = tb / (g.ntile[0] * g.ntile[1]);
+  int t0, t1, t2;
+  tile_coords(g, tb, &t0, &t1, &t2);
   const int o0 = t0 * 16, o1 = t1 * 16, o2 = t2 * TZ;
   T* out = fw + 2 * (int64_t)slot * fw_stride;
   for (RowWalk r(wave, L1); r.a2 < L2; r.advance(NW, L1)) {
@@ -1890,9 +2068,8 @@ __global__ __launch_bounds__(NTHREADS) void interp_point_kernel(
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int t0 = tb % g.ntile[0];
-  const int t1 = (tb / g.ntile[0]) % g.ntile[1];
-  const int t2 = tb / (g.ntile[0] * g.ntile[1]);
+  int t0, t1, t2;
+  tile_coords(g, tb, &t0, &t1, &t2);
   const int o0 = t0 * g.tile[0], o1 = t1 * g.tile[1], o2 = t2 * g.tile[2];
   const T2* in = reinterpret_cast<const T2*>(fw) + (int64_t)slot * fw_stride;
   constexpr int NT = NTHREADS;
@@ -1985,9 +2162,8 @@ __global__ __launch_bounds__(kBlock) void interp_tile_generic_kernel(
   int tb, p0, p1, slot;
   if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1, &slot)) return;
   const int w = g.w, nc = g.ncoef;
-  const int t0 = tb % g.ntile[0];
-  const int t1 = (tb / g.ntile[0]) % g.ntile[1];
-  const int t2 = tb / (g.ntile[0] * g.ntile[1]);
+  int t0, t1, t2;
+  tile_coords(g, tb, &t0, &t1, &t2);
   const int o0 = t0 * g.tile[0], o1 = t1 * g.tile[1], o2 = t2 * g.tile[2];
   const T* in = fw + 2 * (int64_t)slot * fw_stride;
   T* cc = c + 2 * (int64_t)slot * c_stride;
@@ -2229,10 +2405,33 @@ int sort_blocks(const Geom& g, int64_t M, int64_t* per_block) {
   return (int)bpi;
 }
 
+// The two-level sort exists for this plan (tiles numbered by super-tiles) and the point count makes it pay
+// (six launches instead of four; options.tuning SORT2_ON: always)
+constexpr int64_t kSort2MinPoints = (int64_t)1 << 21;
+static bool sort2_wanted(const Geom& g, int64_t M) {
+  if (g.sup_shift[0] + g.sup_shift[1] + g.sup_shift[2] == 0 || g.nitems > 1 || M >= ((int64_t)1 << 31)) return false;
+  return (g.tuning & NUFFT_HIP_TUNE_SORT2_ON) || M >= kSort2MinPoints;
+}
+// Geometry of the first level: the super-tiles as tiles
+static Geom coarse_geom(const Geom& g) {
+  Geom c = g;
+  int nt = 1;
+  for (int d = 0; d < 3; ++d) {
+    c.tile[d] = g.tile[d] << g.sup_shift[d];
+    c.tile_shift[d] = g.tile_shift[d] + g.sup_shift[d];
+    c.ntile[d] = c.nsup[d] = g.nsup[d];
+    c.sup_shift[d] = 0;
+    nt *= c.ntile[d];
+  }
+  c.ntiles = c.ntiles_item = nt;
+  return c;
+}
+
 // 0: LDS histogram, 32-bit counters; 1: LDS histogram, packed 16-bit counters
-// (workgroups capped at 65535 points); 2: global counters.
+// (workgroups capped at 65535 points); 2: global counters; 3: two levels (super-tiles, then tiles).
 int sort_mode(const Geom& g, int64_t M) {
   const int items = g.nitems > 1 ? g.nitems : 1;
+  if (sort2_wanted(g, M)) return 3;
   if (g.ntiles <= kMaxLdsTiles && items <= kScanGroups * kScanRowsMax) return 0;
   if ((int64_t)g.ntiles <= (int64_t)kMaxRanges16 * kMaxLds16Tiles) {
     int64_t pb;
@@ -2242,6 +2441,19 @@ int sort_mode(const Geom& g, int64_t M) {
   return 2;
 }
 bool sort_uses_lds(const Geom& g) { return g.ntiles <= kMaxLdsTiles; }
+
+// Workspace of the two-level sort, in 32-bit words of SortWork::hist: three tables of `table` words (super-tile
+// counts, starts, piece starts), the level-1 histogram [workgroups][super-tiles], the level-2 one [pieces][keys]
+Sort2Layout sort2_layout(const Geom& g, int64_t M) {
+  const Geom g1 = coarse_geom(g);
+  Sort2Layout l;
+  int64_t per_block;
+  l.table = g1.ntiles + 2;
+  l.pieces = M / kSort2Sub + g1.ntiles;   // every super-tile: ceil(count / kSort2Sub) <= count / kSort2Sub + 1
+  l.words = 3 * l.table + (int64_t)sort_blocks(g1, M, &per_block) * g1.ntiles +
+            l.pieces * ((int64_t)1 << (g.sup_shift[0] + g.sup_shift[1] + g.sup_shift[2]));
+  return l;
+}
 
 int sort_blocks16(const Geom& g, int64_t M, int64_t* per_block) {
   const int items = g.nitems > 1 ? g.nitems : 1;
@@ -2302,6 +2514,61 @@ hipError_t launch_sort(const Geom& g, const PointsIn& in_arg, const SortWork& w,
   const int mode = sort_mode(g, in.M);
   if (in.strengths && !(sizeof(T) == 4 && ((mode == 0 && g.rank == 2) || (mode == 1 && g.rank == 3))))
     return hipErrorInvalidValue;   // see fused_sort_supported
+  if (mode == 3) {
+    if constexpr (sizeof(T) == 4) {
+      if (!w.tmp) return hipErrorInvalidValue;
+      const Geom g1 = coarse_geom(g);
+      const int key_bits = g.sup_shift[0] + g.sup_shift[1] + g.sup_shift[2];
+      const int nkeys = 1 << key_bits;
+      int64_t per_block;
+      in.blocks_per_item = sort_blocks(g1, in.M, &per_block);
+      const int nblk = in.blocks_per_item;
+      const Sort2Layout lay = sort2_layout(g, in.M);
+      int32_t* c_count = w.hist;
+      int32_t* c_start = c_count + lay.table;
+      int32_t* c_sub = c_start + lay.table;
+      int32_t* hist1 = c_sub + lay.table;
+      int32_t* hist2 = hist1 + (int64_t)nblk * g1.ntiles;
+      uint4* tmp_rec = reinterpret_cast<uint4*>(w.tmp);
+      const int aos = in.aos == 3 ? 3 : 0;
+      const size_t lds1 = sizeof(int) * (size_t)g1.ntiles;
+      hook.begin(STAGE_SORT_COUNT);
+      if (aos == 3) hist_lds_kernel<T, 3><<<nblk, kSortBlock, lds1, stream>>>(g1, in, per_block, hist1, w.bad_count);
+      else hist_lds_kernel<T, 0><<<nblk, kSortBlock, lds1, stream>>>(g1, in, per_block, hist1, w.bad_count);
+      hook.end(STAGE_SORT_COUNT);
+      hook.begin(STAGE_SORT_SCAN);
+      colscan_kernel<<<(g1.ntiles + kScanCols - 1) / kScanCols, 1024, 0, stream>>>(g1.ntiles, nblk, hist1, c_count);
+      scan_tiles_kernel<<<1, 1024, 0, stream>>>(c_count, g1.ntiles, kSort2Sub, 0, 0, c_start, c_sub);
+      hook.end(STAGE_SORT_SCAN);
+      hook.begin(STAGE_SORT_SCATTER);
+      {
+        SortedOut<T> l1;
+        l1.rec = reinterpret_cast<Rec<T>*>(tmp_rec);
+        const size_t slds = kStagedLds<T, 1024>;
+        if (aos == 3) {
+          e = ensure_lds(scatter_staged_kernel<T, 3, false, 1024, true>, slds);
+          if (e != hipSuccess) return e;
+          scatter_staged_kernel<T, 3, false, 1024, true><<<nblk, kSortBlock, slds, stream>>>(g1, in, per_block, hist1, c_start, l1);
+        } else {
+          e = ensure_lds(scatter_staged_kernel<T, 0, false, 1024, true>, slds);
+          if (e != hipSuccess) return e;
+          scatter_staged_kernel<T, 0, false, 1024, true><<<nblk, kSortBlock, slds, stream>>>(g1, in, per_block, hist1, c_start, l1);
+        }
+      }
+      const int npiece = (int)lay.pieces;
+      count2_kernel<<<npiece, kSort2Threads, 0, stream>>>(g, g1, c_start, c_sub, tmp_rec, hist2, nkeys);
+      scan2_kernel<<<g1.ntiles, 1024, 0, stream>>>(c_sub, hist2, nkeys, key_bits, w.tile_count);
+      scan_tiles_kernel<<<1, 1024, 0, stream>>>(w.tile_count, g.ntiles, g.max_sub, g.sub_small, (int)(in.M_item / g.ntiles_item), w.tile_start, w.sub_start);
+      e = ensure_lds(scatter2_kernel, kSort2Lds);
+      if (e != hipSuccess) return e;
+      scatter2_kernel<<<npiece, kSortBlock, kSort2Lds, stream>>>(g, g1, c_start, c_sub, tmp_rec, hist2, nkeys, key_bits, w.tile_start,
+                                                                 reinterpret_cast<uint4*>(out.rec));
+      hook.end(STAGE_SORT_SCATTER);
+      return hipGetLastError();
+    } else {
+      return hipErrorInvalidValue;
+    }
+  }
   if (mode == 0) {
     int64_t per_block;
     in.blocks_per_item = sort_blocks(g, in.M, &per_block);

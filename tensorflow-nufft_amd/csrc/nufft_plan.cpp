@@ -194,6 +194,13 @@ double fit_horner(const KernelSpec& ks, int nc, double* tab /* [kMaxCoef][kMaxW]
 
 std::once_flag g_rocfft_once;
 
+// tune_mode() reads the bits from a Geom: a Geom that holds nothing but them
+Geom g_tuning_probe(int tuning) {
+  Geom t{};
+  t.tuning = tuning;
+  return t;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------ plan
@@ -537,6 +544,7 @@ int ensure_point_capacity(nufft_hip_plan p, int64_t M, int rec_mult = 1) {
     const int64_t nblk = (int64_t)sort_blocks16(p->g, M, &per_block) * items;
     need = nblk * ((p->g.ntiles + 1) / 2) + nblk * (int64_t)p->g.ntiles;   // hist16 words + 32-bit prefix
   }
+  if (mode == 3) need = sort2_layout(p->g, M).words;
   if (need > p->hist_elems) {
     if ((rc = sync_before_regrow(p))) return rc;
     dev_free(p, p->hist);
@@ -545,7 +553,7 @@ int ensure_point_capacity(nufft_hip_plan p, int64_t M, int rec_mult = 1) {
     if ((rc = dev_alloc(p, (void**)&p->hist, sizeof(int32_t) * (size_t)need))) return rc;
     p->hist_elems = need;
   }
-  if (mode != 0 && M > p->cap_global) {   // per-point rank array (modes 1 and 2; 16-bit ranks in mode 1)
+  if ((mode == 1 || mode == 2) && M > p->cap_global) {   // per-point rank array (16-bit ranks in mode 1)
     if ((rc = sync_before_regrow(p))) return rc;
     dev_free(p, p->rank_of);
     p->rank_of = nullptr;
@@ -627,6 +635,25 @@ int set_points_impl(nufft_hip_plan p, int64_t M, const void* x, const void* y, c
   }
   SortedOut<T> out;
   out.rec = (Rec<T>*)(cells ? p->rec2 : p->rec);
+  w.tmp = nullptr;
+  if (sort_mode(p->g, Mtot) == 3) {
+    // level-1 records of the two-level sort: in the buffer the sort does NOT end in -- the cell-sort target
+    // where there is one (it is written last), else rec2
+    if (cells) {
+      w.tmp = p->rec;
+    } else {
+      const int64_t slots2 = Mtot;
+      if (slots2 > p->cap2) {
+        if ((rc = sync_before_regrow(p))) return rc;
+        dev_free(p, p->rec2);
+        p->rec2 = nullptr;
+        p->cap2 = 0;
+        if ((rc = dev_alloc(p, &p->rec2, (size_t)slots2 * sizeof(Rec<T>)))) return rc;
+        p->cap2 = slots2;
+      }
+      w.tmp = p->rec2;
+    }
+  }
   const StageHook hook = make_hook(p);
   HIP_TRY(p, launch_sort<T>(p->g, in, w, out, p->stream, hook));
   if (cells) {
@@ -1061,6 +1088,25 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
   }
   g.wide = wide ? 1 : 0;
   g.sub_small = 0;
+  // Tile numbering. 3-D float plans with more tiles than the LDS-counter sort takes number them by super-tiles of
+  // 64^3 fine cells, which the two-level sort (launch_sort, mode 3) sorts by first: every dimension a multiple of
+  // 64 cells, at most 1024 super-tiles of at most 256 tiles each, one point set.
+  for (int d = 0; d < 3; ++d) { g.sup_shift[d] = 0; g.nsup[d] = g.ntile[d]; }
+  {
+    const int mode = tune_mode(g_tuning_probe(p->opts.tuning), NUFFT_HIP_TUNE_SORT2_OFF, NUFFT_HIP_TUNE_SORT2_ON);
+    bool ok = rank == 3 && precision == NUFFT_HIP_F32 && p->nitems <= 1 && mode != 0 &&
+              (mode > 0 || g.ntiles > kMaxLdsTiles);
+    int64_t nsuper = 1;
+    int key_bits = 0;
+    for (int d = 0; d < 3 && ok; ++d) {
+      ok = g.tile_shift[d] >= 0 && g.tile_shift[d] <= 6 && g.nf[d] % 64 == 0;
+      nsuper *= g.nf[d] / 64;
+      key_bits += 6 - g.tile_shift[d];
+    }
+    if (ok && nsuper <= 1024 && key_bits <= 8 && key_bits > 0) {
+      for (int d = 0; d < 3; ++d) { g.sup_shift[d] = 6 - g.tile_shift[d]; g.nsup[d] = g.nf[d] / 64; }
+    }
+  }
   if (!wide && spread_lds_bytes(g, NUFFT_HIP_METHOD_TILE_GENERIC, precision) > 160 * 1024) {
     delete p;
     return fail(NUFFT_HIP_RESOURCE_EXHAUSTED, "kernel too wide for an LDS tile");  // cf. nufft_plan.cu.cc:2458-2463
@@ -1334,6 +1380,11 @@ int nufft_hip_execute_with_points(nufft_hip_plan p, int64_t M, const void* x, co
     p->g.fused = 0;
   }
   return rc;
+}
+
+int nufft_hip_debug_sort_path(nufft_hip_plan p) {
+  if (!p || !p->points_set) return -1;
+  return sort_mode(p->g, p->M * p->nitems);
 }
 
 int nufft_hip_debug_stop_after(nufft_hip_plan p, int stage) {

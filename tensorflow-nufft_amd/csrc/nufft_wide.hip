@@ -187,9 +187,8 @@ __global__ __launch_bounds__(kWideNW * 64) void spread_wide_kernel(
   __syncthreads();
 
   // write-out: add the tile to the periodic fine grid
-  const int t0 = tb % g.ntile[0];
-  const int t1 = (tb / g.ntile[0]) % g.ntile[1];
-  const int t2 = tb / (g.ntile[0] * g.ntile[1]);
+  int t0, t1, t2;
+  tile_coords(g, tb, &t0, &t1, &t2);
   const int o0 = t0 * G::T0, o1 = t1 * G::T1, o2 = t2 * G::T2;
   T* out = fw + 2 * (int64_t)slot * fw_stride;
   for (RowWalk rw(wave, G::L1); rw.a2 < G::L2; rw.advance(NW, G::L1)) {
@@ -263,9 +262,8 @@ __global__ __launch_bounds__(kWideNW * 64) void interp_wide_kernel(
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int t0 = tb % g.ntile[0];
-  const int t1 = (tb / g.ntile[0]) % g.ntile[1];
-  const int t2 = tb / (g.ntile[0] * g.ntile[1]);
+  int t0, t1, t2;
+  tile_coords(g, tb, &t0, &t1, &t2);
   const int o0 = t0 * G::T0, o1 = t1 * G::T1, o2 = t2 * G::T2;
   const T2* in = reinterpret_cast<const T2*>(fw) + (int64_t)slot * fw_stride;
   // tile + halo -> LDS: cells are dealt to threads in flat order (rows are only 24-47 cells long: a

@@ -148,6 +148,11 @@ class Plan:
     raw = stream.cuda_stream if hasattr(stream, 'cuda_stream') else int(stream)
     self._check(self.lib.nufft_hip_plan_set_stream(self._handle, ctypes.c_void_p(raw)))
 
+  def sort_path(self):
+    """Debug: the sort the last set_points ran (0 LDS histogram, 1 16-bit histogram + ranked scatter, 2 global
+    counters, 3 two levels), -1 before any points are set."""
+    return int(self.lib.nufft_hip_debug_sort_path(self._handle))
+
   def stop_after(self, stage):
     """Debug: execute returns after the named stage ('spread', 'fft', 'deconvolve'); None = run all."""
     self._check(self.lib.nufft_hip_debug_stop_after(

@@ -1014,6 +1014,76 @@ def test_all_three_sort_paths_give_the_same_transform(tfft, tile, mode):
   plan.close(); plan2.close()
 
 
+@pytest.mark.parametrize('tile,tol,keys', [((16, 16, 8), 1e-4, 128), ((16, 16, 4), 1e-5, 256)])
+@pytest.mark.parametrize('cloud', ['uniform+cluster', 'one-super-tile'])
+def test_two_level_sort_gives_the_same_transform(tfft, tile, tol, keys, cloud):
+  # 3-D float plans whose fine grid is a multiple of 64 cells per dimension number their tiles by 64^3-cell
+  # super-tiles and sort in two levels (nufft_kernels.hip, sort_mode 3): here forced on a small grid (fine grid
+  # 192 x 128 x 128: 12 super-tiles of 128 / 256 tiles) against the one-level sort and the oracle; the second
+  # cloud puts every point into ONE super-tile (74 pieces in its level-2 scan)
+  import torch
+  from oracle import oracle
+  from tensorflow_nufft import _lib
+  rng = np.random.default_rng(43)
+  grid = [64, 64, 96]   # array order: x is the last dimension
+  M = 300000
+  if cloud == 'uniform+cluster':
+    pts = rng.uniform(-np.pi, np.pi, (M, 3)).astype(np.float32)
+    pts[:50000] = (0.05 * rng.standard_normal((50000, 3)) + 1.0).astype(np.float32)
+  else:
+    pts = (rng.uniform(0.1, 0.9, (M, 3)) * (2 * np.pi * 64 / 192) - np.pi).astype(np.float32)
+    pts[:, :2] = (rng.uniform(0.1, 0.9, (M, 2)) * (2 * np.pi * 64 / 128) - np.pi).astype(np.float32)
+  c = (rng.uniform(-.5, .5, M) + 1j * rng.uniform(-.5, .5, M)).astype(np.complex64)
+  f = (rng.uniform(-.5, .5, grid) + 1j * rng.uniform(-.5, .5, grid)).astype(np.complex64)
+  truth1 = oracle.nufft(c.astype(np.complex128), pts, grid, 'type_1', 'forward', tol=1e-10)
+  truth2 = oracle.nufft(f.astype(np.complex128), pts, None, 'type_2', 'backward', tol=1e-10)
+  outs = {}
+  for name in ('SORT2_OFF', 'SORT2_ON'):
+    p1 = tfft.Plan('type_1', grid, 'forward', tol=tol, tile_dims=tile, tuning=_lib.TUNE[name])
+    assert tuple(p1.info().tile_dims) == tile
+    p1.set_points(_dev(pts))
+    assert p1.sort_path() == (3 if name == 'SORT2_ON' else 0), p1.sort_path()
+    o1 = p1.execute(_dev(c))
+    o1b = p1.execute_with_points(_dev(pts), _dev(c))   # (the one-call entry does not fuse behind the two-level sort)
+    p2 = tfft.Plan('type_2', grid, 'backward', tol=tol, tile_dims=tile, tuning=_lib.TUNE[name])
+    p2.set_points(_dev(pts))
+    assert p2.sort_path() == (3 if name == 'SORT2_ON' else 0)
+    o2 = p2.execute(_dev(f))
+    outs[name] = (o1.cpu().numpy(), o1b.cpu().numpy(), o2.cpu().numpy())
+    p1.close(); p2.close()
+  for name, (o1, o1b, o2) in outs.items():
+    assert rel_l2(o1, truth1) < tol, (name, rel_l2(o1, truth1))
+    assert rel_l2(o1b, truth1) < tol, (name, rel_l2(o1b, truth1))
+    assert rel_l2(o2, truth2) < tol, (name, rel_l2(o2, truth2))
+  # same records in every tile, in another order: type 2 reads, so it is bitwise equal; type 1 sums in another
+  # order and splits crowded tiles into other subproblems (each with its own fixed-point step)
+  assert np.array_equal(outs['SORT2_ON'][2], outs['SORT2_OFF'][2])
+  assert rel_l2(outs['SORT2_ON'][0], outs['SORT2_OFF'][0]) < 0.1 * tol
+
+
+def test_two_level_sort_is_the_default_for_large_3d_tile_sets(tfft):
+  # 256^3 modes: 512^3 fine cells = 65536 tiles of 16 x 16 x 8; from 2^21 points on the plan sorts in two levels
+  import torch
+  g = torch.Generator(device='cuda').manual_seed(3)
+  grid = [256, 256, 256]
+  plan = tfft.Plan('type_2', grid, 'backward', tol=1e-4)
+  for M, path in ((1 << 20, 1), (3 << 20, 3)):
+    pts = (torch.rand((M, 3), generator=g, device='cuda') * 2 - 1) * np.pi
+    plan.set_points(pts)
+    assert plan.sort_path() == path, (M, plan.sort_path())
+  # and the transform through it against the direct sum on a few points
+  f = torch.complex(torch.randn(grid, generator=g, device='cuda'), torch.randn(grid, generator=g, device='cuda'))
+  out = plan.execute(f)
+  k = torch.arange(-128, 128, device='cuda', dtype=torch.float64)
+  sel = torch.arange(0, M, M // 7, device='cuda')[:7]
+  for j in sel.tolist():
+    x = pts[j].double()
+    e = [torch.exp(1j * k * x[d]) for d in range(3)]
+    ref = torch.einsum('abc,a,b,c->', f.to(torch.complex128), e[0], e[1], e[2])
+    assert abs(complex(out[j]) - complex(ref)) < 2e-4 * abs(complex(ref)) + 1e-2, (j, complex(out[j]), complex(ref))
+  plan.close()
+
+
 @pytest.mark.parametrize('grid', [[9, 9, 9], [9, 10], [8, 9, 12], [10, 9], [33]])
 @pytest.mark.parametrize('ttype', ['type_1', 'type_2'])
 def test_tiny_and_odd_grids(tfft, grid, ttype):
