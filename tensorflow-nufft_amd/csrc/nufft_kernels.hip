@@ -2407,7 +2407,7 @@ int sort_blocks(const Geom& g, int64_t M, int64_t* per_block) {
 
 // The two-level sort exists for this plan (tiles numbered by super-tiles) and the point count makes it pay
 // (six launches instead of four; options.tuning SORT2_ON: always)
-constexpr int64_t kSort2MinPoints = (int64_t)1 << 21;
+constexpr int64_t kSort2MinPoints = (int64_t)3 << 19;   // (tools/sort2_ab.py: level at 1e6 points, 20 % ahead at 2e6)
 static bool sort2_wanted(const Geom& g, int64_t M) {
   if (g.sup_shift[0] + g.sup_shift[1] + g.sup_shift[2] == 0 || g.nitems > 1 || M >= ((int64_t)1 << 31)) return false;
   return (g.tuning & NUFFT_HIP_TUNE_SORT2_ON) || M >= kSort2MinPoints;

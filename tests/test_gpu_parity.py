@@ -1067,7 +1067,7 @@ def test_two_level_sort_is_the_default_for_large_3d_tile_sets(tfft):
   g = torch.Generator(device='cuda').manual_seed(3)
   grid = [256, 256, 256]
   plan = tfft.Plan('type_2', grid, 'backward', tol=1e-4)
-  for M, path in ((1 << 20, 1), (3 << 20, 3)):
+  for M, path in ((1 << 20, 1), (3 << 20, 3)):   # (the switch is at 1.5 * 2^20 points)
     pts = (torch.rand((M, 3), generator=g, device='cuda') * 2 - 1) * np.pi
     plan.set_points(pts)
     assert plan.sort_path() == path, (M, plan.sort_path())
