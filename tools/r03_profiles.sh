@@ -17,8 +17,11 @@ timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_bench3 -o runc -
 cat $O/r03_bench_kernel_stats.txt
 bash tools/pmc_kernels.sh cfg2 "--type type_1 --grid 1024,1024 --M 1e7 --tol 1e-6 --one-call" > $O/r03_pmc_cfg2.txt 2>&1
 bash tools/pmc_kernels.sh cfg3 "--type type_2 --grid 1024,1024 --M 1e7 --tol 1e-6 --one-call" > $O/r03_pmc_cfg3.txt 2>&1
-bash tools/pmc_kernels.sh cfg4 "--type type_1 --grid 256,256,256 --M 1e8 --tol 1e-4 --one-call" > $O/r03_pmc_cfg4_fused.txt 2>&1
-grep -A2 "spread_2d_w8_group\|interp_point\|dense3" $O/r03_pmc_cfg2.txt $O/r03_pmc_cfg3.txt $O/r03_pmc_cfg4_fused.txt | cut -c1-260
+# (config 4 as shipped since the two-level sort: unfused records; r03_pmc_cfg4_fused.txt is the same call with --tuning SORT2_OFF)
+bash tools/pmc_kernels.sh cfg4 "--type type_1 --grid 256,256,256 --M 1e8 --tol 1e-4 --one-call" > $O/r03_pmc_cfg4_sort2.txt 2>&1
+bash tools/pmc_kernels.sh cfg4f "--type type_1 --grid 256,256,256 --M 1e8 --tol 1e-4 --one-call --tuning SORT2_OFF" > $O/r03_pmc_cfg4_fused.txt 2>&1
+grep -A2 "spread_2d_w8_group\|interp_point\|dense3" $O/r03_pmc_cfg2.txt $O/r03_pmc_cfg3.txt $O/r03_pmc_cfg4_sort2.txt $O/r03_pmc_cfg4_fused.txt | cut -c1-260
+python3 tools/sort2_ab.py --big 2>&1 | grep -v amdgpu > $O/r03_sort2_ab.txt; tail -8 $O/r03_sort2_ab.txt | cut -c1-200
 python3 tools/bench_configs.py 2 3 4 4t2 5 5s 5op 1 3d5 3d6 2>&1 | grep -v amdgpu > $O/r03_configs.txt; cat $O/r03_configs.txt
 for cfg in "type_2 1024,1024 1e7 1e-6 cfg3" "type_1 256,256,256 1e8 1e-4 cfg4" "type_2 256,256,256 1e8 1e-4 cfg4t2"; do
   set -- $cfg
