@@ -1602,7 +1602,8 @@ def test_tuning_bits_give_the_same_transforms(tmp_path):
   # options.tuning forces one of the kernel families the plan otherwise picks by density / geometry (staged or
   # plain scatter, fused records or not, grouped or per-point 2-D spreader, joint or split 3-D w = 8 launches,
   # LDS-free spreader, cell-sorted records, rocFFT + deconvolve instead of the pruned passes, thread-per-point
-  # kernels instead of the wide / line ones): each must give the default path's transform.
+  # kernels instead of the wide / line ones, the two-level 3-D sort where the fine grid is a multiple of 64 cells):
+  # each must give the default path's transform.
   import subprocess
   import sys
   from conftest import PKG, ROOT
@@ -1617,8 +1618,8 @@ def test_tuning_bits_give_the_same_transforms(tmp_path):
 
   ref = run(str(tmp_path / 'base.npz'), 0)
   for bits in (('NO_FUSED', 'GROUP_OFF', 'SPARSE_OFF', 'CELLSORT_OFF', 'CELLSORT3D_OFF', 'ROCFFT', 'NO_WIDE', 'NO_LINE',
-                'JOINT_OFF', 'STAGED_OFF'),
-               ('GROUP_ON', 'SPARSE_OFF', 'CELLSORT_ON', 'CELLSORT3D_ON', 'JOINT_ON', 'STAGED_ON'),
+                'JOINT_OFF', 'STAGED_OFF', 'SORT2_OFF'),
+               ('GROUP_ON', 'SPARSE_OFF', 'CELLSORT_ON', 'CELLSORT3D_ON', 'JOINT_ON', 'STAGED_ON', 'SORT2_ON'),
                ('SPARSE_ON', 'NO_FUSED')):
     tuning = 0
     for b in bits:
