@@ -1134,6 +1134,40 @@ def test_set_points_and_execute_capture_into_a_hip_graph(tfft):
     plan.close()
 
 
+def test_two_level_sort_captures_into_a_hip_graph(tfft):
+  # the six launches of the two-level 3-D sort (and the transform behind it) replay from a graph with new points
+  # in the captured buffer: nothing in them allocates, synchronises or depends on host-side counts
+  import torch
+  from tensorflow_nufft import _lib
+  rng = np.random.default_rng(62)
+  M, grid = 150000, [64, 64, 64]
+  pts1 = rng.uniform(-np.pi, np.pi, (M, 3)).astype(np.float32)
+  pts2 = (0.3 * rng.standard_normal((M, 3))).astype(np.float32)      # another distribution: other piece counts
+  f = _dev((rng.standard_normal(grid) + 1j * rng.standard_normal(grid)).astype(np.complex64))
+  s = torch.cuda.Stream()
+  with torch.cuda.stream(s):
+    plan = tfft.Plan('type_2', grid, 'backward', tol=1e-4, tuning=_lib.TUNE['SORT2_ON'])
+    pbuf = _dev(pts1).clone()
+    out = torch.empty(M, dtype=torch.complex64, device='cuda')
+    refs = []
+    for p in (pts2, pts1):
+      pbuf.copy_(_dev(p))
+      plan.set_points(pbuf); plan.execute(f, out=out)
+      s.synchronize()
+      refs.append(out.clone())
+    assert plan.sort_path() == 3
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+      plan.set_points(pbuf); plan.execute(f, out=out)
+    out.zero_()
+    graph.replay(); s.synchronize()
+    assert torch.equal(out, refs[1])
+    pbuf.copy_(_dev(pts2))
+    graph.replay(); s.synchronize()
+    assert torch.equal(out, refs[0])
+    plan.close()
+
+
 def test_partial_last_batch_and_plan_lifecycle(tfft):
   # 11 transforms with the default batch of 8 => one full batch + a batch of 3 (second rocFFT plan);
   # then create/destroy many plans to catch leaks or stale state
