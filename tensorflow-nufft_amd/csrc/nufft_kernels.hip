@@ -2128,7 +2128,7 @@ __global__ __launch_bounds__(NTHREADS) void interp_point_kernel(
         T rre = (T)0, rim = (T)0;
 #pragma unroll
         for (int dx = 0; dx < W; ++dx) {
-          const T2 v = row[dx];
+          const T2 v = lds_cell(row + dx);
           rre = fma(kx[dx], v.x, rre);
           rim = fma(kx[dx], v.y, rim);
         }

@@ -343,7 +343,7 @@ __global__ __launch_bounds__(kWideNW * 64) void interp_wide_kernel(
       if (RANK == 2) {
 #pragma unroll
         for (int dy = 0; dy < W; ++dy) {
-          const T2 v = tp[dy * LS];
+          const T2 v = lds_cell(tp + dy * LS);
           const T wgt = a * ky[dy];
           sre = fma(wgt, v.x, sre);
           sim = fma(wgt, v.y, sim);
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(kWideNW * 64) void interp_wide_kernel(
           const T az = a * kz[dz];
 #pragma unroll
           for (int dy = 0; dy < W; ++dy) {
-            const T2 v = tp[dz * PS + dy * LS];
+            const T2 v = lds_cell(tp + dz * PS + dy * LS);
             const T wgt = az * ky[dy];
             sre = fma(wgt, v.x, sre);
             sim = fma(wgt, v.y, sim);
