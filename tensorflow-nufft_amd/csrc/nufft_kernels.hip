@@ -2119,7 +2119,9 @@ __global__ __launch_bounds__(NTHREADS) void interp_point_kernel(
     const T2* tp = tile + (int)(rec.loc & 1023) + (int)((rec.loc >> 10) & 1023) * LS +
                    (RANK > 2 ? (int)((rec.loc >> 20) & 1023) * PS : 0);
     T sre = (T)0, sim = (T)0;
-#pragma unroll
+    // (3-D: three z-planes per unrolled body. Fully unrolled -- 216 to 512 cell reads -- the kernel held 114 VGPRs and
+    // up: two workgroups per CU at w = 6, spills at w = 7, 8; this way 75-79: M = 3e7 at w = 8 7.7 -> 4.0 ms, r03)
+#pragma unroll 3
     for (int dz = 0; dz < (RANK > 2 ? W : 1); ++dz) {
       T pre = (T)0, pim = (T)0;
 #pragma unroll
