@@ -1134,6 +1134,42 @@ def test_set_points_and_execute_capture_into_a_hip_graph(tfft):
     plan.close()
 
 
+def test_two_level_sort_with_separate_coordinate_arrays_transforms_and_range_check(tfft):
+  # the same sort fed through the C ABI with three coordinate arrays (stride 1: generic loads instead of the
+  # 12-byte point loads), an odd point count, three transforms per call, and the strict range check on
+  import torch
+  from oracle import oracle
+  from tensorflow_nufft import _lib
+  rng = np.random.default_rng(44)
+  grid, M = [64, 64, 64], 123_457
+  pts = rng.uniform(-np.pi, np.pi, (M, 3)).astype(np.float32)
+  pts[:30000] = (0.2 * rng.standard_normal((30000, 3))).astype(np.float32)
+  c = (rng.standard_normal((3, M)) + 1j * rng.standard_normal((3, M))).astype(np.complex64)
+  plan = tfft.Plan('type_1', grid, 'forward', num_transforms=3, tol=1e-4, tuning=_lib.TUNE['SORT2_ON'])
+  z, y, x = (_dev(np.ascontiguousarray(pts[:, d])) for d in range(3))   # array order: x is the last column
+  lib = tfft._lib.lib()
+  assert lib.nufft_hip_set_points(plan._handle, M, x.data_ptr(), y.data_ptr(), z.data_ptr(), 1) == 0
+  assert plan.sort_path() == 3
+  plan.M = M
+  out = plan.execute(_dev(c)).cpu().numpy()
+  for t in range(3):
+    truth = oracle.nufft(c[t].astype(np.complex128), pts, grid, 'type_1', 'forward', tol=1e-10)
+    assert rel_l2(out[t], truth) < 1e-4, (t, rel_l2(out[t], truth))
+  # the same points through the interleaved path: same tiles, same records
+  plan.set_points(_dev(pts))
+  out2 = plan.execute(_dev(c)).cpu().numpy()
+  assert rel_l2(out2, out) < 1e-5
+  plan.close()
+  # range check: one point outside [-3 pi, 3 pi] (the default, EXTENDED, range) is reported by the level-1 count pass
+  planc = tfft.Plan('type_2', grid, 'backward', tol=1e-4, tuning=_lib.TUNE['SORT2_ON'], check_points_range=1)
+  bad = pts.copy(); bad[77777, 1] = 10.0
+  with pytest.raises(Exception, match='outside expected range'):
+    planc.set_points(_dev(bad))
+  planc.set_points(_dev(pts))
+  assert planc.sort_path() == 3
+  planc.close()
+
+
 def test_two_level_sort_captures_into_a_hip_graph(tfft):
   # the six launches of the two-level 3-D sort (and the transform behind it) replay from a graph with new points
   # in the captured buffer: nothing in them allocates, synchronises or depends on host-side counts
