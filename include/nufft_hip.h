@@ -83,9 +83,9 @@ typedef struct nufft_hip_options {
   int32_t max_subproblem_size; /* points per workgroup pass; 0 = auto */
   int32_t tile_dims[3];        /* fine-grid cells per tile, x fastest; 0 = auto */
   int32_t lds_accumulate;      /* LDS tile accumulation: 0 auto, 1 double, 2 packed 32+32-bit fixed
-                                  point (3-D float, kernel width <= 7 only; width 7 caps
-                                  max_subproblem_size at 512; tiles holding more than 16 subproblems
-                                  are accumulated in double all the same; DESIGN.md sections 4 and 6) */
+                                  point (3-D float, kernel width <= 8 only; tiles holding more than 16
+                                  subproblems, and at widths 7, 8 subproblems whose count-filter bound makes
+                                  the step too coarse, are accumulated in double all the same) */
   int32_t num_point_sets;      /* K > 1: the plan sorts and transforms K independent point sets at once
                                   (batched transforms with per-item points, nufft_kernels.cc:491-540 run as
                                   one pass): set_points takes K * num_points points, set k at
@@ -118,7 +118,10 @@ enum {
   NUFFT_HIP_TUNE_STAGED_OFF = 1 << 14,     /* staged scatter (<= 1024 tiles per point set): never / always */
   NUFFT_HIP_TUNE_STAGED_ON = 1 << 15,
   NUFFT_HIP_TUNE_SORT2_OFF = 1 << 16,      /* 3-D float: two-level sort (64^3-cell super-tiles first): never / wherever it exists */
-  NUFFT_HIP_TUNE_SORT2_ON = 1 << 17
+  NUFFT_HIP_TUNE_SORT2_ON = 1 << 17,
+  NUFFT_HIP_TUNE_FXPATCH_OFF = 1 << 18,    /* 3-D float w = 7, 8: the r03 kernels (fp64 planes at w = 8; w = 7 fixed point on
+                                              depth-4 tiles, 512-point subproblems) instead of spread_patch3_kernel */
+  NUFFT_HIP_TUNE_ALL = (1 << 19) - 1       /* every defined bit: plan creation refuses others, and both bits of a pair */
 };
 
 typedef struct nufft_hip_plan_s* nufft_hip_plan;
@@ -247,6 +250,11 @@ int nufft_hip_debug_stop_after(nufft_hip_plan plan, int stage);
 /* Which sort the plan ran at its last set_points: 0 = LDS histogram, 1 = 16-bit LDS histogram + ranked scatter,
  * 2 = global counters, 3 = two levels (super-tiles, then tiles); -1 = no points set. */
 int nufft_hip_debug_sort_path(nufft_hip_plan plan);
+/* 3-D float plans at kernel widths 7, 8 (packed fixed point, r04): the count-filter bound of every subproblem as the
+ * last set_points wrote it, host copy (synchronises): out[s] > 0 = the bound B of subproblem s (every cell sum of its
+ * spread is at most B largest strengths), < 0 = left to the double-precision LDS planes, 0 = unused launch slot.
+ * Returns the number of launch slots (<= n copied), 0 for other plans, negative on error. */
+int64_t nufft_hip_debug_sub_bounds(nufft_hip_plan plan, float* out, int64_t n);
 
 /* ---- Op-level entry: the host logic of NUFFTBaseOp::Compute/Execute --------
  * (nufft_kernels.cc:54-542): validation with the reference's error messages,

@@ -35,6 +35,8 @@
 // subproblems than Geom::fx_max_subs are left to the fp64-plane kernels (nufft_kernels.hip).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "nufft_device.h"
 #include "nufft_hip_internal.h"
 
@@ -507,6 +509,353 @@ hipError_t launch_dense3(const Geom& g, const SortedPoints<float>& sp, const flo
   return hipGetLastError();
 }
 
+// ================================================================================================
+// Widths 7 and 8 (tol 1e-5 / the default 1e-6): packed fixed point with an EXACT 32-bit conversion and a step
+// that comes from a count-filter bound, on the 8 x 8 (x, y) lane patch of spread_wave3_kernel with the staging
+// scheme of the kernel above. Replaces the 2 w ds_add_f64 per point of the fp64-plane form (r02) by w ds_add_u64.
+//
+// Why the r01-r03 rules do not reach tol 1e-6. The output error added by the quantisation is ~ 11 (step / top)
+// (top = the largest strength; measured r02/r03: 2.4e-6 at step = top / 2^22), so w = 8 needs step <= ~top 2^-25.
+// The FMA conversion of the kernels above is exact to 2^22 steps only, and the sum rule (step = sum of the
+// subproblem's strengths / 2^31: no cell can overflow whatever the points do) allows ~64 points per subproblem at
+// that step. Two changes:
+//
+//  * Conversion: v_pk_mul_f32 + 2 v_cvt_rpi_i32_f32, exact for the whole 32-bit field. The sign fix-up of the low
+//    (imaginary) field would cost two more instructions per atomic; instead every point is spread with a
+//    non-negative imaginary strength -- a point with im c < 0 is negated (both components) and SUBTRACTED
+//    (ds_sub_u64; the choice is wave-uniform, one point per pass) -- and the kernel values are clamped at 0 (the
+//    fit undershoots by ~1e-9 at the stencil's edge), so the low field of every word is >= 0 and
+//    word = n_re 2^32 + n_im needs no fix-up: 3 VALU instructions per atomic.
+//  * Step: a cell's sum is bounded by top * sum_i K_i(cell) <= top * B, B = max over the tile's cells of the
+//    start-cell COUNTS of the subproblem filtered with the per-tap maxima of the kernel polynomials, separably in
+//    x, y, z (bound3_kernel). B depends on the points only, so it is computed once per set_points, and it is ~14
+//    at 0.22 points per fine cell, 37 at 0.75 (the sum rule's figure there: 1536): step = top B / 2^31 = top 2^-26
+//    at 0.75 points per cell. Subproblems whose B would make the step too coarse for the plan's tolerance
+//    (Geom::fx_bound_limit; clustered points) and tiles with more than fx_max_subs subproblems are left to the
+//    fp64-plane kernels, flagged by a negative entry of sub_bound.
+//    `top` is the largest max(|re c|, |im c|) of the whole transform (cstats_kernel, one streaming pass per
+//    launch) unless one strength dominates (largest > 8 x the mean): then every subproblem takes its own pass
+//    over its strengths and uses min(its sum, its largest x B) -- both are bounds.
+//
+// LDS: one plane of 24-element rows (24 = 8 mod 16: the two rows of a 16-lane group cover 16 distinct 8-byte
+// columns, conflict free for every point position), (16 + W - 1) rows, (8 + W - 1) planes = 66 KB at W = 8, and
+// 96 bytes of staged kernel values per point, 8 points per wave at a time: 76 KB, two workgroups per CU.
+constexpr int kPatchLS = 24;
+constexpr int kPatchNW = 12;
+template <int W, int TZ, int HALF> struct PatchCfg {
+  static constexpr int L0 = kDenseTile + W - 1, L1 = kDenseTile + W - 1, L2 = TZ + W - 1;
+  static constexpr int LS = kPatchLS, PS = kPatchLS * L1;
+  // idle lanes (W = 7: dx = 7 or dy = 7) add 0 at their natural patch address: up to row 22, column 22 of the last
+  // plane, i.e. up to 22 * 24 + 22 - PS + 1 elements behind it
+  static constexpr int plane_elems = (PS * L2 + 64 + 1) & ~1;
+  static constexpr int PAIR_BYTES = 8 * 16 + 8 * 8;      // kx (im c, re c) of two points per 16-byte slot; ky of two points per 8
+  static constexpr size_t stage_bytes = (size_t)kPatchNW * (HALF / 2) * PAIR_BYTES;
+  static constexpr size_t lds_bytes = (size_t)plane_elems * 8 + stage_bytes + 2 * kPatchNW * sizeof(float) + 64;
+};
+
+__device__ __forceinline__ int cvt_rpi(float x) {   // floor(x + 0.5) in one instruction
+  int r;
+  asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+typedef __attribute__((address_space(3))) unsigned char lds_byte;
+
+template <int W, int TZ, int HALF>
+__global__ __launch_bounds__(kPatchNW * 64) void spread_patch3_kernel(
+    Geom g, SortedPoints<float> sp, const float* __restrict__ horner, const float* __restrict__ c,
+    float* __restrict__ fw, int64_t c_stride, int64_t fw_stride, float scale) {
+  using C = PatchCfg<W, TZ, HALF>;
+  constexpr int LS = C::LS, PS = C::PS, NW = kPatchNW, L0 = C::L0, L1 = C::L1, L2 = C::L2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned long long* plane = reinterpret_cast<unsigned long long*>(smem_raw);
+  unsigned char* stage_all = smem_raw + (size_t)C::plane_elems * 8;
+  float* red = reinterpret_cast<float*>(stage_all + C::stage_bytes);   // [2 NW]
+
+  int tb, p0, p1, slot, nsub;
+  if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1, &slot, &nsub)) return;
+  const float bound_b = sp.sub_bound[blockIdx.x];
+  if (bound_b < 0.f) return;   // too crowded for the fixed-point grid: the fp64-plane launches behind this one take it
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const float2* cc = reinterpret_cast<const float2*>(c) + (int64_t)slot * c_stride;
+  const int npt = p1 - p0;
+  for (int i = tid; i < C::plane_elems; i += NW * 64) plane[i] = 0ull;
+
+  // step of the fixed-point grid (see the header comment)
+  const float top_g = sp.cstats[2 * slot], sum_g = sp.cstats[2 * slot + 1];
+  const bool skewed = top_g * (float)c_stride > 8.f * sum_g;
+  float top = top_g, sum = 3.0e38f;
+  if (skewed) {   // (workgroup-uniform) one strength dominates the transform: this subproblem's own strengths decide
+    float part = 0.f, big = 0.f;
+    for (int j = p0 + tid; j < p1; j += NW * 64) {
+      const float2 cv = cc[sp.rec[j].idx];
+      const float m = fmaxf(fabsf(cv.x), fabsf(cv.y));
+      part += m;
+      big = fmaxf(big, m);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      part += __shfl_down(part, o);
+      big = fmaxf(big, __shfl_down(big, o));
+    }
+    if (lane == 0) { red[wave] = part; red[NW + wave] = big; }
+    __syncthreads();
+    sum = 0.f; top = 0.f;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) { sum += red[k]; top = fmaxf(top, red[NW + k]); }
+  }
+  const float amp = fabsf(scale) * g.fx_headroom;
+  const float room = 2147483000.f - (float)npt;     // 2^31 minus one step of rounding per contribution
+  // (no finer than top 2^-29: every contribution stays below 2^29 steps)
+  const float step = fmaxf(fminf(sum, top * bound_b), top * 1.8626451e-9f * room) * amp / room;
+  const float pre = step > 0.f ? scale / step : 0.f;
+  __syncthreads();
+
+  const int dx = lane & 7, dy = lane >> 3;
+  const int cell_b = (dy * LS + dx) * 8;
+  const int rd_x = dx * 16, rd_y = 128 + dy * 8;
+  const int nc = g.ncoef;
+  const int share = (npt + NW - 1) / NW;
+  const int wbeg = wave * share;
+  const int wend = (wbeg + share < npt) ? wbeg + share : npt;
+  unsigned char* stage = stage_all + (size_t)wave * (HALF / 2) * C::PAIR_BYTES;
+  lds_byte* plane_l = (lds_byte*)plane;
+
+  for (int base = wbeg; base < wend; base += 64) {
+    // phase 1: one point per lane -- record, strength, 3 W kernel values
+    const int js = base + lane;
+    int off = 0;
+    float kx[8], ky[8], kz[8];
+    float cre = 0.f, cim = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { kx[q] = 0.f; ky[q] = 0.f; kz[q] = 0.f; }
+    if (js < wend) {
+      const PointView<float> rec = unpack_rec<float, 3>(sp.rec[p0 + js]);
+      const float2 cv = cc[rec.idx];
+      cre = cv.x * pre;
+      cim = cv.y * pre;
+      off = ((int)(rec.loc & 1023) + (int)((rec.loc >> 10) & 1023) * LS + (int)((rec.loc >> 20) & 1023) * PS) * 8;
+      float h0[W], h1[W], h2[W];
+      horner3<W>(horner, nc, rec.z0, rec.z1, rec.z2, h0, h1, h2);
+#pragma unroll
+      for (int q = 0; q < W; ++q) { kx[q] = fmaxf(h0[q], 0.f); ky[q] = fmaxf(h1[q], 0.f); kz[q] = fmaxf(h2[q], 0.f); }
+    }
+    // a point with a negative imaginary strength is negated here and subtracted below
+    const unsigned long long negm = __ballot(cim < 0.f);
+    if (cim < 0.f) { cre = -cre; cim = -cim; }
+    int left = wend - base;
+    if (left > 64) left = 64;
+    for (int h = 0; h * HALF < left; ++h) {
+      // stage HALF points: pair p holds points 2p, 2p + 1 of this round side by side
+      if (lane / HALF == h) {
+        unsigned char* s = stage + ((lane % HALF) >> 1) * C::PAIR_BYTES;
+#pragma unroll
+        for (int x = 0; x < 8; ++x) *reinterpret_cast<v2f*>(s + x * 16 + (lane & 1) * 8) = (v2f){kx[x] * cim, kx[x] * cre};
+#pragma unroll
+        for (int y = 0; y < 8; ++y) *reinterpret_cast<float*>(s + 128 + y * 8 + (lane & 1) * 4) = ky[y];
+      }
+      int npts = left - h * HALF;
+      if (npts > HALF) npts = HALF;
+      // phase 2: every lane adds its (dx, dy) column of every point, plane after plane
+      for (int p = 0; 2 * p < npts; ++p) {
+        const v4f rx = *reinterpret_cast<const v4f*>(stage + p * C::PAIR_BYTES + rd_x);
+        const v2f ry = *reinterpret_cast<const v2f*>(stage + p * C::PAIR_BYTES + rd_y);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int q = h * HALF + 2 * p + u;
+          if (u && 2 * p + 1 >= npts) break;
+          const v2f kxc = u ? (v2f){rx.z, rx.w} : (v2f){rx.x, rx.y};
+          const float kyv = u ? ry.y : ry.x;
+          const v2f xy = kxc * (v2f){kyv, kyv};
+          lds_u64* dst = (lds_u64*)(plane_l + __builtin_amdgcn_readlane(off, q) + cell_b);
+          if ((negm >> q) & 1ull) {   // wave-uniform
+#pragma unroll
+            for (int dz = 0; dz < W; ++dz) {
+              const float kzq = bcast_lane(kz[dz], q);
+              const v2f v = xy * (v2f){kzq, kzq};
+              const unsigned long long word = ((unsigned long long)(unsigned)cvt_rpi(v.y) << 32) | (unsigned)cvt_rpi(v.x);
+              __hip_atomic_fetch_sub(dst + dz * PS, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+          } else {
+#pragma unroll
+            for (int dz = 0; dz < W; ++dz) {
+              const float kzq = bcast_lane(kz[dz], q);
+              const v2f v = xy * (v2f){kzq, kzq};
+              const unsigned long long word = ((unsigned long long)(unsigned)cvt_rpi(v.y) << 32) | (unsigned)cvt_rpi(v.x);
+              __hip_atomic_fetch_add(dst + dz * PS, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // write-out: unpack, scale back, add to the periodic fine grid
+  int t0, t1, t2;
+  tile_coords(g, tb, &t0, &t1, &t2);
+  const int o0 = t0 * kDenseTile, o1 = t1 * kDenseTile, o2 = t2 * TZ;
+  float* out = fw + 2 * (int64_t)slot * fw_stride;
+  for (RowWalk r(wave, L1); r.a2 < L2; r.advance(NW, L1)) {
+    const int g1 = wrap1(o1 + r.a1, g.nf[1]);
+    const int g2 = wrap1(o2 + r.a2, g.nf[2]);
+    const int64_t rowbase = (int64_t)g.nf[0] * (g1 + (int64_t)g.nf[1] * g2);
+    const int lrow = r.a2 * PS + r.a1 * LS;
+    for (int e = lane; e < 2 * L0; e += 64) {
+      const int a0 = e >> 1, comp = e & 1;
+      const long long t = (long long)plane[lrow + a0];
+      const int im_sum = (int)(unsigned)(t & 0xffffffffll);
+      const int re_sum = (int)((t - (long long)im_sum) >> 32);
+      const float v = (float)(comp ? im_sum : re_sum) * step;
+      if (v != 0.f) glb_add(&out[2 * (rowbase + wrap1(o0 + a0, g.nf[0])) + comp], v);
+    }
+  }
+}
+
+// ---- count-filter bound of every subproblem (set_points of a patch plan) -----------------------------------------
+// B = max over the cells of the tile (+ halo) of sum_t0 sum_t1 sum_t2 N(i - t0, j - t1, k - t2) kmax[t0] kmax[t1] kmax[t2],
+// N = the subproblem's points per start cell: every cell sum of the spread is at most (largest strength) x B.
+// One workgroup per subproblem; the three filter passes keep a line's inputs in registers.
+constexpr int kBoundThreads = 256;
+template <int W, int TZ>
+__global__ __launch_bounds__(kBoundThreads) void bound3_kernel(Geom g, const Rec<float>* __restrict__ rec, int rec_stride,
+                                                              const int32_t* __restrict__ tile_start,
+                                                              const int32_t* __restrict__ sub_start, TapMax taps,
+                                                              float* __restrict__ sub_bound, unsigned nsub_bound) {
+  constexpr int T = kDenseTile, L = T + W - 1, LZ = TZ + W - 1, NT = kBoundThreads;
+  __shared__ uint32_t cnt[TZ * T * T];
+  __shared__ float a[TZ * T * L];     // [z][y][i]
+  __shared__ float b[TZ * L * L];     // [z][j][i]
+  __shared__ float wmax[NT / 64];
+  int tb, p0, p1, slot, nsub;
+  if (!locate_subproblem(g, tile_start, sub_start, blockIdx.x, &tb, &p0, &p1, &slot, &nsub)) return;
+  const int tid = threadIdx.x, npt = p1 - p0;
+  if (nsub > g.fx_max_subs) {   // (every further subproblem of a tile adds its share of quantisation noise)
+    if (tid == 0) {
+      sub_bound[blockIdx.x] = -1.f;
+      atomicAdd(reinterpret_cast<int*>(sub_bound + nsub_bound), 1);
+    }
+    return;
+  }
+  if (npt <= 16) {   // (B <= the point count; nothing finer is needed of so few points)
+    if (tid == 0) sub_bound[blockIdx.x] = (float)(npt > 0 ? npt : 1);
+    return;
+  }
+  for (int i = tid; i < TZ * T * T; i += NT) cnt[i] = 0u;
+  __syncthreads();
+  for (int j = p0 + tid; j < p1; j += NT) {
+    const Rec<float>& r = rec_at(rec, j, rec_stride);
+    const uint32_t l0 = r.loc >> 28, l1 = __float_as_uint(r.z0) >> 28, l2 = __float_as_uint(r.z1) >> 28;
+    atomicAdd(&cnt[(l2 * T + l1) * T + l0], 1u);
+  }
+  __syncthreads();
+  float km[W];
+#pragma unroll
+  for (int t = 0; t < W; ++t) km[t] = taps.k[t];
+  // x: line (z, y) of T counts -> L values
+  for (int line = tid; line < TZ * T; line += NT) {
+    float in[T];
+#pragma unroll
+    for (int i = 0; i < T; ++i) in[i] = (float)cnt[line * T + i];
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+      float v = 0.f;
+#pragma unroll
+      for (int t = 0; t < W; ++t)
+        if (i - t >= 0 && i - t < T) v = fmaf(km[t], in[i - t], v);
+      a[line * L + i] = v;
+    }
+  }
+  __syncthreads();
+  // y: line (z, i) of T values -> L values
+  for (int line = tid; line < TZ * L; line += NT) {
+    const int z = line / L, i = line - z * L;
+    float in[T];
+#pragma unroll
+    for (int y = 0; y < T; ++y) in[y] = a[(z * T + y) * L + i];
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+      float v = 0.f;
+#pragma unroll
+      for (int t = 0; t < W; ++t)
+        if (j - t >= 0 && j - t < T) v = fmaf(km[t], in[j - t], v);
+      b[(z * L + j) * L + i] = v;
+    }
+  }
+  __syncthreads();
+  // z: line (j, i) of TZ values -> maximum of the LZ outputs
+  float best = 0.f;
+  for (int line = tid; line < L * L; line += NT) {
+    float in[TZ];
+#pragma unroll
+    for (int z = 0; z < TZ; ++z) in[z] = b[z * L * L + line];
+#pragma unroll
+    for (int k = 0; k < LZ; ++k) {
+      float v = 0.f;
+#pragma unroll
+      for (int t = 0; t < W; ++t)
+        if (k - t >= 0 && k - t < TZ) v = fmaf(km[t], in[k - t], v);
+      best = fmaxf(best, v);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) best = fmaxf(best, __shfl_down(best, o));
+  if ((tid & 63) == 0) wmax[tid >> 6] = best;
+  __syncthreads();
+  if (tid == 0) {
+    float m = wmax[0];
+#pragma unroll
+    for (int k = 1; k < NT / 64; ++k) m = fmaxf(m, wmax[k]);
+    m *= 1.0001f;   // (float sums of non-negative terms)
+    if (m > g.fx_bound_limit) {
+      sub_bound[blockIdx.x] = -m;
+      atomicAdd(reinterpret_cast<int*>(sub_bound + nsub_bound), 1);
+    } else {
+      sub_bound[blockIdx.x] = m;
+    }
+  }
+}
+
+// ---- strengths of one spread launch: largest and summed max(|re c|, |im c|) per slot ----------------------------
+__global__ __launch_bounds__(256) void cstats_kernel(const float2* __restrict__ c, int64_t M, int64_t c_stride,
+                                                      float* __restrict__ cstats) {
+  const float2* cc = c + (int64_t)blockIdx.y * c_stride;
+  float big = 0.f, part = 0.f;
+  // (four loads in flight per thread)
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < M; i += 4 * stride) {
+    const float2 v0 = cc[i], v1 = cc[i + stride], v2 = cc[i + 2 * stride], v3 = cc[i + 3 * stride];
+    const float m0 = fmaxf(fabsf(v0.x), fabsf(v0.y)), m1 = fmaxf(fabsf(v1.x), fabsf(v1.y));
+    const float m2 = fmaxf(fabsf(v2.x), fabsf(v2.y)), m3 = fmaxf(fabsf(v3.x), fabsf(v3.y));
+    big = fmaxf(fmaxf(big, fmaxf(m0, m1)), fmaxf(m2, m3));
+    part += (m0 + m1) + (m2 + m3);
+  }
+  for (; i < M; i += stride) {
+    const float2 v = cc[i];
+    const float m = fmaxf(fabsf(v.x), fabsf(v.y));
+    big = fmaxf(big, m);
+    part += m;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    part += __shfl_down(part, o);
+    big = fmaxf(big, __shfl_down(big, o));
+  }
+  __shared__ float r[8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { r[wave] = part; r[4 + wave] = big; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part = (r[0] + r[1]) + (r[2] + r[3]);
+    big = fmaxf(fmaxf(r[4], r[5]), fmaxf(r[6], r[7]));
+    // (non-negative floats order like their bit patterns)
+    atomicMax(reinterpret_cast<unsigned*>(cstats + 2 * blockIdx.y), __float_as_uint(big));
+    unsafeAtomicAdd(cstats + 2 * blockIdx.y + 1, part);
+  }
+}
+
 }  // namespace
 
 #ifdef NUFFT_HIP_PHASE_LOG
@@ -515,6 +864,50 @@ extern "C" int nufft_hip_debug_phase_log3(unsigned long long* dst, int n) {   //
   return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_phase_log3), sizeof(unsigned long long) * (size_t)n);
 }
 #endif
+
+bool patch3_supported(const Geom& g, int precision) {
+  return precision == NUFFT_HIP_F32 && g.rank == 3 && g.fx_patch && (g.w == 7 || g.w == 8) && g.tile[0] == kDenseTile &&
+         g.tile[1] == kDenseTile && g.tile[2] == 8;
+}
+constexpr int kPatchHalf = 8;
+size_t patch3_lds_bytes(int w) {
+  return w == 8 ? PatchCfg<8, 8, kPatchHalf>::lds_bytes : w == 7 ? PatchCfg<7, 8, kPatchHalf>::lds_bytes : 0;
+}
+template <int W>
+static hipError_t launch_patch3(const Geom& g, const SortedPoints<float>& sp, const float* horner, const float* c, float* fw,
+                                dim3 grid, int64_t c_stride, int64_t fw_stride, float scale, hipStream_t stream) {
+  using C = PatchCfg<W, 8, kPatchHalf>;
+  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(spread_patch3_kernel<W, 8, kPatchHalf>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes);
+  if (e != hipSuccess) return e;
+  spread_patch3_kernel<W, 8, kPatchHalf><<<grid, kPatchNW * 64, C::lds_bytes, stream>>>(g, sp, horner, c, fw, c_stride, fw_stride, scale);
+  return hipGetLastError();
+}
+hipError_t launch_spread_patch3(const Geom& g, const SortedPoints<float>& sp, unsigned nsub_bound, const float* horner,
+                                const float* c, float* fw, int batch, int64_t c_stride, int64_t fw_stride, float scale,
+                                hipStream_t stream) {
+  const dim3 grid(nsub_bound, (unsigned)batch);
+  if (g.w == 8) return launch_patch3<8>(g, sp, horner, c, fw, grid, c_stride, fw_stride, scale, stream);
+  if (g.w == 7) return launch_patch3<7>(g, sp, horner, c, fw, grid, c_stride, fw_stride, scale, stream);
+  return hipErrorInvalidValue;
+}
+hipError_t launch_bound3(const Geom& g, const Rec<float>* rec, int rec_stride, const int32_t* tile_start, const int32_t* sub_start,
+                         unsigned nsub_bound, const TapMax& taps, float* sub_bound, hipStream_t stream) {
+  hipError_t e = hipMemsetAsync(sub_bound + nsub_bound, 0, sizeof(float), stream);
+  if (e != hipSuccess) return e;
+  if (nsub_bound == 0) return hipSuccess;
+  if (g.w == 8) bound3_kernel<8, 8><<<nsub_bound, kBoundThreads, 0, stream>>>(g, rec, rec_stride, tile_start, sub_start, taps, sub_bound, nsub_bound);
+  else if (g.w == 7) bound3_kernel<7, 8><<<nsub_bound, kBoundThreads, 0, stream>>>(g, rec, rec_stride, tile_start, sub_start, taps, sub_bound, nsub_bound);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+hipError_t launch_cstats(const float* c, int64_t M, int slots, int64_t c_stride, float* cstats, hipStream_t stream) {
+  hipError_t e = hipMemsetAsync(cstats, 0, sizeof(float) * 2 * (size_t)slots, stream);
+  if (e != hipSuccess || M <= 0 || slots <= 0) return e;
+  const unsigned nblk = (unsigned)std::min<int64_t>(2048, (M + 4095) / 4096);
+  cstats_kernel<<<dim3(nblk, (unsigned)slots), 256, 0, stream>>>(reinterpret_cast<const float2*>(c), M, c_stride, cstats);
+  return hipGetLastError();
+}
 
 bool dense3_supported(const Geom& g, int precision) {
   // (tiles of depth 4 -- only on request, options.tile_dims -- stay on spread_wave3_kernel)

@@ -53,6 +53,10 @@ struct Geom {
   // x-fastest numbering.
   int sup_shift[3];
   int nsup[3];
+  // 3-D float fixed-point plans at w = 7, 8 (spread_patch3_kernel, nufft_dense3.hip): the step of a subproblem comes
+  // from its count-filter bound (SortedPoints::sub_bound, written in set_points), the conversion is exact to 32 bits
+  int fx_patch;
+  float fx_bound_limit;   // subproblems whose bound exceeds this go to the fp64-plane kernels (quantisation noise)
 };
 // OFF / ON pair of nufft_hip_options.tuning: -1 = by the plan's own rule, 0 = never, 1 = always
 inline int tune_mode(const Geom& g, int off_bit, int on_bit) { return (g.tuning & on_bit) ? 1 : ((g.tuning & off_bit) ? 0 : -1); }
@@ -97,7 +101,15 @@ struct SortedPoints {
   const Rec<T>* rec;          // [M] tile-sorted
   const int32_t* tile_start;  // [ntiles + 1]
   const int32_t* sub_start;   // [ntiles + 1] exclusive scan of ceil(count / max_sub)
+  // fixed-point 3-D float plans (nufft_dense3.hip), else null:
+  float* cstats;              // [slots][2]: largest and summed max(|re c|, |im c|) of the strengths a launch spreads
+                              // (written by launch_spread itself, before the spread kernel)
+  const float* sub_bound;     // Geom::fx_patch: [subproblem grid + 1] count-filter bound of every subproblem, negative =
+                              // left to the fp64-plane kernels; the last entry counts those (as an integer)
 };
+// Tap maxima of the fitted kernel, max over z of |P_t(z)| for every stencil cell t (with the fit's and the float
+// evaluation's margin): what bound3_kernel filters the start-cell counts with
+struct TapMax { float k[16]; };
 template <typename T>
 struct SortedOut {
   Rec<T>* rec;
@@ -224,6 +236,19 @@ size_t dense3_lds_bytes(int w);
 hipError_t launch_spread_dense3(const Geom& g, const SortedPoints<float>& sp, unsigned nsub_bound, int64_t M, const float* horner,
                                 const float* c, float* fw, int batch, int64_t c_stride, int64_t fw_stride, float scale,
                                 hipStream_t stream);
+// w = 7, 8 (same file): exact-conversion fixed point on 8 x 8 (x, y) lane patches, step from the count-filter bound
+bool patch3_supported(const Geom& g, int precision);
+size_t patch3_lds_bytes(int w);
+hipError_t launch_spread_patch3(const Geom& g, const SortedPoints<float>& sp, unsigned nsub_bound, const float* horner,
+                                const float* c, float* fw, int batch, int64_t c_stride, int64_t fw_stride, float scale,
+                                hipStream_t stream);
+// set_points of such a plan: sub_bound[s] for every subproblem s of the launch grid, sub_bound[nsub_bound] = how many
+// were left to the fp64-plane kernels (zeroed here); rec_stride: bytes between records
+hipError_t launch_bound3(const Geom& g, const Rec<float>* rec, int rec_stride, const int32_t* tile_start, const int32_t* sub_start,
+                         unsigned nsub_bound, const TapMax& taps, float* sub_bound, hipStream_t stream);
+// strengths of one spread launch: cstats[slot] = {max, sum} of max(|re c|, |im c|) over the slot's M points
+hipError_t launch_cstats(const float* c, int64_t M, int slots, int64_t c_stride, float* cstats, hipStream_t stream);
+unsigned subproblem_grid_bound(const Geom& g, int64_t M);   // launch grid of the subproblem kernels (>= live subproblems)
 int wave3_pad(int w);   // spill elements behind the LDS planes of the 3-D wavefront kernel
 bool sparse_wanted(const Geom& g, int64_t M);   // point set sparse enough for the LDS-free spreader
 bool wave_method_supported(const Geom& g, int precision);

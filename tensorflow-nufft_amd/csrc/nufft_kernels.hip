@@ -1812,8 +1812,11 @@ __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
   T* stage_all = reinterpret_cast<T*>(pad + PAD);
   constexpr int SW = W <= 6 ? 6 : 8;                                  // staging row length
   float* red = reinterpret_cast<float*>(stage_all + NW * CH * 2 * SW);   // [NW] (FX bound reduction)
-  // (fp64-plane launch behind a fixed-point one: nothing to do unless some tile is crowded -- one scalar load)
-  if (!FX && g.fixed_point && sp.tile_start[g.ntiles + 1] <= g.fx_max_subs) return;
+  // (fp64-plane launch behind a fixed-point one: nothing to do unless some tile is crowded -- one scalar load;
+  // plans of spread_patch3_kernel count the subproblems they leave to this kernel behind their bounds)
+  if (!FX && g.fixed_point &&
+      (g.fx_patch ? reinterpret_cast<const int*>(sp.sub_bound)[gridDim.x] == 0 : sp.tile_start[g.ntiles + 1] <= g.fx_max_subs))
+    return;
   // (behind a fused 3-D sort the records are 32-byte FusedRec3: the 16-byte record comes first)
   const int rstride = g.fused ? (int)sizeof(FusedRec3) : (int)sizeof(Rec<T>);
   int tb, p0, p1, slot, nsub;
@@ -1823,7 +1826,11 @@ __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
   // weight, and every further subproblem of the tile adds its share: with 600000 coincident points
   // (1172 subproblems in one tile) the transform missed tol = 1e-5 by 9x (8.8e-5 against 1.4e-6 with
   // fp64 planes; r02 soak, seed 45), while up to ~16 subproblems per tile it stays within a third of tol.
-  if (g.fixed_point && (FX ? nsub > g.fx_max_subs : nsub <= g.fx_max_subs)) return;
+  if (g.fx_patch) {   // (w = 7, 8: the bound kernel of set_points has decided, subproblem by subproblem)
+    if (!(sp.sub_bound[blockIdx.x] < 0.f)) return;
+  } else if (g.fixed_point && (FX ? nsub > g.fx_max_subs : nsub <= g.fx_max_subs)) {
+    return;
+  }
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -2696,7 +2703,7 @@ bool wave_method_supported(const Geom& g, int precision) {
   // (depth 8 at w = 8: float only, one fp64 plane per launch -- see configure())
   if (g.rank == 3)
     return g.tile[0] == 16 && g.tile[1] == 16 &&
-           (g.tile[2] == 4 || (g.tile[2] == 8 && (g.w <= 6 || (g.w == 8 && precision == NUFFT_HIP_F32))));
+           (g.tile[2] == 4 || (g.tile[2] == 8 && (g.w <= 6 || ((g.w == 7 || g.w == 8) && precision == NUFFT_HIP_F32))));
   return false;
 }
 int wave_lstride(int rank) { return rank == 2 ? 40 : 24; }
@@ -2749,6 +2756,8 @@ static int wave3d_nw_rt(int precision, bool fx) { return precision == NUFFT_HIP_
 static inline unsigned subproblem_grid(const Geom& g, int64_t M) {
   return (unsigned)((int64_t)g.ntiles + M / (g.sub_small > 0 && g.sub_small < g.max_sub ? g.sub_small : g.max_sub));
 }
+
+unsigned subproblem_grid_bound(const Geom& g, int64_t M) { return subproblem_grid(g, M); }
 
 // LDS-free spreader for sparse point sets: below a few points per thousand fine cells the
 // per-tile zero-fill and write-out of the LDS kernels outweigh the per-point global atomics.
@@ -2826,6 +2835,7 @@ size_t spread_lds_bytes(const Geom& g, int method, int precision) {
       return group2d_geometry(g) ? std::max(wave2_lds(g, precision), group_lds(8, 64, false, precision)) : wave2_lds(g, precision);
     if (dense3_supported(g, precision))   // (and the fp64-plane launches behind it for crowded tiles)
       return std::max(dense3_lds_bytes(g.w), wave3_split_lds(g));
+    if (patch3_supported(g, precision)) return std::max(patch3_lds_bytes(g.w), wave3_split8_lds(g));
     const int nw = g.split_reim ? 12 : wave3d_nw_rt(precision, g.fixed_point != 0);
     const int ch = (g.split_reim && g.tile[2] == 8) ? 16 : 32;   // (staging chunk: keeps two workgroups per CU)
     if (g.split_reim && g.tile[2] == 8 && g.w == 8) return wave3_joint_lds(g);   // the larger of the two forms
@@ -2871,6 +2881,13 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
     lds_bytes = spread_lds_bytes(g, method, (int)sizeof(T));
   }
   if (method == NUFFT_HIP_METHOD_TILE_WAVE) {
+    if constexpr (sizeof(T) == 4) {
+      // 3-D fixed-point plans: the largest and the mean strength of every slot first (one streaming pass)
+      if (sp.cstats && g.rank == 3 && g.fixed_point) {
+        e = launch_cstats(c, c_stride, batch * (g.nitems > 1 ? g.nitems : 1), c_stride, sp.cstats, stream);
+        if (e != hipSuccess) return e;
+      }
+    }
     if constexpr (sizeof(T) == 4) {
       if (wave8_supported(g, 4)) {
         const bool grouped = g.cell_sorted || wave8_use_group(g, Md);
@@ -3006,10 +3023,16 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
 #define NUFFT_CASE_W3(WW)                                                                        \
   case WW:                                                                                       \
     if (g.tile[2] == 8) {                                                                        \
-      if constexpr (WW == 8) {                                                                   \
+      if constexpr (WW >= 7) {                                                                   \
         if constexpr (sizeof(T) == 4) {                                                          \
-          if (!g.split_reim) return hipErrorInvalidValue;                                        \
-          if (wave3_joint_wanted(g, Md)) {   /* thin point sets: both planes, one write-out */   \
+          if (g.fx_patch) {   /* packed fixed point, exact conversion; flagged subproblems on fp64 planes behind it */ \
+            e = launch_spread_patch3(g, sp, grid.x, horner, c, fw, batch, c_stride, fw_stride, scale, stream); \
+            if (e != hipSuccess) return e;                                                       \
+            lds_bytes = wave3_split8_lds(g);                                                     \
+            NUFFT_LAUNCH_W3S8(WW, 1) NUFFT_LAUNCH_W3S8(WW, 2)                                     \
+          } else if constexpr (WW == 7) { return hipErrorInvalidValue;                           \
+          } else if (!g.split_reim) { return hipErrorInvalidValue;                               \
+          } else if (wave3_joint_wanted(g, Md)) {   /* thin point sets: both planes, one write-out */   \
             lds_bytes = wave3_joint_lds(g);                                                      \
             e = ensure_lds(spread_wave3_kernel<T, WW, 8, 16, 16, false, 0>, lds_bytes);           \
             if (e != hipSuccess) return e;                                                       \

@@ -492,6 +492,8 @@ int nufft_hip_op_compute_ex(const nufft_hip_op_desc* desc, const void* source, c
   // options.op_lanes overrides the lane count (1..kMaxLanes). With a framework allocator
   // everything stays on the caller's stream (its memory is ordered against that stream only).
   const int lanes_opt = desc->options.op_lanes, group_opt = desc->options.op_group;
+  if (lanes_opt < 0 || group_opt < 0)
+    return fail(errbuf, errbuf_len, NUFFT_HIP_INVALID_ARGUMENT, "options.op_group and options.op_lanes must be >= 0");
   std::vector<int64_t> src_outer, pts_outer;
   for (int i : a.outer) { src_outer.push_back(a.source_batch[i]); pts_outer.push_back(a.points_batch[i]); }
   bool groupable = a.num_calls > 1 && !a.transpose;
@@ -500,6 +502,9 @@ int nufft_hip_op_compute_ex(const nufft_hip_op_desc* desc, const void* source, c
   int64_t group = 1;
   if (groupable) {
     group = group_opt > 0 ? group_opt : 16;
+    // (a plan takes at most 4096 point sets and 65535 transforms x sets: an oversized request is cut, not refused)
+    group = std::min<int64_t>(group, std::min<int64_t>(4096, 65535 / std::max<int64_t>(1, a.num_transforms)));
+    if (group < 1) group = 1;
     nufft_hip_plan_info pi;
     char pe[256];
     if (nufft_hip_plan_describe(desc->transform_type, rank, dims, desc->fft_direction, (int)a.num_transforms, tol,

@@ -243,6 +243,10 @@ struct nufft_hip_plan_s {
   int64_t hist_elems = 0;
   int32_t *tile_of = nullptr, *rank_of = nullptr;   // global-counter sort
   int32_t *tile_count = nullptr, *tile_start = nullptr, *sub_start = nullptr, *bad_count = nullptr;
+  float* cstats = nullptr;       // 3-D float fixed-point plans: {largest, summed} strength of every slot of a spread launch
+  float* sub_bound = nullptr;    // Geom::fx_patch: count-filter bound per subproblem (+ 1: how many go to fp64 planes)
+  int64_t cap_sub_bound = 0;
+  TapMax taps = {};              // per-tap maxima of the fitted kernel (bound3_kernel)
   int64_t workspace_bytes = 0;
   bool points_set = false;
   bool host_only = false;        // nufft_hip_plan_create_host: no device state at all
@@ -432,6 +436,7 @@ int ensure_fixed_workspace(nufft_hip_plan p) {
   if (!rc) rc = dev_alloc(p, (void**)&p->tile_start, sizeof(int32_t) * ((size_t)g.ntiles + 2));   // (+1: most subproblems of a tile)
   if (!rc) rc = dev_alloc(p, (void**)&p->sub_start, sizeof(int32_t) * ((size_t)g.ntiles + 1));
   if (!rc) rc = dev_alloc(p, (void**)&p->bad_count, sizeof(int32_t) * 4);
+  if (!rc && g.fixed_point) rc = dev_alloc(p, (void**)&p->cstats, sizeof(float) * 2 * (size_t)p->batch_size * p->nitems);
   if (!rc && !p->opts.spread_only)
     rc = dev_alloc(p, &p->d_fine, (size_t)p->precision * 2 * (size_t)p->fine_elems * p->batch_size * p->nitems);
   if (!rc && p->own_fft) {
@@ -451,12 +456,12 @@ int ensure_fixed_workspace(nufft_hip_plan p) {
 void release_workspace(nufft_hip_plan p) {
   void** bufs[] = {(void**)&p->tile_count, (void**)&p->tile_start, (void**)&p->sub_start, (void**)&p->bad_count,
                    &p->d_fine, &p->fft_work, &p->fft_tmp[0], &p->fft_tmp[1], &p->rec, &p->rec2, (void**)&p->hist, (void**)&p->tile_of,
-                   (void**)&p->rank_of};
+                   (void**)&p->rank_of, (void**)&p->cstats, (void**)&p->sub_bound};
   for (void** b : bufs) {
     dev_free(p, *b);
     *b = nullptr;
   }
-  p->cap = p->cap2 = p->cap_global = p->cap_tile_of = 0;
+  p->cap = p->cap2 = p->cap_global = p->cap_tile_of = p->cap_sub_bound = 0;
   p->hist_elems = 0;
   p->workspace_bytes = 0;
   p->fixed_ws = false;
@@ -569,6 +574,17 @@ int ensure_point_capacity(nufft_hip_plan p, int64_t M, int rec_mult = 1) {
     if ((rc = dev_alloc(p, (void**)&p->tile_of, (size_t)M * 4))) return rc;
     p->cap_tile_of = M;
   }
+  if (p->g.fx_patch && (p->type == NUFFT_HIP_TYPE_1 || p->opts.spread_only)) {
+    const int64_t need_b = (int64_t)subproblem_grid_bound(p->g, M) + 1;
+    if (need_b > p->cap_sub_bound) {
+      if ((rc = sync_before_regrow(p))) return rc;
+      dev_free(p, p->sub_bound);
+      p->sub_bound = nullptr;
+      p->cap_sub_bound = 0;
+      if ((rc = dev_alloc(p, (void**)&p->sub_bound, sizeof(float) * (size_t)need_b))) return rc;
+      p->cap_sub_bound = need_b;
+    }
+  }
   const int64_t slots = M * rec_mult;
   if (slots <= p->cap) return NUFFT_HIP_OK;
   if ((rc = sync_before_regrow(p))) return rc;
@@ -623,7 +639,9 @@ int set_points_impl(nufft_hip_plan p, int64_t M, const void* x, const void* y, c
   p->fused = strengths != nullptr;
   p->spread_uses = 0;
   // 3-D interp plans order every subproblem by start cell right away (rec2 -> rec)
-  const bool cells = (p->type == NUFFT_HIP_TYPE_2 || p->opts.spread_only) &&
+  // (never behind a fused sort: its 32-byte records are consumed by the one type-1 spread they were sorted for,
+  // and the cell sort reads and writes 16-byte records)
+  const bool cells = !strengths && (p->type == NUFFT_HIP_TYPE_2 || p->opts.spread_only) &&
                      cellsort_wanted_interp(p->g, p->method, p->precision, M);
   if (cells && Mtot > p->cap2) {
     if ((rc = sync_before_regrow(p))) return rc;
@@ -662,6 +680,15 @@ int set_points_impl(nufft_hip_plan p, int64_t M, const void* x, const void* y, c
                                   (Rec<T>*)p->rec, p->stream));
     hook.end(STAGE_SORT_CELL);
   }
+  if constexpr (sizeof(T) == 4) {
+    // w = 7, 8 fixed-point plans: the bound that fixes every subproblem's step (and which of them keep fp64 planes)
+    if (p->g.fx_patch && p->sub_bound && Mtot > 0) {
+      hook.begin(STAGE_SORT_CELL);
+      HIP_TRY(p, launch_bound3(p->g, (const Rec<float>*)p->rec, (int)sizeof(Rec<float>), p->tile_start, p->sub_start,
+                               subproblem_grid_bound(p->g, Mtot), p->taps, p->sub_bound, p->stream));
+      hook.end(STAGE_SORT_CELL);
+    }
+  }
   if (check) {
     int32_t bad = 0;
     HIP_TRY(p, hipMemcpyAsync(&bad, p->bad_count, sizeof(int32_t), hipMemcpyDeviceToHost, p->stream));
@@ -685,6 +712,8 @@ SortedPoints<T> sorted_view(nufft_hip_plan p) {
   sp.rec = (const Rec<T>*)p->rec;
   sp.tile_start = p->tile_start;
   sp.sub_start = p->sub_start;
+  sp.cstats = p->cstats;
+  sp.sub_bound = p->sub_bound;
   return sp;
 }
 
@@ -914,6 +943,19 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
   if (iflag != NUFFT_HIP_FORWARD && iflag != NUFFT_HIP_BACKWARD)
     return fail(NUFFT_HIP_INVALID_ARGUMENT, "iflag must be -1 (forward) or +1 (backward)");
   if (!grid_dims) return fail(NUFFT_HIP_INVALID_ARGUMENT, "grid_dims is null");
+  if (opts_in) {
+    // the experiment surface is part of the ABI: unknown bits, contradictory OFF | ON pairs and negative group /
+    // lane counts are refused rather than silently resolved
+    const int32_t t = opts_in->tuning;
+    if (t & ~NUFFT_HIP_TUNE_ALL) return fail(NUFFT_HIP_INVALID_ARGUMENT, format("unknown options.tuning bits 0x%x", (unsigned)(t & ~NUFFT_HIP_TUNE_ALL)));
+    static const int pairs[][2] = {{NUFFT_HIP_TUNE_GROUP_OFF, NUFFT_HIP_TUNE_GROUP_ON}, {NUFFT_HIP_TUNE_SPARSE_OFF, NUFFT_HIP_TUNE_SPARSE_ON},
+                                   {NUFFT_HIP_TUNE_CELLSORT_OFF, NUFFT_HIP_TUNE_CELLSORT_ON}, {NUFFT_HIP_TUNE_CELLSORT3D_OFF, NUFFT_HIP_TUNE_CELLSORT3D_ON},
+                                   {NUFFT_HIP_TUNE_JOINT_OFF, NUFFT_HIP_TUNE_JOINT_ON}, {NUFFT_HIP_TUNE_STAGED_OFF, NUFFT_HIP_TUNE_STAGED_ON},
+                                   {NUFFT_HIP_TUNE_SORT2_OFF, NUFFT_HIP_TUNE_SORT2_ON}};
+    for (const auto& pr : pairs)
+      if ((t & pr[0]) && (t & pr[1])) return fail(NUFFT_HIP_INVALID_ARGUMENT, format("options.tuning has both bits of an OFF / ON pair (0x%x)", (unsigned)(pr[0] | pr[1])));
+    if (opts_in->op_group < 0 || opts_in->op_lanes < 0) return fail(NUFFT_HIP_INVALID_ARGUMENT, "options.op_group and options.op_lanes must be >= 0");
+  }
 
   nufft_hip_plan p = new nufft_hip_plan_s();
   if (opts_in) p->opts = *opts_in; else nufft_hip_default_options(&p->opts);
@@ -1029,7 +1071,14 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
   // 3-D float at w = 8 (fp64 planes, one component per launch): depth 8 as well -- the padded tile
   // (23 x 23 x 15 cells, 66 KB) still lets two workgroups share a CU with a 16-point staging chunk,
   // and the halo written out per fine cell falls from 5.7x to 3.9x.
-  const bool deep8 = w <= 6 || (w == 8 && precision == NUFFT_HIP_F32 && p->opts.lds_accumulate != 2);
+  // 3-D float at w = 7, 8 (r04): packed fixed point with the exact conversion and the count-filter bound
+  // (spread_patch3_kernel, nufft_dense3.hip) on the same depth-8 tiles; lds_accumulate = 1 keeps the fp64 planes
+  // (w = 7: on depth-4 tiles, as before), options.tuning FXPATCH_OFF the r03 kernels.
+  const bool patch_want = rank == 3 && precision == NUFFT_HIP_F32 && (w == 7 || w == 8) && p->opts.lds_accumulate != 1 &&
+                          !(p->opts.tuning & NUFFT_HIP_TUNE_FXPATCH_OFF) &&
+                          (p->opts.spread_method == NUFFT_HIP_METHOD_AUTO || p->opts.spread_method == NUFFT_HIP_METHOD_TILE_WAVE);
+  const bool deep8 = w <= 6 || (w == 8 && precision == NUFFT_HIP_F32 && (patch_want || p->opts.lds_accumulate != 2)) ||
+                     (w == 7 && patch_want);
   int def_tile[3][3] = {{1024, 1, 1}, {t2d, t2d, 1}, {16, 16, deep8 ? 8 : 4}};
   // w = 9..16 (tol < 1e-7): the 16 x 4-lane spread kernels of nufft_wide.hip and their tiles
   // (2-D 32 x 32; 3-D 16 x 8 x 4 up to w = 12, 8 x 8 x 4 above: one fp64 plane of LDS per launch)
@@ -1076,9 +1125,9 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
     if (spread_lds_bytes(g, NUFFT_HIP_METHOD_TILE_GENERIC, precision) <= lds_limit) break;
     // the depth-8 tile of the 3-D float wavefront kernel at w = 8 holds one fp64 plane per launch:
     // it fits although two full planes (what the generic kernel would need) do not
-    if (rank == 3 && w == 8 && precision == NUFFT_HIP_F32 && g.tile[0] == 16 && g.tile[1] == 16 && g.tile[2] == 8 &&
+    if (rank == 3 && (w == 8 || (w == 7 && patch_want)) && precision == NUFFT_HIP_F32 && g.tile[0] == 16 && g.tile[1] == 16 && g.tile[2] == 8 &&
         (p->opts.spread_method == NUFFT_HIP_METHOD_AUTO || p->opts.spread_method == NUFFT_HIP_METHOD_TILE_WAVE) &&
-        p->opts.lds_accumulate != 2)
+        (patch_want || p->opts.lds_accumulate != 2))
       break;
     int big = 0;
     for (int d = 1; d < rank; ++d)
@@ -1168,13 +1217,33 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
   g.fixed_point = 0;
   g.split_reim = 0;
   g.cell_sorted = 0;
-  if (method == NUFFT_HIP_METHOD_TILE_WAVE && rank == 3 && precision == NUFFT_HIP_F32 && w <= 7 &&
-      p->opts.lds_accumulate != 1)
+  g.fx_patch = (patch_want && method == NUFFT_HIP_METHOD_TILE_WAVE && !g.wide && g.tile[0] == 16 && g.tile[1] == 16 &&
+                g.tile[2] == 8) ? 1 : 0;
+  if (method == NUFFT_HIP_METHOD_TILE_WAVE && rank == 3 && precision == NUFFT_HIP_F32 && (w <= 7 || g.fx_patch) &&
+      p->opts.lds_accumulate != 1 && (w <= 6 || g.fx_patch || g.tile[2] == 4))
     g.fixed_point = 1;
   if (p->opts.lds_accumulate == 2 && !g.fixed_point) {
     delete p;
     return fail(NUFFT_HIP_INVALID_ARGUMENT,
-                "lds_accumulate = 2 (fixed point) needs the 3-D float wavefront method with kernel width <= 7");
+                "lds_accumulate = 2 (fixed point) needs the 3-D float wavefront method with kernel width <= 8");
+  }
+  // The output error the quantisation adds is ~ 11 (step / largest strength) = 11 B / 2^31 (measured: 2.4e-6 at a
+  // step of 2^-22 largest strengths); a subproblem may spend 0.3 of the width's tolerance 10^(2 - w) on it.
+  g.fx_bound_limit = (float)(0.3 * std::pow(10.0, 2 - w) * 2147483648.0 / 11.5);
+  if (g.fx_patch) {
+    // per-tap maxima of the fitted polynomials over z in [-1, 1] (sampled; margins for the sampling, the float
+    // evaluation and the products)
+    for (int t = 0; t < 16; ++t) p->taps.k[t] = 0.f;
+    for (int t = 0; t < w; ++t) {
+      double m = 0.0;
+      for (int sidx = 0; sidx <= 4096; ++sidx) {
+        const double z = -1.0 + 2.0 * sidx / 4096.0;
+        double acc = p->horner_h[(nc - 1) * kMaxW + t];
+        for (int k = nc - 2; k >= 0; --k) acc = acc * z + p->horner_h[k * kMaxW + t];
+        m = std::max(m, std::fabs(acc));
+      }
+      p->taps.k[t] = (float)(m * 1.001 + 1e-6);
+    }
   }
   // fp64 planes in 3-D float at tile depth 4 (w = 8, or w <= 7 with lds_accumulate = 1):
   // one plane per launch, so that two workgroups share a CU
@@ -1188,7 +1257,10 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
   // clustered point sets: scan_tiles_kernel falls back to 4096-point subproblems
   if (method == NUFFT_HIP_METHOD_TILE_WAVE && auto_sub && t2_wave) g.sub_small = 4096;
   if (g.wide && auto_sub && rank == 3) g.max_sub = 1024;   // (hundreds of LDS atomics per point: keep workgroups short)
-  if (g.fixed_point && w > 6) g.max_sub = std::min(g.max_sub, 512);
+  const bool spreads = type == NUFFT_HIP_TYPE_1 || p->opts.spread_only;
+  if (g.fixed_point && w > 6 && !g.fx_patch) g.max_sub = std::min(g.max_sub, 512);
+  // w = 8: 1536 points on 2048 cells keep the bound of a uniform subproblem at 37-45 of the 56 tol 1e-6 allows
+  if (g.fx_patch && w == 8 && auto_sub && spreads) g.max_sub = 1536;
   g.fx_max_subs = 16;
   p->lds_bytes = spread_lds_bytes(g, method, precision);
   if (p->lds_bytes > 160 * 1024 || interp_lds_bytes(g, method, precision) > 160 * 1024) {
@@ -1385,6 +1457,23 @@ int nufft_hip_execute_with_points(nufft_hip_plan p, int64_t M, const void* x, co
 int nufft_hip_debug_sort_path(nufft_hip_plan p) {
   if (!p || !p->points_set) return -1;
   return sort_mode(p->g, p->M * p->nitems);
+}
+
+int64_t nufft_hip_debug_sub_bounds(nufft_hip_plan p, float* out, int64_t n) {
+  if (!p || p->host_only || !p->points_set) return -1;
+  if (!p->g.fx_patch || !p->sub_bound) return 0;
+  const int64_t slots = (int64_t)subproblem_grid_bound(p->g, p->M * p->nitems);
+  const int64_t take = std::min(n, slots);
+  if (take > 0 && out) {
+    // (launch slots past the live subproblems are never written: report them as 0)
+    std::vector<int32_t> ss(1);
+    if (hipMemcpyAsync(ss.data(), p->sub_start + p->g.ntiles, sizeof(int32_t), hipMemcpyDeviceToHost, p->stream) != hipSuccess ||
+        hipMemcpyAsync(out, p->sub_bound, sizeof(float) * (size_t)take, hipMemcpyDeviceToHost, p->stream) != hipSuccess ||
+        hipStreamSynchronize(p->stream) != hipSuccess)
+      return -1;
+    for (int64_t i = ss[0]; i < take; ++i) out[i] = 0.f;
+  }
+  return slots;
 }
 
 int nufft_hip_debug_stop_after(nufft_hip_plan p, int stage) {

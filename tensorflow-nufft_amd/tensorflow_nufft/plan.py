@@ -153,6 +153,18 @@ class Plan:
     counters, 3 two levels), -1 before any points are set."""
     return int(self.lib.nufft_hip_debug_sort_path(self._handle))
 
+  def sub_bounds(self):
+    """Debug: the count-filter bounds of a 3-D float w = 7 / 8 plan's subproblems (numpy float32; > 0 bound,
+    < 0 left to the fp64 planes, 0 unused launch slot); empty for other plans."""
+    import numpy as np
+    n = int(self.lib.nufft_hip_debug_sub_bounds(self._handle, None, 0))
+    if n < 0:
+      self._check(1)
+    out = np.zeros(max(n, 0), dtype=np.float32)
+    if n > 0:
+      self.lib.nufft_hip_debug_sub_bounds(self._handle, out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), n)
+    return out
+
   def stop_after(self, stage):
     """Debug: execute returns after the named stage ('spread', 'fft', 'deconvolve'); None = run all."""
     self._check(self.lib.nufft_hip_debug_stop_after(

@@ -49,6 +49,23 @@ def test_default_options_and_struct_layout():
   assert list(i.grid_dims) == [1024, 1024, 1]
 
 
+def test_tuning_bits_and_op_counts_are_validated():
+  # (advisor, r03) the experiment surface is public ABI: unknown bits, OFF | ON pairs and negative counts are refused
+  T = _lib.TUNE
+  ok, _, _ = _describe(2, [64, 64], 1e-6, 4, tuning=T['GROUP_ON'] | T['NO_FUSED'] | T['SORT2_OFF'])
+  assert ok == 0
+  rc, err, _ = _describe(2, [64, 64], 1e-6, 4, tuning=1 << 30)
+  assert rc == _lib.INVALID_ARGUMENT and 'unknown options.tuning bits' in err, (rc, err)
+  for a, b in (('GROUP_OFF', 'GROUP_ON'), ('SPARSE_OFF', 'SPARSE_ON'), ('CELLSORT_OFF', 'CELLSORT_ON'),
+               ('CELLSORT3D_OFF', 'CELLSORT3D_ON'), ('JOINT_OFF', 'JOINT_ON'), ('STAGED_OFF', 'STAGED_ON'),
+               ('SORT2_OFF', 'SORT2_ON')):
+    rc, err, _ = _describe(3, [32, 32, 32], 1e-4, 4, tuning=T[a] | T[b])
+    assert rc == _lib.INVALID_ARGUMENT and 'OFF / ON pair' in err, (a, b, rc, err)
+  for name in ('op_group', 'op_lanes'):
+    rc, err, _ = _describe(2, [64, 64], 1e-6, 4, **{name: -1})
+    assert rc == _lib.INVALID_ARGUMENT and 'must be >= 0' in err, (name, rc, err)
+
+
 @pytest.mark.parametrize('rank,dims,tol,prec,w,nf,method', [
     (2, [1024, 1024], float(np.float32(1e-6)), 4, 8, [2048, 2048, 1], 2),   # BASELINE config 2/3
     (3, [256, 256, 256], float(np.float32(1e-4)), 4, 6, [512, 512, 512], 2),  # config 4

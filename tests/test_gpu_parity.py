@@ -645,6 +645,173 @@ def test_3d_one_call_sorts_the_strengths_into_32_byte_records(tfft):
     assert rel_l2(one, two) < 2e-6 and rel_l2(one, ref) < 2e-6, (name, rel_l2(one, two), rel_l2(one, ref))
 
 
+def test_spread_only_one_call_on_a_cell_sorting_plan(tfft):
+  # (advisor, r03) a spread_only 3-D float type-1 plan that also wants the interp cell order (dense point set, or
+  # tuning CELLSORT3D_ON) used to run the cell sort over the one-call entry's 32-byte fused records: 16-byte reads
+  # and writes over 32-byte records, and a 16 M-byte overrun of the second record buffer. The fused sort now
+  # switches the cell sort off; the one-call result must equal set_points + spread and the unfused one-call.
+  from tensorflow_nufft._lib import TUNE
+  rng = np.random.default_rng(321)
+  grid = [512, 384, 384]    # spread_only: no upsampling, 36864 tiles of 16 x 16 x 8 (> 16384: the 16-bit-counter sort with SORT2_OFF)
+  M = 400000
+  pts = rng.uniform(-np.pi, np.pi, (M, 3)).astype(np.float32)
+  c = (rng.uniform(-.5, .5, M) + 1j * rng.uniform(-.5, .5, M)).astype(np.complex64)
+  tune = TUNE['CELLSORT3D_ON'] | TUNE['SORT2_OFF']
+  plan = tfft.Plan('type_1', grid, 'forward', tol=1e-4, spread_only=True, tuning=tune)
+  i = plan.info()
+  assert i.kernel_width == 6 and int(np.prod(list(i.num_tiles))) > 16384
+  one = plan.execute_with_points(_dev(pts), _dev(c)).cpu().numpy()
+  assert plan.sort_path() == -1          # fused: the points are consumed
+  plan.set_points(_dev(pts))
+  assert plan.sort_path() == 1
+  two = plan.spread(_dev(c)).cpu().numpy()
+  back = plan.interp(_dev(two)).cpu().numpy()   # the cell-sorted records of the two-call path still serve interp
+  plan.close()
+  unfused = tfft.Plan('type_1', grid, 'forward', tol=1e-4, spread_only=True, tuning=tune | TUNE['NO_FUSED'])
+  ref = unfused.execute_with_points(_dev(pts), _dev(c)).cpu().numpy()
+  unfused.close()
+  assert np.isfinite(one).all() and np.linalg.norm(one) > 0
+  assert rel_l2(one, two) < 2e-6 and rel_l2(one, ref) < 2e-6, (rel_l2(one, two), rel_l2(one, ref))
+  assert np.isfinite(back).all()
+
+
+def _count_filter_bounds(plan, pts, grid):
+  """numpy restatement of bound3_kernel for tiles that hold ONE subproblem: start-cell counts of every tile filtered
+  with the per-tap maxima of the plan's polynomial kernel, maximum over the tile + halo. Returns {tile id: bound}."""
+  i = plan.info()
+  w = int(i.kernel_width)
+  nf = [int(i.fine_dims[d]) for d in range(3)]        # x fastest
+  tile = [int(i.tile_dims[d]) for d in range(3)]
+  ntile = [int(i.num_tiles[d]) for d in range(3)]
+  z = -1.0 + 2.0 * np.arange(4097) / 4096.0
+  kmax = np.abs(plan.eval_kernel((z + 1.0 - w) / 2.0)).max(axis=0) * 1.001 + 1e-6     # [w]
+  x = pts.astype(np.float64)[:, ::-1]                    # x fastest first
+  cells = []
+  for d in range(3):
+    xp = (x[:, d] + np.pi) * (nf[d] / (2 * np.pi))
+    cells.append(np.ceil(xp - w / 2).astype(np.int64) % nf[d])
+  tid = (cells[0] // tile[0]) + ntile[0] * ((cells[1] // tile[1]) + ntile[1] * (cells[2] // tile[2]))
+  out = {}
+  for t in np.unique(tid):
+    sel = tid == t
+    cnt = np.zeros((tile[2], tile[1], tile[0]))
+    np.add.at(cnt, (cells[2][sel] % tile[2], cells[1][sel] % tile[1], cells[0][sel] % tile[0]), 1.0)
+    a = cnt
+    for ax in range(3):
+      a = np.apply_along_axis(lambda v: np.convolve(v, kmax), ax, a)
+    out[int(t)] = (a.max() * 1.0001, int(sel.sum()))
+  return out
+
+
+def test_3d_w8_bound_kernel_matches_its_numpy_restatement(tfft):
+  # r04: 3-D float plans at w = 7 / 8 fix every subproblem's fixed-point step from a count-filter bound computed in
+  # set_points (bound3_kernel). Host-logic check of that kernel against numpy on a grid with plain tile numbering,
+  # uniform points (one subproblem per tile) plus a blob that must be flagged for the fp64 planes.
+  rng = np.random.default_rng(11)
+  grid = [64, 64, 64]
+  pts = rng.uniform(-np.pi, np.pi, (300_000, 3)).astype(np.float32)
+  for tol, w in ((1e-6, 8), (1e-5, 7)):
+    plan = tfft.Plan('type_1', grid, 'forward', tol=tol)
+    i = plan.info()
+    assert i.kernel_width == w and list(i.tile_dims) == [16, 16, 8]
+    plan.set_points(_dev(pts))
+    got = plan.sub_bounds()
+    want = _count_filter_bounds(plan, pts, grid)
+    plan.close()
+    live = got[got != 0]
+    assert live.size == len(want), (live.size, len(want))       # one subproblem per non-empty tile, in tile order
+    assert (live > 0).all()
+    ref = np.array([want[t][0] for t in sorted(want)])
+    npt = np.array([want[t][1] for t in sorted(want)])
+    big = npt > 16                                              # (<= 16 points: the kernel reports the count)
+    assert big.sum() > 500
+    assert np.allclose(live[big], ref[big], rtol=2e-5), np.abs(live[big] / ref[big] - 1).max()
+    assert (live[~big] == npt[~big]).all()
+    assert live.max() < (56 if w == 8 else 560)
+  # a blob of 3000 points inside one tile: its bound is far above the w = 8 limit -> negative entry
+  blob = (np.array([0.3, -0.7, 1.1]) + 2e-3 * rng.standard_normal((3000, 3))).astype(np.float32)
+  plan = tfft.Plan('type_1', grid, 'forward', tol=1e-6)
+  plan.set_points(_dev(np.concatenate([pts[:100_000], blob])))
+  got = plan.sub_bounds()
+  plan.close()
+  assert (got < 0).sum() >= 1 and (got < 0).sum() <= 8
+
+
+@pytest.mark.parametrize('tol,bar', [(1e-6, 4e-7), (1e-5, 4e-6)])
+def test_3d_w8_w7_fixed_point_total_parity(tfft, tol, bar):
+  # The default-tolerance 3-D transform (w = 8; and w = 7) on packed fixed point with the exact conversion
+  # (spread_patch3_kernel): whole output against the fp64 oracle, against the r03 kernels (fp64 planes at w = 8),
+  # through the one-call entry and set_points + execute, several transforms (strength statistics per slot).
+  import torch
+  from oracle import oracle
+  from tensorflow_nufft._lib import TUNE
+  rng = np.random.default_rng(21)
+  grid = [64, 96, 128]
+  M = 1_200_000                       # 0.19 points per fine cell
+  pts = rng.uniform(-np.pi, np.pi, (M, 3)).astype(np.float32)
+  c = (rng.uniform(-.5, .5, (3, M)) + 1j * rng.uniform(-.5, .5, (3, M))).astype(np.complex64)
+  c[1] *= 1e-3                         # slots of very different scale: the step follows each slot's own largest strength
+  c[2, ::2] = np.conj(c[2, ::2])
+  plan = tfft.Plan('type_1', grid, 'forward', tol=tol, num_transforms=3)
+  assert list(plan.info().tile_dims) == [16, 16, 8]
+  plan.set_points(_dev(pts))
+  assert (plan.sub_bounds() > 0).sum() > 1000 and (plan.sub_bounds() < 0).sum() == 0
+  out = plan.execute(_dev(c)).cpu().numpy()
+  plan.close()
+  old = tfft.Plan('type_1', grid, 'forward', tol=tol, num_transforms=3, tuning=TUNE['FXPATCH_OFF'])
+  old.set_points(_dev(pts))
+  ref = old.execute(_dev(c)).cpu().numpy()
+  old.close()
+  one = tfft.Plan('type_1', grid, 'forward', tol=tol)
+  single = one.execute_with_points(_dev(pts), _dev(c[0])).cpu().numpy()
+  one.close()
+  for t in range(3):
+    truth = oracle.nufft(c[t].astype(np.complex128), pts, grid, 'type_1', 'forward', tol=1e-12, sigma=2.0)
+    e_new, e_old = rel_l2(out[t], truth), rel_l2(ref[t], truth)
+    assert e_new < bar, (tol, t, e_new, e_old)
+    assert e_new < 1.6 * e_old + 1e-7, (tol, t, e_new, e_old)
+    if t == 0:
+      assert rel_l2(single, truth) < bar
+      assert rel_l2(single, out[0]) < 3e-7
+
+
+def test_3d_w8_fixed_point_clustered_and_skewed(tfft):
+  # Clustered points: subproblems whose bound is too large, and tiles with more than 16 subproblems, go to the
+  # fp64-plane kernels behind the fixed-point one. One dominant strength: every subproblem takes its own pass over
+  # its strengths (min of its sum and its largest x bound). All-negative / all-zero imaginary parts: the subtract path.
+  from oracle import oracle
+  rng = np.random.default_rng(31)
+  grid = [48, 64, 64]
+  M = 400_000
+  pts = rng.uniform(-np.pi, np.pi, (M, 3)).astype(np.float32)
+  pts[:150_000] = (np.array([1.0, -2.0, 0.5]) + np.array([0.15, 0.02, 0.08]) * rng.standard_normal((150_000, 3))).astype(np.float32)
+  pts[150_000:190_000] = (np.array([-2.5, 2.9, -3.0]) + 1e-3 * rng.standard_normal((40_000, 3))).astype(np.float32)   # 40000 points in one tile (wraps)
+  pts = np.clip(pts, -np.pi, np.pi).astype(np.float32)
+  cases = {}
+  c = (rng.uniform(-.5, .5, M) + 1j * rng.uniform(-.5, .5, M)).astype(np.complex64)
+  cases['clustered'] = c
+  c2 = c.copy(); c2[200_123] = 3e5 + 2e5j
+  cases['one huge'] = c2
+  cases['lognormal'] = (np.exp(3 * rng.standard_normal(M)) * np.exp(2j * np.pi * rng.uniform(0, 1, M))).astype(np.complex64)
+  cases['negative imaginary'] = (rng.uniform(-.5, .5, M) - 1j * rng.uniform(0, 1, M)).astype(np.complex64)
+  cases['real'] = rng.uniform(-.5, .5, M).astype(np.complex64)
+  plan = tfft.Plan('type_1', grid, 'forward', tol=1e-6)
+  plan.set_points(_dev(pts))
+  b = plan.sub_bounds()
+  assert (b < 0).sum() >= 10 and (b > 0).sum() > 100, ((b < 0).sum(), (b > 0).sum())
+  for name, cv in cases.items():
+    out = plan.execute(_dev(cv)).cpu().numpy()
+    truth = oracle.nufft(cv.astype(np.complex128), pts, grid, 'type_1', 'forward', tol=1e-12, sigma=2.0)
+    e = rel_l2(out, truth)
+    assert e < 6e-7, (name, e)
+  plan.close()
+  # the spread op (no upsampling, scaled) on the same kernel
+  g2 = [32, 48, 64]
+  out = tfft.spread(_dev(cases['clustered']), _dev(pts), g2, tol=1e-6).cpu().numpy()
+  ref = oracle.nufft(cases['clustered'].astype(np.complex128), pts, g2, 'type_1', op='spread', tol=1e-6)
+  assert rel_l2(out, ref) < 2e-6, rel_l2(out, ref)
+
+
 def test_radial_trajectories_total_parity_at_scale(tfft):
   # Non-uniform densities at scale, whole output against the fp64 oracle: a 2-D radial trajectory in acquisition
   # order (config 2's size: 10000 spokes of 1000 samples, density ~ 1 / r: crowded centre tiles, subproblem
@@ -1282,7 +1449,7 @@ def test_fixed_point_lds_accumulation_3d(tfft, tol):
     assert errs[0] == pytest.approx(errs[2], rel=0.5) or errs[0] < 0.1 * tol   # auto = fixed point here
     assert errs[2] < errs[1] + 0.2 * tol, (name, errs)
   with pytest.raises(tfft.InvalidArgumentError, match='fixed point'):
-    tfft.Plan('type_1', grid, 'forward', tol=1e-6, lds_accumulate=2)   # w = 8: not accurate enough
+    tfft.Plan('type_1', grid, 'forward', tol=1e-7, lds_accumulate=2)   # w = 9 (w = 8 has a fixed-point kernel since r04)
 
 
 def test_radial_mri_example_shape(tfft):
@@ -2002,6 +2169,7 @@ def test_bench_spawns_its_own_ranks():
     (2, [64, 64], 40, 'c64', 1e-6, 1),         # sparse sets: LDS-free kernel
     (3, [24, 32, 20], 30_000, 'c64', 1e-4, 1), # 3-D fixed point
     (3, [128, 128, 128], 200_000, 'c64', 1e-4, 1),   # 3 x 8192 composite tiles: the 16-bit-counter sort path with several sets
+    (3, [32, 40, 32], 90_000, 'c64', 1e-6, 2),  # 3-D float w = 8: fixed point with per-subproblem bounds, two transforms per set
     (2, [40, 48], 20_000, 'c128', 1e-9, 1),    # double
     (1, [256], 9_000, 'c128', 1e-9, 1),        # 1-D
     (3, [20, 16, 24], 12_000, 'c128', 1e-9, 2),  # 3-D, w = 11: wide kernels, two transforms per set
