@@ -573,9 +573,12 @@ __global__ __launch_bounds__(kPatchNW * 64) void spread_patch3_kernel(
   float* red = reinterpret_cast<float*>(stage_all + C::stage_bytes);   // [2 NW]
 
   int tb, p0, p1, slot, nsub;
+  NUFFT_PHASE3(0);
   if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1, &slot, &nsub)) return;
   const float bound_b = sp.sub_bound[blockIdx.x];
   if (bound_b < 0.f) return;   // too crowded for the fixed-point grid: the fp64-plane launches behind this one take it
+  NUFFT_PHASE3(1);
+  NUFFT_PHASE3(2);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const float2* cc = reinterpret_cast<const float2*>(c) + (int64_t)slot * c_stride;
@@ -611,6 +614,7 @@ __global__ __launch_bounds__(kPatchNW * 64) void spread_patch3_kernel(
   const float step = fmaxf(fminf(sum, top * bound_b), top * 1.8626451e-9f * room) * amp / room;
   const float pre = step > 0.f ? scale / step : 0.f;
   __syncthreads();
+  NUFFT_PHASE3(3);
 
   const int dx = lane & 7, dy = lane >> 3;
   const int cell_b = (dy * LS + dx) * 8;
@@ -691,6 +695,7 @@ __global__ __launch_bounds__(kPatchNW * 64) void spread_patch3_kernel(
     }
   }
   __syncthreads();
+  NUFFT_PHASE3(4);
 
   // write-out: unpack, scale back, add to the periodic fine grid
   int t0, t1, t2;
@@ -711,6 +716,7 @@ __global__ __launch_bounds__(kPatchNW * 64) void spread_patch3_kernel(
       if (v != 0.f) glb_add(&out[2 * (rowbase + wrap1(o0 + a0, g.nf[0])) + comp], v);
     }
   }
+  NUFFT_PHASE3(5);
 }
 
 // ---- count-filter bound of every subproblem (set_points of a patch plan) -----------------------------------------

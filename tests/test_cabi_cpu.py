@@ -267,3 +267,64 @@ def test_tf_glue_type_checks_against_the_api_stub():
   # and the glue stays plumbing: no arithmetic on tensor contents, no parsing
   text = open(src).read()
   assert len(text.splitlines()) <= 210 and 'ReadVarint' not in text and 'ParseOptions' not in text
+
+
+def test_tf_glue_shape_function_runs_on_the_reference_shape_cases(tmp_path):
+  # The one piece of logic that lives only in the TF glue -- the graph-time shape function (BaseShapeFn /
+  # NUFFTShapeFn, reference cc/ops/nufft_ops.cc:27-103) -- EXECUTED through a behavioural stand-in for
+  # InferenceContext (tests/tf_api_stub/README.md; still not TensorFlow) on the reference tests' shape grid
+  # (nufft_ops_test.py:87-98: three grids x three source batch shapes x four points batch shapes x both types),
+  # the Interp / Spread cases, partially unknown shapes, and the two error messages.
+  import itertools
+  import subprocess
+  exe = str(tmp_path / 'tf_shape_fn_driver')
+  libdir = os.path.dirname(_lib.LIB_PATH)
+  r = subprocess.run(['g++', '-std=c++17', '-Wall', '-Werror', '-Wno-unused-function', '-I', os.path.join(ROOT, 'tests', 'tf_api_stub'),
+                      '-I', os.path.join(ROOT, 'include'), os.path.join(ROOT, 'tests', 'tf_shape_fn_driver.cc'), '-o', exe,
+                      '-L', libdir, '-lnufft_hip', '-Wl,-rpath,' + libdir, '-Wl,-rpath,/opt/rocm/lib'],
+                     capture_output=True, text=True)
+  assert r.returncode == 0, r.stderr[-3000:]
+
+  def fmt(shape):
+    return ','.join('?' if d is None else str(d) for d in shape) if len(shape) else '-'
+
+  cases, want = [], []
+  for grid, sb, pb, ttype in itertools.product([[8], [6, 8], [4, 8, 6]], [[], [2, 4], [4]], [[], [2, 1], [1, 4], [4]],
+                                               ['type_1', 'type_2']):
+    m = int(np.prod(grid))
+    batch = list(np.broadcast_shapes(tuple(sb), tuple(pb)))
+    src = sb + ([m] if ttype == 'type_1' else grid)
+    pts = pb + [m, len(grid)]
+    cases.append(f'NUFFT {ttype} {fmt(src)} {fmt(pts)} v:{fmt(grid)}')
+    want.append('OK [' + fmt(batch + (grid if ttype == 'type_1' else [m])).replace('-', '') + ']')
+  extra = [
+      ('Interp - 128,128 16384,2 none', 'OK [16384]'),                   # nufft_ops_test.py:224-252
+      ('Spread - 4096 4096,2 v:64,64', 'OK [64,64]'),                    # :255-284
+      ('Interp - 5,64,96 5,6144,2 none', 'OK [5,6144]'),                 # :287-316 (batch of sources)
+      ('Spread - 5,6144 5,6144,2 v:64,96', 'OK [5,64,96]'),              # :319-348
+      ('NUFFT type_1 2,4,576 1,576,2 v:24,24', 'OK [2,4,24,24]'),        # :351-417 (broadcast either way)
+      ('NUFFT type_2 1,24,24 2,4,576,2 v:24,24', 'OK [2,4,576]'),
+      # unknown pieces: the static shape is as specific as the inputs allow
+      ('NUFFT type_2 ? ? r:?', 'OK ?'),                                  # rank of the transform unknown
+      ('NUFFT type_1 ?,100 ?,100,2 r:2', 'OK [?,?,?]'),                  # grid_shape not constant: two unknown grid dims
+      ('NUFFT type_1 7,? ?,3 v:4,?,6', 'OK [7,4,?,6]'),
+      ('NUFFT type_2 ?,8,8 3,?,2 v:8,8', 'OK [3,?]'),
+      ('NUFFT type_2 ? 5,40,3 r:3', 'OK ?'),                             # source of unknown rank: batch unknown
+      ('Interp - 4,1,8,8 3,50,2 none', 'OK [4,3,50]'),
+      # errors, with the reference's / TensorFlow's messages
+      ('NUFFT type_2 8,8 64,4 v:8,8', 'ERR Dimension must be 1, 2 or 3, but is 4'),
+      ('Spread - 10 10,4 v:2,2', 'ERR Dimension must be 1, 2 or 3, but is 4'),
+      ('NUFFT type_1 3,20 3,21,2 v:4,4', 'ERR Dimensions must be equal, but are 21 and 20'),
+      ('NUFFT type_1 2,48 3,48,2 v:6,8', 'ERR Dimensions must be equal, but are 2 and 3'),   # batch shapes do not broadcast
+      ('NUFFT type_1 48 48,2 v:4,4,3', 'ERR Shape must be rank 2 but is rank 3'),            # grid_shape vs points
+      ('NUFFT type_3 3 3,1 r:1', "ERR transform_type attr must be 'type_1' or 'type_2', but is type_3"),
+  ]
+  cases += [c for c, _ in extra]
+  want += [w for _, w in extra]
+  r = subprocess.run([exe], input='\n'.join(cases) + '\n', capture_output=True, text=True)
+  assert r.returncode == 0, r.stderr[-2000:]
+  got = r.stdout.splitlines()
+  assert len(got) == len(want) == 72 + len(extra)
+  for c, g, w in zip(cases, got, want):
+    assert g == w, (c, g, w)
+
