@@ -3,21 +3,26 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-N = 1 (default): BASELINE.json `configs[1]`, the configuration the metric is
-  quoted on -- 2D type-1 NUFFT, 1024 x 1024 modes, M = 1e7 random points,
-  tol = 1e-6, complex64. A "step" is one pass of the hot path over one batch of
-  synthetic input already resident in HBM: what one
+Every N: BASELINE.json `configs[1]`, the configuration the metric is quoted on
+  -- 2D type-1 NUFFT, 1024 x 1024 modes, M = 1e7 random points, tol = 1e-6,
+  complex64 -- one independent transform per rank and step (transforms are the
+  unit the path shards by; a single transform is not split: "weak" scaling,
+  per-GPU work fixed, `value` = N x M / max-over-ranks time, no data-path
+  collective). A "step" is one pass of the hot path over one batch of synthetic
+  input already resident in HBM: what one
   `tfft.nufft(source, points, grid_shape, 'type_1')` call runs once its plan is
   cached, i.e. `nufft_hip_execute_with_points` = fold + tile sort (the strengths
-  travel inside the sorted records) -> spread -> rocFFT -> deconvolve.
-N > 1: BASELINE.json `configs[4]`, the configuration north_star shards --
-  batched 2D type-1, 512 x 512, batch = 256 items of M = 1e6 points each,
-  complex64, split over the N ranks in contiguous blocks
-  (`tensorflow_nufft.sharding.shard_bounds`); every rank runs its block through
-  `tfft.nufft` (one op call = its items' set_points + execute calls). The items
-  are independent, so there is no data-path collective; RCCL carries the barrier,
-  the max-over-ranks time and the optional result all_gather (reported beside the
-  headline, never inside it). Total work is fixed at 256 items ("strong").
+  travel inside the sorted records) -> spread -> pruned FFT passes (deconvolution
+  fused). The same metric at every N, so that value(N) / (N value(1)) is the
+  scaling efficiency.
+N > 1 additionally (`config.config5_sharded`, after the timed region): BASELINE.json
+  `configs[4]`, the batched workload north_star shards -- 2D type-1, 512 x 512,
+  batch = 256 items of M = 1e6 points each, split over the N ranks in contiguous
+  blocks (`tensorflow_nufft.sharding.shard_bounds`), every rank one `tfft.nufft`
+  call per step over its block ("strong": 256 items in total), with its own
+  roofline block, the result all_gather over RCCL beside it, the whole 256-item
+  job on rank 0's GPU alone and `equal_work_efficiency` = sharded rate / (N x
+  that). `--workload config5` makes that leg the line itself.
 
 When `--gpus N` > 1 and the process was not started by torch.distributed.run
 (no WORLD_SIZE in the environment), bench.py starts the N ranks itself as child
@@ -51,7 +56,20 @@ C5_M = 1_000_000
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 LDS_ADD_F64_CYCLES = 8.6   # cycles per ds_add_f64 wave-instruction per CU, conflict free (profiles/r01_lds_atomic_ubench.txt)
 NUM_CUS = 256
-CLOCK_GHZ = 2.4
+CLOCK_GHZ_NOMINAL = 2.4
+
+
+def shader_clock_ghz():
+  """The clock the LDS roofline is priced at: measured on this device while every CU runs LDS atomics
+  (nufft_hip_debug_shader_clock_mhz), not the nominal 2.4 GHz (r03's phase logs: ~2.05 GHz under this load)."""
+  import ctypes
+  import torch
+  from tensorflow_nufft import _lib
+  mhz = ctypes.c_double(0.0)
+  rc = _lib.lib().nufft_hip_debug_shader_clock_mhz(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), ctypes.byref(mhz))
+  if rc != 0 or not (500.0 < mhz.value < 4000.0):
+    return CLOCK_GHZ_NOMINAL, 'nominal (measurement failed)'
+  return mhz.value * 1e-3, 'measured under an LDS-atomic load (nufft_hip_debug_shader_clock_mhz)'
 
 
 def algorithmic_spread_bytes(m, nf, rank):
@@ -81,6 +99,19 @@ def pmc_traffic(kernel_name, m):
   except (OSError, ValueError, KeyError):
     pass
   return None, None
+
+
+def pmc_traffic_of(config_key):
+  """The same for the dominant kernels of configs 3, 4, 5 (profiles/pmc_traffic_configs.json: one entry per
+  config with the kernel, the corrected and raw byte counts and the profile file they come from)."""
+  try:
+    d = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic_configs.json'))).get(config_key)
+    if d:
+      return {'traffic': int(d['traffic_bytes_corrected']), 'traffic_raw': int(d.get('traffic_bytes_raw', 0)) or None,
+              'traffic_kernel': d.get('kernel'), 'traffic_source': 'offline: ' + d.get('source', 'profiles/')}
+  except (OSError, ValueError, KeyError, TypeError):
+    pass
+  return {'traffic': None}
 
 
 def cpu_baseline(args):
@@ -164,13 +195,14 @@ def lds_roofline(pts, info, spread_ms):
   m = pts.shape[0]
   groups += (m - groups) // 32      # a run also ends where the 32-point staging block ends
   instr = 2.0 * groups
-  peak = NUM_CUS * CLOCK_GHZ * 1e9 / LDS_ADD_F64_CYCLES
+  ghz, how = shader_clock_ghz()
+  peak = NUM_CUS * ghz * 1e9 / LDS_ADD_F64_CYCLES
   achieved = instr / (spread_ms * 1e-3)
   return {
       'bound': 'lds-atomic', 'achieved': round(achieved / 1e9, 2), 'peak': round(peak / 1e9, 2),
       'unit': 'G wave-instr/s (ds_add_f64)', 'frac': round(achieved / peak, 4),
-      'atomics_per_point': round(instr / m, 3),
-      'note': 'peak = 256 CUs x 2.4 GHz / 8.6 cycles per conflict-free ds_add_f64 wave-instruction '
+      'atomics_per_point': round(instr / m, 3), 'clock_ghz': round(ghz, 3), 'clock': how,
+      'note': 'peak = 256 CUs x clock_ghz / 8.6 cycles per conflict-free ds_add_f64 wave-instruction '
               '(tools/ubench/lds_atomic_bench.hip); achieved counts only the atomics, the same pipe also '
               'serves 0.75 ds_read_b128 + 0.375 ds_write_b32 wave-instructions per point',
   }
@@ -232,8 +264,66 @@ def other_configs(args, dev):
     del pts, src, res
     torch.cuda.empty_cache()
 
-  plan_case('config3_2d_type2_1024_M1e7', 'type_2', GRID, M, TOL, 3, max(5, args.steps // 2), 'interp')
-  plan_case('config4_3d_type1_256_M1e8_tol1e-4', 'type_1', [256, 256, 256], 100_000_000, 1e-4, 4, 5, 'spread')
+  def guarded(name, fn):
+    # (a memory or time failure in one of these legs must not lose the headline line)
+    try:
+      fn()
+    except Exception as e:   # pylint: disable=broad-except
+      out[name] = {'error': f'{type(e).__name__}: {str(e)[:200]}'}
+      torch.cuda.empty_cache()
+
+  guarded('config3_2d_type2_1024_M1e7',
+          lambda: plan_case('config3_2d_type2_1024_M1e7', 'type_2', GRID, M, TOL, 3, max(5, args.steps // 2), 'interp'))
+  guarded('config4_3d_type1_256_M1e8_tol1e-4',
+          lambda: plan_case('config4_3d_type1_256_M1e8_tol1e-4', 'type_1', [256, 256, 256], 100_000_000, 1e-4, 4, 5, 'spread'))
+  # the reference harness's own 3-D case at the API's default tolerance, scaled to config 4's grid (w = 8)
+  guarded('3d_type1_256_M3e7_tol1e-6',
+          lambda: plan_case('3d_type1_256_M3e7_tol1e-6', 'type_1', [256, 256, 256], 30_000_000, 1e-6, 6, 5, 'spread'))
+  for k in list(out):
+    if 'error' not in out[k]:
+      out[k].update(pmc_traffic_of(k))
+  try:
+    out.update(config5_one_gpu(args, dev))
+  except Exception as e:   # pylint: disable=broad-except
+    out['config5_batched_2d_type1_512_32_items'] = {'error': f'{type(e).__name__}: {str(e)[:200]}'}
+  return out
+
+
+def config5_spread_kernel(dev, pts, c, grp=16):
+  """Dominant kernel of config 5 as the op runs it (one plan, num_point_sets = 16): per-item spread time from the
+  plan's own HIP events, algorithmic bytes per item, HBM fraction."""
+  import torch
+  import tensorflow_nufft as tfft
+  grp = min(grp, pts.shape[0])
+  plan = tfft.Plan('type_1', C5_GRID, 'forward', tol=TOL, dtype=torch.complex64, device=dev, num_point_sets=grp)
+  info = plan.info()
+  pg, cg = pts[:grp].contiguous(), c[:grp].contiguous()
+  if grp == 1:
+    pg, cg = pg[0], cg[0]
+  for _ in range(2):
+    plan.execute_with_points(pg, cg)
+  plan.set_timing(2)
+  plan.get_timing()
+  for _ in range(5):
+    plan.execute_with_points(pg, cg)
+  tm = plan.get_timing()
+  plan.close()
+  k_ms = tm['spread'][0] / max(tm['spread'][1], 1) / grp     # per item
+  nf = [int(info.fine_dims[d]) for d in range(2)]
+  algo = algorithmic_spread_bytes(C5_M, nf, 2)
+  return {'dominant_kernel': 'spread', 'dominant_kernel_ms_per_item': round(k_ms, 4), 'algorithmic_bytes_per_item': algo,
+          'hbm_frac': round(algo / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), 'kernel_width': int(info.kernel_width),
+          'fine_grid': nf[::-1], **pmc_traffic_of('config5_item')}
+
+
+def config5_one_gpu(args, dev):
+  import numpy as np
+  import torch
+  import tensorflow_nufft as tfft
+  out = {}
+
+  def rnd_c(shape, g):
+    return torch.complex(torch.rand(shape, generator=g, device=dev) - .5, torch.rand(shape, generator=g, device=dev) - .5)
 
   # config 5: one GPU's share at N = 8 (32 items), and the whole 256-item job on this GPU (the
   # N = 1 anchor of the scaling curve), both through tfft.nufft with per-item points
@@ -249,25 +339,7 @@ def other_configs(args, dev):
     for _ in range(C5_ITEMS // share):
       call()
   ms256 = _event_timed(whole, 3)
-  # dominant kernel of a group of 16 point sets, as the op runs them (one plan, num_point_sets = 16)
-  grp = 16
-  plan = tfft.Plan('type_1', C5_GRID, 'forward', tol=TOL, dtype=torch.complex64, device=dev, num_point_sets=grp)
-  info = plan.info()
-  pg, cg = pts[:grp].contiguous(), c[:grp].contiguous()
-  for _ in range(2):
-    plan.execute_with_points(pg, cg)
-  plan.set_timing(2)
-  plan.get_timing()
-  for _ in range(5):
-    plan.execute_with_points(pg, cg)
-  tm = plan.get_timing()
-  plan.close()
-  k_ms = tm['spread'][0] / max(tm['spread'][1], 1) / grp     # per item
-  nf = [int(info.fine_dims[d]) for d in range(2)]
-  algo = algorithmic_spread_bytes(C5_M, nf, 2)
-  c5 = {'dominant_kernel': 'spread', 'dominant_kernel_ms_per_item': round(k_ms, 4), 'algorithmic_bytes_per_item': algo,
-        'hbm_frac': round(algo / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), 'kernel_width': int(info.kernel_width),
-        'fine_grid': nf[::-1]}
+  c5 = config5_spread_kernel(dev, pts, c)
   out['config5_batched_2d_type1_512_32_items'] = dict(c5, ms_per_step=round(ms32, 4), Gpts_s=round(share * C5_M / ms32 / 1e6, 2))
   out['config5_whole_job_256_items_one_gpu'] = dict(c5, ms_per_step=round(ms256, 4), Gpts_s=round(C5_ITEMS * C5_M / ms256 / 1e6, 2),
                                                      note='the N = 1 anchor for the sharded runs (bench.py --gpus N reports this workload)')
@@ -277,25 +349,34 @@ def other_configs(args, dev):
 def spawn_ranks(args, argv):
   """--gpus N > 1 without a launcher: one child process per rank, started before any GPU
   call in this process (a process that touched the GPU must not exec or fork workers)."""
+  # Rendezvous through a FILE store in a private temporary directory (nobody can take it between its creation
+  # and the children's use, unlike a "free" TCP port picked here and bound later); an explicit MASTER_PORT in the
+  # environment is honoured as before.
+  import shutil
+  import tempfile
+  tmpdir = None
+  extra = {}
   if 'MASTER_PORT' in os.environ:
-    port = int(os.environ['MASTER_PORT'])
-  else:   # a free port picked by the kernel: two benches on one host do not collide
-    import socket
-    with socket.socket() as sk:
-      sk.bind(('127.0.0.1', 0))
-      port = sk.getsockname()[1]
+    extra = {'MASTER_ADDR': os.environ.get('MASTER_ADDR', '127.0.0.1'), 'MASTER_PORT': os.environ['MASTER_PORT']}
+  else:
+    tmpdir = tempfile.mkdtemp(prefix='nufft_bench_')
+    extra = {'NUFFT_BENCH_INIT_FILE': os.path.join(tmpdir, 'store')}
   procs = []
-  for r in range(args.gpus):
-    env = dict(os.environ)
-    env.update({'RANK': str(r), 'LOCAL_RANK': str(r), 'WORLD_SIZE': str(args.gpus),
-                'LOCAL_WORLD_SIZE': str(args.gpus), 'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port),
-                'HSA_ENABLE_IPC_MODE_LEGACY': os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0')})
-    procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
-  rc = 0
-  for p in procs:
-    p.wait()
-    rc = rc or p.returncode
-  return rc
+  try:
+    for r in range(args.gpus):
+      env = dict(os.environ)
+      env.update({'RANK': str(r), 'LOCAL_RANK': str(r), 'WORLD_SIZE': str(args.gpus),
+                  'LOCAL_WORLD_SIZE': str(args.gpus),
+                  'HSA_ENABLE_IPC_MODE_LEGACY': os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'), **extra})
+      procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    for p in procs:
+      p.wait()
+      rc = rc or p.returncode
+    return rc
+  finally:
+    if tmpdir:
+      shutil.rmtree(tmpdir, ignore_errors=True)
 
 
 def main():
@@ -334,25 +415,38 @@ def main():
   dist = None
   if world > 1 or args.force_dist:
     import torch.distributed as dist
-    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    if 'MASTER_PORT' not in os.environ:   # (--force-dist at world size 1: nobody else needs to know the port)
-      import socket
-      with socket.socket() as sk:
-        sk.bind(('127.0.0.1', 0))
-        os.environ['MASTER_PORT'] = str(sk.getsockname()[1])
     os.environ.setdefault('RANK', '0')
     os.environ.setdefault('WORLD_SIZE', '1')
-    if args.dist_backend == 'nccl':
-      dist.init_process_group('nccl', device_id=dev)   # "nccl" is RCCL on ROCm
+    kw = {}
+    init_file = os.environ.get('NUFFT_BENCH_INIT_FILE')
+    tmp_store = None
+    if 'MASTER_PORT' not in os.environ and not init_file:   # (--force-dist at world size 1: a private file store)
+      import tempfile
+      tmp_store = tempfile.mkdtemp(prefix='nufft_bench_')
+      init_file = os.path.join(tmp_store, 'store')
+    if init_file and 'MASTER_PORT' not in os.environ:
+      kw = {'init_method': 'file://' + init_file, 'rank': rank, 'world_size': world}
     else:
-      dist.init_process_group(args.dist_backend)
+      os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    if args.dist_backend == 'nccl':
+      dist.init_process_group('nccl', device_id=dev, **kw)   # "nccl" is RCCL on ROCm
+    else:
+      dist.init_process_group(args.dist_backend, **kw)
   workload = args.workload
   if workload == 'auto':
-    workload = 'config5' if world > 1 else 'config2'
+    workload = 'config2'
   if workload == 'config5':
     result = run_config5(args, dev, dist, world, rank)
   else:
     result = run_config2(args, dev, dist, world, rank)
+    if world > 1 and not args.no_extras:
+      # the batched workload north_star shards, on the same ranks (every rank takes part; rank 0 keeps the result)
+      try:
+        c5 = run_config5(args, dev, dist, world, rank)
+      except Exception as e:   # pylint: disable=broad-except
+        c5 = {'error': f'{type(e).__name__}: {str(e)[:200]}'}
+      if rank == 0:
+        result['config']['config5_sharded'] = c5
   if rank == 0:
     print(json.dumps(result), flush=True)
   if dist is not None:
@@ -463,8 +557,8 @@ def run_config2(args, dev, dist, world, rank):
       'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
       'config': {
           'workload': 'BASELINE configs[1]: 2D type-1, 1024x1024 modes, M=1e7 uniform random points, '
-                      'tol=1e-6, complex64; one transform per step through nufft_hip_execute_with_points '
-                      '(the call tfft.nufft makes)',
+                      'tol=1e-6, complex64; one transform per rank and step through nufft_hip_execute_with_points '
+                      '(the call tfft.nufft makes); ranks hold independent transforms (no collective in the data path)',
           'points_per_gpu': m, 'grid': GRID, 'fine_grid': nf, 'kernel_width': int(info.kernel_width),
           'upsampling_factor': info.upsampling_factor, 'spread_method': int(info.spread_method),
           'stage_us': {k: round(v[0] / max(v[1], 1) * 1e3, 1) for k, v in stage_all.items() if v[1]},
@@ -530,7 +624,7 @@ def run_config5(args, dev, dist, world, rank):
       # the WHOLE 256-item job on this one GPU, for the scaling comparison on equal work
       torch.cuda.synchronize()
       g1 = torch.Generator(device=dev).manual_seed(105)
-      chunk = 32
+      chunk = min(32, items)
       pc = (torch.rand((chunk, m, 2), generator=g1, device=dev) * 2 - 1) * np.pi
       cc = torch.complex(torch.rand((chunk, m), generator=g1, device=dev) - .5,
                          torch.rand((chunk, m), generator=g1, device=dev) - .5)
@@ -543,7 +637,7 @@ def run_config5(args, dev, dist, world, rank):
       for _ in range(args.steps):
         whole()
       torch.cuda.synchronize()
-      extras['one_gpu_whole_job_Mpts_s'] = round(items * m / ((time.perf_counter() - t1) / args.steps) / 1e6, 2)
+      extras['one_gpu_whole_job_Mpts_s'] = round((items // chunk) * chunk * m / ((time.perf_counter() - t1) / args.steps) / 1e6, 2)
     if dist is not None:
       dist.barrier()
 
@@ -557,18 +651,33 @@ def run_config5(args, dev, dist, world, rank):
     return None
   ms_per_step = elapsed / args.steps * 1e3
   value = items * m / (elapsed / args.steps) / 1e6
+  if 'one_gpu_whole_job_Mpts_s' in extras and extras['one_gpu_whole_job_Mpts_s'] > 0:
+    # sharded rate over N x the same 256-item job on ONE of these GPUs: the scaling efficiency on equal work
+    extras['equal_work_efficiency'] = round(value / (world * extras['one_gpu_whole_job_Mpts_s']), 4)
+  roofline = None
+  if not args.no_extras:
+    try:
+      k = config5_spread_kernel(dev, pts, c)
+      ach = k['algorithmic_bytes_per_item'] / (k['dominant_kernel_ms_per_item'] * 1e-3) / 1e9
+      roofline = {'bound': 'hbm', 'kernel': SPREAD_KERNEL + ' (16 point sets per launch; per item)', 'achieved': round(ach, 1),
+                  'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': k.get('traffic'),
+                  'traffic_source': k.get('traffic_source'), 'algorithmic_bytes': k['algorithmic_bytes_per_item'],
+                  'kernel_ms': k['dominant_kernel_ms_per_item'], 'measured_on': 'rank 0'}
+    except Exception as e:   # pylint: disable=broad-except
+      roofline = {'error': f'{type(e).__name__}: {str(e)[:200]}'}
   return {
       'metric': 'non-uniform pts/s, batched 2D type-1 512^2 x 256 items, M=1e6 each, tol=1e-6 (set_points + execute), '
                 'batch sharded over the GPUs',
       'value': round(value, 2), 'unit': 'Mpts/s', 'n_gpus': world, 'steps': args.steps,
       'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True,
       'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+      'roofline': roofline,
       'config': {
           'workload': f'BASELINE configs[4]: batched 2D type-1, 512x512 modes, batch={items}, M=1e6 per item, '
                       f'per-item points, tol=1e-6, complex64; contiguous blocks of the batch per rank '
                       f'(shard_bounds), each rank one tfft.nufft call per step over its block; no data-path '
-                      f'collective. The N=1 line of this script is configs[1] (a different workload); '
-                      f'config.one_gpu_whole_job_Mpts_s is this workload on one GPU.',
+                      f'collective. config.one_gpu_whole_job_Mpts_s is this workload on one GPU, '
+                      f'config.equal_work_efficiency = value / (N x that).',
           'items': items, 'items_per_rank': nloc, 'points_per_item': m, 'grid': C5_GRID,
           'rccl_world_size': measured_world, 'backend': args.dist_backend if dist is not None else None,
           **extras,

@@ -255,6 +255,11 @@ int nufft_hip_debug_sort_path(nufft_hip_plan plan);
  * spread is at most B largest strengths), < 0 = left to the double-precision LDS planes, 0 = unused launch slot.
  * Returns the number of launch slots (<= n copied), 0 for other plans, negative on error. */
 int64_t nufft_hip_debug_sub_bounds(nufft_hip_plan plan, float* out, int64_t n);
+/* Shader clock of the current device in MHz, measured while every CU runs LDS atomics for about a millisecond
+ * (ratio of the shader-cycle counter to the constant-rate wall clock inside the kernel): what the LDS roofline of
+ * bench.py is priced at -- the nominal 2400 MHz is not what these kernels run at. Allocates, launches on `stream`,
+ * synchronises. */
+int nufft_hip_debug_shader_clock_mhz(void* stream, double* mhz);
 
 /* ---- Op-level entry: the host logic of NUFFTBaseOp::Compute/Execute --------
  * (nufft_kernels.cc:54-542): validation with the reference's error messages,

@@ -862,6 +862,53 @@ __global__ __launch_bounds__(256) void cstats_kernel(const float2* __restrict__ 
   }
 }
 
+// ---- shader clock under an LDS-atomic load (bench.py prices the LDS roofline with it) -----------------------------
+// Every workgroup runs `iters` conflict-free ds_add_u64 per thread and reports the shader-clock and the
+// constant-rate wall-clock ticks that took.
+__global__ __launch_bounds__(768) void clock_probe_kernel(unsigned long long* __restrict__ out, int iters) {
+  __shared__ unsigned long long cell[768];
+  cell[threadIdx.x] = 0ull;
+  __syncthreads();
+  const unsigned long long c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
+  for (int i = 0; i < iters; ++i) atomicAdd(&cell[threadIdx.x], (unsigned long long)i);
+  __syncthreads();
+  const unsigned long long c1 = __builtin_readcyclecounter(), w1 = wall_clock64();
+  if (threadIdx.x == 0) {
+    out[2 * blockIdx.x] = c1 - c0;
+    out[2 * blockIdx.x + 1] = w1 - w0;
+  }
+  if (cell[threadIdx.x] == 0xdeadbeefdeadbeefull) out[0] = 0;   // (keeps the loop)
+}
+
+}  // namespace
+
+// Shader clock in MHz while every CU runs LDS atomics (~1 ms of them), from the ratio of the two counters;
+// scratch: device buffer of >= 2 * 512 unsigned long long. Synchronises the stream.
+hipError_t measure_shader_clock_mhz(hipStream_t stream, unsigned long long* scratch, double* mhz) {
+  constexpr int kBlocks = 512;
+  int dev = 0, wall_khz = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  e = hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, dev);
+  if (e != hipSuccess) return e;
+  unsigned long long host[2 * kBlocks];
+  for (int rep = 0; rep < 2; ++rep) {   // (the first launch warms the clocks up)
+    clock_probe_kernel<<<kBlocks, 768, 0, stream>>>(scratch, 20000);
+    e = hipMemcpyAsync(host, scratch, sizeof(host), hipMemcpyDeviceToHost, stream);
+    if (e != hipSuccess) return e;
+    e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return e;
+  }
+  std::vector<double> r;
+  for (int b = 0; b < kBlocks; ++b)
+    if (host[2 * b + 1] > 0) r.push_back((double)host[2 * b] / (double)host[2 * b + 1]);
+  if (r.empty() || wall_khz <= 0) return hipErrorUnknown;
+  std::nth_element(r.begin(), r.begin() + r.size() / 2, r.end());
+  *mhz = r[r.size() / 2] * (double)wall_khz * 1e-3;
+  return hipSuccess;
+}
+
+namespace {
 }  // namespace
 
 #ifdef NUFFT_HIP_PHASE_LOG

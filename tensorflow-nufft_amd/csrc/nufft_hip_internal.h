@@ -249,6 +249,7 @@ hipError_t launch_bound3(const Geom& g, const Rec<float>* rec, int rec_stride, c
 // strengths of one spread launch: cstats[slot] = {max, sum} of max(|re c|, |im c|) over the slot's M points
 hipError_t launch_cstats(const float* c, int64_t M, int slots, int64_t c_stride, float* cstats, hipStream_t stream);
 unsigned subproblem_grid_bound(const Geom& g, int64_t M);   // launch grid of the subproblem kernels (>= live subproblems)
+hipError_t measure_shader_clock_mhz(hipStream_t stream, unsigned long long* scratch, double* mhz);
 int wave3_pad(int w);   // spill elements behind the LDS planes of the 3-D wavefront kernel
 bool sparse_wanted(const Geom& g, int64_t M);   // point set sparse enough for the LDS-free spreader
 bool wave_method_supported(const Geom& g, int precision);

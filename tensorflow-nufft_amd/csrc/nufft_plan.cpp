@@ -1476,6 +1476,16 @@ int64_t nufft_hip_debug_sub_bounds(nufft_hip_plan p, float* out, int64_t n) {
   return slots;
 }
 
+int nufft_hip_debug_shader_clock_mhz(void* stream, double* mhz) {
+  if (!mhz) return NUFFT_HIP_INVALID_ARGUMENT;
+  if (preload_device_code() != hipSuccess) return NUFFT_HIP_INTERNAL;
+  unsigned long long* scratch = nullptr;
+  if (hipMalloc((void**)&scratch, sizeof(unsigned long long) * 2 * 512) != hipSuccess) return NUFFT_HIP_RESOURCE_EXHAUSTED;
+  const hipError_t e = measure_shader_clock_mhz((hipStream_t)stream, scratch, mhz);
+  (void)hipFree(scratch);
+  return e == hipSuccess ? NUFFT_HIP_OK : NUFFT_HIP_INTERNAL;
+}
+
 int nufft_hip_debug_stop_after(nufft_hip_plan p, int stage) {
   if (!p) return NUFFT_HIP_INVALID_ARGUMENT;
   p->stop_after = stage;

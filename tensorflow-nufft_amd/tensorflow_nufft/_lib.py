@@ -121,6 +121,7 @@ SYMBOLS = {
     'nufft_hip_debug_stop_after': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     'nufft_hip_debug_sort_path': (ctypes.c_int, [ctypes.c_void_p]),
     'nufft_hip_debug_sub_bounds': (ctypes.c_int64, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.c_int64]),
+    'nufft_hip_debug_shader_clock_mhz': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]),
     'nufft_hip_set_points': (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
         ctypes.c_void_p, ctypes.c_int64]),

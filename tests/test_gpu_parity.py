@@ -2143,17 +2143,33 @@ def test_transposed_batch_call_captures_into_a_hip_graph(tfft):
 
 
 def test_bench_spawns_its_own_ranks():
-  # `python bench.py --gpus 2` without a launcher starts two ranks itself (here both on
-  # device 0 over gloo -- a 1-GPU box; the driver's 8-GPU run uses nccl) and prints one line
+  # `python bench.py --gpus 2` without a launcher starts two ranks itself (here both on device 0 over gloo -- a
+  # 1-GPU box; the driver's 8-GPU run uses nccl), rendezvous through a private file store, and prints ONE line:
+  # the headline workload on every rank (weak scaling, the N = 1 metric) with the sharded config 5 leg inside.
   import json
   import os
   import subprocess
   import sys
   from conftest import ROOT
-  env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+  env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
+  r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+                      '--points', '300000', '--items', '6', '--dist-backend', 'gloo', '--device', '0',
+                      '--no-cpu-baseline'],
+                     capture_output=True, text=True, env=env, timeout=900)
+  assert r.returncode == 0, r.stderr[-2000:]
+  lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+  assert len(lines) == 1, r.stdout
+  d = json.loads(lines[0])
+  assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['value'] > 0 and d['config']['points_per_gpu'] == 300000
+  assert d['roofline']['frac'] > 0 and 'clock_ghz' in d['roofline']['lds']
+  c5 = d['config']['config5_sharded']
+  assert 'error' not in c5, c5
+  assert c5['scaling'] == 'strong' and c5['config']['items'] == 6 and c5['config']['items_per_rank'] == 3
+  assert c5['roofline']['frac'] > 0 and c5['config']['equal_work_efficiency'] > 0 and c5['config']['rccl_world_size'] == 2
+  # the sharded workload as the line itself, explicit port (the launcher-less path honours MASTER_PORT)
   env['MASTER_PORT'] = '29644'
   r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
-                      '--items', '6', '--dist-backend', 'gloo', '--device', '0', '--no-extras'],
+                      '--items', '6', '--dist-backend', 'gloo', '--device', '0', '--no-extras', '--workload', 'config5'],
                      capture_output=True, text=True, env=env, timeout=600)
   assert r.returncode == 0, r.stderr[-2000:]
   lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
