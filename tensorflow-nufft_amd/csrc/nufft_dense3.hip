@@ -265,30 +265,40 @@ __global__ __launch_bounds__(kDenseNW * 64) void spread_dense3_kernel(
   NUFFT_PHASE3(2);
   for (int i = tid; i < C::plane_elems; i += NW * 64) plane[i] = 0ull;
 
-  // step of the fixed-point grid (see the header comment): the subproblem's sum of max(|re c|, |im c|)
+  // step of the fixed-point grid (see the header comment). The transform's largest and mean strength are known
+  // (cstats_kernel, one streaming pass before this launch): unless one strength dominates (largest > 8 x the mean)
+  // the subproblem's sum is bounded by its point COUNT x the largest strength and no pass over its own strengths --
+  // a second random gather of every c[idx], r03: 16.6 % of a workgroup's life at config 4 -- is needed.
+  const float top_g = sp.cstats[2 * slot], sum_g = sp.cstats[2 * slot + 1];
+  const bool own_pass = top_g * (float)c_stride > 8.f * sum_g;   // (workgroup-uniform)
   float part = 0.f, big = 0.f;
-  for (int j = p0 + tid; j < p1; j += NW * 64) {
-    float2 cv;
-    if constexpr (FUSED) cv = *reinterpret_cast<const float2*>(&rec3[j].re);
-    else cv = cc[sp.rec[j].idx];
-    const float m = fmaxf(fabsf(cv.x), fabsf(cv.y));
-    part += m;
-    big = fmaxf(big, m);
-  }
+  if (own_pass) {
+    for (int j = p0 + tid; j < p1; j += NW * 64) {
+      float2 cv;
+      if constexpr (FUSED) cv = *reinterpret_cast<const float2*>(&rec3[j].re);
+      else cv = cc[sp.rec[j].idx];
+      const float m = fmaxf(fabsf(cv.x), fabsf(cv.y));
+      part += m;
+      big = fmaxf(big, m);
+    }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    part += __shfl_down(part, o);
-    big = fmaxf(big, __shfl_down(big, o));
+    for (int o = 32; o > 0; o >>= 1) {
+      part += __shfl_down(part, o);
+      big = fmaxf(big, __shfl_down(big, o));
+    }
+    if (lane == 0) { red[wave] = part; red[NW + wave] = big; }
   }
-  if (lane == 0) { red[wave] = part; red[NW + wave] = big; }
   // this wave's staging area: zero the kx slot the idle lanes read (never written again)
   unsigned char* stage = stage_all + (size_t)wave * (HALF / 2) * SLOTS * 16;
   if (lane < HALF / 2) *reinterpret_cast<v4f*>(stage + (lane * SLOTS + W) * 16) = (v4f){0.f, 0.f, 0.f, 0.f};
   __syncthreads();
   NUFFT_PHASE3(3);
-  float bound = 0.f, top = 0.f;
+  float bound = (float)npt * top_g, top = top_g;
+  if (own_pass) {
+    bound = 0.f; top = 0.f;
 #pragma unroll
-  for (int k = 0; k < NW; ++k) { bound += red[k]; top = fmaxf(top, red[NW + k]); }
+    for (int k = 0; k < NW; ++k) { bound += red[k]; top = fmaxf(top, red[NW + k]); }
+  }
   const float amp = fabsf(scale) * g.fx_headroom;   // (the fitted polynomials overshoot 1 slightly)
   const float room = 2147483000.f - (float)npt;     // 2^31 minus the rounding of every contribution
   // Two constraints on the step: no cell may overflow 32 bits (sum rule), and the FMA conversion is exact only
@@ -724,14 +734,18 @@ __global__ __launch_bounds__(kPatchNW * 64) void spread_patch3_kernel(
 // N = the subproblem's points per start cell: every cell sum of the spread is at most (largest strength) x B.
 // One workgroup per subproblem; the three filter passes keep a line's inputs in registers.
 constexpr int kBoundThreads = 256;
+// (Measured r04, 65536 subproblems of 458 points: this form 0.36-0.38 ms before the count rows were padded. A form
+// with two lines per thread in v_pk_fma_f32 -- 40 % fewer wave-instructions -- ran 0.49-0.69 ms: a phase then keeps
+// one or two waves of the workgroup busy and the kernel is bound by the latency of each phase, not by VALU issue.)
 template <int W, int TZ>
 __global__ __launch_bounds__(kBoundThreads) void bound3_kernel(Geom g, const Rec<float>* __restrict__ rec, int rec_stride,
                                                               const int32_t* __restrict__ tile_start,
                                                               const int32_t* __restrict__ sub_start, TapMax taps,
                                                               float* __restrict__ sub_bound, unsigned nsub_bound) {
-  constexpr int T = kDenseTile, L = T + W - 1, LZ = TZ + W - 1, NT = kBoundThreads;
-  __shared__ uint32_t cnt[TZ * T * T];
-  __shared__ float a[TZ * T * L];     // [z][y][i]
+  // count rows of 17 words: the x pass reads one LINE per lane, and a lane stride of 16 words would put a wave on 4 banks
+  constexpr int T = kDenseTile, L = T + W - 1, CP = T + 1, LZ = TZ + W - 1, NT = kBoundThreads;
+  __shared__ uint32_t cnt[TZ * T * CP];
+  __shared__ float a[TZ * T * L];     // [z][y][i]  (L is odd: conflict-free line-per-lane writes)
   __shared__ float b[TZ * L * L];     // [z][j][i]
   __shared__ float wmax[NT / 64];
   int tb, p0, p1, slot, nsub;
@@ -748,12 +762,12 @@ __global__ __launch_bounds__(kBoundThreads) void bound3_kernel(Geom g, const Rec
     if (tid == 0) sub_bound[blockIdx.x] = (float)(npt > 0 ? npt : 1);
     return;
   }
-  for (int i = tid; i < TZ * T * T; i += NT) cnt[i] = 0u;
+  for (int i = tid; i < TZ * T * CP; i += NT) cnt[i] = 0u;
   __syncthreads();
   for (int j = p0 + tid; j < p1; j += NT) {
     const Rec<float>& r = rec_at(rec, j, rec_stride);
     const uint32_t l0 = r.loc >> 28, l1 = __float_as_uint(r.z0) >> 28, l2 = __float_as_uint(r.z1) >> 28;
-    atomicAdd(&cnt[(l2 * T + l1) * T + l0], 1u);
+    atomicAdd(&cnt[(l2 * T + l1) * CP + l0], 1u);
   }
   __syncthreads();
   float km[W];
@@ -763,7 +777,7 @@ __global__ __launch_bounds__(kBoundThreads) void bound3_kernel(Geom g, const Rec
   for (int line = tid; line < TZ * T; line += NT) {
     float in[T];
 #pragma unroll
-    for (int i = 0; i < T; ++i) in[i] = (float)cnt[line * T + i];
+    for (int i = 0; i < T; ++i) in[i] = (float)cnt[line * CP + i];
 #pragma unroll
     for (int i = 0; i < L; ++i) {
       float v = 0.f;
@@ -824,19 +838,26 @@ __global__ __launch_bounds__(kBoundThreads) void bound3_kernel(Geom g, const Rec
 }
 
 // ---- strengths of one spread launch: largest and summed max(|re c|, |im c|) per slot ----------------------------
-__global__ __launch_bounds__(256) void cstats_kernel(const float2* __restrict__ c, int64_t M, int64_t c_stride,
-                                                      float* __restrict__ cstats) {
+// Two stages, no atomics: a first form had every workgroup add its partial sums to the slot's two floats --
+// 4096 atomics on two addresses, serialised at ~60 ns each: 0.24 ms for a 60 us read of 3e7 strengths.
+constexpr int kStatsMaxBlocks = 1024;
+__global__ __launch_bounds__(256) void cstats_partial_kernel(const float2* __restrict__ c, int64_t M, int64_t c_stride,
+                                                              float* __restrict__ partial) {
   const float2* cc = c + (int64_t)blockIdx.y * c_stride;
   float big = 0.f, part = 0.f;
-  // (four loads in flight per thread)
+  // (eight loads in flight per thread)
   const int64_t stride = (int64_t)gridDim.x * 256;
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  for (; i + 3 * stride < M; i += 4 * stride) {
-    const float2 v0 = cc[i], v1 = cc[i + stride], v2 = cc[i + 2 * stride], v3 = cc[i + 3 * stride];
-    const float m0 = fmaxf(fabsf(v0.x), fabsf(v0.y)), m1 = fmaxf(fabsf(v1.x), fabsf(v1.y));
-    const float m2 = fmaxf(fabsf(v2.x), fabsf(v2.y)), m3 = fmaxf(fabsf(v3.x), fabsf(v3.y));
-    big = fmaxf(fmaxf(big, fmaxf(m0, m1)), fmaxf(m2, m3));
-    part += (m0 + m1) + (m2 + m3);
+  for (; i + 7 * stride < M; i += 8 * stride) {
+    float2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = cc[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float m = fmaxf(fabsf(v[u].x), fabsf(v[u].y));
+      big = fmaxf(big, m);
+      part += m;
+    }
   }
   for (; i < M; i += stride) {
     const float2 v = cc[i];
@@ -854,11 +875,30 @@ __global__ __launch_bounds__(256) void cstats_kernel(const float2* __restrict__ 
   if (lane == 0) { r[wave] = part; r[4 + wave] = big; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    part = (r[0] + r[1]) + (r[2] + r[3]);
-    big = fmaxf(fmaxf(r[4], r[5]), fmaxf(r[6], r[7]));
-    // (non-negative floats order like their bit patterns)
-    atomicMax(reinterpret_cast<unsigned*>(cstats + 2 * blockIdx.y), __float_as_uint(big));
-    unsafeAtomicAdd(cstats + 2 * blockIdx.y + 1, part);
+    float* dst = partial + 2 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+    dst[0] = fmaxf(fmaxf(r[4], r[5]), fmaxf(r[6], r[7]));
+    dst[1] = (r[0] + r[1]) + (r[2] + r[3]);
+  }
+}
+__global__ __launch_bounds__(256) void cstats_final_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ cstats) {
+  const float* src = partial + 2 * (size_t)blockIdx.x * nblk;
+  float big = 0.f, part = 0.f;
+  for (int i = threadIdx.x; i < nblk; i += 256) {
+    big = fmaxf(big, src[2 * i]);
+    part += src[2 * i + 1];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    part += __shfl_down(part, o);
+    big = fmaxf(big, __shfl_down(big, o));
+  }
+  __shared__ float r[8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { r[wave] = part; r[4 + wave] = big; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    cstats[2 * blockIdx.x] = fmaxf(fmaxf(r[4], r[5]), fmaxf(r[6], r[7]));
+    cstats[2 * blockIdx.x + 1] = (r[0] + r[1]) + (r[2] + r[3]);
   }
 }
 
@@ -954,11 +994,20 @@ hipError_t launch_bound3(const Geom& g, const Rec<float>* rec, int rec_stride, c
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }
-hipError_t launch_cstats(const float* c, int64_t M, int slots, int64_t c_stride, float* cstats, hipStream_t stream) {
-  hipError_t e = hipMemsetAsync(cstats, 0, sizeof(float) * 2 * (size_t)slots, stream);
-  if (e != hipSuccess || M <= 0 || slots <= 0) return e;
-  const unsigned nblk = (unsigned)std::min<int64_t>(2048, (M + 4095) / 4096);
-  cstats_kernel<<<dim3(nblk, (unsigned)slots), 256, 0, stream>>>(reinterpret_cast<const float2*>(c), M, c_stride, cstats);
+int cstats_blocks(int64_t M, int slots) {
+  // (workgroups per slot: 16384 strengths each, at most 1024, and at most 2^20 partial pairs over all slots)
+  int64_t n = std::min<int64_t>(kStatsMaxBlocks, (M + 16383) / 16384);
+  n = std::min<int64_t>(n, ((int64_t)1 << 20) / std::max(1, slots));
+  return (int)std::max<int64_t>(1, n);
+}
+size_t cstats_floats(int64_t M, int slots) { return 2 * (size_t)slots * (1 + (size_t)cstats_blocks(M, slots)); }
+// cstats: [max_slots][2] results followed by the partial pairs (cstats_floats(M, max_slots) floats in all)
+hipError_t launch_cstats(const float* c, int64_t M, int slots, int nblk, int max_slots, int64_t c_stride, float* cstats, hipStream_t stream) {
+  if (slots <= 0) return hipSuccess;
+  if (M <= 0 || nblk <= 0) return hipMemsetAsync(cstats, 0, sizeof(float) * 2 * (size_t)slots, stream);
+  float* partial = cstats + 2 * (size_t)max_slots;
+  cstats_partial_kernel<<<dim3((unsigned)nblk, (unsigned)slots), 256, 0, stream>>>(reinterpret_cast<const float2*>(c), M, c_stride, partial);
+  cstats_final_kernel<<<(unsigned)slots, 256, 0, stream>>>(partial, nblk, cstats);
   return hipGetLastError();
 }
 

@@ -103,7 +103,9 @@ struct SortedPoints {
   const int32_t* sub_start;   // [ntiles + 1] exclusive scan of ceil(count / max_sub)
   // fixed-point 3-D float plans (nufft_dense3.hip), else null:
   float* cstats;              // [slots][2]: largest and summed max(|re c|, |im c|) of the strengths a launch spreads
-                              // (written by launch_spread itself, before the spread kernel)
+                              // (written by launch_spread itself, before the spread kernel), then the partial pairs of
+  int cstats_blocks;          // this many workgroups per slot (fixed by the plan from its largest slot count,
+  int cstats_slots;           // cstats_slots: the partial pairs start behind that many result pairs)
   const float* sub_bound;     // Geom::fx_patch: [subproblem grid + 1] count-filter bound of every subproblem, negative =
                               // left to the fp64-plane kernels; the last entry counts those (as an integer)
 };
@@ -246,8 +248,11 @@ hipError_t launch_spread_patch3(const Geom& g, const SortedPoints<float>& sp, un
 // were left to the fp64-plane kernels (zeroed here); rec_stride: bytes between records
 hipError_t launch_bound3(const Geom& g, const Rec<float>* rec, int rec_stride, const int32_t* tile_start, const int32_t* sub_start,
                          unsigned nsub_bound, const TapMax& taps, float* sub_bound, hipStream_t stream);
-// strengths of one spread launch: cstats[slot] = {max, sum} of max(|re c|, |im c|) over the slot's M points
-hipError_t launch_cstats(const float* c, int64_t M, int slots, int64_t c_stride, float* cstats, hipStream_t stream);
+// strengths of one spread launch: cstats[slot] = {max, sum} of max(|re c|, |im c|) over the slot's M points;
+// the buffer holds cstats_floats(M, slots) floats (the results, then per-workgroup partial pairs)
+hipError_t launch_cstats(const float* c, int64_t M, int slots, int nblk, int max_slots, int64_t c_stride, float* cstats, hipStream_t stream);
+int cstats_blocks(int64_t M, int max_slots);                 // workgroups per slot
+size_t cstats_floats(int64_t M, int max_slots);
 unsigned subproblem_grid_bound(const Geom& g, int64_t M);   // launch grid of the subproblem kernels (>= live subproblems)
 hipError_t measure_shader_clock_mhz(hipStream_t stream, unsigned long long* scratch, double* mhz);
 int wave3_pad(int w);   // spill elements behind the LDS planes of the 3-D wavefront kernel

@@ -2884,7 +2884,7 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
     if constexpr (sizeof(T) == 4) {
       // 3-D fixed-point plans: the largest and the mean strength of every slot first (one streaming pass)
       if (sp.cstats && g.rank == 3 && g.fixed_point) {
-        e = launch_cstats(c, c_stride, batch * (g.nitems > 1 ? g.nitems : 1), c_stride, sp.cstats, stream);
+        e = launch_cstats(c, c_stride, batch * (g.nitems > 1 ? g.nitems : 1), sp.cstats_blocks, sp.cstats_slots, c_stride, sp.cstats, stream);
         if (e != hipSuccess) return e;
       }
     }

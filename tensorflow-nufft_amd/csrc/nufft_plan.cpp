@@ -244,6 +244,7 @@ struct nufft_hip_plan_s {
   int32_t *tile_of = nullptr, *rank_of = nullptr;   // global-counter sort
   int32_t *tile_count = nullptr, *tile_start = nullptr, *sub_start = nullptr, *bad_count = nullptr;
   float* cstats = nullptr;       // 3-D float fixed-point plans: {largest, summed} strength of every slot of a spread launch
+  int64_t cap_cstats = 0;        //   (+ the per-workgroup partials of the reduction: sized per point count)
   float* sub_bound = nullptr;    // Geom::fx_patch: count-filter bound per subproblem (+ 1: how many go to fp64 planes)
   int64_t cap_sub_bound = 0;
   TapMax taps = {};              // per-tap maxima of the fitted kernel (bound3_kernel)
@@ -436,7 +437,6 @@ int ensure_fixed_workspace(nufft_hip_plan p) {
   if (!rc) rc = dev_alloc(p, (void**)&p->tile_start, sizeof(int32_t) * ((size_t)g.ntiles + 2));   // (+1: most subproblems of a tile)
   if (!rc) rc = dev_alloc(p, (void**)&p->sub_start, sizeof(int32_t) * ((size_t)g.ntiles + 1));
   if (!rc) rc = dev_alloc(p, (void**)&p->bad_count, sizeof(int32_t) * 4);
-  if (!rc && g.fixed_point) rc = dev_alloc(p, (void**)&p->cstats, sizeof(float) * 2 * (size_t)p->batch_size * p->nitems);
   if (!rc && !p->opts.spread_only)
     rc = dev_alloc(p, &p->d_fine, (size_t)p->precision * 2 * (size_t)p->fine_elems * p->batch_size * p->nitems);
   if (!rc && p->own_fft) {
@@ -461,7 +461,7 @@ void release_workspace(nufft_hip_plan p) {
     dev_free(p, *b);
     *b = nullptr;
   }
-  p->cap = p->cap2 = p->cap_global = p->cap_tile_of = p->cap_sub_bound = 0;
+  p->cap = p->cap2 = p->cap_global = p->cap_tile_of = p->cap_sub_bound = p->cap_cstats = 0;
   p->hist_elems = 0;
   p->workspace_bytes = 0;
   p->fixed_ws = false;
@@ -573,6 +573,17 @@ int ensure_point_capacity(nufft_hip_plan p, int64_t M, int rec_mult = 1) {
     p->cap_tile_of = 0;
     if ((rc = dev_alloc(p, (void**)&p->tile_of, (size_t)M * 4))) return rc;
     p->cap_tile_of = M;
+  }
+  if (p->g.fixed_point && p->rank == 3 && (p->type == NUFFT_HIP_TYPE_1 || p->opts.spread_only)) {
+    const int64_t need_s = (int64_t)cstats_floats(M / std::max(1, p->nitems), p->batch_size * std::max(1, p->nitems));
+    if (need_s > p->cap_cstats) {
+      if ((rc = sync_before_regrow(p))) return rc;
+      dev_free(p, p->cstats);
+      p->cstats = nullptr;
+      p->cap_cstats = 0;
+      if ((rc = dev_alloc(p, (void**)&p->cstats, sizeof(float) * (size_t)need_s))) return rc;
+      p->cap_cstats = need_s;
+    }
   }
   if (p->g.fx_patch && (p->type == NUFFT_HIP_TYPE_1 || p->opts.spread_only)) {
     const int64_t need_b = (int64_t)subproblem_grid_bound(p->g, M) + 1;
@@ -713,6 +724,8 @@ SortedPoints<T> sorted_view(nufft_hip_plan p) {
   sp.tile_start = p->tile_start;
   sp.sub_start = p->sub_start;
   sp.cstats = p->cstats;
+  sp.cstats_slots = p->batch_size * std::max(1, p->nitems);
+  sp.cstats_blocks = p->cstats ? cstats_blocks(p->M, sp.cstats_slots) : 0;
   sp.sub_bound = p->sub_bound;
   return sp;
 }

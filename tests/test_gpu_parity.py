@@ -2104,6 +2104,166 @@ def test_framework_allocator_and_workspace_lease(tfft):
   lib.nufft_hip_op_clear_cache()
 
 
+def _op_compute_with_torch_allocator(lib, op_type, ttype, src, pts, grid, tol, out, tuning=0):
+  """nufft_hip_op_compute_ex with a torch-backed nufft_hip_allocator (what the TF glue does with allocate_temp,
+  csrc/tf_glue/nufft_tf_ops.cc). Returns (log of request sizes, buffers still held after the call)."""
+  import ctypes
+  import torch
+  from tensorflow_nufft import _lib
+  live, log = {}, []
+
+  def alloc(nbytes, user):
+    t = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device='cuda')
+    p = (t.data_ptr() + 255) & ~255
+    live[p] = t
+    log.append(int(nbytes))
+    return p
+
+  def free(ptr, user):
+    del live[ptr]
+
+  a = _lib.Allocator(_lib.ALLOC_FN(alloc), _lib.FREE_FN(free), None)
+  d = _lib.OpDesc()
+  d.op_type, d.transform_type, d.fft_direction, d.tol = op_type, 1 if ttype == 'type_1' else 2, -1, tol
+  d.precision = 4 if src.dtype == torch.complex64 else 8
+  lib.nufft_hip_default_options(ctypes.byref(d.options))
+  d.options.tuning = tuning
+  d.source_ndim, d.points_ndim, d.grid_shape_len = src.dim(), pts.dim(), len(grid)
+  for i, s in enumerate(src.shape): d.source_shape[i] = s
+  for i, s in enumerate(pts.shape): d.points_shape[i] = s
+  for i, s in enumerate(grid): d.grid_shape[i] = s
+  err = ctypes.create_string_buffer(512)
+  stream = torch.cuda.current_stream().cuda_stream
+  rc = lib.nufft_hip_op_compute_ex(ctypes.byref(d), src.data_ptr(), pts.data_ptr(), out.data_ptr(),
+                                   ctypes.c_void_p(stream), ctypes.byref(a), err, 512)
+  assert rc == 0, err.value
+  torch.cuda.synchronize()
+  return log, dict(live)
+
+
+@pytest.mark.parametrize('case', ['config4 geometry type 1 (two-level sort, dense fixed point)',
+                                  'config4 geometry type 2 (two-level sort, 3-D cell sort)',
+                                  '3-D default tolerance type 1 (two-level sort, bounds, fixed point w = 8)',
+                                  'config5 batch (grouped multi-set plans)',
+                                  'w = 11 double 3-D'])
+def test_framework_allocator_on_the_large_workspaces(tfft, case):
+  # (r03 verdict) The TF-facing allocator path -- the ONLY path csrc/tf_glue/nufft_tf_ops.cc uses -- on the
+  # workspaces rounds 3 and 4 added: level-1 records / piece tables / staging of the two-level sort, the 3-D cell
+  # sort's second record buffer, grouped multi-set plans, the wide fp64 kernels, the r04 subproblem bounds and
+  # strength statistics. Every buffer must come from the callbacks and be handed back before the call returns, the
+  # cached plan must keep none, and the result must equal the internal-workspace path.
+  import torch
+  from tensorflow_nufft import _lib
+  from tensorflow_nufft._lib import TUNE
+  lib = _lib.lib()
+  g = torch.Generator(device='cuda').manual_seed(41)
+
+  def rnd_c(shape, dt=torch.float32):
+    return torch.complex(torch.rand(shape, generator=g, device='cuda', dtype=dt) - .5, torch.rand(shape, generator=g, device='cuda', dtype=dt) - .5)
+
+  tuning, bar = 0, 1e-6
+  if case.startswith('config4 geometry type 1'):
+    grid, M, tol, ttype = [256, 256, 256], 3_000_000, 1e-4, 'type_1'
+    pts = (torch.rand((M, 3), generator=g, device='cuda') * 2 - 1) * np.pi
+    src = rnd_c([M])
+    bar = 3e-6          # (fixed-point accumulation: the tiles' sums reach the grid in another order)
+  elif case.startswith('config4 geometry type 2'):
+    grid, M, tol, ttype = [256, 256, 256], 3_000_000, 1e-4, 'type_2'
+    pts = (torch.rand((M, 3), generator=g, device='cuda') * 2 - 1) * np.pi
+    src = rnd_c(grid)
+    tuning = TUNE['CELLSORT3D_ON']
+  elif case.startswith('3-D default tolerance'):
+    grid, M, tol, ttype = [256, 256, 256], 3_000_000, 1e-6, 'type_1'
+    pts = (torch.rand((M, 3), generator=g, device='cuda') * 2 - 1) * np.pi
+    pts[: M // 8] = 0.4 + 0.01 * pts[: M // 8]          # a crowd: subproblems left to the fp64 planes
+    src = rnd_c([M])
+  elif case.startswith('config5'):
+    grid, M, tol, ttype = [512, 512], 1_000_000, 1e-6, 'type_1'
+    pts = (torch.rand((32, M, 2), generator=g, device='cuda') * 2 - 1) * np.pi
+    src = rnd_c([32, M])
+  else:
+    grid, M, tol, ttype = [48, 64, 40], 400_000, 1e-9, 'type_1'
+    pts = (torch.rand((M, 3), generator=g, device='cuda', dtype=torch.float64) * 2 - 1) * np.pi
+    src = rnd_c([M], torch.float64)
+  lib.nufft_hip_op_clear_cache()
+  opts = tfft.Options()
+  opts._internal = {'tuning': tuning}
+  ref = tfft.nufft(src, pts, grid_shape=grid if ttype == 'type_1' else None, transform_type=ttype, tol=tol, options=opts)
+  lib.nufft_hip_op_clear_cache()   # (that call cached plans with internal workspace)
+  out = torch.empty_like(ref)
+  for rep in range(2):
+    out.zero_()
+    log, held = _op_compute_with_torch_allocator(lib, 0, ttype, src, pts, grid if ttype == 'type_1' else [], tol, out, tuning)
+    assert not held, f'{len(held)} buffers not handed back'
+    assert len(log) >= 5, log
+    err = float((out - ref).abs().pow(2).sum().sqrt() / ref.abs().pow(2).sum().sqrt())
+    assert err < bar, (case, rep, err)
+    assert lib.nufft_hip_op_cache_bytes() == 0            # the cached plan holds no workspace
+  if 'two-level' in case:
+    assert max(log) >= 16 * M                             # the record buffers came through the callbacks
+  lib.nufft_hip_op_clear_cache()
+
+
+_EFENCE_CHILD_R04 = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+import tensorflow_nufft as tfft
+from tensorflow_nufft._lib import TUNE
+g = torch.Generator(device='cuda').manual_seed(9)
+def rnd_c(shape, dt=torch.float32):
+  return torch.complex(torch.rand(shape, generator=g, device='cuda', dtype=dt) - .5, torch.rand(shape, generator=g, device='cuda', dtype=dt) - .5)
+n = 0
+# r03 / r04 workspaces: the two-level sort (64-multiple 3-D fine grids, >= 1.5 * 2^20 points; forced on a smaller
+# tile set too), the dense fixed-point spreader with 32-byte fused records (ranked-scatter path), the 3-D cell sort,
+# the w = 7 / 8 fixed-point kernels with their bounds, strength statistics and a crowd on the fp64 planes,
+# grouped multi-set plans, a w = 11 double plan
+cases = (
+  ('type_1', [128, 128, 128], 1_700_000, 1e-4, torch.complex64, TUNE['SORT2_ON'], 1),
+  ('type_2', [128, 128, 128], 1_700_000, 1e-4, torch.complex64, TUNE['SORT2_ON'] | TUNE['CELLSORT3D_ON'], 1),
+  ('type_1', [128, 256, 192], 1_700_000, 1e-4, torch.complex64, TUNE['SORT2_OFF'], 1),      # 36864 tiles: ranked scatter, fused records
+  ('type_1', [128, 128, 128], 1_700_000, 1e-6, torch.complex64, TUNE['SORT2_ON'], 1),      # w = 8 fixed point behind the two-level sort
+  ('type_1', [64, 64, 96], 500_000, 1e-5, torch.complex64, 0, 1),                          # w = 7
+  ('type_1', [64, 64, 64], 150_000, 1e-6, torch.complex64, 0, 3),                          # w = 8, three point sets
+  ('type_1', [512, 512], 200_000, 1e-6, torch.complex64, 0, 4),                            # grouped multi-set plan (config 5's shape)
+  ('type_1', [24, 32, 20], 60_000, 1e-9, torch.complex128, 0, 1),                          # w = 11 double
+)
+for ttype, grid, M, tol, cdt, tune, K in cases:
+  rank = len(grid)
+  rdt = torch.float32 if cdt == torch.complex64 else torch.float64
+  pts = (torch.rand((K, M, rank), generator=g, device='cuda', dtype=rdt) * 2 - 1) * np.pi
+  if tol == 1e-6 and rank == 3: pts[:, : M // 10] = 0.3 + 0.01 * pts[:, : M // 10]          # a crowd for the fp64-plane fallback
+  shape = [K, M] if ttype == 'type_1' else [K] + grid
+  src = rnd_c(shape, rdt)
+  plan = tfft.Plan(ttype, grid, 'forward', tol=tol, dtype=cdt, num_point_sets=K, tuning=tune)
+  p_in, s_in = (pts[0], src[0]) if K == 1 else (pts, src)
+  plan.set_points(p_in)
+  outs = [plan.execute(s_in) for _ in range(2)]
+  outs.append(plan.execute_with_points(p_in, s_in))
+  torch.cuda.synchronize()
+  for o in outs[1:]:
+    assert float((o - outs[0]).abs().max()) <= 1e-4 * float(outs[0].abs().max()), (grid, ttype, tol)
+  if ttype == 'type_1' and tol <= 1e-5 and rank == 3:
+    b = plan.sub_bounds() if plan.sort_path() >= 0 else None
+  plan.close()
+  n += 1
+print('PLANS', n)
+'''
+
+
+def test_r04_workspaces_under_electric_fence():
+  # The standing fence test for what rounds 3 and 4 added (r03 verdict: the two-level sort had only a one-off run):
+  # two-level sort, 32-byte fused 3-D records, 3-D cell sort, w = 7 / 8 fixed point with bounds / statistics / fp64
+  # fallback, grouped multi-set plans -- every plan buffer ends at an unmapped page.
+  import os
+  import subprocess
+  import sys
+  from conftest import PKG, ROOT
+  env = dict(os.environ, NUFFT_HIP_DEBUG_EFENCE='1')
+  r = subprocess.run([sys.executable, '-c', _EFENCE_CHILD_R04, ROOT, PKG], env=env, capture_output=True, text=True, timeout=1200)
+  assert r.returncode == 0, r.stderr[-2000:]
+  assert r.stdout.strip().splitlines()[-1] == 'PLANS 8', r.stdout[-500:]
+
+
 def test_plan_cache_is_byte_capped(tfft):
   import torch
   lib = tfft._lib.lib()
