@@ -571,7 +571,7 @@ def run_config2(args, dev, dist, world, rank):
           'algorithmic_bytes': algo, 'kernel_ms': round(spread_ms, 4),
           'lds': lds_stats,
           'note': 'algorithmic bytes = M (4 d + 8) + 8 nf^d (SURVEY.md 8d). The kernel is bound by the LDS '
-                  'pipe and its per-tile phases, not by HBM (DESIGN.md section 4): roofline.lds is the bound '
+                  'pipe and its per-tile phases, not by HBM (EXPERIMENTS.md section 4): roofline.lds is the bound '
                   'that tracks it.',
       },
   }

@@ -23,11 +23,11 @@
 //    lane needs kx[x] (re c, im c), ky[y'], ky[y' + YB], kz[z'], kz[z' + ZB] -- three ds_read_b128 per
 //    point pair; no v_readlane broadcasts in the loop except the point's tile offset.
 //
-// What bounds it (profiles/r03_pmc_cfg4*.txt): the VGPR -> LDS data path, 2 cycles per source
+// What bounds it (EXPERIMENTS.md section 4b, profiles/r03_pmc_cfg4*.txt): the VGPR -> LDS data path, 2 cycles per source
 // dword of an LDS write or atomic: 4 x 7.0 (ds_add_u64) + 4.5 (12 ds_write_b64 per 16 staged points) = 33 cycles per
 // point and CU at W = 6 (measured main loop: 30 with two workgroups per CU), against ~12 VALU instructions.
 //
-// Accumulation format (unchanged from r01/r02): one 64-bit integer per fine cell
+// Accumulation format (unchanged from r01/r02, EXPERIMENTS.md section 4): one 64-bit integer per fine cell
 // holding (re, im) as two signed 32-bit fields in units of `step`, chosen per subproblem so that no
 // cell can overflow (sum of max(|re c|, |im c|) of the subproblem's strengths <= 2^31 steps) and no
 // single contribution leaves the exact range of the FMA conversion (|n| < 2^22; a dominant strength is converted

@@ -86,7 +86,7 @@ struct alignas(16) FusedRec {
 // 3-D float counterpart (fixed-point plans on the ranked-scatter sort path, nufft_dense3.hip): the 16-byte
 // record (index kept: the fp64-plane launches for crowded tiles still gather through it) followed by the
 // strength, padded to 32 bytes -- ONE scattered 32-byte store per point in the sort (scattered stores are bound
-// by transactions, not bytes: DESIGN.md section 5), and the spread kernel gathers nothing (the gather of 8-byte
+// by transactions, not bytes: EXPERIMENTS.md section 5), and the spread kernel gathers nothing (the gather of 8-byte
 // strengths through the sort permutation cost a 64-byte sector per point, twice: profiles/r03_pmc_cfg4.txt).
 struct alignas(32) FusedRec3 {
   Rec<float> r;

@@ -15,7 +15,7 @@
 // search in a scanned array, no host sync) and the wavefront-per-point
 // scatter are specific to this build. Wavefront = 64 lanes throughout.
 //
-// Map of this file (DESIGN.md sections 3-5 have the measurements). Kernels for widths 9-16 live in
+// Map of this file (EXPERIMENTS.md sections 3-5 have the measurements). Kernels for widths 9-16 live in
 // nufft_wide.hip, the 1-D interpolation in nufft_line.hip, the pruned FFT passes in nufft_fft.hip; the
 // device helpers they share (record decoding, RowWalk, locate_subproblem, LDS / global adds) in
 // nufft_device.h.
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(kSortBlock, NUFFT_SORT_MIN_WAVES) void scatter_lds_
 // --- path A, staged scatter (at most kStagedMaxTiles tiles per point set: 2-D type-2 plans
 // with 64 x 64 tiles, batches of 512^2-sized items, small grids). Scattered 16-byte stores are
 // bound by write TRANSACTIONS, and records of one (workgroup, tile) run that arrive at
-// different times are separate transactions. Here a workgroup takes its
+// different times are separate transactions (EXPERIMENTS.md section 5). Here a workgroup takes its
 // points kStagedChunk at a time, orders the chunk by tile in LDS (counting sort: returning LDS
 // atomics for the ranks, a 1024-entry scan) and writes every tile's records of the chunk with
 // CONSECUTIVE LANES: ~8 records = 128 bytes per store group at 1024 tiles.
@@ -740,7 +740,7 @@ __global__ __launch_bounds__(256) void scatter_ranked_kernel(Geom g, PointsIn in
 // --- path S (two levels; 3-D float plans whose tiles are numbered by super-tiles, Geom::sup_shift).
 // The one-pass scatters above write every record to a random place: one 32-byte write transaction per
 // record, ~3e10 per second whatever the record size, and the 16-bit path adds a random 4-byte read of its
-// [workgroup][tile] prefix table per point (a 64-byte sector each). Here the points go
+// [workgroup][tile] prefix table per point (a 64-byte sector each; EXPERIMENTS.md section 5). Here the points go
 // to their super-tile first (64^3 fine cells; <= 1024 destinations, so a workgroup's 8192-point pass writes
 // ~16 records = 256 bytes per destination with consecutive lanes), and then every <= 4096-record piece of a
 // super-tile is ordered by tile inside it (<= 256 keys: segments of ~32-64 records). Neither level stages
@@ -1451,7 +1451,7 @@ constexpr int kGroupBlk = 36;   // staging words per block of 4 points (8 x 4 + 
 template <int CH> constexpr int kGroupStageWave = 3 * (CH / 4) * kGroupBlk;   // words per wave (kx, ky re, ky im)
 // FUSED: the records are FusedRec (strength inside, no index): no gather at all.
 // (r03 measured this kernel on 64 x 64 tiles -- 82 KB of planes, 4096 start cells, one workgroup per CU -- so that the
-// sort becomes ONE staged pass: scatter 161 -> 97 us, spread 283 -> 397 us at config 2, a net loss)
+// sort becomes ONE staged pass: scatter 161 -> 97 us, spread 283 -> 397 us at config 2, a net loss; EXPERIMENTS.md section 5.)
 template <typename T, int W, int NW, int CH, bool PRE, bool FUSED = false>
 __global__ __launch_bounds__(NW * 64) void spread_2d_w8_group_kernel(
     Geom g, SortedPoints<T> sp, const T* __restrict__ horner, const T* __restrict__ c,

@@ -1072,7 +1072,7 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
   // (w <= 6): fewer halo cells per point (r01: 22.7 -> 21.2 ms at M = 1e8).
   // 2-D float type-2 (and interp-only) plans: 64 x 64. Their LDS tile is single-precision
   // complex (71^2 x 8 B = 40 KB), and four times fewer tiles make the (workgroup, tile) runs
-  // of the scatter four times longer (the scatter is transaction bound).
+  // of the scatter four times longer (EXPERIMENTS.md section 5: the scatter is transaction bound).
   const bool t2_big = type == NUFFT_HIP_TYPE_2 && rank == 2 && precision == NUFFT_HIP_F32 && w <= 8 &&
                       p->opts.spread_method == NUFFT_HIP_METHOD_AUTO && p->opts.tile_dims[0] == 0 &&
                       p->opts.tile_dims[1] == 0 && p->opts.max_subproblem_size <= 0 &&
@@ -1240,9 +1240,10 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
     return fail(NUFFT_HIP_INVALID_ARGUMENT,
                 "lds_accumulate = 2 (fixed point) needs the 3-D float wavefront method with kernel width <= 8");
   }
-  // The output error the quantisation adds is ~ 11 (step / largest strength) = 11 B / 2^31 (measured: 2.4e-6 at a
-  // step of 2^-22 largest strengths); a subproblem may spend 0.3 of the width's tolerance 10^(2 - w) on it.
-  g.fx_bound_limit = (float)(0.3 * std::pow(10.0, 2 - w) * 2147483648.0 / 11.5);
+  // The output error the quantisation adds is <= ~3.5e-9 B for uniform strengths (measured r04 at w = 8: 0.49e-7 in
+  // quadrature at a mean bound of 14, 0.61e-7 at 28; r02 / r03: 2.4e-6 at a step of 2^-22 largest strengths = B of
+  // 512); a subproblem may spend 0.28 of the width's tolerance 10^(2 - w) on it: B <= 80 at w = 8.
+  g.fx_bound_limit = (float)(0.28 * std::pow(10.0, 2 - w) / 3.5e-9);
   if (g.fx_patch) {
     // per-tap maxima of the fitted polynomials over z in [-1, 1] (sampled; margins for the sampling, the float
     // evaluation and the products)
@@ -1259,7 +1260,7 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
     }
   }
   // fp64 planes in 3-D float at tile depth 4 (w = 8, or w <= 7 with lds_accumulate = 1):
-  // one plane per launch, so that two workgroups share a CU
+  // one plane per launch, so that two workgroups share a CU (EXPERIMENTS.md section 4)
   g.split_reim = (method == NUFFT_HIP_METHOD_TILE_WAVE && rank == 3 && precision == NUFFT_HIP_F32 &&
                   !g.fixed_point && (g.tile[2] == 4 || (g.tile[2] == 8 && w == 8))) ? 1 : 0;
   if (method == NUFFT_HIP_METHOD_TILE_WAVE)
@@ -1272,8 +1273,9 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
   if (g.wide && auto_sub && rank == 3) g.max_sub = 1024;   // (hundreds of LDS atomics per point: keep workgroups short)
   const bool spreads = type == NUFFT_HIP_TYPE_1 || p->opts.spread_only;
   if (g.fixed_point && w > 6 && !g.fx_patch) g.max_sub = std::min(g.max_sub, 512);
-  // w = 8: 1536 points on 2048 cells keep the bound of a uniform subproblem at 37-45 of the 56 tol 1e-6 allows
-  if (g.fx_patch && w == 8 && auto_sub && spreads) g.max_sub = 1536;
+  // w = 8: 2560 points on 2048 cells keep the bound of a uniform subproblem at 55-65 of the 80 tol 1e-6 allows
+  // (and tiles of config 4's density, 1526 points on average, in ONE subproblem: a cap of 1536 split 40 % of them)
+  if (g.fx_patch && w == 8 && auto_sub && spreads) g.max_sub = 2560;
   g.fx_max_subs = 16;
   p->lds_bytes = spread_lds_bytes(g, method, precision);
   if (p->lds_bytes > 160 * 1024 || interp_lds_bytes(g, method, precision) > 160 * 1024) {

@@ -14,7 +14,7 @@
 // stride is 8 mod 32 for four 8-cell rows).
 //
 // Accumulation is fp64 in LDS for both precisions (ds_add_f32 is 22x slower on this
-// chip). 3-D runs one launch per component (one fp64 plane of
+// chip, EXPERIMENTS.md section 4). 3-D runs one launch per component (one fp64 plane of
 // 45-85 KB in LDS), 2-D both in one launch (2 x 18 KB).
 //
 // Kernel values: CH points of a wave's share at a time, lane = (point, dimension)

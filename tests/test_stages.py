@@ -62,7 +62,7 @@ def test_plan_kernel_matches_oracle_formula(w):
   ours = plan.eval_kernel(x1) * np.exp(plan.info().beta)
   plan.close()
   ref = oracle.eval_kernel(x1, w=w, kerevalmeth=0)
-  # fit plateau ~5e-(w+1) of the peak
+  # fit plateau ~5e-(w+1) of the peak (EXPERIMENTS.md section 1)
   assert np.abs(ours - ref).max() / np.abs(ref).max() < 10.0 ** (-w) * 30 + 1e-13
 
 

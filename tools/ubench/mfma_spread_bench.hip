@@ -3,7 +3,7 @@
 // synthetic cell-sorted points. What it measures: cycles per point and CU of the accumulate phase alone -- operands
 // built from LDS-staged kernel values (8 per point and dimension, as spread_2d_w8_group_kernel stages them) with
 // lane-indexed, window-masked reads, then one MFMA per (4 points, block, component) into wave-private accumulators --
-// against the 13 cycles per point and CU of the LDS-atomic form. Not measured: the kernel
+// against the 13 cycles per point and CU of the LDS-atomic form (EXPERIMENTS.md section 4). Not measured: the kernel
 // evaluation (same as today), the in-LDS sort by block, the end-of-tile reduction of the wave-private accumulators
 // into the tile, and the periodic fp64 flush that fp32 accumulators would need on crowded tiles.
 // Geometry: a wave works on points whose stencils start in one 16 x 16 block; an 8 x 8 stencil then meets 1, 2 or 4
