@@ -117,7 +117,10 @@ enum {
   NUFFT_HIP_TUNE_JOINT_ON = 1 << 13,
   NUFFT_HIP_TUNE_STAGED_OFF = 1 << 14,     /* staged scatter (<= 1024 tiles per point set): never / always */
   NUFFT_HIP_TUNE_STAGED_ON = 1 << 15,
-  NUFFT_HIP_TUNE_SORT2_OFF = 1 << 16,      /* 3-D float: two-level sort (64^3-cell super-tiles first): never / wherever it exists */
+  NUFFT_HIP_TUNE_SORT2_OFF = 1 << 16,      /* 3-D float: two-level sort (64^3-cell super-tiles first): never / wherever it exists.
+                                              Its level-1 records keep the Horner argument to 2^-25 (the one-level sorts: 2^-27),
+                                              so switching it moves a point by up to 1.5e-8 of a fine cell -- below what a float
+                                              argument resolves near |z| = 1 (6e-8), but not bit-identical */
   NUFFT_HIP_TUNE_SORT2_ON = 1 << 17,
   NUFFT_HIP_TUNE_FXPATCH_OFF = 1 << 18,    /* 3-D float w = 7, 8: the r03 kernels (fp64 planes at w = 8; w = 7 fixed point on
                                               depth-4 tiles, 512-point subproblems) instead of spread_patch3_kernel */

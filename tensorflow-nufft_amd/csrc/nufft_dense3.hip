@@ -269,7 +269,10 @@ __global__ __launch_bounds__(kDenseNW * 64) void spread_dense3_kernel(
   // (cstats_kernel, one streaming pass before this launch): unless one strength dominates (largest > 8 x the mean)
   // the subproblem's sum is bounded by its point COUNT x the largest strength and no pass over its own strengths --
   // a second random gather of every c[idx], r03: 16.6 % of a workgroup's life at config 4 -- is needed.
-  const float top_g = sp.cstats[2 * slot], sum_g = sp.cstats[2 * slot + 1];
+  // (a NaN strength makes the slot's sum NaN -- fmaxf would drop it from the maximum -- and then the step, i.e. every
+  // cell this launch writes: non-finite input gives non-finite output, as it does on the floating-point paths)
+  const float sum_g = sp.cstats[2 * slot + 1];
+  const float top_g = sum_g == sum_g ? sp.cstats[2 * slot] : sum_g;
   const bool own_pass = top_g * (float)c_stride > 8.f * sum_g;   // (workgroup-uniform)
   float part = 0.f, big = 0.f;
   if (own_pass) {
@@ -308,7 +311,8 @@ __global__ __launch_bounds__(kDenseNW * 64) void spread_dense3_kernel(
   // few strengths above 2^22 steps are added behind the loop with the exact conversion (v_cvt, any |n| < 2^31).
   const float s_sum = bound * amp / room;
   const bool skewed = top * (float)npt > 8.f * bound;
-  const float step = fmaxf(s_sum, (skewed ? 2.f * bound / (float)npt : top) * amp * (1.f / 4194000.f));
+  float step = fmaxf(s_sum, (skewed ? 2.f * bound / (float)npt : top) * amp * (1.f / 4194000.f));
+  if (!(top == top) || !(bound == bound)) step = top + bound;   // NaN strengths (fmaxf would drop them)
   const float pre = step > 0.f ? scale / step : 0.f;
   const float big_limit = 4194000.f / g.fx_headroom;   // |c| in steps above which a point waits for the exact pass
 
@@ -596,7 +600,8 @@ __global__ __launch_bounds__(kPatchNW * 64) void spread_patch3_kernel(
   for (int i = tid; i < C::plane_elems; i += NW * 64) plane[i] = 0ull;
 
   // step of the fixed-point grid (see the header comment)
-  const float top_g = sp.cstats[2 * slot], sum_g = sp.cstats[2 * slot + 1];
+  const float sum_g = sp.cstats[2 * slot + 1];
+  const float top_g = sum_g == sum_g ? sp.cstats[2 * slot] : sum_g;   // (NaN strengths: see spread_dense3_kernel)
   const bool skewed = top_g * (float)c_stride > 8.f * sum_g;
   float top = top_g, sum = 3.0e38f;
   if (skewed) {   // (workgroup-uniform) one strength dominates the transform: this subproblem's own strengths decide
@@ -621,7 +626,8 @@ __global__ __launch_bounds__(kPatchNW * 64) void spread_patch3_kernel(
   const float amp = fabsf(scale) * g.fx_headroom;
   const float room = 2147483000.f - (float)npt;     // 2^31 minus one step of rounding per contribution
   // (no finer than top 2^-29: every contribution stays below 2^29 steps)
-  const float step = fmaxf(fminf(sum, top * bound_b), top * 1.8626451e-9f * room) * amp / room;
+  float step = fmaxf(fminf(sum, top * bound_b), top * 1.8626451e-9f * room) * amp / room;
+  if (!(top == top) || !(sum == sum)) step = top + sum;   // NaN strengths (fminf / fmaxf would drop them)
   const float pre = step > 0.f ? scale / step : 0.f;
   __syncthreads();
   NUFFT_PHASE3(3);

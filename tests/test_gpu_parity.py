@@ -812,6 +812,24 @@ def test_3d_w8_fixed_point_clustered_and_skewed(tfft):
   assert rel_l2(out, ref) < 2e-6, rel_l2(out, ref)
 
 
+@pytest.mark.parametrize('tol', [1e-4, 1e-6])
+def test_3d_fixed_point_paths_do_not_swallow_non_finite_strengths(tfft, tol):
+  # The packed fixed-point spreaders convert contributions to integers; a NaN or Inf strength must not turn into a
+  # silently dropped point (v_cvt of NaN is 0): the launch's strength statistics carry it into the step and the
+  # output is non-finite, as on the floating-point paths and in the reference.
+  rng = np.random.default_rng(5)
+  grid = [32, 48, 32]
+  M = 60_000
+  pts = rng.uniform(-np.pi, np.pi, (M, 3)).astype(np.float32)
+  for bad in (np.nan, np.inf):
+    c = (rng.uniform(-.5, .5, M) + 1j * rng.uniform(-.5, .5, M)).astype(np.complex64)
+    c[1234] = bad
+    out = tfft.nufft(_dev(c), _dev(pts), grid_shape=grid, transform_type='type_1', tol=tol).cpu().numpy()
+    assert not np.isfinite(out).all(), (tol, bad)
+  c = (rng.uniform(-.5, .5, M) + 1j * rng.uniform(-.5, .5, M)).astype(np.complex64)
+  assert np.isfinite(tfft.nufft(_dev(c), _dev(pts), grid_shape=grid, transform_type='type_1', tol=tol).cpu().numpy()).all()
+
+
 def test_radial_trajectories_total_parity_at_scale(tfft):
   # Non-uniform densities at scale, whole output against the fp64 oracle: a 2-D radial trajectory in acquisition
   # order (config 2's size: 10000 spokes of 1000 samples, density ~ 1 / r: crowded centre tiles, subproblem
