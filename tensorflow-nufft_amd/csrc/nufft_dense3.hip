@@ -281,7 +281,7 @@ __global__ __launch_bounds__(kDenseNW * 64) void spread_dense3_kernel(
       if constexpr (FUSED) cv = *reinterpret_cast<const float2*>(&rec3[j].re);
       else cv = cc[sp.rec[j].idx];
       const float m = fmaxf(fabsf(cv.x), fabsf(cv.y));
-      part += m;
+      part += fmaf(0.f, cv.x + cv.y, m);   // (NaN / Inf components make the sum NaN)
       big = fmaxf(big, m);
     }
 #pragma unroll
@@ -609,7 +609,7 @@ __global__ __launch_bounds__(kPatchNW * 64) void spread_patch3_kernel(
     for (int j = p0 + tid; j < p1; j += NW * 64) {
       const float2 cv = cc[sp.rec[j].idx];
       const float m = fmaxf(fabsf(cv.x), fabsf(cv.y));
-      part += m;
+      part += fmaf(0.f, cv.x + cv.y, m);   // (NaN / Inf components make the sum NaN)
       big = fmaxf(big, m);
     }
 #pragma unroll
@@ -747,7 +747,7 @@ template <int W, int TZ>
 __global__ __launch_bounds__(kBoundThreads) void bound3_kernel(Geom g, const Rec<float>* __restrict__ rec, int rec_stride,
                                                               const int32_t* __restrict__ tile_start,
                                                               const int32_t* __restrict__ sub_start, TapMax taps,
-                                                              float* __restrict__ sub_bound, unsigned nsub_bound) {
+                                                              float* __restrict__ sub_bound, int* __restrict__ fb_list) {
   // count rows of 17 words: the x pass reads one LINE per lane, and a lane stride of 16 words would put a wave on 4 banks
   constexpr int T = kDenseTile, L = T + W - 1, CP = T + 1, LZ = TZ + W - 1, NT = kBoundThreads;
   __shared__ uint32_t cnt[TZ * T * CP];
@@ -760,7 +760,7 @@ __global__ __launch_bounds__(kBoundThreads) void bound3_kernel(Geom g, const Rec
   if (nsub > g.fx_max_subs) {   // (every further subproblem of a tile adds its share of quantisation noise)
     if (tid == 0) {
       sub_bound[blockIdx.x] = -1.f;
-      atomicAdd(reinterpret_cast<int*>(sub_bound + nsub_bound), 1);
+      fb_list[1 + atomicAdd(&fb_list[0], 1)] = (int)blockIdx.x;
     }
     return;
   }
@@ -836,7 +836,7 @@ __global__ __launch_bounds__(kBoundThreads) void bound3_kernel(Geom g, const Rec
     m *= 1.0001f;   // (float sums of non-negative terms)
     if (m > g.fx_bound_limit) {
       sub_bound[blockIdx.x] = -m;
-      atomicAdd(reinterpret_cast<int*>(sub_bound + nsub_bound), 1);
+      fb_list[1 + atomicAdd(&fb_list[0], 1)] = (int)blockIdx.x;
     } else {
       sub_bound[blockIdx.x] = m;
     }
@@ -862,14 +862,14 @@ __global__ __launch_bounds__(256) void cstats_partial_kernel(const float2* __res
     for (int u = 0; u < 8; ++u) {
       const float m = fmaxf(fabsf(v[u].x), fabsf(v[u].y));
       big = fmaxf(big, m);
-      part += m;
+      part += fmaf(0.f, v[u].x + v[u].y, m);   // (m, or NaN when a component is NaN / Inf: fmaxf alone would drop a NaN)
     }
   }
   for (; i < M; i += stride) {
     const float2 v = cc[i];
     const float m = fmaxf(fabsf(v.x), fabsf(v.y));
     big = fmaxf(big, m);
-    part += m;
+    part += fmaf(0.f, v.x + v.y, m);
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -991,12 +991,12 @@ hipError_t launch_spread_patch3(const Geom& g, const SortedPoints<float>& sp, un
   return hipErrorInvalidValue;
 }
 hipError_t launch_bound3(const Geom& g, const Rec<float>* rec, int rec_stride, const int32_t* tile_start, const int32_t* sub_start,
-                         unsigned nsub_bound, const TapMax& taps, float* sub_bound, hipStream_t stream) {
-  hipError_t e = hipMemsetAsync(sub_bound + nsub_bound, 0, sizeof(float), stream);
+                         unsigned nsub_bound, const TapMax& taps, float* sub_bound, int* fb_list, hipStream_t stream) {
+  hipError_t e = hipMemsetAsync(fb_list, 0, sizeof(int), stream);
   if (e != hipSuccess) return e;
   if (nsub_bound == 0) return hipSuccess;
-  if (g.w == 8) bound3_kernel<8, 8><<<nsub_bound, kBoundThreads, 0, stream>>>(g, rec, rec_stride, tile_start, sub_start, taps, sub_bound, nsub_bound);
-  else if (g.w == 7) bound3_kernel<7, 8><<<nsub_bound, kBoundThreads, 0, stream>>>(g, rec, rec_stride, tile_start, sub_start, taps, sub_bound, nsub_bound);
+  if (g.w == 8) bound3_kernel<8, 8><<<nsub_bound, kBoundThreads, 0, stream>>>(g, rec, rec_stride, tile_start, sub_start, taps, sub_bound, fb_list);
+  else if (g.w == 7) bound3_kernel<7, 8><<<nsub_bound, kBoundThreads, 0, stream>>>(g, rec, rec_stride, tile_start, sub_start, taps, sub_bound, fb_list);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }

@@ -107,7 +107,9 @@ struct SortedPoints {
   int cstats_blocks;          // this many workgroups per slot (fixed by the plan from its largest slot count,
   int cstats_slots;           // cstats_slots: the partial pairs start behind that many result pairs)
   const float* sub_bound;     // Geom::fx_patch: [subproblem grid + 1] count-filter bound of every subproblem, negative =
-                              // left to the fp64-plane kernels; the last entry counts those (as an integer)
+                              // left to the fp64-plane kernels
+  const int* fb_list;         // fixed-point plans: fb_list[0] = how many subproblems set_points left to the fp64-plane
+                              // kernels, fb_list[1..] = their launch slots (bound3_kernel / crowded_list_kernel)
 };
 // Tap maxima of the fitted kernel, max over z of |P_t(z)| for every stencil cell t (with the fit's and the float
 // evaluation's margin): what bound3_kernel filters the start-cell counts with
@@ -244,10 +246,12 @@ size_t patch3_lds_bytes(int w);
 hipError_t launch_spread_patch3(const Geom& g, const SortedPoints<float>& sp, unsigned nsub_bound, const float* horner,
                                 const float* c, float* fw, int batch, int64_t c_stride, int64_t fw_stride, float scale,
                                 hipStream_t stream);
-// set_points of such a plan: sub_bound[s] for every subproblem s of the launch grid, sub_bound[nsub_bound] = how many
-// were left to the fp64-plane kernels (zeroed here); rec_stride: bytes between records
+// set_points of such a plan: sub_bound[s] for every subproblem s of the launch grid, fb_list = those left to the
+// fp64-plane kernels (count zeroed here); rec_stride: bytes between records
 hipError_t launch_bound3(const Geom& g, const Rec<float>* rec, int rec_stride, const int32_t* tile_start, const int32_t* sub_start,
-                         unsigned nsub_bound, const TapMax& taps, float* sub_bound, hipStream_t stream);
+                         unsigned nsub_bound, const TapMax& taps, float* sub_bound, int* fb_list, hipStream_t stream);
+// the other fixed-point plans: fb_list from the tiles with more than fx_max_subs subproblems
+hipError_t launch_crowded_list(const Geom& g, const int32_t* sub_start, int* fb_list, hipStream_t stream);
 // strengths of one spread launch: cstats[slot] = {max, sum} of max(|re c|, |im c|) over the slot's M points;
 // the buffer holds cstats_floats(M, slots) floats (the results, then per-workgroup partial pairs)
 hipError_t launch_cstats(const float* c, int64_t M, int slots, int nblk, int max_slots, int64_t c_stride, float* cstats, hipStream_t stream);

@@ -1792,10 +1792,11 @@ __global__ __launch_bounds__(NW * 64) void spread_wave2_kernel(
 // COMP (fp64 planes only): 0 = both components in one launch (two planes); 1 / 2 = only
 // the real / imaginary part (ONE plane, so two workgroups fit a CU; the host launches both).
 template <int W> constexpr int kWave3Pad = (551 - 24 * (15 + W) + 1) > 64 ? ((551 - 24 * (15 + W) + 1 + 7) & ~7) : 64;
-template <typename T, int W, int TZ, int NW, int CH, bool FX, int COMP = 0>
-__global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
-    Geom g, SortedPoints<T> sp, const T* __restrict__ horner, const T* __restrict__ c,
-    T* __restrict__ fw, int64_t c_stride, int64_t fw_stride, T scale) {
+// sub: the subproblem (launch slot) this call works on -- blockIdx.x, or an entry of the fallback list (see the kernel)
+template <typename T, int W, int TZ, int NW, int CH, bool FX, int COMP>
+__device__ __forceinline__ void spread_wave3_body(
+    const Geom& g, const SortedPoints<T>& sp, const T* __restrict__ horner, const T* __restrict__ c,
+    T* __restrict__ fw, int64_t c_stride, int64_t fw_stride, T scale, int sub, bool listed) {
   using T2 = typename Pair<T>::type;
   constexpr int LS = 24, L0 = 16 + W - 1, L1 = 16 + W - 1, L2 = TZ + W - 1;
   constexpr int PS = LS * L1;
@@ -1812,25 +1813,18 @@ __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
   T* stage_all = reinterpret_cast<T*>(pad + PAD);
   constexpr int SW = W <= 6 ? 6 : 8;                                  // staging row length
   float* red = reinterpret_cast<float*>(stage_all + NW * CH * 2 * SW);   // [NW] (FX bound reduction)
-  // (fp64-plane launch behind a fixed-point one: nothing to do unless some tile is crowded -- one scalar load;
-  // plans of spread_patch3_kernel count the subproblems they leave to this kernel behind their bounds)
-  if (!FX && g.fixed_point &&
-      (g.fx_patch ? reinterpret_cast<const int*>(sp.sub_bound)[gridDim.x] == 0 : sp.tile_start[g.ntiles + 1] <= g.fx_max_subs))
-    return;
   // (behind a fused 3-D sort the records are 32-byte FusedRec3: the 16-byte record comes first)
   const int rstride = g.fused ? (int)sizeof(FusedRec3) : (int)sizeof(Rec<T>);
   int tb, p0, p1, slot, nsub;
-  if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1, &slot, &nsub)) return;
+  if (!locate_subproblem(g, sp.tile_start, sp.sub_start, sub, &tb, &p0, &p1, &slot, &nsub)) return;
   // Fixed-point plans: crowded tiles go to the fp64-plane kernels. The quantisation noise of the
   // packed fields is the same in every cell of a subproblem's tile, whatever the cell's kernel
   // weight, and every further subproblem of the tile adds its share: with 600000 coincident points
   // (1172 subproblems in one tile) the transform missed tol = 1e-5 by 9x (8.8e-5 against 1.4e-6 with
   // fp64 planes; r02 soak, seed 45), while up to ~16 subproblems per tile it stays within a third of tol.
-  if (g.fx_patch) {   // (w = 7, 8: the bound kernel of set_points has decided, subproblem by subproblem)
-    if (!(sp.sub_bound[blockIdx.x] < 0.f)) return;
-  } else if (g.fixed_point && (FX ? nsub > g.fx_max_subs : nsub <= g.fx_max_subs)) {
-    return;
-  }
+  // (subproblems that reach this function through the fallback list were chosen by set_points: bound3_kernel /
+  // crowded_list_kernel)
+  if (!listed && g.fixed_point && (FX ? nsub > g.fx_max_subs : nsub <= g.fx_max_subs)) return;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -2003,6 +1997,40 @@ __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
       if (v != (T)0) glb_add(&out[2 * (rowbase + wrap1(o0 + a0, g.nf[0])) + comp], v);
     }
   }
+}
+
+// The kernel: one subproblem per workgroup (blockIdx.x), or -- the fp64-plane launches BEHIND a fixed-point spreader,
+// !FX on a fixed-point plan -- a small persistent grid walking the list of subproblems that set_points left to the
+// fp64 planes (crowded tiles, bounds above the limit). r04: as full-grid launches whose workgroups exit on one scalar
+// load these two launches cost ~75 us each at 85 000 workgroups (GRBM_GUI_ACTIVE), 3 % of the 3-D spread stage, for
+// nothing in the common case; an empty list now costs a few microseconds.
+template <typename T, int W, int TZ, int NW, int CH, bool FX, int COMP = 0>
+__global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
+    Geom g, SortedPoints<T> sp, const T* __restrict__ horner, const T* __restrict__ c,
+    T* __restrict__ fw, int64_t c_stride, int64_t fw_stride, T scale) {
+  if constexpr (!FX) {
+    if (g.fixed_point && sp.fb_list) {
+      const int n = sp.fb_list[0];   // (entries follow the count)
+      for (int it = blockIdx.x; it < n; it += gridDim.x) {
+        spread_wave3_body<T, W, TZ, NW, CH, FX, COMP>(g, sp, horner, c, fw, c_stride, fw_stride, scale, sp.fb_list[1 + it], true);
+        __syncthreads();   // (the next subproblem zeroes the planes this one's write-out reads)
+      }
+      return;
+    }
+  }
+  spread_wave3_body<T, W, TZ, NW, CH, FX, COMP>(g, sp, horner, c, fw, c_stride, fw_stride, scale, (int)blockIdx.x, false);
+}
+
+// Fixed-point plans of the r01-r03 kernels (w <= 6 dense, w = 7 on depth-4 tiles): the subproblems of every tile with more
+// than fx_max_subs of them, as a list for the persistent fp64-plane launches (run in set_points; list[0] = count, zeroed
+// by the launcher)
+__global__ __launch_bounds__(256) void crowded_list_kernel(Geom g, const int32_t* __restrict__ sub_start, int* __restrict__ list) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= g.ntiles) return;
+  const int s0 = sub_start[t], k = sub_start[t + 1] - s0;
+  if (k <= g.fx_max_subs) return;
+  const int base = atomicAdd(&list[0], k);
+  for (int j = 0; j < k; ++j) list[1 + base + j] = s0 + j;
 }
 
 // ---------------- interp: LDS tile, one thread per point, compile-time width
@@ -2759,6 +2787,13 @@ static inline unsigned subproblem_grid(const Geom& g, int64_t M) {
 
 unsigned subproblem_grid_bound(const Geom& g, int64_t M) { return subproblem_grid(g, M); }
 
+hipError_t launch_crowded_list(const Geom& g, const int32_t* sub_start, int* fb_list, hipStream_t stream) {
+  const hipError_t e = hipMemsetAsync(fb_list, 0, sizeof(int), stream);
+  if (e != hipSuccess) return e;
+  crowded_list_kernel<<<(unsigned)((g.ntiles + 255) / 256), 256, 0, stream>>>(g, sub_start, fb_list);
+  return hipGetLastError();
+}
+
 // LDS-free spreader for sparse point sets: below a few points per thousand fine cells the
 // per-tile zero-fill and write-out of the LDS kernels outweigh the per-point global atomics.
 // Crossover measured r02 (profiles/r02_sparse_crossover.txt, spread stage): 3-D 512^3 w = 6
@@ -3010,16 +3045,17 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
   if (e != hipSuccess) return e;                                                                 \
   spread_wave3_kernel<T, WW, TZV, wave3d_nw<T, FXV>(), 32, FXV>                                   \
       <<<grid, wave3d_nw<T, FXV>() * 64, lds_bytes, stream>>>(g, sp, horner, c, fw, c_stride, fw_stride, scale);
+// (fgrid: a persistent grid over the fallback list when the launch runs behind a fixed-point spreader)
 #define NUFFT_LAUNCH_W3S(WW, TZV, CV)                                                            \
   e = ensure_lds(spread_wave3_kernel<T, WW, TZV, 12, 32, false, CV>, lds_bytes);                  \
   if (e != hipSuccess) return e;                                                                 \
   spread_wave3_kernel<T, WW, TZV, 12, 32, false, CV>                                              \
-      <<<grid, 12 * 64, lds_bytes, stream>>>(g, sp, horner, c, fw, c_stride, fw_stride, scale);
+      <<<fgrid, 12 * 64, lds_bytes, stream>>>(g, sp, horner, c, fw, c_stride, fw_stride, scale);
 #define NUFFT_LAUNCH_W3S8(WW, CV)                                                                \
   e = ensure_lds(spread_wave3_kernel<T, WW, 8, 12, 16, false, CV>, lds_bytes);                    \
   if (e != hipSuccess) return e;                                                                 \
   spread_wave3_kernel<T, WW, 8, 12, 16, false, CV>                                                \
-      <<<grid, 12 * 64, lds_bytes, stream>>>(g, sp, horner, c, fw, c_stride, fw_stride, scale);
+      <<<fgrid, 12 * 64, lds_bytes, stream>>>(g, sp, horner, c, fw, c_stride, fw_stride, scale);
 #define NUFFT_CASE_W3(WW)                                                                        \
   case WW:                                                                                       \
     if (g.tile[2] == 8) {                                                                        \
@@ -3070,6 +3106,7 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
       } else { NUFFT_LAUNCH_W3(WW, 4, false) }                                                   \
     } else { return hipErrorInvalidValue; }                                                      \
     break;
+      const dim3 fgrid = (g.fixed_point && sp.fb_list) ? dim3(std::min(grid.x, 2048u), grid.y) : grid;
       switch (g.w) {
         NUFFT_CASE_W3(2) NUFFT_CASE_W3(3) NUFFT_CASE_W3(4) NUFFT_CASE_W3(5)
         NUFFT_CASE_W3(6) NUFFT_CASE_W3(7) NUFFT_CASE_W3(8)

@@ -245,8 +245,10 @@ struct nufft_hip_plan_s {
   int32_t *tile_count = nullptr, *tile_start = nullptr, *sub_start = nullptr, *bad_count = nullptr;
   float* cstats = nullptr;       // 3-D float fixed-point plans: {largest, summed} strength of every slot of a spread launch
   int64_t cap_cstats = 0;        //   (+ the per-workgroup partials of the reduction: sized per point count)
-  float* sub_bound = nullptr;    // Geom::fx_patch: count-filter bound per subproblem (+ 1: how many go to fp64 planes)
+  float* sub_bound = nullptr;    // Geom::fx_patch: count-filter bound per subproblem
   int64_t cap_sub_bound = 0;
+  int* fb_list = nullptr;        // fixed-point 3-D plans: count + launch slots of the subproblems left to the fp64 planes
+  int64_t cap_fb_list = 0;
   TapMax taps = {};              // per-tap maxima of the fitted kernel (bound3_kernel)
   int64_t workspace_bytes = 0;
   bool points_set = false;
@@ -456,12 +458,12 @@ int ensure_fixed_workspace(nufft_hip_plan p) {
 void release_workspace(nufft_hip_plan p) {
   void** bufs[] = {(void**)&p->tile_count, (void**)&p->tile_start, (void**)&p->sub_start, (void**)&p->bad_count,
                    &p->d_fine, &p->fft_work, &p->fft_tmp[0], &p->fft_tmp[1], &p->rec, &p->rec2, (void**)&p->hist, (void**)&p->tile_of,
-                   (void**)&p->rank_of, (void**)&p->cstats, (void**)&p->sub_bound};
+                   (void**)&p->rank_of, (void**)&p->cstats, (void**)&p->sub_bound, (void**)&p->fb_list};
   for (void** b : bufs) {
     dev_free(p, *b);
     *b = nullptr;
   }
-  p->cap = p->cap2 = p->cap_global = p->cap_tile_of = p->cap_sub_bound = p->cap_cstats = 0;
+  p->cap = p->cap2 = p->cap_global = p->cap_tile_of = p->cap_sub_bound = p->cap_cstats = p->cap_fb_list = 0;
   p->hist_elems = 0;
   p->workspace_bytes = 0;
   p->fixed_ws = false;
@@ -585,6 +587,17 @@ int ensure_point_capacity(nufft_hip_plan p, int64_t M, int rec_mult = 1) {
       p->cap_cstats = need_s;
     }
   }
+  if (p->g.fixed_point && p->rank == 3 && (p->type == NUFFT_HIP_TYPE_1 || p->opts.spread_only)) {
+    const int64_t need_l = (int64_t)subproblem_grid_bound(p->g, M) + 1;
+    if (need_l > p->cap_fb_list) {
+      if ((rc = sync_before_regrow(p))) return rc;
+      dev_free(p, p->fb_list);
+      p->fb_list = nullptr;
+      p->cap_fb_list = 0;
+      if ((rc = dev_alloc(p, (void**)&p->fb_list, sizeof(int) * (size_t)need_l))) return rc;
+      p->cap_fb_list = need_l;
+    }
+  }
   if (p->g.fx_patch && (p->type == NUFFT_HIP_TYPE_1 || p->opts.spread_only)) {
     const int64_t need_b = (int64_t)subproblem_grid_bound(p->g, M) + 1;
     if (need_b > p->cap_sub_bound) {
@@ -696,8 +709,12 @@ int set_points_impl(nufft_hip_plan p, int64_t M, const void* x, const void* y, c
     if (p->g.fx_patch && p->sub_bound && Mtot > 0) {
       hook.begin(STAGE_SORT_CELL);
       HIP_TRY(p, launch_bound3(p->g, (const Rec<float>*)p->rec, (int)sizeof(Rec<float>), p->tile_start, p->sub_start,
-                               subproblem_grid_bound(p->g, Mtot), p->taps, p->sub_bound, p->stream));
+                               subproblem_grid_bound(p->g, Mtot), p->taps, p->sub_bound, p->fb_list, p->stream));
       hook.end(STAGE_SORT_CELL);
+    } else if (p->g.fixed_point && p->rank == 3 && p->fb_list) {
+      // the other fixed-point plans: the subproblems of crowded tiles (none can exist below fx_max_subs full subproblems)
+      if (M > (int64_t)p->g.fx_max_subs * p->g.max_sub) HIP_TRY(p, launch_crowded_list(p->g, p->sub_start, p->fb_list, p->stream));
+      else HIP_TRY(p, hipMemsetAsync(p->fb_list, 0, sizeof(int), p->stream));
     }
   }
   if (check) {
@@ -727,6 +744,7 @@ SortedPoints<T> sorted_view(nufft_hip_plan p) {
   sp.cstats_slots = p->batch_size * std::max(1, p->nitems);
   sp.cstats_blocks = p->cstats ? cstats_blocks(p->M, sp.cstats_slots) : 0;
   sp.sub_bound = p->sub_bound;
+  sp.fb_list = p->fb_list;
   return sp;
 }
 

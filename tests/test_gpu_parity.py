@@ -616,6 +616,51 @@ def test_config4_total_parity_at_full_size(tfft):
   assert err <= 1e-4, err
 
 
+def test_3d_default_tolerance_total_parity_at_full_size(tfft):
+  # The 3-D case at the API's default tolerance (tol 1e-6 -> w = 8), the one the reference's own harness times in 3-D
+  # (nufft_ops_test.py:739-740), at config 4's grid: 256^3 modes, M = 3e7 (0.22 points per fine cell) and, denser,
+  # M = 1e8 on the same grid (0.75: bounds near their limit) -- the WHOLE output of the r04 fixed-point kernel against
+  # the fp64 oracle (sigma 2, tol 1e-12). Bar (r03 verdict): 4e-7 (the fp64 planes of r03: 2.4e-7).
+  import time
+  import torch
+  from oracle import oracle
+  for seed, M in ((6, 30_000_000), (7, 100_000_000)):
+    rng = np.random.default_rng(seed)
+    N = 256
+    pts = rng.uniform(-np.pi, np.pi, (M, 3)).astype(np.float32)
+    c = np.empty(M, np.complex64)
+    c.real = rng.uniform(-.5, .5, M)
+    c.imag = rng.uniform(-.5, .5, M)
+    plan = tfft.Plan('type_1', [N, N, N], 'forward', tol=1e-6)
+    assert plan.info().kernel_width == 8
+    out = plan.execute_with_points(_dev(pts), _dev(c)).cpu().numpy()
+    plan.set_points(_dev(pts))
+    b = plan.sub_bounds()
+    plan.close()
+    torch.cuda.empty_cache()
+    t0 = time.time()
+    truth = oracle.nufft(c.astype(np.complex128), pts, [N, N, N], 'type_1', 'forward', tol=1e-12, sigma=2.0)
+    t_truth = time.time() - t0
+    err = rel_l2(out, truth)
+    live = b[b != 0]
+    _note(f'3-D default tolerance (type 1, 256^3, M={M:.0e}, tol 1e-6 -> w = 8, c64), all {N ** 3} outputs: ours-truth {err:.3e}; '
+          f'{live.size} subproblems, bound mean {np.abs(live).mean():.1f} max {np.abs(live).max():.1f}, {int((live < 0).sum())} on fp64 planes; '
+          f'oracle truth {t_truth:.1f} s')
+    assert err <= 4e-7, (M, err)
+    assert (live < 0).sum() == 0
+    del pts, c, out, truth
+
+
+def test_shader_clock_probe(tfft):
+  # nufft_hip_debug_shader_clock_mhz: the clock bench.py prices the LDS roofline at, measured under an LDS-atomic load
+  import ctypes
+  import torch
+  from tensorflow_nufft import _lib
+  mhz = ctypes.c_double(0.0)
+  rc = _lib.lib().nufft_hip_debug_shader_clock_mhz(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), ctypes.byref(mhz))
+  assert rc == 0 and 800.0 < mhz.value < 3000.0, (rc, mhz.value)
+
+
 def test_3d_one_call_sorts_the_strengths_into_32_byte_records(tfft):
   # 3-D float fixed-point plans with more than 16384 tiles (ranked-scatter sort path): the one-call entry writes
   # FusedRec3 records (strength inside) and the dense-lane spreader gathers nothing; a tile holding more than
