@@ -539,6 +539,12 @@ StageHook make_hook(nufft_hip_plan p) {
   return h;
 }
 
+// Most (transform, point set) slots one spread launch of this plan covers: execute passes batch_size transforms,
+// the spread-only entry up to 32768 (spread_interp_impl)
+int spread_slots(nufft_hip_plan p) {
+  return (p->opts.spread_only ? std::min(32768, p->ntransf) : p->batch_size) * std::max(1, p->nitems);
+}
+
 // rec_mult: record slots per point (2 for the 32-byte fused records of 3-D float plans)
 int ensure_point_capacity(nufft_hip_plan p, int64_t M, int rec_mult = 1) {
   int rc = ensure_fixed_workspace(p);
@@ -577,7 +583,7 @@ int ensure_point_capacity(nufft_hip_plan p, int64_t M, int rec_mult = 1) {
     p->cap_tile_of = M;
   }
   if (p->g.fixed_point && p->rank == 3 && (p->type == NUFFT_HIP_TYPE_1 || p->opts.spread_only)) {
-    const int64_t need_s = (int64_t)cstats_floats(M / std::max(1, p->nitems), p->batch_size * std::max(1, p->nitems));
+    const int64_t need_s = (int64_t)cstats_floats(M / std::max(1, p->nitems), spread_slots(p));
     if (need_s > p->cap_cstats) {
       if ((rc = sync_before_regrow(p))) return rc;
       dev_free(p, p->cstats);
@@ -741,7 +747,7 @@ SortedPoints<T> sorted_view(nufft_hip_plan p) {
   sp.tile_start = p->tile_start;
   sp.sub_start = p->sub_start;
   sp.cstats = p->cstats;
-  sp.cstats_slots = p->batch_size * std::max(1, p->nitems);
+  sp.cstats_slots = spread_slots(p);
   sp.cstats_blocks = p->cstats ? cstats_blocks(p->M, sp.cstats_slots) : 0;
   sp.sub_bound = p->sub_bound;
   sp.fb_list = p->fb_list;

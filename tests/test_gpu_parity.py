@@ -875,6 +875,25 @@ def test_3d_fixed_point_paths_do_not_swallow_non_finite_strengths(tfft, tol):
   assert np.isfinite(tfft.nufft(_dev(c), _dev(pts), grid_shape=grid, transform_type='type_1', tol=tol).cpu().numpy()).all()
 
 
+@pytest.mark.parametrize('tol', [1e-4, 1e-6])
+def test_3d_spread_op_with_more_transforms_than_the_plan_batch(tfft, tol):
+  # The spread-only entry passes up to 32768 transforms to ONE spread launch whatever the plan's batch size
+  # (8 on a fine grid of 2^20 cells): the fixed-point kernels' per-slot strength statistics must be sized for that
+  # (r04: they were sized by batch_size). 12 transforms of different scale in one call against one call each.
+  import torch
+  rng = np.random.default_rng(77)
+  grid = [64, 128, 128]
+  M, T = 50_000, 12
+  pts = _dev(rng.uniform(-np.pi, np.pi, (M, 3)).astype(np.float32))
+  c = (rng.uniform(-.5, .5, (T, M)) + 1j * rng.uniform(-.5, .5, (T, M))).astype(np.complex64)
+  c *= (10.0 ** np.arange(T))[:, None].astype(np.float32) * 1e-6
+  out = tfft.spread(_dev(c), pts, grid, tol=tol).cpu().numpy()
+  assert out.shape == (T, 64, 128, 128)
+  for t in (0, 5, 11):
+    one = tfft.spread(_dev(c[t]), pts, grid, tol=tol).cpu().numpy()
+    assert rel_l2(out[t], one) < 2e-6, (t, rel_l2(out[t], one))
+
+
 def test_radial_trajectories_total_parity_at_scale(tfft):
   # Non-uniform densities at scale, whole output against the fp64 oracle: a 2-D radial trajectory in acquisition
   # order (config 2's size: 10000 spokes of 1000 samples, density ~ 1 / r: crowded centre tiles, subproblem
