@@ -555,20 +555,16 @@ hipError_t launch_dense3(const Geom& g, const SortedPoints<float>& sp, const flo
 // columns, conflict free for every point position), (16 + W - 1) rows, (8 + W - 1) planes = 66 KB at W = 8, and
 // 96 bytes of staged kernel values per point, 8 points per wave at a time: 76 KB, two workgroups per CU.
 constexpr int kPatchLS = 24;
-// Tile depth 8: 12 waves, two workgroups per CU. Depth 16 (r04, sparse point sets: the tile + halo write-out is the
-// kernel there, and 23 x 23 x 23 cells per 16 x 16 x 16 tile are 2.97 x the fine grid instead of 3.87 x): 102 KB of plane,
-// ONE workgroup of 16 waves per CU.
-template <int TZ> constexpr int kPatchNWOf = TZ > 8 ? 16 : 12;
+constexpr int kPatchNW = 12;
 template <int W, int TZ, int HALF> struct PatchCfg {
-  static constexpr int NW = kPatchNWOf<TZ>;
   static constexpr int L0 = kDenseTile + W - 1, L1 = kDenseTile + W - 1, L2 = TZ + W - 1;
   static constexpr int LS = kPatchLS, PS = kPatchLS * L1;
   // idle lanes (W = 7: dx = 7 or dy = 7) add 0 at their natural patch address: up to row 22, column 22 of the last
   // plane, i.e. up to 22 * 24 + 22 - PS + 1 elements behind it
   static constexpr int plane_elems = (PS * L2 + 64 + 1) & ~1;
   static constexpr int PAIR_BYTES = 8 * 16 + 8 * 8;      // kx (im c, re c) of two points per 16-byte slot; ky of two points per 8
-  static constexpr size_t stage_bytes = (size_t)NW * (HALF / 2) * PAIR_BYTES;
-  static constexpr size_t lds_bytes = (size_t)plane_elems * 8 + stage_bytes + 2 * NW * sizeof(float) + 64;
+  static constexpr size_t stage_bytes = (size_t)kPatchNW * (HALF / 2) * PAIR_BYTES;
+  static constexpr size_t lds_bytes = (size_t)plane_elems * 8 + stage_bytes + 2 * kPatchNW * sizeof(float) + 64;
 };
 
 __device__ __forceinline__ int cvt_rpi(float x) {   // floor(x + 0.5) in one instruction
@@ -580,11 +576,11 @@ typedef __attribute__((address_space(3))) unsigned long long lds_u64;
 typedef __attribute__((address_space(3))) unsigned char lds_byte;
 
 template <int W, int TZ, int HALF>
-__global__ __launch_bounds__(kPatchNWOf<TZ> * 64) void spread_patch3_kernel(
+__global__ __launch_bounds__(kPatchNW * 64) void spread_patch3_kernel(
     Geom g, SortedPoints<float> sp, const float* __restrict__ horner, const float* __restrict__ c,
     float* __restrict__ fw, int64_t c_stride, int64_t fw_stride, float scale) {
   using C = PatchCfg<W, TZ, HALF>;
-  constexpr int LS = C::LS, PS = C::PS, NW = C::NW, L0 = C::L0, L1 = C::L1, L2 = C::L2;
+  constexpr int LS = C::LS, PS = C::PS, NW = kPatchNW, L0 = C::L0, L1 = C::L1, L2 = C::L2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned long long* plane = reinterpret_cast<unsigned long long*>(smem_raw);
   unsigned char* stage_all = smem_raw + (size_t)C::plane_elems * 8;
@@ -754,11 +750,10 @@ __global__ __launch_bounds__(kBoundThreads) void bound3_kernel(Geom g, const Rec
                                                               float* __restrict__ sub_bound, int* __restrict__ fb_list) {
   // count rows of 17 words: the x pass reads one LINE per lane, and a lane stride of 16 words would put a wave on 4 banks
   constexpr int T = kDenseTile, L = T + W - 1, CP = T + 1, LZ = TZ + W - 1, NT = kBoundThreads;
-  extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];   // (75 KB at depth 16: dynamic)
-  uint32_t* cnt = reinterpret_cast<uint32_t*>(bsm);                    // [TZ * T * CP]
-  float* a = reinterpret_cast<float*>(cnt + TZ * T * CP);              // [z][y][i]  (L is odd: conflict-free line-per-lane writes)
-  float* b = a + TZ * T * L;                                           // [z][j][i]
-  float* wmax = b + TZ * L * L;                                        // [NT / 64]
+  __shared__ uint32_t cnt[TZ * T * CP];
+  __shared__ float a[TZ * T * L];     // [z][y][i]  (L is odd: conflict-free line-per-lane writes)
+  __shared__ float b[TZ * L * L];     // [z][j][i]
+  __shared__ float wmax[NT / 64];
   int tb, p0, p1, slot, nsub;
   if (!locate_subproblem(g, tile_start, sub_start, blockIdx.x, &tb, &p0, &p1, &slot, &nsub)) return;
   const int tid = threadIdx.x, npt = p1 - p0;
@@ -971,61 +966,39 @@ extern "C" int nufft_hip_debug_phase_log3(unsigned long long* dst, int n) {   //
 
 bool patch3_supported(const Geom& g, int precision) {
   return precision == NUFFT_HIP_F32 && g.rank == 3 && g.fx_patch && (g.w == 7 || g.w == 8) && g.tile[0] == kDenseTile &&
-         g.tile[1] == kDenseTile && (g.tile[2] == 8 || g.tile[2] == 16);
+         g.tile[1] == kDenseTile && g.tile[2] == 8;
 }
 constexpr int kPatchHalf = 8;
-size_t patch3_lds_bytes(int w, int tz) {
-  if (tz == 16) return w == 8 ? PatchCfg<8, 16, kPatchHalf>::lds_bytes : w == 7 ? PatchCfg<7, 16, kPatchHalf>::lds_bytes : 0;
+size_t patch3_lds_bytes(int w) {
   return w == 8 ? PatchCfg<8, 8, kPatchHalf>::lds_bytes : w == 7 ? PatchCfg<7, 8, kPatchHalf>::lds_bytes : 0;
 }
-template <int W, int TZ>
+template <int W>
 static hipError_t launch_patch3(const Geom& g, const SortedPoints<float>& sp, const float* horner, const float* c, float* fw,
                                 dim3 grid, int64_t c_stride, int64_t fw_stride, float scale, hipStream_t stream) {
-  using C = PatchCfg<W, TZ, kPatchHalf>;
-  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(spread_patch3_kernel<W, TZ, kPatchHalf>),
+  using C = PatchCfg<W, 8, kPatchHalf>;
+  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(spread_patch3_kernel<W, 8, kPatchHalf>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes);
   if (e != hipSuccess) return e;
-  spread_patch3_kernel<W, TZ, kPatchHalf><<<grid, C::NW * 64, C::lds_bytes, stream>>>(g, sp, horner, c, fw, c_stride, fw_stride, scale);
+  spread_patch3_kernel<W, 8, kPatchHalf><<<grid, kPatchNW * 64, C::lds_bytes, stream>>>(g, sp, horner, c, fw, c_stride, fw_stride, scale);
   return hipGetLastError();
 }
 hipError_t launch_spread_patch3(const Geom& g, const SortedPoints<float>& sp, unsigned nsub_bound, const float* horner,
                                 const float* c, float* fw, int batch, int64_t c_stride, int64_t fw_stride, float scale,
                                 hipStream_t stream) {
   const dim3 grid(nsub_bound, (unsigned)batch);
-  if (g.tile[2] == 16) {
-    if (g.w == 8) return launch_patch3<8, 16>(g, sp, horner, c, fw, grid, c_stride, fw_stride, scale, stream);
-    if (g.w == 7) return launch_patch3<7, 16>(g, sp, horner, c, fw, grid, c_stride, fw_stride, scale, stream);
-    return hipErrorInvalidValue;
-  }
-  if (g.w == 8) return launch_patch3<8, 8>(g, sp, horner, c, fw, grid, c_stride, fw_stride, scale, stream);
-  if (g.w == 7) return launch_patch3<7, 8>(g, sp, horner, c, fw, grid, c_stride, fw_stride, scale, stream);
+  if (g.w == 8) return launch_patch3<8>(g, sp, horner, c, fw, grid, c_stride, fw_stride, scale, stream);
+  if (g.w == 7) return launch_patch3<7>(g, sp, horner, c, fw, grid, c_stride, fw_stride, scale, stream);
   return hipErrorInvalidValue;
-}
-template <int W, int TZ>
-static hipError_t launch_bound3_t(const Geom& g, const Rec<float>* rec, int rec_stride, const int32_t* tile_start, const int32_t* sub_start,
-                                  unsigned nsub_bound, const TapMax& taps, float* sub_bound, int* fb_list, hipStream_t stream) {
-  constexpr int T = kDenseTile, L = T + W - 1;
-  constexpr size_t lds = sizeof(uint32_t) * TZ * T * (T + 1) + sizeof(float) * (TZ * T * L + TZ * L * L + kBoundThreads / 64);
-  if (lds > 64 * 1024) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bound3_kernel<W, TZ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-  }
-  bound3_kernel<W, TZ><<<nsub_bound, kBoundThreads, lds, stream>>>(g, rec, rec_stride, tile_start, sub_start, taps, sub_bound, fb_list);
-  return hipGetLastError();
 }
 hipError_t launch_bound3(const Geom& g, const Rec<float>* rec, int rec_stride, const int32_t* tile_start, const int32_t* sub_start,
                          unsigned nsub_bound, const TapMax& taps, float* sub_bound, int* fb_list, hipStream_t stream) {
   hipError_t e = hipMemsetAsync(fb_list, 0, sizeof(int), stream);
   if (e != hipSuccess) return e;
   if (nsub_bound == 0) return hipSuccess;
-  if (g.tile[2] == 16) {
-    if (g.w == 8) return launch_bound3_t<8, 16>(g, rec, rec_stride, tile_start, sub_start, nsub_bound, taps, sub_bound, fb_list, stream);
-    if (g.w == 7) return launch_bound3_t<7, 16>(g, rec, rec_stride, tile_start, sub_start, nsub_bound, taps, sub_bound, fb_list, stream);
-    return hipErrorInvalidValue;
-  }
-  if (g.w == 8) return launch_bound3_t<8, 8>(g, rec, rec_stride, tile_start, sub_start, nsub_bound, taps, sub_bound, fb_list, stream);
-  if (g.w == 7) return launch_bound3_t<7, 8>(g, rec, rec_stride, tile_start, sub_start, nsub_bound, taps, sub_bound, fb_list, stream);
-  return hipErrorInvalidValue;
+  if (g.w == 8) bound3_kernel<8, 8><<<nsub_bound, kBoundThreads, 0, stream>>>(g, rec, rec_stride, tile_start, sub_start, taps, sub_bound, fb_list);
+  else if (g.w == 7) bound3_kernel<7, 8><<<nsub_bound, kBoundThreads, 0, stream>>>(g, rec, rec_stride, tile_start, sub_start, taps, sub_bound, fb_list);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
 }
 int cstats_blocks(int64_t M, int slots) {
   // (workgroups per slot: 16384 strengths each, at most 1024, and at most 2^20 partial pairs over all slots)

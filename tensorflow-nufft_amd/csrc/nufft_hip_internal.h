@@ -242,7 +242,7 @@ hipError_t launch_spread_dense3(const Geom& g, const SortedPoints<float>& sp, un
                                 hipStream_t stream);
 // w = 7, 8 (same file): exact-conversion fixed point on 8 x 8 (x, y) lane patches, step from the count-filter bound
 bool patch3_supported(const Geom& g, int precision);
-size_t patch3_lds_bytes(int w, int tile_depth);
+size_t patch3_lds_bytes(int w);
 hipError_t launch_spread_patch3(const Geom& g, const SortedPoints<float>& sp, unsigned nsub_bound, const float* horner,
                                 const float* c, float* fw, int batch, int64_t c_stride, int64_t fw_stride, float scale,
                                 hipStream_t stream);

@@ -2731,8 +2731,7 @@ bool wave_method_supported(const Geom& g, int precision) {
   // (depth 8 at w = 8: float only, one fp64 plane per launch -- see configure())
   if (g.rank == 3)
     return g.tile[0] == 16 && g.tile[1] == 16 &&
-           (g.tile[2] == 4 || (g.tile[2] == 8 && (g.w <= 6 || ((g.w == 7 || g.w == 8) && precision == NUFFT_HIP_F32))) ||
-            (g.tile[2] == 16 && g.fx_patch));   // (depth 16: the w = 7 / 8 fixed-point kernel only, on request)
+           (g.tile[2] == 4 || (g.tile[2] == 8 && (g.w <= 6 || ((g.w == 7 || g.w == 8) && precision == NUFFT_HIP_F32))));
   return false;
 }
 int wave_lstride(int rank) { return rank == 2 ? 40 : 24; }
@@ -2871,7 +2870,7 @@ size_t spread_lds_bytes(const Geom& g, int method, int precision) {
       return group2d_geometry(g) ? std::max(wave2_lds(g, precision), group_lds(8, 64, false, precision)) : wave2_lds(g, precision);
     if (dense3_supported(g, precision))   // (and the fp64-plane launches behind it for crowded tiles)
       return std::max(dense3_lds_bytes(g.w), wave3_split_lds(g));
-    if (patch3_supported(g, precision)) return std::max(patch3_lds_bytes(g.w, g.tile[2]), wave3_split8_lds(g));
+    if (patch3_supported(g, precision)) return std::max(patch3_lds_bytes(g.w), wave3_split8_lds(g));
     const int nw = g.split_reim ? 12 : wave3d_nw_rt(precision, g.fixed_point != 0);
     const int ch = (g.split_reim && g.tile[2] == 8) ? 16 : 32;   // (staging chunk: keeps two workgroups per CU)
     if (g.split_reim && g.tile[2] == 8 && g.w == 8) return wave3_joint_lds(g);   // the larger of the two forms
@@ -3057,22 +3056,9 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
   if (e != hipSuccess) return e;                                                                 \
   spread_wave3_kernel<T, WW, 8, 12, 16, false, CV>                                                \
       <<<fgrid, 12 * 64, lds_bytes, stream>>>(g, sp, horner, c, fw, c_stride, fw_stride, scale);
-#define NUFFT_LAUNCH_W3S16(WW, CV)                                                               \
-  e = ensure_lds(spread_wave3_kernel<T, WW, 16, 12, 16, false, CV>, lds_bytes);                   \
-  if (e != hipSuccess) return e;                                                                 \
-  spread_wave3_kernel<T, WW, 16, 12, 16, false, CV>                                               \
-      <<<fgrid, 12 * 64, lds_bytes, stream>>>(g, sp, horner, c, fw, c_stride, fw_stride, scale);
 #define NUFFT_CASE_W3(WW)                                                                        \
   case WW:                                                                                       \
-    if (g.tile[2] == 16) {   /* (sparse sets, on request: the w = 7 / 8 fixed-point kernel on 16 x 16 x 16 tiles) */ \
-      if constexpr (WW >= 7 && sizeof(T) == 4) {                                                 \
-        if (!g.fx_patch) return hipErrorInvalidValue;                                            \
-        e = launch_spread_patch3(g, sp, grid.x, horner, c, fw, batch, c_stride, fw_stride, scale, stream); \
-        if (e != hipSuccess) return e;                                                           \
-        lds_bytes = wave3_split8_lds(g);                                                         \
-        NUFFT_LAUNCH_W3S16(WW, 1) NUFFT_LAUNCH_W3S16(WW, 2)                                       \
-      } else { return hipErrorInvalidValue; }                                                    \
-    } else if (g.tile[2] == 8) {                                                                 \
+    if (g.tile[2] == 8) {                                                                        \
       if constexpr (WW >= 7) {                                                                   \
         if constexpr (sizeof(T) == 4) {                                                          \
           if (g.fx_patch) {   /* packed fixed point, exact conversion; flagged subproblems on fp64 planes behind it */ \
@@ -3127,7 +3113,6 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
         default: return hipErrorInvalidValue;
       }
 #undef NUFFT_CASE_W3
-#undef NUFFT_LAUNCH_W3S16
 #undef NUFFT_LAUNCH_W3S8
 #undef NUFFT_LAUNCH_W3S
 #undef NUFFT_LAUNCH_W3

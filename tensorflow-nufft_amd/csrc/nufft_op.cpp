@@ -26,9 +26,6 @@ namespace {
 
 using nufft_hip::launch_permute;
 
-// 3-D float type-1 / spread calls at w = 7, 8 below this many points per fine cell run on 16 x 16 x 16 tiles
-constexpr double kDeepTileMaxDensity = 0.12;
-
 std::string shape_str(const int64_t* s, int n) {   // TensorShape::DebugString format
   std::string r = "[";
   for (int i = 0; i < n; ++i) {
@@ -477,30 +474,6 @@ int nufft_hip_op_compute_ex(const nufft_hip_op_desc* desc, const void* source, c
     opts.upsampling_factor = 2.0;
   }
   const double tol = (double)(float)desc->tol;   // `tol: float` attr cast to FloatType (:361)
-  // Sparse 3-D float point sets at the default tolerance (w = 7, 8): the spread is bound by the write-out of every
-  // tile + halo, whatever the point count, so the plan is asked for 16 x 16 x 16 tiles (2.97 x the fine grid instead of
-  // 3.87 x; EXPERIMENTS.md section 10.9 has the crossover). The op knows the point count when it creates the plan; a
-  // caller of the plan interface passes options.tile_dims itself.
-  if (rank == 3 && t1 && desc->precision == NUFFT_HIP_F32 && opts.tile_dims[0] == 0 && opts.tile_dims[1] == 0 &&
-      opts.tile_dims[2] == 0 && a.num_points > 0) {
-    nufft_hip_plan_info pi;
-    char pe[256];
-    if (nufft_hip_plan_describe(desc->transform_type, rank, dims, desc->fft_direction, (int)a.num_transforms, tol,
-                                desc->precision, &opts, &pi, pe, sizeof(pe)) == NUFFT_HIP_OK &&
-        (pi.kernel_width == 7 || pi.kernel_width == 8) && pi.spread_method == NUFFT_HIP_METHOD_TILE_WAVE &&
-        pi.tile_dims[0] == 16 && pi.tile_dims[1] == 16 && pi.tile_dims[2] == 8 && pi.fine_dims[2] >= 32) {
-      const double cells = (double)pi.fine_dims[0] * (double)pi.fine_dims[1] * (double)pi.fine_dims[2];
-      if ((double)a.num_points < kDeepTileMaxDensity * cells) {
-        nufft_hip_options deep = opts;
-        deep.tile_dims[0] = 16; deep.tile_dims[1] = 16; deep.tile_dims[2] = 16;
-        nufft_hip_plan_info pd;
-        if (nufft_hip_plan_describe(desc->transform_type, rank, dims, desc->fft_direction, (int)a.num_transforms, tol,
-                                    desc->precision, &deep, &pd, pe, sizeof(pe)) == NUFFT_HIP_OK &&
-            pd.spread_method == NUFFT_HIP_METHOD_TILE_WAVE && pd.tile_dims[2] == 16)
-          opts = deep;
-      }
-    }
-  }
   int device = 0;
   if (hipGetDevice(&device) != hipSuccess) {
     (void)hipGetLastError();

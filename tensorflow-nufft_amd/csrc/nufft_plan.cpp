@@ -1166,10 +1166,6 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
         (p->opts.spread_method == NUFFT_HIP_METHOD_AUTO || p->opts.spread_method == NUFFT_HIP_METHOD_TILE_WAVE) &&
         (patch_want || p->opts.lds_accumulate != 2))
       break;
-    // 16 x 16 x 16 on request (options.tile_dims; the op-level entry asks for it for sparse point sets): type-1 / spread-only
-    // plans of the w = 7, 8 fixed-point kernel, one 102 KB plane per workgroup
-    if (patch_want && g.tile[0] == 16 && g.tile[1] == 16 && g.tile[2] == 16 && (type == NUFFT_HIP_TYPE_1 || p->opts.spread_only))
-      break;
     int big = 0;
     for (int d = 1; d < rank; ++d)
       if (g.tile[d] > g.tile[big]) big = d;
@@ -1197,11 +1193,7 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
       for (int d = 0; d < 3; ++d) { g.sup_shift[d] = 6 - g.tile_shift[d]; g.nsup[d] = g.nf[d] / 64; }
     }
   }
-  // (provisional: wave_method_supported() below looks at it; settled once the method is known)
-  g.fx_patch = (patch_want && !wide && g.tile[0] == 16 && g.tile[1] == 16 &&
-                (g.tile[2] == 8 || (g.tile[2] == 16 && (type == NUFFT_HIP_TYPE_1 || p->opts.spread_only)))) ? 1 : 0;
-  const bool patch16 = g.fx_patch && g.tile[2] == 16;   // (one 8-byte plane of 23^3 cells: fits although two fp64 planes do not)
-  if (!wide && !patch16 && spread_lds_bytes(g, NUFFT_HIP_METHOD_TILE_GENERIC, precision) > 160 * 1024) {
+  if (!wide && spread_lds_bytes(g, NUFFT_HIP_METHOD_TILE_GENERIC, precision) > 160 * 1024) {
     delete p;
     return fail(NUFFT_HIP_RESOURCE_EXHAUSTED, "kernel too wide for an LDS tile");  // cf. nufft_plan.cu.cc:2458-2463
   }
@@ -1262,7 +1254,8 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
   g.fixed_point = 0;
   g.split_reim = 0;
   g.cell_sorted = 0;
-  if (method != NUFFT_HIP_METHOD_TILE_WAVE || g.wide) g.fx_patch = 0;
+  g.fx_patch = (patch_want && method == NUFFT_HIP_METHOD_TILE_WAVE && !g.wide && g.tile[0] == 16 && g.tile[1] == 16 &&
+                g.tile[2] == 8) ? 1 : 0;
   if (method == NUFFT_HIP_METHOD_TILE_WAVE && rank == 3 && precision == NUFFT_HIP_F32 && (w <= 7 || g.fx_patch) &&
       p->opts.lds_accumulate != 1 && (w <= 6 || g.fx_patch || g.tile[2] == 4))
     g.fixed_point = 1;

@@ -894,55 +894,6 @@ def test_3d_spread_op_with_more_transforms_than_the_plan_batch(tfft, tol):
     assert rel_l2(out[t], one) < 2e-6, (t, rel_l2(out[t], one))
 
 
-@pytest.mark.parametrize('tol', [1e-6, 1e-5])
-def test_3d_sparse_sets_on_depth_16_tiles(tfft, tol):
-  # Sparse 3-D float point sets at w = 7 / 8 run on 16 x 16 x 16 tiles (the op-level entry asks the plan for them below
-  # 0.12 points per fine cell; a plan takes them through options.tile_dims): same kernels, 23^3-cell LDS plane, one
-  # workgroup of 16 waves per CU; the bound kernel and the fp64-plane fallback at that depth. Against the fp64 oracle,
-  # against the depth-8 plan, the bounds against their numpy restatement, a crowd for the fallback list.
-  from oracle import oracle
-  rng = np.random.default_rng(61)
-  grid = [64, 64, 96]
-  M = 150_000                       # 0.024 points per fine cell
-  pts = rng.uniform(-np.pi, np.pi, (M, 3)).astype(np.float32)
-  c = (rng.uniform(-.5, .5, M) + 1j * rng.uniform(-.5, .5, M)).astype(np.complex64)
-  truth = oracle.nufft(c.astype(np.complex128), pts, grid, 'type_1', 'forward', tol=1e-12, sigma=2.0)
-  deep = tfft.Plan('type_1', grid, 'forward', tol=tol, tile_dims=(16, 16, 16))
-  assert list(deep.info().tile_dims) == [16, 16, 16] and deep.info().spread_method == 2
-  deep.set_points(_dev(pts))
-  got = deep.sub_bounds()
-  want = _count_filter_bounds(deep, pts, grid)
-  live = got[got != 0]
-  assert live.size == len(want) and (live > 0).all()
-  ref = np.array([want[t][0] for t in sorted(want)])
-  npt = np.array([want[t][1] for t in sorted(want)])
-  big = npt > 16
-  assert big.sum() > 100 and np.allclose(live[big], ref[big], rtol=2e-5)
-  out_deep = deep.execute(_dev(c)).cpu().numpy()
-  one_call = deep.execute_with_points(_dev(pts), _dev(c)).cpu().numpy()
-  deep.close()
-  flat = tfft.Plan('type_1', grid, 'forward', tol=tol)
-  assert list(flat.info().tile_dims) == [16, 16, 8]
-  out_flat = flat.execute_with_points(_dev(pts), _dev(c)).cpu().numpy()
-  flat.close()
-  op = tfft.nufft(_dev(c), _dev(pts), grid_shape=grid, transform_type='type_1', tol=tol).cpu().numpy()   # (picks depth 16 itself)
-  bar = 4e-7 if tol == 1e-6 else 4e-6
-  for name, o in (('plan', out_deep), ('one-call', one_call), ('depth 8', out_flat), ('op', op)):
-    assert rel_l2(o, truth) < bar, (name, rel_l2(o, truth))
-  assert rel_l2(out_deep, out_flat) < 3e-7 and rel_l2(op, out_deep) < 3e-7
-  # a crowd: flagged subproblems go to the fp64 planes of the same depth
-  pts2 = pts.copy()
-  pts2[:40_000] = (np.array([0.9, -0.4, 2.2]) + 0.02 * rng.standard_normal((40_000, 3))).astype(np.float32)
-  truth2 = oracle.nufft(c.astype(np.complex128), pts2, grid, 'type_1', 'forward', tol=1e-12, sigma=2.0)
-  deep = tfft.Plan('type_1', grid, 'forward', tol=tol, tile_dims=(16, 16, 16))
-  deep.set_points(_dev(pts2))
-  if tol == 1e-6:
-    assert (deep.sub_bounds() < 0).sum() >= 1
-  out2 = deep.execute(_dev(c)).cpu().numpy()
-  deep.close()
-  assert rel_l2(out2, truth2) < 1.5 * bar, rel_l2(out2, truth2)
-
-
 def test_radial_trajectories_total_parity_at_scale(tfft):
   # Non-uniform densities at scale, whole output against the fp64 oracle: a 2-D radial trajectory in acquisition
   # order (config 2's size: 10000 spokes of 1000 samples, density ~ 1 / r: crowded centre tiles, subproblem

@@ -26,7 +26,6 @@ def main():
   ap.add_argument('--tols', default='1e-1,1e-2,1e-3,1e-4,1e-5,1e-6')
   ap.add_argument('--no-oracle', action='store_true')
   ap.add_argument('--steps', type=int, default=3)
-  ap.add_argument('--deep', action='store_true', help='also time the w = 7 / 8 kernel on 16 x 16 x 16 tiles (options.tile_dims)')
   args = ap.parse_args()
   n, M = args.grid, args.M
   grid = [n, n, n]
@@ -37,14 +36,11 @@ def main():
   c = torch.complex(torch.rand(M, generator=g, device='cuda') - .5, torch.rand(M, generator=g, device='cuda') - .5)
   truth = None
   for tol in [float(t) for t in args.tols.split(',')]:
-    variants = [('r04', 0, None)]
+    variants = [('r04', 0)]
     if tol <= 2e-5:
-      if args.deep:
-        variants.append(('r04, 16 x 16 x 16 tiles', 0, (16, 16, 16)))
-      variants.append(('r03 kernels (FXPATCH_OFF)', TUNE['FXPATCH_OFF'], None))
-    for name, tune, tile in variants:
-      kw = {'tile_dims': tile} if tile else {}
-      plan = tfft.Plan('type_1', grid, 'forward', tol=tol, tuning=tune, **kw)
+      variants.append(('r03 kernels (FXPATCH_OFF)', TUNE['FXPATCH_OFF']))
+    for name, tune in variants:
+      plan = tfft.Plan('type_1', grid, 'forward', tol=tol, tuning=tune)
       for _ in range(2):
         plan.set_points(pts); out = plan.execute(c)
       plan.set_timing(True); plan.get_timing()
