@@ -739,7 +739,10 @@ __global__ __launch_bounds__(kPatchNW * 64) void spread_patch3_kernel(
 // B = max over the cells of the tile (+ halo) of sum_t0 sum_t1 sum_t2 N(i - t0, j - t1, k - t2) kmax[t0] kmax[t1] kmax[t2],
 // N = the subproblem's points per start cell: every cell sum of the spread is at most (largest strength) x B.
 // One workgroup per subproblem; the three filter passes keep a line's inputs in registers.
-constexpr int kBoundThreads = 256;
+#ifndef NUFFT_BOUND_THREADS
+#define NUFFT_BOUND_THREADS 512   // (tools/ab_bound_threads.sh, 65536 subproblems: 256 threads 361 us, 384 466, 512 331)
+#endif
+constexpr int kBoundThreads = NUFFT_BOUND_THREADS;
 // (Measured r04, 65536 subproblems of 458 points: this form 0.36-0.38 ms before the count rows were padded. A form
 // with two lines per thread in v_pk_fma_f32 -- 40 % fewer wave-instructions -- ran 0.49-0.69 ms: a phase then keeps
 // one or two waves of the workgroup busy and the kernel is bound by the latency of each phase, not by VALU issue.)
