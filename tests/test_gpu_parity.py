@@ -416,6 +416,37 @@ def test_empty_and_tiny_inputs(tfft):
   assert rel_l2(out, ref) < 1e-6
 
 
+def test_3d_default_tolerance_edge_cases(tfft):
+  # The w = 8 / 7 fixed-point path (bounds, strength statistics, fallback list) on the inputs that break bookkeeping:
+  # no points, one point, every point identical (one subproblem chain in one tile: all on the fp64 planes), strengths
+  # all zero (largest strength 0: the step is 0), and ONE plan taking point sets of very different sizes in turn.
+  from oracle import oracle
+  rng = np.random.default_rng(17)
+  grid = [32, 32, 48]
+  for tol in (1e-6, 1e-5):
+    plan = tfft.Plan('type_1', grid, 'forward', tol=tol)
+    assert list(plan.info().tile_dims) == [16, 16, 8]
+    for M, kind in ((0, 'empty'), (1, 'one'), (5000, 'identical'), (40_000, 'uniform'), (3, 'few'), (40_000, 'zeros'), (0, 'empty'), (200_000, 'uniform')):
+      if kind == 'identical':
+        pts = np.tile(np.array([[0.7, -2.1, 1.3]], np.float32), (M, 1))
+      else:
+        pts = rng.uniform(-np.pi, np.pi, (M, 3)).astype(np.float32)
+      c = (rng.uniform(-.5, .5, M) + 1j * rng.uniform(-.5, .5, M)).astype(np.complex64)
+      if kind == 'zeros':
+        c[:] = 0
+      out = plan.execute_with_points(_dev(pts), _dev(c)).cpu().numpy()
+      assert out.shape == tuple(grid) and np.isfinite(out).all(), (tol, kind)
+      if M == 0 or kind == 'zeros':
+        assert np.abs(out).max() == 0.0, (tol, kind)
+        continue
+      truth = oracle.nufft(c.astype(np.complex128), pts, grid, 'type_1', 'forward', tol=1e-12, sigma=2.0)
+      # (a lone point / identical points do not average the kernel's pointwise error: bar as in the randomised sweep)
+      same = oracle.nufft(c.astype(np.complex128), pts, grid, 'type_1', 'forward', tol=tol, sigma=2.0)
+      bar = max(tol, 1.05 * rel_l2(same, truth) + 1e-6)
+      assert rel_l2(out, truth) < bar, (tol, kind, M, rel_l2(out, truth), bar)
+    plan.close()
+
+
 def test_clustered_points_many_subproblems(tfft):
   # all points inside one tile => many subproblems of the same tile
   from oracle import oracle
