@@ -114,13 +114,40 @@ def pmc_traffic_of(config_key):
   return {'traffic': None}
 
 
+def effective_cpus():
+  """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (the GPU boxes of this pool
+  show 256 hardware threads and a quota of 16 CPUs: more OpenMP threads than that are throttled, which is what made the
+  CPU baseline 'peak at 32 of 256 threads' in r01-r03)."""
+  try:
+    n = len(os.sched_getaffinity(0))
+  except AttributeError:
+    n = os.cpu_count() or 1
+  quota = None
+  try:
+    q, p = open('/sys/fs/cgroup/cpu.max').read().split()[:2]          # cgroup v2
+    if q != 'max':
+      quota = int(q) / int(p)
+  except (OSError, ValueError):
+    try:                                                               # cgroup v1
+      q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+      p = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+      if q > 0:
+        quota = q / p
+    except (OSError, ValueError):
+      pass
+  if quota:
+    n = max(1, min(n, int(quota + 0.5)))
+  return n, quota
+
+
 def cpu_baseline(args):
   """Times the CPU oracle (port of the reference CPU path) on a bounded sample of the
   same workload: median of >= 5 runs after a warm-up, full transform and spreader
   alone, over a few OpenMP thread counts (the best median is reported)."""
   import numpy as np
   from oracle import oracle
-  cores = os.cpu_count() or 1
+  hw = os.cpu_count() or 1
+  cores, quota = effective_cpus()
   m = args.cpu_points
   rng = np.random.default_rng(2)
   pts = rng.uniform(-np.pi, np.pi, (m, 2)).astype(np.float32)
@@ -129,17 +156,15 @@ def cpu_baseline(args):
   # reference CPU rule for this config: sigma = 1.25, w = 10,
   # float arithmetic, piecewise-polynomial kernel (kerevalmeth 1). Above 10 threads the
   # subgrids merge with atomics, below under a critical section (nufft_plan.cc:1109-1114).
-  cand = sorted({cores, max(1, cores // 2), min(cores, 64), min(cores, 32)}, reverse=True)
+  # thread counts around what the process may use (a little above it too: SMT siblings, quota granularity)
+  cand = sorted({max(1, cores // 2), max(1, (3 * cores) // 4), cores, min(hw, (3 * cores) // 2), min(hw, 2 * cores)})
   budget = time.perf_counter() + 40.0
   best = None
   for nt in cand:
-    full, spread = [], []
-    oracle.nufft(c, pts, GRID, 'type_1', 'forward', tol=TOL, kerevalmeth=1, nthreads=nt)   # warm-up
-    for _ in range(5):
-      t0 = time.perf_counter()
-      oracle.nufft(c, pts, GRID, 'type_1', 'forward', tol=TOL, kerevalmeth=1, nthreads=nt)
-      full.append(time.perf_counter() - t0)
-      spread.append(oracle.time_spread(c, pts, GRID, tol=tol, sigma=0.0, kerevalmeth=1, nthreads=nt))
+    # the C entry alone, on inputs already in its layout (r04: the numpy transpose of the points inside oracle.nufft,
+    # ~50 ms on one thread at M = 1e7, used to sit in the timed region and capped the rate near 100 Mpts/s)
+    full = oracle.time_nufft(c, pts, GRID, tol=TOL, kerevalmeth=1, nthreads=nt, repeats=5)
+    spread = [oracle.time_spread(c, pts, GRID, tol=tol, sigma=0.0, kerevalmeth=1, nthreads=nt) for _ in range(5)]
     med_full, med_spread = float(np.median(full)), float(np.median(spread))
     if best is None or med_full < best[0]:
       best = (med_full, med_spread, nt, sorted(full))
@@ -169,9 +194,11 @@ def cpu_baseline(args):
       'spread_only_Mpts_s': round(m / med_spread / 1e6, 3),
       'sample': f'{m} of the {M} points on the same 1024x1024 grid, reference CPU rule sigma={sigma} w={w} '
                 f'fine grid {nf[0]}x{nf[1]}, fp32; value = full type-1 transform (sort + spread + FFT + '
-                f'deconvolve), spread_only = the spreader on pre-sorted points; median of 5 runs after a '
-                f'warm-up at the best of the thread counts {cand}: {nt} OpenMP threads of {cores} hardware '
-                f'threads; full-transform runs {[round(r, 3) for r in runs]} s',
+                f'deconvolve: the C entry alone on coordinate arrays), spread_only = the spreader on pre-sorted points; median of 5 runs after a '
+                f'warm-up at the best of the thread counts {cand}: {nt} OpenMP threads; this process may use {cores} CPUs '
+                f'(cgroup quota {quota if quota else "none"}, {hw} hardware threads on the host); '
+                f'full-transform runs {[round(r, 3) for r in runs]} s',
+      'usable_cpus': cores, 'hardware_threads': hw,
   }
 
 

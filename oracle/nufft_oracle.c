@@ -33,6 +33,7 @@
 #include <math.h>
 #include <omp.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 

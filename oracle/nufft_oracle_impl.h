@@ -502,9 +502,14 @@ int SUF(oracle_nufft)(const oracle_opts *o, int64_t M, const FLT *x,
     fser[d] = (double *)malloc(sizeof(double) * (size_t)(nf[d] / 2 + 1));
     oracle_kernel_fseries(nf[d], &kp, fser[d]);
   }
+  /* ORACLE_TIMING=1: stage times of a type-1 call on stderr (bench tooling) */
+  const int timing = getenv("ORACLE_TIMING") != NULL;
+  double tm[5];
+  tm[0] = omp_get_wtime();
   int32_t *perm = (int32_t *)malloc(sizeof(int32_t) * (size_t)(M > 0 ? M : 1));
   SUF(binsort)(M, xyz, rank, nf, o->points_range, perm, nthreads);
   CPLX *fw = (CPLX *)malloc(sizeof(CPLX) * (size_t)nftot);
+  tm[1] = omp_get_wtime();
 
   for (int t = 0; t < o->ntransf; ++t) {
     FLT *ct = c + 2 * (size_t)t * (size_t)M;
@@ -512,8 +517,14 @@ int SUF(oracle_nufft)(const oracle_opts *o, int64_t M, const FLT *x,
     if (o->type == 1) {
       SUF(spread_sorted)(perm, nf, (FLT *)fw, M, xyz, ct, rank,
                          o->points_range, &kp, nthreads, 1.0);
+      tm[2] = omp_get_wtime();
       SUF(fft_nd)(fw, nf, rank, o->iflag, nthreads);
+      tm[3] = omp_get_wtime();
       SUF(deconvolve)(1, ft, fw, N, nf, rank, fser);
+      tm[4] = omp_get_wtime();
+      if (timing)
+        fprintf(stderr, "oracle type 1, %d threads: sort %.1f ms, spread %.1f, fft %.1f, deconvolve %.1f\n", nthreads,
+                1e3 * (tm[1] - tm[0]), 1e3 * (tm[2] - tm[1]), 1e3 * (tm[3] - tm[2]), 1e3 * (tm[4] - tm[3]));
     } else {
       SUF(deconvolve)(2, ft, fw, N, nf, rank, fser);
       SUF(fft_nd)(fw, nf, rank, o->iflag, nthreads);

@@ -163,6 +163,36 @@ def nufft(source, points, grid_shape=None, transform_type='type_2',
   return out if batched else out[0]
 
 
+def time_nufft(c, points, grid_shape, tol=1e-6, sigma=0.0, w=0, kerevalmeth=1, nthreads=0, repeats=5):
+  """Seconds per call (list of `repeats` samples, after one warm-up call) of the C entry `oracle_nufft` alone for a
+  type-1 transform: bin sort + spread + FFT + deconvolve on inputs that are ALREADY in the layout the C code takes
+  (coordinate arrays, x first). `nufft()` above also transposes the [M, rank] points with numpy on one thread --
+  ~50 ms at M = 1e7, which is not part of the algorithm being timed. For bench.py's cpu_baseline leg."""
+  import time
+  tol = float(np.float32(tol))
+  c = np.ascontiguousarray(c)
+  cdt = c.dtype
+  rdt = np.float32 if cdt == np.complex64 else np.float64
+  suf = '_f32' if cdt == np.complex64 else '_f64'
+  M, rank = points.shape
+  pts = np.ascontiguousarray(np.asarray(points).T[::-1].astype(rdt))
+  grid_shape = [int(g) for g in grid_shape]
+  o = _mk_opts('type_1', rank, grid_shape, 'forward', 1, tol, sigma, w, False, 'extended', kerevalmeth, nthreads)
+  info = OracleInfo()
+  f = np.zeros((1,) + tuple(grid_shape), dtype=cdt)
+  fn = getattr(lib(), 'oracle_nufft' + suf)
+  args = (ctypes.byref(o), ctypes.c_int64(M), _ptr(pts[0]), _ptr(pts[1]) if rank > 1 else None,
+          _ptr(pts[2]) if rank > 2 else None, _ptr(c), _ptr(f), ctypes.byref(info))
+  if fn(*args):
+    raise ValueError('oracle_nufft failed')
+  out = []
+  for _ in range(repeats):
+    t0 = time.perf_counter()
+    fn(*args)
+    out.append(time.perf_counter() - t0)
+  return out
+
+
 def nudft(source, points, grid_shape=None, transform_type='type_2',
           fft_direction='forward', chunk=4096):
   """Dense float64 NUDFT. Definition from the reference's own test oracle
