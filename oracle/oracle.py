@@ -78,8 +78,39 @@ def _ptr(a):
   return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
 
 
+_DEFAULT_THREADS = None
+
+
+def default_threads():
+  """OpenMP threads when the caller passes nthreads = 0: the CPUs this process may really use -- its affinity mask
+  capped by the cgroup CPU quota (the GPU boxes show 256 hardware threads under a quota of 16 CPUs; a team of 256
+  throttled threads makes the oracle several times slower and its timing erratic)."""
+  global _DEFAULT_THREADS
+  if _DEFAULT_THREADS is None:
+    try:
+      n = len(os.sched_getaffinity(0))
+    except AttributeError:
+      n = os.cpu_count() or 1
+    try:
+      q, p = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+      if q != 'max':
+        n = max(1, min(n, int(int(q) / int(p) + 0.5)))
+    except (OSError, ValueError):
+      try:
+        q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+        p = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+        if q > 0:
+          n = max(1, min(n, int(q / p + 0.5)))
+      except (OSError, ValueError):
+        pass
+    _DEFAULT_THREADS = n
+  return _DEFAULT_THREADS
+
+
 def _mk_opts(transform_type, rank, grid_shape, fft_direction, ntransf, tol,
              sigma, w, spread_only, points_range, kerevalmeth, nthreads):
+  if not nthreads:
+    nthreads = default_threads()
   o = OracleOpts()
   o.type = 1 if transform_type == 'type_1' else 2
   o.rank = rank
@@ -253,7 +284,7 @@ def spread_stage(c, points, grid_shape, tol=1e-6, sigma=2.0, w=0, points_range='
   perm = np.zeros(max(M, 1), dtype=np.int32)
   getattr(lib(), 'oracle_binsort' + suf)(
       ctypes.c_int64(M), _ptr(pts[0]), _ptr(pts[1]) if rank > 1 else None,
-      _ptr(pts[2]) if rank > 2 else None, rank, nf, RANGE[points_range], _ptr(perm), int(nthreads))
+      _ptr(pts[2]) if rank > 2 else None, rank, nf, RANGE[points_range], _ptr(perm), int(nthreads or default_threads()))
   shape = [int(info.nf[rank - 1 - d]) for d in range(rank)]
   fw = np.zeros(shape, dtype=cdt)
   rc = getattr(lib(), 'oracle_spread_stage' + suf)(
@@ -283,7 +314,7 @@ def time_spread(c, points, grid_shape, tol=1e-6, sigma=0.0, w=0, kerevalmeth=1, 
   perm = np.zeros(max(M, 1), dtype=np.int32)
   args = (_ptr(pts[0]), _ptr(pts[1]) if rank > 1 else None, _ptr(pts[2]) if rank > 2 else None)
   getattr(lib(), 'oracle_binsort' + suf)(ctypes.c_int64(M), *args, rank, nf, RANGE['extended'], _ptr(perm),
-                                         int(nthreads))
+                                         int(nthreads or default_threads()))
   fw = np.zeros([int(info.nf[rank - 1 - d]) for d in range(rank)], dtype=cdt)
   fn = getattr(lib(), 'oracle_spread_stage' + suf)
   t0 = time.perf_counter()
@@ -299,7 +330,7 @@ def fft(a, sign, nthreads=0):
   a = np.array(a, copy=True, order='C')
   suf = '_f32' if a.dtype == np.complex64 else '_f64'
   nf = (ctypes.c_int64 * 3)(*([int(n) for n in a.shape[::-1]] + [1] * (3 - a.ndim)))
-  getattr(lib(), 'oracle_fft' + suf)(_ptr(a), nf, a.ndim, int(sign), int(nthreads))
+  getattr(lib(), 'oracle_fft' + suf)(_ptr(a), nf, a.ndim, int(sign), int(nthreads or default_threads()))
   return a
 
 
