@@ -1866,6 +1866,75 @@ def test_randomised_3d_fixed_point_strengths_vs_oracle(tfft):
     assert errs[0] <= errs[1] + 0.2 * tol, info
 
 
+def test_randomised_3d_default_tolerance_strengths_vs_oracle(tfft):
+  # The same sweep for the r04 kernels: 3-D float at tol 1e-6 / 1e-5 (w = 8 / 7) accumulates packed fixed-point words
+  # with a step from the count-filter bound of every subproblem (spread_patch3_kernel, bound3_kernel), crowded or
+  # over-bound subproblems on the fp64 planes behind it. Seeded random cases over grid (16 x 16 x 8 tiles, whole and
+  # clipped), point count and distribution (uniform, half in a blob, one tile, on fine-grid nodes), strengths
+  # (uniform, six decades, one / a few huge, all equal, mostly zero, one sign only), transforms per call and entry
+  # point. Bars: tol against the fp64 oracle; the fp64-plane accumulation (lds_accumulate = 1) + 0.2 tol.
+  from oracle import oracle
+  import os
+  rng = np.random.default_rng(int(os.environ.get('NUFFT_TEST_SEED', '20261006')))
+  used_patch = 0
+  for case in range(12):
+    grid = [int(rng.integers(8, 72)) for _ in range(3)]
+    tol = float(rng.choice([1e-6, 1e-6, 1e-5]))
+    M = int(rng.choice([50, 3000, 40000, 250000] + ([1500000] if os.environ.get('NUFFT_TEST_BIGM') else [])))
+    dist = int(rng.integers(0, 4))
+    if dist == 0:
+      pts = rng.uniform(-np.pi, np.pi, (M, 3))
+    elif dist == 1:   # half of the points in a blob of a few cells
+      pts = rng.uniform(-np.pi, np.pi, (M, 3))
+      pts[: M // 2] = rng.uniform(-2.5, 2.5, (1, 3)) + 0.05 * rng.standard_normal((M // 2, 3))
+    elif dist == 2:   # everything in one tile
+      pts = rng.uniform(-2.5, 2.5, (1, 3)) + 0.01 * rng.standard_normal((M, 3))
+    else:             # on the nodes of the sigma = 2 fine grid
+      pts = np.stack([(rng.integers(0, 2 * g, M) / (2 * g) - 0.5) * 2 * np.pi for g in grid], axis=-1)
+    pts = pts.astype(np.float32)
+    kind = int(rng.integers(0, 7))
+    ntr = int(rng.choice([1, 1, 3]))
+    c = rng.standard_normal((ntr, M)) + 1j * rng.standard_normal((ntr, M))
+    if kind == 1:
+      c = c * 10.0 ** rng.uniform(-3, 3, (ntr, M))
+    elif kind == 2:
+      c[:, int(rng.integers(0, M))] *= 10.0 ** rng.uniform(3, 7)
+    elif kind == 3:
+      c[:, rng.integers(0, M, max(1, M // 100))] *= 1e3
+    elif kind == 4:
+      c = np.full((ntr, M), 0.7 - 0.2j)
+    elif kind == 5:
+      c[rng.uniform(0, 1, (ntr, M)) < 0.95] = 0.0
+    elif kind == 6:   # negative imaginary parts only (the subtracting half of the accumulation)
+      c = np.abs(c.real) - 1j * np.abs(c.imag)
+    c = c.astype(np.complex64)
+    truth = np.stack([oracle.nufft(c[t].astype(np.complex128), pts, grid, 'type_1', 'forward', tol=1e-12, sigma=2.0)
+                      for t in range(ntr)])
+    den = np.sqrt((np.abs(truth) ** 2).sum(axis=(1, 2, 3)))
+    if (den == 0).any():
+      continue
+    errs = {}
+    one_call = bool(rng.integers(0, 2)) and ntr == 1
+    for mode in (1, 0):
+      plan = tfft.Plan('type_1', grid, 'forward', num_transforms=ntr, tol=tol, lds_accumulate=mode)
+      if one_call:
+        out = plan.execute_with_points(_dev(pts), _dev(c[0])).cpu().numpy()
+      else:
+        plan.set_points(_dev(pts))
+        out = plan.execute(_dev(c if ntr > 1 else c[0])).cpu().numpy()
+      out = out.reshape([ntr] + grid)
+      if mode == 0:
+        used_patch += int(plan.sub_bounds().size > 0)
+      plan.close()
+      errs[mode] = float((np.sqrt((np.abs(out - truth) ** 2).sum(axis=(1, 2, 3))) / den).max())
+    same = oracle.nufft(c[0].astype(np.complex128), pts, grid, 'type_1', 'forward', tol=tol, sigma=2.0)
+    ref_err = np.linalg.norm(same - truth[0]) / den[0]
+    info = (case, grid, tol, M, dist, kind, ntr, one_call, errs, ref_err)
+    assert errs[0] <= max(tol, 1.05 * ref_err + 1e-6), info
+    assert errs[0] <= errs[1] + 0.2 * tol, info
+  assert used_patch >= 6, used_patch   # the sweep is about the bound-driven kernel: most cases must be on it
+
+
 def test_3d_interp_on_cell_sorted_records(tfft):
   # Dense 3-D type-2 plans reorder every subproblem by stencil start cell in set_points
   # (removes the LDS bank conflicts of the interp stencil loop). Same answer as the fp64
@@ -2450,6 +2519,36 @@ def test_bench_spawns_its_own_ranks():
   d = json.loads(lines[0])
   assert d['n_gpus'] == 2 and d['config']['items'] == 6 and d['config']['items_per_rank'] == 3
   assert d['scaling'] == 'strong' and d['value'] > 0
+
+
+def test_bench_under_the_drivers_launcher():
+  # The driver's N > 1 command line: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+  # 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from
+  # the launcher's environment). Two ranks on this box's one GPU over gloo; rank 0 alone prints, ONE line.
+  import json
+  import os
+  import socket
+  import subprocess
+  import sys
+  from conftest import ROOT
+  with socket.socket() as s:
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+  env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
+  r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                      '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'),
+                      '--gpus', '2', '--steps', '2', '--warmup', '1', '--points', '300000', '--items', '6',
+                      '--dist-backend', 'gloo', '--device', '0'],
+                     capture_output=True, text=True, env=env, timeout=900)
+  assert r.returncode == 0, r.stderr[-2000:]
+  lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+  assert len(lines) == 1, r.stdout
+  d = json.loads(lines[0])
+  assert d['n_gpus'] == 2 and d['steps'] == 2 and d['warmup'] == 1 and d['scaling'] == 'weak' and d['value'] > 0
+  assert d['roofline']['frac'] > 0 and 'cpu_baseline' not in d   # the CPU leg is rank 0's at N = 1 only
+  c5 = d['config']['config5_sharded']
+  assert 'error' not in c5, c5
+  assert c5['config']['rccl_world_size'] == 2 and c5['config']['items_per_rank'] == 3
 
 
 @pytest.mark.parametrize('rank,grid,M,dtype,tol,ntransf', [
