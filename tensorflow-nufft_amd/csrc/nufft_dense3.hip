@@ -548,12 +548,86 @@ hipError_t launch_dense3(const Geom& g, const SortedPoints<float>& sp, const flo
 //    (Geom::fx_bound_limit; clustered points) and tiles with more than fx_max_subs subproblems are left to the
 //    fp64-plane kernels, flagged by a negative entry of sub_bound.
 //    `top` is the largest max(|re c|, |im c|) of the whole transform (cstats_kernel, one streaming pass per
-//    launch) unless one strength dominates (largest > 8 x the mean): then every subproblem takes its own pass
-//    over its strengths and uses min(its sum, its largest x B) -- both are bounds.
+//    launch) unless the strengths are too uneven for the subproblem's B (B x largest / mean strength above
+//    2.9 x the limit, kPatchCrest below): then the subproblem takes its own pass over its strengths and uses the
+//    smallest of three bounds -- its sum, its largest x B, and the start-cell sums of its strengths filtered with
+//    the tap maxima (the count filter with the strengths as weights, run in the plane's LDS before it is zeroed).
+//    r04 measurements (64^3 modes, tol 1e-6, error added in quadrature to the kernel's own 2.3e-7): largest x B
+//    alone 5.1e-7 for lognormal strengths at B = 37 and 6.8e-7 at B = 48; with the weighted bound 0.7e-7 / 0.8e-7.
 //
 // LDS: one plane of 24-element rows (24 = 8 mod 16: the two rows of a 16-lane group cover 16 distinct 8-byte
 // columns, conflict free for every point position), (16 + W - 1) rows, (8 + W - 1) planes = 66 KB at W = 8, and
 // 96 bytes of staged kernel values per point, 8 points per wave at a time: 76 KB, two workgroups per CU.
+// The separable filter of bound3_kernel (and of the strength-weighted bound in spread_patch3_kernel): cnt[TZ][T][T + 1]
+// start-cell weights -> max over the (T + W - 1)^2 (TZ + W - 1) cells of the weights filtered with the tap maxima km.
+// Every thread of the NT-thread workgroup calls it with cnt complete (barrier passed) and gets the maximum;
+// a: TZ T L floats, b: TZ L L floats, wmax: NT / 64 floats of scratch (L = T + W - 1).
+template <int W, int TZ, int NT>
+__device__ __forceinline__ float count_filter_max(const uint32_t* cnt, float* a, float* b, float* wmax, const float (&km)[W],
+                                                  int tid) {
+  // count rows of 17 words: the x pass reads one LINE per lane, and a lane stride of 16 words would put a wave on 4 banks
+  constexpr int T = kDenseTile, L = T + W - 1, CP = T + 1, LZ = TZ + W - 1;
+  // x: line (z, y) of T counts -> L values
+  for (int line = tid; line < TZ * T; line += NT) {
+    float in[T];
+#pragma unroll
+    for (int i = 0; i < T; ++i) in[i] = (float)cnt[line * CP + i];
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+      float v = 0.f;
+#pragma unroll
+      for (int t = 0; t < W; ++t)
+        if (i - t >= 0 && i - t < T) v = fmaf(km[t], in[i - t], v);
+      a[line * L + i] = v;
+    }
+  }
+  __syncthreads();
+  // y: line (z, i) of T values -> L values
+  for (int line = tid; line < TZ * L; line += NT) {
+    const int z = line / L, i = line - z * L;
+    float in[T];
+#pragma unroll
+    for (int y = 0; y < T; ++y) in[y] = a[(z * T + y) * L + i];
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+      float v = 0.f;
+#pragma unroll
+      for (int t = 0; t < W; ++t)
+        if (j - t >= 0 && j - t < T) v = fmaf(km[t], in[j - t], v);
+      b[(z * L + j) * L + i] = v;
+    }
+  }
+  __syncthreads();
+  // z: line (j, i) of TZ values -> maximum of the LZ outputs
+  float best = 0.f;
+  for (int line = tid; line < L * L; line += NT) {
+    float in[TZ];
+#pragma unroll
+    for (int z = 0; z < TZ; ++z) in[z] = b[z * L * L + line];
+#pragma unroll
+    for (int k = 0; k < LZ; ++k) {
+      float v = 0.f;
+#pragma unroll
+      for (int t = 0; t < W; ++t)
+        if (k - t >= 0 && k - t < TZ) v = fmaf(km[t], in[k - t], v);
+      best = fmaxf(best, v);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) best = fmaxf(best, __shfl_down(best, o));
+  if ((tid & 63) == 0) wmax[tid >> 6] = best;
+  __syncthreads();
+  float m = wmax[0];
+#pragma unroll
+  for (int k = 1; k < NT / 64; ++k) m = fmaxf(m, wmax[k]);
+  return m;
+}
+
+// With the step from the transform's largest strength, the quantisation adds ~1.2e-9 B x (largest / rms strength) to
+// the output (tools/fx_error_vs_crest.py, profiles/r04_fx_error_vs_crest.txt; uniform strengths: largest / rms = 1.41).
+// A subproblem whose B x (largest / MEAN strength, which is >= largest / rms) exceeds kPatchCrest x Geom::fx_bound_limit
+// (= the same 0.28 of the tolerance: 3.5e-9 limit = 1.2e-9 x 2.9 limit) bounds its cells from its own strengths instead.
+constexpr float kPatchCrest = 2.9f;
 constexpr int kPatchLS = 24;
 constexpr int kPatchNW = 12;
 template <int W, int TZ, int HALF> struct PatchCfg {
@@ -597,20 +671,35 @@ __global__ __launch_bounds__(kPatchNW * 64) void spread_patch3_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const float2* cc = reinterpret_cast<const float2*>(c) + (int64_t)slot * c_stride;
   const int npt = p1 - p0;
-  for (int i = tid; i < C::plane_elems; i += NW * 64) plane[i] = 0ull;
 
   // step of the fixed-point grid (see the header comment)
   const float sum_g = sp.cstats[2 * slot + 1];
   const float top_g = sum_g == sum_g ? sp.cstats[2 * slot] : sum_g;   // (NaN strengths: see spread_dense3_kernel)
-  const bool skewed = top_g * (float)c_stride > 8.f * sum_g;
-  float top = top_g, sum = 3.0e38f;
-  if (skewed) {   // (workgroup-uniform) one strength dominates the transform: this subproblem's own strengths decide
+  const bool skewed = bound_b * top_g * (float)c_stride > kPatchCrest * g.fx_bound_limit * sum_g;
+  float top = top_g, sum = 3.0e38f, cap = top_g * bound_b;
+  if (skewed) {
+    // (workgroup-uniform) strengths too far from uniform for this subproblem's B: its own strengths decide. Its cells are bounded by
+    // the start-cell sums of max(|re c|, |im c|) filtered with the tap maxima -- the count filter of bound3_kernel with
+    // the strengths as weights (in units of the transform's largest / 2^19, rounded up) --, by the sum of its
+    // strengths, and by its largest one x the count bound. The plane is not in use yet: its LDS holds the filter.
+    constexpr int T = kDenseTile, FL = T + W - 1, CP = T + 1;
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(smem_raw);                 // [TZ][T][CP]
+    float* fa = reinterpret_cast<float*>(cnt + TZ * T * CP);               // [TZ][T][FL]
+    float* fb = fa + TZ * T * FL;                                          // [TZ][FL][FL]
+    float* fmx = fb + TZ * FL * FL;                                        // [NW]
+    static_assert((size_t)(TZ * T * CP + TZ * T * FL + TZ * FL * FL + NW) * 4 <= (size_t)C::plane_elems * 8, "filter scratch");
+    for (int i = tid; i < TZ * T * CP; i += NW * 64) cnt[i] = 0u;
+    __syncthreads();
+    const float inv = top_g > 0.f ? 524288.f / top_g : 0.f;
     float part = 0.f, big = 0.f;
     for (int j = p0 + tid; j < p1; j += NW * 64) {
-      const float2 cv = cc[sp.rec[j].idx];
+      const PointView<float> rec = unpack_rec<float, 3>(sp.rec[j]);
+      const float2 cv = cc[rec.idx];
       const float m = fmaxf(fabsf(cv.x), fabsf(cv.y));
       part += fmaf(0.f, cv.x + cv.y, m);   // (NaN / Inf components make the sum NaN)
       big = fmaxf(big, m);
+      const uint32_t wgt = (uint32_t)ceilf(m * inv);   // <= 2^19 + 1; NaN -> 0 (the NaN step below takes over)
+      atomicAdd(&cnt[(((rec.loc >> 20) & 1023u) * T + ((rec.loc >> 10) & 1023u)) * CP + (rec.loc & 1023u)], wgt);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -622,11 +711,18 @@ __global__ __launch_bounds__(kPatchNW * 64) void spread_patch3_kernel(
     sum = 0.f; top = 0.f;
 #pragma unroll
     for (int k = 0; k < NW; ++k) { sum += red[k]; top = fmaxf(top, red[NW + k]); }
+    float km[W];
+#pragma unroll
+    for (int t = 0; t < W; ++t) km[t] = g.fx_tap[t];
+    const float wb = count_filter_max<W, TZ, NW * 64>(cnt, fa, fb, fmx, km, tid);
+    cap = fminf(top * bound_b, top_g * wb * (1.0001f / 524288.f));
+    __syncthreads();   // (the scratch becomes the plane)
   }
+  for (int i = tid; i < C::plane_elems; i += NW * 64) plane[i] = 0ull;
   const float amp = fabsf(scale) * g.fx_headroom;
   const float room = 2147483000.f - (float)npt;     // 2^31 minus one step of rounding per contribution
   // (no finer than top 2^-29: every contribution stays below 2^29 steps)
-  float step = fmaxf(fminf(sum, top * bound_b), top * 1.8626451e-9f * room) * amp / room;
+  float step = fmaxf(fminf(sum, cap), top * 1.8626451e-9f * room) * amp / room;
   if (!(top == top) || !(sum == sum)) step = top + sum;   // NaN strengths (fminf / fmaxf would drop them)
   const float pre = step > 0.f ? scale / step : 0.f;
   __syncthreads();
@@ -751,8 +847,7 @@ __global__ __launch_bounds__(kBoundThreads) void bound3_kernel(Geom g, const Rec
                                                               const int32_t* __restrict__ tile_start,
                                                               const int32_t* __restrict__ sub_start, TapMax taps,
                                                               float* __restrict__ sub_bound, int* __restrict__ fb_list) {
-  // count rows of 17 words: the x pass reads one LINE per lane, and a lane stride of 16 words would put a wave on 4 banks
-  constexpr int T = kDenseTile, L = T + W - 1, CP = T + 1, LZ = TZ + W - 1, NT = kBoundThreads;
+  constexpr int T = kDenseTile, L = T + W - 1, CP = T + 1, NT = kBoundThreads;
   __shared__ uint32_t cnt[TZ * T * CP];
   __shared__ float a[TZ * T * L];     // [z][y][i]  (L is odd: conflict-free line-per-lane writes)
   __shared__ float b[TZ * L * L];     // [z][j][i]
@@ -782,60 +877,8 @@ __global__ __launch_bounds__(kBoundThreads) void bound3_kernel(Geom g, const Rec
   float km[W];
 #pragma unroll
   for (int t = 0; t < W; ++t) km[t] = taps.k[t];
-  // x: line (z, y) of T counts -> L values
-  for (int line = tid; line < TZ * T; line += NT) {
-    float in[T];
-#pragma unroll
-    for (int i = 0; i < T; ++i) in[i] = (float)cnt[line * CP + i];
-#pragma unroll
-    for (int i = 0; i < L; ++i) {
-      float v = 0.f;
-#pragma unroll
-      for (int t = 0; t < W; ++t)
-        if (i - t >= 0 && i - t < T) v = fmaf(km[t], in[i - t], v);
-      a[line * L + i] = v;
-    }
-  }
-  __syncthreads();
-  // y: line (z, i) of T values -> L values
-  for (int line = tid; line < TZ * L; line += NT) {
-    const int z = line / L, i = line - z * L;
-    float in[T];
-#pragma unroll
-    for (int y = 0; y < T; ++y) in[y] = a[(z * T + y) * L + i];
-#pragma unroll
-    for (int j = 0; j < L; ++j) {
-      float v = 0.f;
-#pragma unroll
-      for (int t = 0; t < W; ++t)
-        if (j - t >= 0 && j - t < T) v = fmaf(km[t], in[j - t], v);
-      b[(z * L + j) * L + i] = v;
-    }
-  }
-  __syncthreads();
-  // z: line (j, i) of TZ values -> maximum of the LZ outputs
-  float best = 0.f;
-  for (int line = tid; line < L * L; line += NT) {
-    float in[TZ];
-#pragma unroll
-    for (int z = 0; z < TZ; ++z) in[z] = b[z * L * L + line];
-#pragma unroll
-    for (int k = 0; k < LZ; ++k) {
-      float v = 0.f;
-#pragma unroll
-      for (int t = 0; t < W; ++t)
-        if (k - t >= 0 && k - t < TZ) v = fmaf(km[t], in[k - t], v);
-      best = fmaxf(best, v);
-    }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) best = fmaxf(best, __shfl_down(best, o));
-  if ((tid & 63) == 0) wmax[tid >> 6] = best;
-  __syncthreads();
+  float m = count_filter_max<W, TZ, NT>(cnt, a, b, wmax, km, tid);
   if (tid == 0) {
-    float m = wmax[0];
-#pragma unroll
-    for (int k = 1; k < NT / 64; ++k) m = fmaxf(m, wmax[k]);
     m *= 1.0001f;   // (float sums of non-negative terms)
     if (m > g.fx_bound_limit) {
       sub_bound[blockIdx.x] = -m;

@@ -57,6 +57,7 @@ struct Geom {
   // from its count-filter bound (SortedPoints::sub_bound, written in set_points), the conversion is exact to 32 bits
   int fx_patch;
   float fx_bound_limit;   // subproblems whose bound exceeds this go to the fp64-plane kernels (quantisation noise)
+  float fx_tap[8];        // fx_patch: per-tap maxima of the fitted kernel (TapMax, the first w of them)
 };
 // OFF / ON pair of nufft_hip_options.tuning: -1 = by the plan's own rule, 0 = never, 1 = always
 inline int tune_mode(const Geom& g, int off_bit, int on_bit) { return (g.tuning & on_bit) ? 1 : ((g.tuning & off_bit) ? 0 : -1); }

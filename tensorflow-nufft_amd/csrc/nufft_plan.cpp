@@ -1268,6 +1268,9 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
   // quadrature at a mean bound of 14, 0.61e-7 at 28; r02 / r03: 2.4e-6 at a step of 2^-22 largest strengths = B of
   // 512); a subproblem may spend 0.28 of the width's tolerance 10^(2 - w) on it: B <= 80 at w = 8.
   g.fx_bound_limit = (float)(0.28 * std::pow(10.0, 2 - w) / 3.5e-9);
+#ifdef NUFFT_FX_BOUND_LIMIT   // experiment builds (tools/fx_error_vs_crest.sh): a fixed limit instead of the rule
+  g.fx_bound_limit = (float)(NUFFT_FX_BOUND_LIMIT);
+#endif
   if (g.fx_patch) {
     // per-tap maxima of the fitted polynomials over z in [-1, 1] (sampled; margins for the sampling, the float
     // evaluation and the products)
@@ -1282,6 +1285,7 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
       }
       p->taps.k[t] = (float)(m * 1.001 + 1e-6);
     }
+    for (int t = 0; t < 8; ++t) g.fx_tap[t] = p->taps.k[t];
   }
   // fp64 planes in 3-D float at tile depth 4 (w = 8, or w <= 7 with lds_accumulate = 1):
   // one plane per launch, so that two workgroups share a CU (EXPERIMENTS.md section 4)

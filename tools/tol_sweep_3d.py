@@ -26,6 +26,7 @@ def main():
   ap.add_argument('--tols', default='1e-1,1e-2,1e-3,1e-4,1e-5,1e-6')
   ap.add_argument('--no-oracle', action='store_true')
   ap.add_argument('--steps', type=int, default=3)
+  ap.add_argument('--strengths', default='uniform', help='uniform | gaussian | lognormal (exp of a unit normal times a complex normal)')
   args = ap.parse_args()
   n, M = args.grid, args.M
   grid = [n, n, n]
@@ -33,7 +34,13 @@ def main():
         f'complex64: HIP-event stage times per call (set_points + execute)')
   g = torch.Generator(device='cuda').manual_seed(1)
   pts = (torch.rand((M, 3), generator=g, device='cuda') * 2 - 1) * np.pi
-  c = torch.complex(torch.rand(M, generator=g, device='cuda') - .5, torch.rand(M, generator=g, device='cuda') - .5)
+  if args.strengths == 'uniform':
+    c = torch.complex(torch.rand(M, generator=g, device='cuda') - .5, torch.rand(M, generator=g, device='cuda') - .5)
+  else:
+    c = torch.complex(torch.randn(M, generator=g, device='cuda'), torch.randn(M, generator=g, device='cuda'))
+    if args.strengths == 'lognormal':
+      c = c * torch.exp(torch.randn(M, generator=g, device='cuda'))
+  print(f'# strengths: {args.strengths}')
   truth = None
   for tol in [float(t) for t in args.tols.split(',')]:
     variants = [('r04', 0)]
