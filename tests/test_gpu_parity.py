@@ -905,7 +905,8 @@ def test_3d_w8_uneven_strengths_take_the_weighted_bound(tfft):
   plans = {mode: tfft.Plan('type_1', grid, 'forward', tol=1e-6, lds_accumulate=mode) for mode in (0, 1)}
   for pl in plans.values():
     pl.set_points(_dev(pts))
-  assert (plans[0].sub_bounds() > 0).all()
+  b = plans[0].sub_bounds()
+  assert (b >= 0).all() and (b > 0).sum() >= 1024   # every subproblem on the fixed-point kernel (0 = unused launch slot)
   for name, (c, allowed) in laws.items():
     c = c.astype(np.complex64)
     truth = oracle.nufft(c.astype(np.complex128), pts, grid, 'type_1', 'forward', tol=1e-12, sigma=2.0)
