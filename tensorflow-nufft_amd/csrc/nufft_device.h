@@ -130,7 +130,8 @@ __device__ __forceinline__ void tile_to_grid(const Geom& g, const double* plane_
 // strengths of that pair start at c + slot * c_stride, its fine grid at fw + slot * fw_stride.
 __device__ __forceinline__ bool locate_subproblem(const Geom& g, const int32_t* __restrict__ tile_start,
                                                   const int32_t* __restrict__ sub_start, int s,
-                                                  int* tile, int* p0, int* p1, int* slot, int* nsub = nullptr) {
+                                                  int* tile, int* p0, int* p1, int* slot, int* nsub = nullptr,
+                                                  int* chunk_of = nullptr, int* tile_end = nullptr) {
   const int nt = g.ntiles;
   if (s >= sub_start[nt]) return false;
   // Invariant: sub_start[lo] <= s < sub_start[hi]. Most tiles own exactly one
@@ -164,6 +165,8 @@ __device__ __forceinline__ bool locate_subproblem(const Geom& g, const int32_t* 
   const int sz = (e - b + k - 1) / k;
   const int a = b + chunk * sz;
   if (nsub) *nsub = k;   // subproblems of this tile
+  if (chunk_of) *chunk_of = chunk;   // which of them this is, and where the tile's points end
+  if (tile_end) *tile_end = e;
   if (g.nitems > 1) {
     const int item = lo / g.ntiles_item;
     *tile = lo - item * g.ntiles_item;

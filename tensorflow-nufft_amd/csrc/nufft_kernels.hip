@@ -1793,6 +1793,7 @@ __global__ __launch_bounds__(NW * 64) void spread_wave2_kernel(
 // the real / imaginary part (ONE plane, so two workgroups fit a CU; the host launches both).
 template <int W> constexpr int kWave3Pad = (551 - 24 * (15 + W) + 1) > 64 ? ((551 - 24 * (15 + W) + 1 + 7) & ~7) : 64;
 // sub: the subproblem (launch slot) this call works on -- blockIdx.x, or an entry of the fallback list (see the kernel)
+constexpr int kCrowdJoinFrom = 64, kCrowdJoinMax = 8;   // (spread_wave3_body: subproblems of a crowded tile joined per workgroup)
 template <typename T, int W, int TZ, int NW, int CH, bool FX, int COMP>
 __device__ __forceinline__ void spread_wave3_body(
     const Geom& g, const SortedPoints<T>& sp, const T* __restrict__ horner, const T* __restrict__ c,
@@ -1815,8 +1816,8 @@ __device__ __forceinline__ void spread_wave3_body(
   float* red = reinterpret_cast<float*>(stage_all + NW * CH * 2 * SW);   // [NW] (FX bound reduction)
   // (behind a fused 3-D sort the records are 32-byte FusedRec3: the 16-byte record comes first)
   const int rstride = g.fused ? (int)sizeof(FusedRec3) : (int)sizeof(Rec<T>);
-  int tb, p0, p1, slot, nsub;
-  if (!locate_subproblem(g, sp.tile_start, sp.sub_start, sub, &tb, &p0, &p1, &slot, &nsub)) return;
+  int tb, p0, p1, slot, nsub, chunk, tile_end;
+  if (!locate_subproblem(g, sp.tile_start, sp.sub_start, sub, &tb, &p0, &p1, &slot, &nsub, &chunk, &tile_end)) return;
   // Fixed-point plans: crowded tiles go to the fp64-plane kernels. The quantisation noise of the
   // packed fields is the same in every cell of a subproblem's tile, whatever the cell's kernel
   // weight, and every further subproblem of the tile adds its share: with 600000 coincident points
@@ -1825,6 +1826,20 @@ __device__ __forceinline__ void spread_wave3_body(
   // (subproblems that reach this function through the fallback list were chosen by set_points: bound3_kernel /
   // crowded_list_kernel)
   if (!listed && g.fixed_point && (FX ? nsub > g.fx_max_subs : nsub <= g.fx_max_subs)) return;
+  if constexpr (!FX && sizeof(T) == 4) {
+    // Very crowded tiles, float fine grid: every subproblem adds its partial sums to the same cells with float
+    // atomics, ~3.3e-8 sqrt(subproblems) of rounding (r04 soak: 1.5e6 points in one tile = 586 subproblems: 1.3e-6
+    // at tol 1e-6). The planes are fp64 and nothing here is sized by the point count: above kCrowdJoinFrom
+    // subproblems, up to kCrowdJoinMax consecutive ones are accumulated by the workgroup of the first and written
+    // out once (the others exit) -- fewer, longer workgroups, on point sets that have one hot tile anyway.
+    if (nsub > kCrowdJoinFrom) {
+      int join = (nsub + kCrowdJoinFrom - 1) / kCrowdJoinFrom;
+      if (join > kCrowdJoinMax) join = kCrowdJoinMax;
+      if (chunk % join) return;
+      const long long end = (long long)p0 + (long long)join * (p1 - p0);   // (an even split: p1 - p0 is the chunk size unless this is the last one)
+      p1 = end < (long long)tile_end ? (int)end : tile_end;
+    }
+  }
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;

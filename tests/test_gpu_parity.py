@@ -888,6 +888,30 @@ def test_3d_w8_fixed_point_clustered_and_skewed(tfft):
   assert rel_l2(out, ref) < 2e-6, rel_l2(out, ref)
 
 
+@pytest.mark.parametrize('mode', [0, 1])
+def test_3d_very_crowded_tile_joins_its_subproblems(tfft, mode):
+  # 1.5e6 points within a few cells of one spot: ~590 subproblems (2560 points each) of one tile, every one adding its
+  # partial sums to the same fine-grid cells in float -- 1.2-1.3e-6 at tol 1e-6 (r04 soak seed 403; the fp64-plane
+  # plan's 366 subproblems 0.7e-6). Above 64 subproblems per tile the fp64-plane kernel now accumulates up to 8
+  # consecutive ones per workgroup before it writes out. Bar: the reference rule's own error + 4e-7.
+  from oracle import oracle
+  rng = np.random.default_rng(403)
+  grid = [11, 9, 60]
+  M = 1_500_000
+  pts = (rng.uniform(-2.5, 2.5, (1, 3)) + 0.01 * rng.standard_normal((M, 3))).astype(np.float32)
+  c = (rng.standard_normal(M) + 1j * rng.standard_normal(M)).astype(np.complex64)
+  truth = oracle.nufft(c.astype(np.complex128), pts, grid, 'type_1', 'forward', tol=1e-12, sigma=2.0)
+  same = oracle.nufft(c.astype(np.complex128), pts, grid, 'type_1', 'forward', tol=1e-6, sigma=2.0)
+  plan = tfft.Plan('type_1', grid, 'forward', tol=1e-6, lds_accumulate=mode)
+  plan.set_points(_dev(pts))
+  out = plan.execute(_dev(c)).cpu().numpy()
+  nsub = M / plan.info().max_subproblem_size
+  plan.close()
+  err, ref_err = rel_l2(out, truth), rel_l2(same, truth)
+  print(f'crowded tile, lds_accumulate {mode}: {err:.3e} (reference rule {ref_err:.3e})')
+  assert nsub > 300 and err <= 1.05 * ref_err + 4e-7, (err, ref_err)
+
+
 def test_3d_w8_uneven_strengths_take_the_weighted_bound(tfft):
   # With the step from the transform's largest strength the quantisation adds ~1.2e-9 B (largest / rms strength):
   # 5.1e-7 for lognormal strengths at 0.75 points per fine cell (B = 37), twice the kernel's own error. Subproblems
