@@ -124,7 +124,10 @@ enum {
   NUFFT_HIP_TUNE_SORT2_ON = 1 << 17,
   NUFFT_HIP_TUNE_FXPATCH_OFF = 1 << 18,    /* 3-D float w = 7, 8: the r03 kernels (fp64 planes at w = 8; w = 7 fixed point on
                                               depth-4 tiles, 512-point subproblems) instead of spread_patch3_kernel */
-  NUFFT_HIP_TUNE_ALL = (1 << 19) - 1       /* every defined bit: plan creation refuses others, and both bits of a pair */
+  NUFFT_HIP_TUNE_QFOLD_OFF = 1 << 19,      /* LDS-histogram sorts: the general coordinate fold (fmod / division / 64-bit modulo
+                                              paths compiled in) although the plan's tiles are powers of two and the points'
+                                              range is STRICT or EXTENDED -- same results, for A/B runs */
+  NUFFT_HIP_TUNE_ALL = (1 << 20) - 1       /* every defined bit: plan creation refuses others, and both bits of a pair */
 };
 
 typedef struct nufft_hip_plan_s* nufft_hip_plan;

@@ -26,6 +26,7 @@ struct Geom {
   int nf[3];        // fine grid, x fastest
   int tile[3];      // tile size in fine cells
   int tile_shift[3];  // log2(tile) when tile is a power of two, else -1
+  int fold_pow2;    // every used dimension's tile edge is a power of two (the sort kernels' short fold path; 0 with tuning QFOLD_OFF)
   int ntile[3];     // tiles per dimension
   int ldim[3];      // LDS tile extent = tile + w - 1
   int lstride;      // padded LDS row length (>= ldim[0])

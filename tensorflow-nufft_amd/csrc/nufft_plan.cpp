@@ -1305,6 +1305,9 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
   // (and tiles of config 4's density, 1526 points on average, in ONE subproblem: a cap of 1536 split 40 % of them)
   if (g.fx_patch && w == 8 && auto_sub && spreads) g.max_sub = 2560;
   g.fx_max_subs = 16;
+  g.fold_pow2 = (p->opts.tuning & NUFFT_HIP_TUNE_QFOLD_OFF) ? 0 : 1;
+  for (int d = 0; d < rank; ++d)
+    if (g.tile_shift[d] < 0) g.fold_pow2 = 0;
   p->lds_bytes = spread_lds_bytes(g, method, precision);
   if (p->lds_bytes > 160 * 1024 || interp_lds_bytes(g, method, precision) > 160 * 1024) {
     // does not fit (e.g. 3-D double at w = 8): fall back to the generic tile path

@@ -2079,8 +2079,8 @@ def test_tuning_bits_give_the_same_transforms(tmp_path):
   # options.tuning forces one of the kernel families the plan otherwise picks by density / geometry (staged or
   # plain scatter, fused records or not, grouped or per-point 2-D spreader, joint or split 3-D w = 8 launches,
   # LDS-free spreader, cell-sorted records, rocFFT + deconvolve instead of the pruned passes, thread-per-point
-  # kernels instead of the wide / line ones, the two-level 3-D sort where the fine grid is a multiple of 64 cells):
-  # each must give the default path's transform.
+  # kernels instead of the wide / line ones, the two-level 3-D sort where the fine grid is a multiple of 64 cells, the
+  # general coordinate fold in the sort kernels): each must give the default path's transform.
   import subprocess
   import sys
   from conftest import PKG, ROOT
@@ -2097,13 +2097,16 @@ def test_tuning_bits_give_the_same_transforms(tmp_path):
   for bits in (('NO_FUSED', 'GROUP_OFF', 'SPARSE_OFF', 'CELLSORT_OFF', 'CELLSORT3D_OFF', 'ROCFFT', 'NO_WIDE', 'NO_LINE',
                 'JOINT_OFF', 'STAGED_OFF', 'SORT2_OFF'),
                ('GROUP_ON', 'SPARSE_OFF', 'CELLSORT_ON', 'CELLSORT3D_ON', 'JOINT_ON', 'STAGED_ON', 'SORT2_ON'),
-               ('SPARSE_ON', 'NO_FUSED')):
+               ('SPARSE_ON', 'NO_FUSED'), ('QFOLD_OFF',)):
     tuning = 0
     for b in bits:
       tuning |= T[b]
     got = run(str(tmp_path / 'alt.npz'), tuning)
     for k in ref.files:
-      assert rel_l2(got[k], ref[k]) < (2e-6 if not k.startswith(('t1_3d_sparse', 't2_3d_dense', 't1_3d_w')) else 2e-5), (bits, k, rel_l2(got[k], ref[k]))
+      bar = 2e-6 if not k.startswith(('t1_3d_sparse', 't2_3d_dense', 't1_3d_w')) else 2e-5
+      if bits == ('QFOLD_OFF',):
+        bar = 5e-7   # the short and the general coordinate fold are the same arithmetic: only the order of the float atomics differs
+      assert rel_l2(got[k], ref[k]) < bar, (bits, k, rel_l2(got[k], ref[k]))
 
 
 _EFENCE_CHILD = r'''
