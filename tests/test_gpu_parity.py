@@ -378,6 +378,38 @@ def test_points_range_and_check(tfft):
   tfft.nufft(_dev(src), _dev(pts), grid_shape=grid, transform_type='type_1', options=o)   # in range: fine
 
 
+@pytest.mark.parametrize('rank,grid,M', [(1, [300], 20000), (2, [96, 80], 60001), (2, [1024, 1024], 2_200_000), (3, [20, 24, 18], 50000),
+                                         (3, [64, 64, 64], 1_700_000)])
+def test_garbage_coordinates_stay_memory_safe(tfft, rank, grid, M):
+  # With the range check off (the default) out-of-range points are the caller's problem -- but never a memory fault:
+  # NaN, +-Inf, +-1e30, +-100 and +-pi itself among the points, in the STRICT and EXTENDED modes (the straight-line
+  # fold of the sort kernels: saturating conversion + clamp) and INFINITE (the general fold), both types, float and
+  # double, the one-level, staged and two-level sorts. Afterwards the same plan must still transform clean points.
+  from oracle import oracle
+  import torch
+  rng = np.random.default_rng(13)
+  junk = np.array([np.nan, np.inf, -np.inf, 1e30, -1e30, 100.0, -100.0, np.pi, -np.pi, 3 * np.pi, -3 * np.pi, 4.0, -4.0])
+  for rdt, cdt, tol in ((np.float32, np.complex64, 1e-6), (np.float64, np.complex128, 1e-9)):
+    clean = rng.uniform(-np.pi, np.pi, (M, rank)).astype(rdt)
+    dirty = clean.copy()
+    rows = rng.integers(0, M, 4 * junk.size)
+    dirty[rows, rng.integers(0, rank, rows.size)] = np.tile(junk, 4).astype(rdt)
+    c = (rng.uniform(-.5, .5, M) + 1j * rng.uniform(-.5, .5, M)).astype(cdt)
+    f = (rng.uniform(-.5, .5, grid) + 1j * rng.uniform(-.5, .5, grid)).astype(cdt)
+    for mode in ('STRICT', 'EXTENDED', 'INFINITE'):
+      o = tfft.Options()
+      o.points_range = getattr(tfft.PointsRange, mode)
+      tfft.nufft(_dev(c), _dev(dirty), grid_shape=grid, transform_type='type_1', tol=tol, options=o)
+      tfft.nufft(_dev(f), _dev(dirty), transform_type='type_2', tol=tol, options=o)
+      torch.cuda.synchronize()
+      out = tfft.nufft(_dev(c), _dev(clean), grid_shape=grid, transform_type='type_1', tol=tol, options=o).cpu().numpy()
+      if mode == 'STRICT' and M <= 100000:
+        truth = oracle.nufft(c.astype(np.complex128), clean, grid, 'type_1', 'forward', tol=1e-12, sigma=2.0)
+        assert rel_l2(out, truth) < tol
+      else:
+        assert np.isfinite(out).all()
+
+
 def test_error_messages(tfft):
   # nufft_ops_test.py:438-503
   pts = np.zeros((10, 2), np.float32)
