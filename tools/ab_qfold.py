@@ -1,5 +1,10 @@
+"""Same-run A/B of the short coordinate fold of the sort kernels (options.tuning QFOLD_OFF = the general fold):
+HIP-event stage times of configs 2, 3 and 4, each variant twice. EXPERIMENTS.md section 10.15.
+
+    python tools/ab_qfold.py [path/to/another/libnufft_hip.so]
+"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tensorflow-nufft_amd'))
 import tensorflow_nufft._lib as L
 if len(sys.argv) > 1 and sys.argv[1] != '-':

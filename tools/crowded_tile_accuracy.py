@@ -1,5 +1,8 @@
+"""Whole-output error at tol 1e-6 when 1e6-2e6 points sit within a few cells of one spot (hundreds of subproblems of
+one tile adding float partial sums to the same fine-grid cells), 2-D and 1-D. EXPERIMENTS.md section 10.14.
+"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tensorflow-nufft_amd'))
 import numpy as np, torch
 import tensorflow_nufft as tfft
