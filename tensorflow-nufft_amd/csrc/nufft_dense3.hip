@@ -678,10 +678,11 @@ __global__ __launch_bounds__(kPatchNW * 64) void spread_patch3_kernel(
   const bool skewed = bound_b * top_g * (float)c_stride > kPatchCrest * g.fx_bound_limit * sum_g;
   float top = top_g, sum = 3.0e38f, cap = top_g * bound_b;
   if (skewed) {
-    // (workgroup-uniform) strengths too far from uniform for this subproblem's B: its own strengths decide. Its cells are bounded by
-    // the start-cell sums of max(|re c|, |im c|) filtered with the tap maxima -- the count filter of bound3_kernel with
-    // the strengths as weights (in units of the transform's largest / 2^19, rounded up) --, by the sum of its
-    // strengths, and by its largest one x the count bound. The plane is not in use yet: its LDS holds the filter.
+    // (workgroup-uniform) strengths too far from uniform for this subproblem's B: its own strengths decide. Its cells
+    // are bounded by the start-cell sums of max(|re c|, |im c|) filtered with the tap maxima -- the count filter of
+    // bound3_kernel with the strengths as weights (in units of the transform's largest / 2^19, rounded up) --, by the
+    // sum of its strengths, and by its largest one x the count bound. The plane is not in use yet: its LDS holds
+    // the filter.
     constexpr int T = kDenseTile, FL = T + W - 1, CP = T + 1;
     uint32_t* cnt = reinterpret_cast<uint32_t*>(smem_raw);                 // [TZ][T][CP]
     float* fa = reinterpret_cast<float*>(cnt + TZ * T * CP);               // [TZ][T][FL]
