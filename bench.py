@@ -55,6 +55,7 @@ C5_ITEMS = 256
 C5_M = 1_000_000
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 LDS_ADD_F64_CYCLES = 8.6   # cycles per ds_add_f64 wave-instruction per CU, conflict free (profiles/r01_lds_atomic_ubench.txt)
+LDS_ADD_U64_CYCLES = 7.0   # the same for ds_add_u64, the packed fixed-point accumulation of the 3-D float kernels
 NUM_CUS = 256
 CLOCK_GHZ_NOMINAL = 2.4
 
@@ -253,7 +254,9 @@ def other_configs(args, dev):
   """BASELINE configs 3, 4 and 5 on this one GPU, after the headline region: ms per step (HIP
   events), whole-step rate, the dominant kernel's average duration (HIP events of the plan's
   own stage timing around that kernel) and its HBM fraction on the SURVEY 8(d) algorithmic
-  bytes. `value` stays config 2; these are the driver-timed figures of the other configs."""
+  bytes; the 3-D type-1 entries also carry `lds`: the spread kernel's ds_add_u64 rate against
+  the LDS-atomic peak at the measured clock (the bound that tracks those kernels).
+  `value` stays config 2; these are the driver-timed figures of the other configs."""
   import numpy as np
   import torch
   import tensorflow_nufft as tfft
@@ -287,6 +290,18 @@ def other_configs(args, dev):
                  'dominant_kernel_ms': round(k_ms, 4), 'algorithmic_bytes': algo,
                  'hbm_frac': round(algo / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                  'kernel_width': int(info.kernel_width), 'fine_grid': nf[::-1], 'steps': steps}
+    if ttype == 'type_1' and rank == 3 and int(info.kernel_width) <= 8:
+      # the 3-D float fixed-point spreaders are bound by the LDS-atomic data path, not by HBM: ds_add_u64
+      # wave-instructions per point of the kernel family (spread_dense3_kernel: one W x 3 x 3 lane block per
+      # instruction, 1 at w <= 4 and 4 at w = 5, 6; spread_patch3_kernel: one 8 x 8 (x, y) patch per z plane, w of them)
+      w_ = int(info.kernel_width)
+      per_pt = 1 if w_ <= 4 else (4 if w_ <= 6 else w_)
+      ghz, how = shader_clock_ghz()
+      peak = NUM_CUS * ghz * 1e9 / LDS_ADD_U64_CYCLES
+      achieved = m * per_pt / (k_ms * 1e-3)
+      out[name]['lds'] = {'bound': 'lds-atomic', 'unit': 'G wave-instr/s (ds_add_u64)', 'achieved': round(achieved / 1e9, 2),
+                          'peak': round(peak / 1e9, 2), 'frac': round(achieved / peak, 4), 'atomics_per_point': per_pt,
+                          'clock_ghz': round(ghz, 3), 'clock': how}
     plan.close()
     del pts, src, res
     torch.cuda.empty_cache()
