@@ -41,7 +41,7 @@ print('# source_shape | points_shape | type | grid | GPU ms per call (tfft.nufft
 for source_shape, points_shape, ttype, grid, ms, npts, src, pts, outn in rows:
   p0 = pts if pts.ndim == 2 else pts[0]
   s0 = src if pts.ndim == 2 else src[0]
-  nth = min(os.cpu_count() or 1, 64)
+  nth = oracle.default_threads()   # (the container's cgroup CPU quota, not the host's hardware threads: EXPERIMENTS.md 10.12)
   t1 = time.perf_counter()
   for _ in range(3):
     oracle.nufft(s0, p0, grid, ttype, 'forward', tol=1e-6, kerevalmeth=1, nthreads=nth)
