@@ -289,7 +289,12 @@ constexpr int kSortBlock = 1024;
 #ifndef NUFFT_SORT_MIN_WAVES
 #define NUFFT_SORT_MIN_WAVES 8
 #endif
-constexpr int kSortBatch = 4;    // load slots in flight per thread in the count / scatter loops
+constexpr int kSortBatch = 4;    // load slots in flight per thread in the count / staged-scatter loops
+// The plain scatter of the two-call form (one scattered 16-byte store per point, strengths not read) runs ahead of its
+// stores with twice the loads in flight: r04 same-run A/B at config 2 (set_points + execute), slots 2 / 4 / 8: scatter
+// 180 / 164 / 146-153 us (the count pass: 30 / 30 / 31 us, the 3-D count 272 / 259 / 309 us with spills: it keeps 4;
+// the fused scatter of the one-call form: 166 / 167 us with 4 / 8).
+constexpr int kScatterBatch = 8;
 
 // Walks the points [lo, hi) of a workgroup, kSortBatch load slots per thread per pass, the
 // loads of a pass issued back to back on clamped indices (with one load in flight per
@@ -316,11 +321,11 @@ struct BlockRange {
   }
 };
 
-template <typename T, int AOS>
+template <typename T, int AOS, int BATCH = kSortBatch>
 struct PointWalk {
   static constexpr bool PAIR = (AOS == 2 && sizeof(T) == 4);
   static constexpr int PP = PAIR ? 2 : 1;
-  static constexpr int NS = PAIR ? kSortBatch / 2 : kSortBatch;   // load slots per pass: 4 points per thread either way
+  static constexpr int NS = PAIR ? BATCH / 2 : BATCH;   // load slots per pass: BATCH points per thread either way
   template <typename Pre, typename Body>
   static __device__ __forceinline__ void run(const PointsIn& in, int64_t lo, int64_t hi, Pre pre, Body body) {
     const int64_t hi_main = PAIR ? (hi & ~(int64_t)1) : hi;
@@ -458,7 +463,9 @@ __global__ __launch_bounds__(kSortBlock, NUFFT_SORT_MIN_WAVES) void scatter_lds_
   const BlockRange br(in, per_block, g);
   const int64_t lo = br.lo, hi = br.hi;
   bool bad = false;
-  using Walk = PointWalk<T, AOS>;
+  // (float [M, 2] points with the short fold, unfused: 57 VGPRs, no scratch; the fused form already reads two arrays --
+  // no gain measured, 20 bytes of scratch -- and the other forms would spill 50-200 bytes)
+  using Walk = PointWalk<T, AOS, (sizeof(T) == 4 && AOS == 2 && QF && !FUSED ? kScatterBatch : kSortBatch)>;
   if constexpr (FUSED) {
     static_assert(sizeof(T) == 4, "fused records are float only");
     float2 cs[Walk::NS * Walk::PP];
