@@ -56,6 +56,13 @@ def test_tuning_bits_and_op_counts_are_validated():
   assert ok == 0
   rc, err, _ = _describe(2, [64, 64], 1e-6, 4, tuning=1 << 30)
   assert rc == _lib.INVALID_ARGUMENT and 'unknown options.tuning bits' in err, (rc, err)
+  # the table in _lib.py and NUFFT_HIP_TUNE_ALL in the header move together: every named bit is accepted alone,
+  # the first unnamed one is refused
+  for name, bit in T.items():
+    rc, err, _ = _describe(3, [32, 32, 32], 1e-4, 4, tuning=bit)
+    assert rc == 0, (name, err)
+  rc, err, _ = _describe(2, [64, 64], 1e-6, 4, tuning=max(T.values()) << 1)
+  assert rc == _lib.INVALID_ARGUMENT and 'unknown options.tuning bits' in err, (rc, err)
   for a, b in (('GROUP_OFF', 'GROUP_ON'), ('SPARSE_OFF', 'SPARSE_ON'), ('CELLSORT_OFF', 'CELLSORT_ON'),
                ('CELLSORT3D_OFF', 'CELLSORT3D_ON'), ('JOINT_OFF', 'JOINT_ON'), ('STAGED_OFF', 'STAGED_ON'),
                ('SORT2_OFF', 'SORT2_ON')):
