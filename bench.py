@@ -535,10 +535,13 @@ def run_config2(args, dev, dist, world, rank):
 
   for _ in range(args.warmup):
     step()
-  # full per-stage breakdown from an untimed pass (14 events per step cost ~7 %)
+  # full per-stage breakdown from an untimed pass (14 events per step cost ~7 %). At least 20 steps: the averages
+  # need them, and the device's clocks settle only after ~10 ms of work -- a timed region that starts after 6 steps
+  # measured 2-3 % below the sustained rate (EXPERIMENTS.md section 10.19); config.untimed_steps says how many ran.
   plan.set_timing(1)
   plan.get_timing()
-  for _ in range(max(3, args.warmup)):
+  stage_steps = max(3, args.warmup, 20)
+  for _ in range(stage_steps):
     step()
   stage_all = plan.get_timing()
   # timed region: HIP events around the dominant (spread) kernel only, recorded
@@ -604,6 +607,7 @@ def run_config2(args, dev, dist, world, rank):
           'points_per_gpu': m, 'grid': GRID, 'fine_grid': nf, 'kernel_width': int(info.kernel_width),
           'upsampling_factor': info.upsampling_factor, 'spread_method': int(info.spread_method),
           'stage_us': {k: round(v[0] / max(v[1], 1) * 1e3, 1) for k, v in stage_all.items() if v[1]},
+          'untimed_steps': args.warmup + stage_steps,   # the W warm-up steps + the per-stage timing pass, before the timed K
           **extras,
       },
       'roofline': {
