@@ -562,11 +562,11 @@ hipError_t launch_dense3(const Geom& g, const SortedPoints<float>& sp, const flo
 // start-cell weights -> max over the (T + W - 1)^2 (TZ + W - 1) cells of the weights filtered with the tap maxima km.
 // Every thread of the NT-thread workgroup calls it with cnt complete (barrier passed) and gets the maximum;
 // a: TZ T L floats, b: TZ L L floats, wmax: NT / 64 floats of scratch (L = T + W - 1).
+// x and y passes: cnt[TZ][T][T + 1] -> b[TZ][L][L] (a: TZ T L floats of scratch); ends with a barrier
 template <int W, int TZ, int NT>
-__device__ __forceinline__ float count_filter_max(const uint32_t* cnt, float* a, float* b, float* wmax, const float (&km)[W],
-                                                  int tid) {
+__device__ __forceinline__ void count_filter_xy(const uint32_t* cnt, float* a, float* b, const float (&km)[W], int tid) {
   // count rows of 17 words: the x pass reads one LINE per lane, and a lane stride of 16 words would put a wave on 4 banks
-  constexpr int T = kDenseTile, L = T + W - 1, CP = T + 1, LZ = TZ + W - 1;
+  constexpr int T = kDenseTile, L = T + W - 1, CP = T + 1;
   // x: line (z, y) of T counts -> L values
   for (int line = tid; line < TZ * T; line += NT) {
     float in[T];
@@ -598,6 +598,24 @@ __device__ __forceinline__ float count_filter_max(const uint32_t* cnt, float* a,
     }
   }
   __syncthreads();
+}
+// the workgroup's maximum of every thread's `best` (wmax: NT / 64 floats); ends with the value in every thread
+template <int NT>
+__device__ __forceinline__ float workgroup_max(float best, float* wmax, int tid) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) best = fmaxf(best, __shfl_down(best, o));
+  if ((tid & 63) == 0) wmax[tid >> 6] = best;
+  __syncthreads();
+  float m = wmax[0];
+#pragma unroll
+  for (int k = 1; k < NT / 64; ++k) m = fmaxf(m, wmax[k]);
+  return m;
+}
+template <int W, int TZ, int NT>
+__device__ __forceinline__ float count_filter_max(const uint32_t* cnt, float* a, float* b, float* wmax, const float (&km)[W],
+                                                  int tid) {
+  constexpr int T = kDenseTile, L = T + W - 1, LZ = TZ + W - 1;
+  count_filter_xy<W, TZ, NT>(cnt, a, b, km, tid);
   // z: line (j, i) of TZ values -> maximum of the LZ outputs
   float best = 0.f;
   for (int line = tid; line < L * L; line += NT) {
@@ -613,14 +631,7 @@ __device__ __forceinline__ float count_filter_max(const uint32_t* cnt, float* a,
       best = fmaxf(best, v);
     }
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) best = fmaxf(best, __shfl_down(best, o));
-  if ((tid & 63) == 0) wmax[tid >> 6] = best;
-  __syncthreads();
-  float m = wmax[0];
-#pragma unroll
-  for (int k = 1; k < NT / 64; ++k) m = fmaxf(m, wmax[k]);
-  return m;
+  return workgroup_max<NT>(best, wmax, tid);
 }
 
 // With the step from the transform's largest strength, the quantisation adds ~1.2e-9 B x (largest / rms strength) to
@@ -629,15 +640,25 @@ __device__ __forceinline__ float count_filter_max(const uint32_t* cnt, float* a,
 // (= the same 0.28 of the tolerance: 3.5e-9 limit = 1.2e-9 x 2.9 limit) bounds its cells from its own strengths instead.
 constexpr float kPatchCrest = 2.9f;
 constexpr int kPatchLS = 24;
-constexpr int kPatchNW = 12;
+#ifndef NUFFT_PATCH_NW
+#define NUFFT_PATCH_NW 12
+#endif
+#ifndef NUFFT_STACK_ROWS
+#define NUFFT_STACK_ROWS 4
+#endif
+constexpr int kPatchNW = NUFFT_PATCH_NW;
+#ifdef NUFFT_PATCH_MINW   // (experiment builds: waves per SIMD the register allocation must leave room for)
+#define NUFFT_PATCH_BOUNDS __launch_bounds__(kPatchNW * 64, NUFFT_PATCH_MINW)
+#else
+#define NUFFT_PATCH_BOUNDS __launch_bounds__(kPatchNW * 64)
+#endif
 template <int W, int TZ, int HALF> struct PatchCfg {
   static constexpr int L0 = kDenseTile + W - 1, L1 = kDenseTile + W - 1, L2 = TZ + W - 1;
   static constexpr int LS = kPatchLS, PS = kPatchLS * L1;
   // idle lanes (W = 7: dx = 7 or dy = 7) add 0 at their natural patch address: up to row 22, column 22 of the last
   // plane, i.e. up to 22 * 24 + 22 - PS + 1 elements behind it
   static constexpr int plane_elems = (PS * L2 + 64 + 1) & ~1;
-  static constexpr int PAIR_BYTES = 8 * 16 + 8 * 8;      // kx (im c, re c) of two points per 16-byte slot; ky of two points per 8
-  static constexpr size_t stage_bytes = (size_t)kPatchNW * (HALF / 2) * PAIR_BYTES;
+  static constexpr size_t stage_bytes = 0;   // (nothing is staged since r05; HALF is unused)
   static constexpr size_t lds_bytes = (size_t)plane_elems * 8 + stage_bytes + 2 * kPatchNW * sizeof(float) + 64;
 };
 
@@ -649,8 +670,101 @@ __device__ __forceinline__ int cvt_rpi(float x) {   // floor(x + 0.5) in one ins
 typedef __attribute__((address_space(3))) unsigned long long lds_u64;
 typedef __attribute__((address_space(3))) unsigned char lds_byte;
 
+// The accumulation loop of the w = 7, 8 kernels: this wave's points [wbeg, wend) of the records starting at `rec`
+// (strengths gathered through cc), every lane adding its (dx, dy) column of every point's stencil, plane after plane.
+// r05: nothing is staged in LDS. Each lane evaluates the kernel polynomial of ITS OWN tap pair (dx, dy) for the point
+// of the pass: the coefficients of a lane's two taps stay in 20 VGPRs for the whole kernel, the point's Horner
+// arguments reach the lanes as scalars (v_readlane), and one v_pk_fma_f32 per term evaluates kx[dx] and ky[dy]
+// together (9 per point). Only kz (needed by every lane, plane after plane) is evaluated one point per lane and
+// broadcast. The r04 loop staged kx c and ky of 8 points at a time through 9 KB of LDS (8 active lanes per store);
+// same arithmetic term for term, bit-identical LDS sums, and the same speed (r05, profiles/r05_stack_ab.txt): the
+// loop is bound by VALU issue -- ~51 instructions per point at the ~4.4 cycles per wave-instruction and SIMD the
+// chip sustains (tools/ubench/valu_rate_bench.hip) = 56 cycles per point and CU -- beside 8 ds_add_u64 at ~6 = 48.
+constexpr int kPatchCoef = kDenseCoef;   // (terms held per lane; plans with more keep the staged loop)
+template <int W>
+__device__ __forceinline__ void horner1(const float* __restrict__ tab, float z, float (&k)[W]) {
+#pragma unroll
+  for (int q = 0; q < W; ++q) k[q] = tab[(kPatchCoef - 1) * kMaxW + q];
+#pragma unroll
+  for (int j = kPatchCoef - 2; j >= 0; --j) {
+#pragma unroll
+    for (int q = 0; q < W; ++q) k[q] = fmaf(k[q], z, tab[j * kMaxW + q]);
+  }
+}
 template <int W, int TZ, int HALF>
-__global__ __launch_bounds__(kPatchNW * 64) void spread_patch3_kernel(
+__device__ __forceinline__ void patch3_accumulate(const Rec<float>* __restrict__ rec, const float2* __restrict__ cc, int wbeg,
+                                                         int wend, float pre, const float* __restrict__ horner,
+                                                         const v2f (&coef)[kPatchCoef], lds_byte* plane_l, int lane) {
+  using C = PatchCfg<W, TZ, HALF>;
+  constexpr int LS = C::LS, PS = C::PS;
+  const int dx = lane & 7, dy = lane >> 3;
+  const int cell_b = (dy * LS + dx) * 8;
+  for (int base = wbeg; base < wend; base += 64) {
+    // phase 1: one point per lane -- record, strength, the W kernel values in z
+    const int js = base + lane;
+    int off = 0;
+    float kz[8], z0 = 0.f, z1 = 0.f, cre = 0.f, cim = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) kz[q] = 0.f;
+    if (js < wend) {
+      const PointView<float> pv = unpack_rec<float, 3>(rec[js]);
+      const float2 cv = cc[pv.idx];
+      cre = cv.x * pre;
+      cim = cv.y * pre;
+      off = ((int)(pv.loc & 1023) + (int)((pv.loc >> 10) & 1023) * LS + (int)((pv.loc >> 20) & 1023) * PS) * 8;
+      z0 = pv.z0;
+      z1 = pv.z1;
+      float h2[W];
+      horner1<W>(horner, pv.z2, h2);
+#pragma unroll
+      for (int q = 0; q < W; ++q) kz[q] = fmaxf(h2[q], 0.f);
+    }
+    // a point with a negative imaginary strength is negated here and subtracted below
+    const unsigned long long negm = __ballot(cim < 0.f);
+    if (cim < 0.f) { cre = -cre; cim = -cim; }
+    int left = wend - base;
+    if (left > 64) left = 64;
+    // phase 2: a pass per point; every lane evaluates its taps and adds its (dx, dy) column, plane after plane
+    for (int q = 0; q < left; ++q) {
+      const v2f zz = {bcast_lane(z0, q), bcast_lane(z1, q)};
+      v2f k = coef[kPatchCoef - 1];
+#pragma unroll
+      for (int j = kPatchCoef - 2; j >= 0; --j) k = __builtin_elementwise_fma(k, zz, coef[j]);
+      const float kxv = fmaxf(k.x, 0.f), kyv = fmaxf(k.y, 0.f);
+      const v2f kxc = (v2f){kxv, kxv} * (v2f){bcast_lane(cim, q), bcast_lane(cre, q)};
+      const v2f xy = kxc * (v2f){kyv, kyv};
+      lds_u64* dst = (lds_u64*)(plane_l + __builtin_amdgcn_readlane(off, q) + cell_b);
+      if ((negm >> q) & 1ull) {   // wave-uniform
+#pragma unroll
+        for (int dz = 0; dz < W; ++dz) {
+          const float kzq = bcast_lane(kz[dz], q);
+          const v2f v = xy * (v2f){kzq, kzq};
+          const unsigned long long word = ((unsigned long long)(unsigned)cvt_rpi(v.y) << 32) | (unsigned)cvt_rpi(v.x);
+          __hip_atomic_fetch_sub(dst + dz * PS, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      } else {
+#pragma unroll
+        for (int dz = 0; dz < W; ++dz) {
+          const float kzq = bcast_lane(kz[dz], q);
+          const v2f v = xy * (v2f){kzq, kzq};
+          const unsigned long long word = ((unsigned long long)(unsigned)cvt_rpi(v.y) << 32) | (unsigned)cvt_rpi(v.x);
+          __hip_atomic_fetch_add(dst + dz * PS, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+    }
+  }
+}
+// the lane's coefficient pairs: term j of tap dx = lane & 7 (x) and of tap dy = lane >> 3 (y); taps >= W: zero
+template <int W>
+__device__ __forceinline__ void patch3_lane_coef(const float* __restrict__ horner, int lane, v2f (&coef)[kPatchCoef]) {
+  const int dx = lane & 7, dy = lane >> 3;
+#pragma unroll
+  for (int j = 0; j < kPatchCoef; ++j)
+    coef[j] = (v2f){dx < W ? horner[j * kMaxW + dx] : 0.f, dy < W ? horner[j * kMaxW + dy] : 0.f};
+}
+
+template <int W, int TZ, int HALF>
+__global__ NUFFT_PATCH_BOUNDS void spread_patch3_kernel(
     Geom g, SortedPoints<float> sp, const float* __restrict__ horner, const float* __restrict__ c,
     float* __restrict__ fw, int64_t c_stride, int64_t fw_stride, float scale) {
   using C = PatchCfg<W, TZ, HALF>;
@@ -729,84 +843,12 @@ __global__ __launch_bounds__(kPatchNW * 64) void spread_patch3_kernel(
   __syncthreads();
   NUFFT_PHASE3(3);
 
-  const int dx = lane & 7, dy = lane >> 3;
-  const int cell_b = (dy * LS + dx) * 8;
-  const int rd_x = dx * 16, rd_y = 128 + dy * 8;
-  const int nc = g.ncoef;
   const int share = (npt + NW - 1) / NW;
   const int wbeg = wave * share;
   const int wend = (wbeg + share < npt) ? wbeg + share : npt;
-  unsigned char* stage = stage_all + (size_t)wave * (HALF / 2) * C::PAIR_BYTES;
-  lds_byte* plane_l = (lds_byte*)plane;
-
-  for (int base = wbeg; base < wend; base += 64) {
-    // phase 1: one point per lane -- record, strength, 3 W kernel values
-    const int js = base + lane;
-    int off = 0;
-    float kx[8], ky[8], kz[8];
-    float cre = 0.f, cim = 0.f;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { kx[q] = 0.f; ky[q] = 0.f; kz[q] = 0.f; }
-    if (js < wend) {
-      const PointView<float> rec = unpack_rec<float, 3>(sp.rec[p0 + js]);
-      const float2 cv = cc[rec.idx];
-      cre = cv.x * pre;
-      cim = cv.y * pre;
-      off = ((int)(rec.loc & 1023) + (int)((rec.loc >> 10) & 1023) * LS + (int)((rec.loc >> 20) & 1023) * PS) * 8;
-      float h0[W], h1[W], h2[W];
-      horner3<W>(horner, nc, rec.z0, rec.z1, rec.z2, h0, h1, h2);
-#pragma unroll
-      for (int q = 0; q < W; ++q) { kx[q] = fmaxf(h0[q], 0.f); ky[q] = fmaxf(h1[q], 0.f); kz[q] = fmaxf(h2[q], 0.f); }
-    }
-    // a point with a negative imaginary strength is negated here and subtracted below
-    const unsigned long long negm = __ballot(cim < 0.f);
-    if (cim < 0.f) { cre = -cre; cim = -cim; }
-    int left = wend - base;
-    if (left > 64) left = 64;
-    for (int h = 0; h * HALF < left; ++h) {
-      // stage HALF points: pair p holds points 2p, 2p + 1 of this round side by side
-      if (lane / HALF == h) {
-        unsigned char* s = stage + ((lane % HALF) >> 1) * C::PAIR_BYTES;
-#pragma unroll
-        for (int x = 0; x < 8; ++x) *reinterpret_cast<v2f*>(s + x * 16 + (lane & 1) * 8) = (v2f){kx[x] * cim, kx[x] * cre};
-#pragma unroll
-        for (int y = 0; y < 8; ++y) *reinterpret_cast<float*>(s + 128 + y * 8 + (lane & 1) * 4) = ky[y];
-      }
-      int npts = left - h * HALF;
-      if (npts > HALF) npts = HALF;
-      // phase 2: every lane adds its (dx, dy) column of every point, plane after plane
-      for (int p = 0; 2 * p < npts; ++p) {
-        const v4f rx = *reinterpret_cast<const v4f*>(stage + p * C::PAIR_BYTES + rd_x);
-        const v2f ry = *reinterpret_cast<const v2f*>(stage + p * C::PAIR_BYTES + rd_y);
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int q = h * HALF + 2 * p + u;
-          if (u && 2 * p + 1 >= npts) break;
-          const v2f kxc = u ? (v2f){rx.z, rx.w} : (v2f){rx.x, rx.y};
-          const float kyv = u ? ry.y : ry.x;
-          const v2f xy = kxc * (v2f){kyv, kyv};
-          lds_u64* dst = (lds_u64*)(plane_l + __builtin_amdgcn_readlane(off, q) + cell_b);
-          if ((negm >> q) & 1ull) {   // wave-uniform
-#pragma unroll
-            for (int dz = 0; dz < W; ++dz) {
-              const float kzq = bcast_lane(kz[dz], q);
-              const v2f v = xy * (v2f){kzq, kzq};
-              const unsigned long long word = ((unsigned long long)(unsigned)cvt_rpi(v.y) << 32) | (unsigned)cvt_rpi(v.x);
-              __hip_atomic_fetch_sub(dst + dz * PS, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-          } else {
-#pragma unroll
-            for (int dz = 0; dz < W; ++dz) {
-              const float kzq = bcast_lane(kz[dz], q);
-              const v2f v = xy * (v2f){kzq, kzq};
-              const unsigned long long word = ((unsigned long long)(unsigned)cvt_rpi(v.y) << 32) | (unsigned)cvt_rpi(v.x);
-              __hip_atomic_fetch_add(dst + dz * PS, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-          }
-        }
-      }
-    }
-  }
+  v2f coef[kPatchCoef];
+  patch3_lane_coef<W>(horner, lane, coef);
+  patch3_accumulate<W, TZ, HALF>(sp.rec + p0, cc, wbeg, wend, pre, horner, coef, (lds_byte*)plane, lane);
   __syncthreads();
   NUFFT_PHASE3(4);
 
@@ -888,6 +930,397 @@ __global__ __launch_bounds__(kBoundThreads) void bound3_kernel(Geom g, const Rec
       sub_bound[blockIdx.x] = m;
     }
   }
+}
+
+// ================================================================================================
+// Stacks (r05): the w = 7, 8 kernel over runs of tiles that are consecutive in z.
+//
+// A subproblem of spread_patch3_kernel writes its tile + halo, (16 + W - 1)^2 (8 + W - 1) cells = 3.9 x the tile at
+// W = 8, to the fine grid with float atomics; the memory side takes those at ~1.3 TB/s (one 64-byte request per
+// ~50 ps chip-wide, MI355X_MICROARCH.md: global float atomics), and below ~0.3 points per fine cell that write-out,
+// not the LDS accumulation, is the kernel (r04: 456 us of 0.65 ms for the reference harness's 3-D case).
+// The halo in z is the largest part of it (15 planes for 8). A STACK is a run of tiles of one (x, y) tile column,
+// z0 .. z0 + nz - 1, spread by one workgroup: after tile t its 8 finished planes are written out, the W - 1 halo
+// planes MOVE DOWN to become the first planes of tile t + 1 and the freed planes are zeroed -- one pass over the
+// plane in LDS, what the zero-fill of a fresh subproblem costs anyway. Cells written per tile: 23 x 23 x (8 + 7 / nz)
+// instead of 23 x 23 x 15 at W = 8: 2.1-2.3 x the fine grid instead of 3.9 x.
+//
+// The packed fixed-point planes carry over from tile to tile, so a stack has ONE step: from its count-filter bound
+// (the filter of bound3_kernel run over the stack's tiles with the last W - 1 start-cell layers of the previous tile
+// carried into the z pass: the exact maximum over every cell the stack writes) and, for uneven strengths, from the
+// same filter over the strengths. Stacks are cut so that none holds more than `cap` points (workgroups stay of
+// similar length whatever the density) or more than `len` tiles; a tile with more than max_sub points is cut into
+// the subproblems locate_subproblem would give it, each a stack of its own (PIECES: one tile, a point range).
+// Flagged stacks (bound above Geom::fx_bound_limit, tiles of more than fx_max_subs pieces) go to the fp64-plane
+// launches behind this one as the subproblems they consist of.
+struct StackDesc {
+  int col, z0, nz, p0, p1;   // column, first tile in z, tiles; piece: its points [p0, p1), else p0 < 0
+};
+__device__ __forceinline__ StackDesc stack_load(const int4* __restrict__ segs, int s) {
+  const int4 v = segs[s];
+  StackDesc d;
+  d.col = v.x; d.z0 = v.y & 0xffff; d.nz = v.y >> 16; d.p0 = v.z; d.p1 = v.w;
+  return d;
+}
+struct StackColumn { int item, t0, t1; };
+__device__ __forceinline__ StackColumn stack_column(const Geom& g, int col) {
+  const int ncol_item = g.ntile[0] * g.ntile[1];
+  StackColumn c;
+  c.item = col / ncol_item;
+  const int r = col - c.item * ncol_item;
+  c.t1 = r / g.ntile[0];
+  c.t0 = r - c.t1 * g.ntile[0];
+  return c;
+}
+__device__ __forceinline__ int stack_tile_index(const Geom& g, const StackColumn& c, int t2) {
+  const int tc[3] = {c.t0, c.t1, t2};
+  return c.item * g.ntiles_item + tile_id(g, tc);
+}
+
+// One wave per tile column: cuts the column into stacks (greedy along z), two passes -- count, take a range of
+// descriptor slots with one atomic, write. The order of the descriptors depends on arrival; nothing else does.
+constexpr int kStackPlanWaves = 4;
+__global__ __launch_bounds__(kStackPlanWaves * 64) void stack_plan_kernel(Geom g, const int32_t* __restrict__ tile_start,
+                                                                         int ncol, int cap, int len, int4* __restrict__ segs,
+                                                                         int* __restrict__ seg_count, int max_segs) {
+  const int lane = threadIdx.x & 63;
+  const int col = blockIdx.x * kStackPlanWaves + (threadIdx.x >> 6);
+  if (col >= ncol) return;
+  const StackColumn cc = stack_column(g, col);
+  const int ntz = g.ntile[2], S = g.max_sub;
+  int base = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    int nseg = 0, first = 0, last = 0, pts = 0;   // open stack: tiles [first, last], `pts` points (0: none open)
+    for (int zb = 0; zb < ntz; zb += 64) {
+      int n = 0, b = 0;
+      if (zb + lane < ntz) {
+        const int t = stack_tile_index(g, cc, zb + lane);
+        b = tile_start[t];
+        n = tile_start[t + 1] - b;
+      }
+      const int m = ntz - zb < 64 ? ntz - zb : 64;
+      for (int i = 0; i < m; ++i) {
+        const int ni = __shfl(n, i), bi = __shfl(b, i), tz = zb + i;   // (wave-uniform)
+        if (ni == 0) continue;   // (empty tiles neither open nor end a stack; the length rule below counts them)
+        const bool big = ni > S;
+        if (pts > 0 && (big || pts + ni > cap || tz - first + 1 > len)) {
+          if (pass && lane == 0 && base + nseg < max_segs) segs[base + nseg] = make_int4(col, first | ((last - first + 1) << 16), -1, -1);
+          ++nseg;
+          pts = 0;
+        }
+        if (big) {
+          const int k = (ni + S - 1) / S, sz = (ni + k - 1) / k;
+          if (pass)
+            for (int j = lane; j < k; j += 64) {
+              const int a = bi + j * sz, e = a + sz < bi + ni ? a + sz : bi + ni;
+              if (base + nseg + j < max_segs) segs[base + nseg + j] = make_int4(col, tz | (1 << 16), a, e);
+            }
+          nseg += k;
+        } else {
+          if (pts == 0) first = tz;
+          last = tz;
+          pts += ni;
+        }
+      }
+    }
+    if (pts > 0) {
+      if (pass && lane == 0 && base + nseg < max_segs) segs[base + nseg] = make_int4(col, first | ((last - first + 1) << 16), -1, -1);
+      ++nseg;
+    }
+    if (pass == 0) {
+      if (nseg == 0) return;
+      if (lane == 0) base = atomicAdd(seg_count, nseg);
+      base = __shfl(base, 0);
+    }
+  }
+}
+
+// Filter maximum over a stack: the start-cell weights of every tile through the x and y passes of the count filter,
+// the z pass over the tile's TZ layers and the last W - 1 layers of the tile before it. add_tile(i, cnt) adds the
+// weights of the stack's i-th tile to cnt[TZ][T][T + 1] (zeroed, behind a barrier; called by every thread).
+// a: TZ T L floats, b: 2 TZ L L floats, wmax: NT / 64 floats. Returns the maximum in every thread.
+template <int W, int TZ, int NT, typename AddTile>
+__device__ __forceinline__ float stack_filter_max(int nz, AddTile add_tile, uint32_t* cnt, float* a, float* b, float* wmax,
+                                                  const float (&km)[W], int tid) {
+  constexpr int T = kDenseTile, L = T + W - 1, CP = T + 1, H = W - 1;
+  static_assert(H <= TZ, "the z halo must end inside the next tile");
+  float best = 0.f;
+  for (int i = 0; i <= nz; ++i) {   // (i == nz: the halo planes behind the last tile)
+    float* cur = b + (i & 1) * (TZ * L * L);
+    const float* prev = b + ((i & 1) ^ 1) * (TZ * L * L);
+    if (i < nz) {
+      for (int q = tid; q < TZ * T * CP; q += NT) cnt[q] = 0u;
+      __syncthreads();
+      add_tile(i, cnt);
+      __syncthreads();
+      count_filter_xy<W, TZ, NT>(cnt, a, cur, km, tid);
+    }
+    for (int line = tid; line < L * L; line += NT) {
+      float in[H + TZ];   // layers TZ - H .. TZ - 1 of the previous tile, then this tile's
+#pragma unroll
+      for (int m = 0; m < H; ++m) in[m] = i > 0 ? prev[(TZ - H + m) * L * L + line] : 0.f;
+#pragma unroll
+      for (int z = 0; z < TZ; ++z) in[H + z] = i < nz ? cur[z * L * L + line] : 0.f;
+#pragma unroll
+      for (int k = 0; k < TZ; ++k) {
+        if (i == nz && k >= H) break;
+        float v = 0.f;
+#pragma unroll
+        for (int t = 0; t < W; ++t) v = fmaf(km[t], in[H + k - t], v);
+        best = fmaxf(best, v);
+      }
+    }
+    // (the next tile's y pass writes the buffer this z pass read as `prev` three barriers from here)
+  }
+  return workgroup_max<NT>(best, wmax, tid);
+}
+
+template <int W, int TZ>
+__global__ __launch_bounds__(kBoundThreads) void bound3_stack_kernel(Geom g, const Rec<float>* __restrict__ rec, int rec_stride,
+                                                                    const int32_t* __restrict__ tile_start,
+                                                                    const int32_t* __restrict__ sub_start, TapMax taps,
+                                                                    const int4* __restrict__ segs, const int* __restrict__ seg_count,
+                                                                    float* __restrict__ seg_bound, int* __restrict__ fb_list) {
+  constexpr int T = kDenseTile, L = T + W - 1, CP = T + 1, NT = kBoundThreads;
+  __shared__ uint32_t cnt[TZ * T * CP];
+  __shared__ float a[TZ * T * L];
+  __shared__ float b[2 * TZ * L * L];
+  __shared__ float wmax[NT / 64];
+  const int s = blockIdx.x, tid = threadIdx.x;
+  if (s >= seg_count[0]) return;
+  const StackDesc d = stack_load(segs, s);
+  const StackColumn cc = stack_column(g, d.col);
+  if (d.p0 >= 0) {
+    // a piece of a tile with more than max_sub points = subproblem `chunk` of that tile
+    const int t = stack_tile_index(g, cc, d.z0);
+    const int s0 = sub_start[t], k = sub_start[t + 1] - s0;
+    if (k > g.fx_max_subs) {   // (every further subproblem of a tile adds its share of quantisation noise)
+      if (tid == 0) {
+        const int n = tile_start[t + 1] - tile_start[t], sz = (n + k - 1) / k;
+        seg_bound[s] = -1.f;
+        fb_list[1 + atomicAdd(&fb_list[0], 1)] = s0 + (d.p0 - tile_start[t]) / sz;
+      }
+      return;
+    }
+  }
+  float km[W];
+#pragma unroll
+  for (int t = 0; t < W; ++t) km[t] = taps.k[t];
+  float m = stack_filter_max<W, TZ, NT>(d.nz, [&](int i, uint32_t* c) {
+    int p0 = d.p0, p1 = d.p1;
+    if (p0 < 0) {
+      const int t = stack_tile_index(g, cc, d.z0 + i);
+      p0 = tile_start[t];
+      p1 = tile_start[t + 1];
+    }
+    for (int j = p0 + tid; j < p1; j += NT) {
+      const Rec<float>& r = rec_at(rec, j, rec_stride);
+      const uint32_t l0 = r.loc >> 28, l1 = __float_as_uint(r.z0) >> 28, l2 = __float_as_uint(r.z1) >> 28;
+      atomicAdd(&c[(l2 * T + l1) * CP + l0], 1u);
+    }
+  }, cnt, a, b, wmax, km, tid);
+  if (tid == 0) {
+    m *= 1.0001f;   // (float sums of non-negative terms)
+    if (m > g.fx_bound_limit) {
+      seg_bound[s] = -m;
+      if (d.p0 >= 0) {
+        const int t = stack_tile_index(g, cc, d.z0);
+        const int s0 = sub_start[t], k = sub_start[t + 1] - s0;
+        const int n = tile_start[t + 1] - tile_start[t], sz = (n + k - 1) / k;
+        fb_list[1 + atomicAdd(&fb_list[0], 1)] = s0 + (d.p0 - tile_start[t]) / sz;
+      } else {
+        for (int i = 0; i < d.nz; ++i) {   // (tiles of at most max_sub points: one subproblem each, none when empty)
+          const int t = stack_tile_index(g, cc, d.z0 + i);
+          if (sub_start[t + 1] > sub_start[t]) fb_list[1 + atomicAdd(&fb_list[0], 1)] = sub_start[t];
+        }
+      }
+    } else {
+      seg_bound[s] = m > 1.f ? m : 1.f;
+    }
+  }
+}
+
+// The w = 7, 8 kernel over a stack. PLAIN = false: finished planes are added to the fine grid with float atomics.
+template <int W, int TZ, int HALF>
+__global__ NUFFT_PATCH_BOUNDS void spread_stack3_kernel(
+    Geom g, SortedPoints<float> sp, const float* __restrict__ horner, const float* __restrict__ c,
+    float* __restrict__ fw, int64_t c_stride, int64_t fw_stride, float scale) {
+  using C = PatchCfg<W, TZ, HALF>;
+  constexpr int LS = C::LS, PS = C::PS, NW = kPatchNW, L0 = C::L0, L1 = C::L1, L2 = C::L2, H = W - 1, NT = NW * 64;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned long long* plane = reinterpret_cast<unsigned long long*>(smem_raw);
+  unsigned char* stage_all = smem_raw + (size_t)C::plane_elems * 8;
+  float* red = reinterpret_cast<float*>(stage_all + C::stage_bytes);   // [2 NW]
+
+  const int s = blockIdx.x;
+#ifdef NUFFT_HIP_PHASE_LOG
+  const unsigned long long ph_start = __builtin_readcyclecounter();
+#endif
+  if (s >= sp.seg_count[0]) return;
+  const float bound_b = sp.seg_bound[s];
+  if (bound_b < 0.f) return;   // flagged: its subproblems are on the fallback list of the fp64-plane launches
+  const StackDesc d = stack_load(sp.segs, s);
+  const StackColumn col = stack_column(g, d.col);
+  const int slot = col.item * (int)gridDim.y + (int)blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const float2* cc = reinterpret_cast<const float2*>(c) + (int64_t)slot * c_stride;
+  // points of the whole stack (tiles of a column need not be neighbours in the sorted order)
+  int npt_all = 0;
+  if (d.p0 >= 0) npt_all = d.p1 - d.p0;
+  else
+    for (int i = 0; i < d.nz; ++i) {
+      const int t = stack_tile_index(g, col, d.z0 + i);
+      npt_all += sp.tile_start[t + 1] - sp.tile_start[t];
+    }
+
+  // step of the fixed-point grid (spread_patch3_kernel; here one for the whole stack)
+  const float sum_g = sp.cstats[2 * slot + 1];
+  const float top_g = sum_g == sum_g ? sp.cstats[2 * slot] : sum_g;   // (NaN strengths: see spread_dense3_kernel)
+  const bool skewed = bound_b * top_g * (float)c_stride > kPatchCrest * g.fx_bound_limit * sum_g;
+  float top = top_g, sum = 3.0e38f, cap = top_g * bound_b;
+  if (skewed) {
+    // (workgroup-uniform) the stack's own strengths decide: start-cell sums of max(|re c|, |im c|) through the stack
+    // filter (weights in units of the transform's largest / wscale, rounded up; a start cell holds at most max_sub
+    // points: wscale (max_sub + 1) < 2^32), the sum of its strengths, its largest one x the count bound
+    constexpr int T = kDenseTile, FL = T + W - 1, CP = T + 1;
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(smem_raw);                 // [TZ][T][CP]
+    float* fa = reinterpret_cast<float*>(cnt + TZ * T * CP);               // [TZ][T][FL]
+    float* fb = fa + TZ * T * FL;                                          // [2][TZ][FL][FL]
+    float* fmx = fb + 2 * TZ * FL * FL;                                    // [NW]
+    static_assert((size_t)(TZ * T * CP + TZ * T * FL + 2 * TZ * FL * FL + NW) * 4 <= (size_t)C::plane_elems * 8, "filter scratch");
+    float wscale = 524288.f;
+    if ((float)(g.max_sub + 1) * wscale > 4.0e9f) wscale = floorf(4.0e9f / (float)(g.max_sub + 1));
+    const float inv = top_g > 0.f ? wscale / top_g : 0.f;
+    float part = 0.f, big = 0.f;
+    float km[W];
+#pragma unroll
+    for (int t = 0; t < W; ++t) km[t] = g.fx_tap[t];
+    const float wb = stack_filter_max<W, TZ, NT>(d.nz, [&](int i, uint32_t* cn) {
+      int p0 = d.p0, p1 = d.p1;
+      if (p0 < 0) {
+        const int t = stack_tile_index(g, col, d.z0 + i);
+        p0 = sp.tile_start[t];
+        p1 = sp.tile_start[t + 1];
+      }
+      for (int j = p0 + tid; j < p1; j += NT) {
+        const PointView<float> rec = unpack_rec<float, 3>(sp.rec[j]);
+        const float2 cv = cc[rec.idx];
+        const float m = fmaxf(fabsf(cv.x), fabsf(cv.y));
+        part += fmaf(0.f, cv.x + cv.y, m);   // (NaN / Inf components make the sum NaN)
+        big = fmaxf(big, m);
+        const uint32_t wgt = (uint32_t)ceilf(m * inv);   // NaN -> 0 (the NaN step below takes over)
+        atomicAdd(&cn[(((rec.loc >> 20) & 1023u) * T + ((rec.loc >> 10) & 1023u)) * CP + (rec.loc & 1023u)], wgt);
+      }
+    }, cnt, fa, fb, fmx, km, tid);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      part += __shfl_down(part, o);
+      big = fmaxf(big, __shfl_down(big, o));
+    }
+    if (lane == 0) { red[wave] = part; red[NW + wave] = big; }
+    __syncthreads();
+    sum = 0.f; top = 0.f;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) { sum += red[k]; top = fmaxf(top, red[NW + k]); }
+    cap = fminf(top * bound_b, top_g * wb * (1.0001f / wscale));
+    __syncthreads();   // (the scratch becomes the plane)
+  }
+  for (int i = tid; i < C::plane_elems; i += NT) plane[i] = 0ull;
+  const float amp = fabsf(scale) * g.fx_headroom;
+  const float room = 2147483000.f - (float)npt_all;     // 2^31 minus one step of rounding per contribution
+  float step = fmaxf(fminf(sum, cap), top * 1.8626451e-9f * room) * amp / room;
+  if (!(top == top) || !(sum == sum)) step = top + sum;   // NaN strengths (fminf / fmaxf would drop them)
+  const float pre = step > 0.f ? scale / step : 0.f;
+  __syncthreads();
+
+#ifdef NUFFT_HIP_PHASE_LOG
+  // (experiment build) thread 0's cycles by phase, summed over the stack's tiles: [0] setup, then per tile
+  // accumulate (its own wave) / wait for the others / write-out + move / barrier behind it
+  unsigned long long ph_acc[5] = {0, 0, 0, 0, 0}, ph_prev = __builtin_readcyclecounter();
+  ph_acc[0] = ph_prev - ph_start;
+#define NUFFT_STACK_PH(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); if ((k) > 0) ph_acc[k] += now_ - ph_prev; else ph_acc[0] += 0; ph_prev = now_; } while (0)
+#else
+#define NUFFT_STACK_PH(k) do { } while (0)
+#endif
+  v2f coef[kPatchCoef];
+  patch3_lane_coef<W>(horner, lane, coef);
+  const int o0 = col.t0 * kDenseTile, o1 = col.t1 * kDenseTile;
+  float* out = fw + 2 * (int64_t)slot * fw_stride;
+  for (int i = 0; i < d.nz; ++i) {
+    int p0 = d.p0, p1 = d.p1;
+    if (p0 < 0) {
+      const int t = stack_tile_index(g, col, d.z0 + i);
+      p0 = sp.tile_start[t];
+      p1 = sp.tile_start[t + 1];
+    }
+    const int npt = p1 - p0;
+    const int share = (npt + NW - 1) / NW;
+    const int wbeg = wave * share;
+    const int wend = (wbeg + share < npt) ? wbeg + share : npt;
+    NUFFT_STACK_PH(0);
+    patch3_accumulate<W, TZ, HALF>(sp.rec + p0, cc, wbeg, wend, pre, horner, coef, (lds_byte*)plane, lane);
+    NUFFT_STACK_PH(1);
+    __syncthreads();
+    NUFFT_STACK_PH(2);
+    // tile d.z0 + i is complete in its first TZ planes (the last tile of the stack: in all of them): unpack, scale
+    // back, add to the periodic fine grid (consecutive lanes carry (re, im) of consecutive cells); then the halo
+    // planes move down to be the first planes of the next tile and what they leave is zeroed
+    const bool last = i == d.nz - 1;
+    const int o2 = (d.z0 + i) * TZ;
+    const int nplanes = last ? L2 : TZ;
+    // (R rows per wave at a time: the LDS reads of a batch are issued together -- with the sibling workgroup's
+    // atomics queued in front of every LDS access, a row at a time cost ~700 cycles per row, r05 phase log)
+    constexpr int R = NUFFT_STACK_ROWS;
+    const int nrows = nplanes * L1;
+    const int e = lane < 2 * L0 ? lane : 2 * L0 - 1, a0 = e >> 1, comp = e & 1;
+    const bool active = lane < 2 * L0;
+    const int gx = wrap1(o0 + a0, g.nf[0]);
+    for (int r0 = wave; r0 < nrows; r0 += NW * R) {
+      int lrow[R], a2v[R];
+      int64_t gbase[R];
+      long long t[R], hi[R];
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        const int rho = r0 + u * NW < nrows ? r0 + u * NW : r0;   // (a batch's rows past the end repeat its first)
+        const int a2 = rho / L1, a1 = rho - a2 * L1;
+        a2v[u] = a2;
+        lrow[u] = a2 * PS + a1 * LS;
+        gbase[u] = (int64_t)g.nf[0] * (wrap1(o1 + a1, g.nf[1]) + (int64_t)g.nf[1] * wrap1(o2 + a2, g.nf[2]));
+        t[u] = (long long)plane[lrow[u] + a0];
+      }
+      if (!last) {
+#pragma unroll
+        for (int u = 0; u < R; ++u) hi[u] = a2v[u] < H ? (long long)plane[lrow[u] + TZ * PS + a0] : 0ll;
+      }
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        if (u > 0 && r0 + u * NW >= nrows) break;
+        const int im_sum = (int)(unsigned)(t[u] & 0xffffffffll);
+        const int re_sum = (int)((t[u] - (long long)im_sum) >> 32);
+        const float v = (float)(comp ? im_sum : re_sum) * step;
+        if (active && v != 0.f) glb_add(&out[2 * (gbase[u] + gx) + comp], v);
+      }
+      if (!last && active && comp == 0) {   // (both lanes of a cell have read it: LDS operations of a wave complete in order)
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+          if (u > 0 && r0 + u * NW >= nrows) break;
+          plane[lrow[u] + a0] = (unsigned long long)hi[u];
+          if (a2v[u] < H) plane[lrow[u] + TZ * PS + a0] = 0ull;
+        }
+      }
+    }
+    NUFFT_STACK_PH(3);
+    if (!last) __syncthreads();
+    NUFFT_STACK_PH(4);
+  }
+#ifdef NUFFT_HIP_PHASE_LOG
+  if (tid == 0 && blockIdx.y == 0 && blockIdx.x < kPhaseLogWgs3) {
+    unsigned long long* lg = g_phase_log3 + (size_t)blockIdx.x * kPhaseSlots3;
+    lg[0] = ph_start; lg[1] = ph_acc[0]; lg[2] = ph_acc[1]; lg[3] = ph_acc[2]; lg[4] = ph_acc[3]; lg[5] = ph_acc[4];
+    lg[6] = __builtin_readcyclecounter(); lg[7] = (unsigned long long)d.nz;
+  }
+#endif
 }
 
 // ---- strengths of one spread launch: largest and summed max(|re c|, |im c|) per slot ----------------------------
@@ -1046,6 +1479,82 @@ hipError_t launch_bound3(const Geom& g, const Rec<float>* rec, int rec_stride, c
   else if (g.w == 7) bound3_kernel<7, 8><<<nsub_bound, kBoundThreads, 0, stream>>>(g, rec, rec_stride, tile_start, sub_start, taps, sub_bound, fb_list);
   else return hipErrorInvalidValue;
   return hipGetLastError();
+}
+// ---- stacks (r05) ------------------------------------------------------------------------------------------------
+// Points per stack and tiles per stack. Tiles: a stack of nz tiles writes 8 + (W - 1) / nz planes per tile, and
+// 512 stacks (one per workgroup slot of the chip) already beat 2048 shorter ones (r05 sweep, 128^3 modes at 0.05
+// points per cell: 16 tiles 313 us, 8 320, 4 334, 2 372; 256 stacks of 32 tiles 399): at least 512 stacks where the
+// tile count allows, at most 16 tiles. Points: 8192, so that workgroups stay of similar length whatever the density
+// (and never below the subproblem cap: pieces are subproblems).
+constexpr double kStackDensity = 0.15;   // points per fine cell below which a plan spreads over stacks
+void stack_params(const Geom& g, int* cap, int* len) {
+  int l = g.ntiles / 512;
+  l = l < 2 ? 2 : (l > 16 ? 16 : l);
+  if (l > g.ntile[2]) l = g.ntile[2];
+  *len = g.stack_len > 0 ? g.stack_len : l;
+  *cap = std::max(g.stack_cap > 0 ? g.stack_cap : 8192, g.max_sub);
+}
+// launch grid of the stack kernels: an upper bound on the stacks stack_plan_kernel can cut (known without reading
+// the device): per column ceil(ntz / len) closed by the length rule + the open one; a stack closed by the point cap
+// holds more than cap points together with its successor; a tile above max_sub points closes one stack and becomes
+// at most n / max_sub + 1 pieces
+unsigned stack_grid_bound(const Geom& g, int64_t M) {
+  int cap, len;
+  stack_params(g, &cap, &len);
+  const int64_t ncol = (int64_t)g.ntile[0] * g.ntile[1] * std::max(1, g.nitems);
+  const int64_t n = ncol * ((g.ntile[2] + len - 1) / len + 1) + 2 * M / cap + 3 * M / g.max_sub + 2;
+  return (unsigned)std::min<int64_t>(n, 0x7fffffff);
+}
+// The stack form pays where the tile + halo write-out is a visible part of the spread (r05, profiles/r05_stack_ab.txt,
+// spread stage, stacks against subproblems, w = 8): 256^3 modes at 0.022 points per fine cell 2.07 against 2.97 ms,
+// 0.075: 2.46 against 3.62; 0.22: 4.59 against 4.57 and 0.75: 12.7 against 12.4 -- from there the accumulation
+// loop (VALU issue + LDS atomics) hides the write-out either way, and the bound of a stack costs 0.15 ms more than
+// the bounds of its tiles. options.tuning STACK_OFF / STACK_ON force the choice.
+bool stack3_wanted(const Geom& g, int64_t M) {
+  if (!g.fx_patch || g.ntile[2] < 2 || g.ntile[2] > 32767) return false;
+  const int mode = tune_mode(g, NUFFT_HIP_TUNE_STACK_OFF, NUFFT_HIP_TUNE_STACK_ON);
+  if (mode >= 0) return mode != 0;
+  const double cells = (double)g.nf[0] * g.nf[1] * g.nf[2] * (g.nitems > 1 ? g.nitems : 1);
+  return (double)M < kStackDensity * cells;
+}
+hipError_t launch_stack_plan(const Geom& g, const int32_t* tile_start, int64_t M, int4* segs, int* seg_count, hipStream_t stream) {
+  hipError_t e = hipMemsetAsync(seg_count, 0, sizeof(int), stream);
+  if (e != hipSuccess) return e;
+  int cap, len;
+  stack_params(g, &cap, &len);
+  const int ncol = g.ntile[0] * g.ntile[1] * std::max(1, g.nitems);
+  stack_plan_kernel<<<(unsigned)((ncol + kStackPlanWaves - 1) / kStackPlanWaves), kStackPlanWaves * 64, 0, stream>>>(
+      g, tile_start, ncol, cap, len, segs, seg_count, (int)stack_grid_bound(g, M));
+  return hipGetLastError();
+}
+hipError_t launch_bound3_stack(const Geom& g, const Rec<float>* rec, int rec_stride, const int32_t* tile_start,
+                               const int32_t* sub_start, int64_t M, const TapMax& taps, const int4* segs, const int* seg_count,
+                               float* seg_bound, int* fb_list, hipStream_t stream) {
+  hipError_t e = hipMemsetAsync(fb_list, 0, sizeof(int), stream);
+  if (e != hipSuccess) return e;
+  const unsigned grid = stack_grid_bound(g, M);
+  if (g.w == 8) bound3_stack_kernel<8, 8><<<grid, kBoundThreads, 0, stream>>>(g, rec, rec_stride, tile_start, sub_start, taps, segs, seg_count, seg_bound, fb_list);
+  else if (g.w == 7) bound3_stack_kernel<7, 8><<<grid, kBoundThreads, 0, stream>>>(g, rec, rec_stride, tile_start, sub_start, taps, segs, seg_count, seg_bound, fb_list);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+template <int W>
+static hipError_t launch_stack3(const Geom& g, const SortedPoints<float>& sp, const float* horner, const float* c, float* fw,
+                                dim3 grid, int64_t c_stride, int64_t fw_stride, float scale, hipStream_t stream) {
+  using C = PatchCfg<W, 8, kPatchHalf>;
+  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(spread_stack3_kernel<W, 8, kPatchHalf>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes);
+  if (e != hipSuccess) return e;
+  spread_stack3_kernel<W, 8, kPatchHalf><<<grid, kPatchNW * 64, C::lds_bytes, stream>>>(g, sp, horner, c, fw, c_stride, fw_stride, scale);
+  return hipGetLastError();
+}
+hipError_t launch_spread_stack3(const Geom& g, const SortedPoints<float>& sp, int64_t M, const float* horner,
+                                const float* c, float* fw, int batch, int64_t c_stride, int64_t fw_stride, float scale,
+                                hipStream_t stream) {
+  const dim3 grid(stack_grid_bound(g, M), (unsigned)batch);
+  if (g.w == 8) return launch_stack3<8>(g, sp, horner, c, fw, grid, c_stride, fw_stride, scale, stream);
+  if (g.w == 7) return launch_stack3<7>(g, sp, horner, c, fw, grid, c_stride, fw_stride, scale, stream);
+  return hipErrorInvalidValue;
 }
 int cstats_blocks(int64_t M, int slots) {
   // (workgroups per slot: 16384 strengths each, at most 1024, and at most 2^20 partial pairs over all slots)

@@ -59,6 +59,10 @@ struct Geom {
   int fx_patch;
   float fx_bound_limit;   // subproblems whose bound exceeds this go to the fp64-plane kernels (quantisation noise)
   float fx_tap[8];        // fx_patch: per-tap maxima of the fitted kernel (TapMax, the first w of them)
+  // fx_patch plans whose spread runs over STACKS of tiles (spread_stack3_kernel; set per set_points) and the cutting
+  // parameters when a debug call overrides the defaults (0: stack_params' rule)
+  int stack;
+  int stack_len, stack_cap;
 };
 // OFF / ON pair of nufft_hip_options.tuning: -1 = by the plan's own rule, 0 = never, 1 = always
 inline int tune_mode(const Geom& g, int off_bit, int on_bit) { return (g.tuning & on_bit) ? 1 : ((g.tuning & off_bit) ? 0 : -1); }
@@ -112,6 +116,11 @@ struct SortedPoints {
                               // left to the fp64-plane kernels
   const int* fb_list;         // fixed-point plans: fb_list[0] = how many subproblems set_points left to the fp64-plane
                               // kernels, fb_list[1..] = their launch slots (bound3_kernel / crowded_list_kernel)
+  // Geom::stack: the stacks stack_plan_kernel cut ({column, z0 | nz << 16, piece's points or -1}), how many, and
+  // their count-filter bounds (negative: on the fallback list)
+  const int4* segs;
+  const int* seg_count;
+  const float* seg_bound;
 };
 // Tap maxima of the fitted kernel, max over z of |P_t(z)| for every stencil cell t (with the fit's and the float
 // evaluation's margin): what bound3_kernel filters the start-cell counts with
@@ -252,6 +261,17 @@ hipError_t launch_spread_patch3(const Geom& g, const SortedPoints<float>& sp, un
 // fp64-plane kernels (count zeroed here); rec_stride: bytes between records
 hipError_t launch_bound3(const Geom& g, const Rec<float>* rec, int rec_stride, const int32_t* tile_start, const int32_t* sub_start,
                          unsigned nsub_bound, const TapMax& taps, float* sub_bound, int* fb_list, hipStream_t stream);
+// stacks of tiles (r05, same file): which plans take them, the launch grid bound, cutting, bounds, spreading
+bool stack3_wanted(const Geom& g, int64_t M);
+void stack_params(const Geom& g, int* cap, int* len);
+unsigned stack_grid_bound(const Geom& g, int64_t M);
+hipError_t launch_stack_plan(const Geom& g, const int32_t* tile_start, int64_t M, int4* segs, int* seg_count, hipStream_t stream);
+hipError_t launch_bound3_stack(const Geom& g, const Rec<float>* rec, int rec_stride, const int32_t* tile_start,
+                               const int32_t* sub_start, int64_t M, const TapMax& taps, const int4* segs, const int* seg_count,
+                               float* seg_bound, int* fb_list, hipStream_t stream);
+hipError_t launch_spread_stack3(const Geom& g, const SortedPoints<float>& sp, int64_t M, const float* horner,
+                                const float* c, float* fw, int batch, int64_t c_stride, int64_t fw_stride, float scale,
+                                hipStream_t stream);
 // the other fixed-point plans: fb_list from the tiles with more than fx_max_subs subproblems
 hipError_t launch_crowded_list(const Geom& g, const int32_t* sub_start, int* fb_list, hipStream_t stream);
 // strengths of one spread launch: cstats[slot] = {max, sum} of max(|re c|, |im c|) over the slot's M points;

@@ -3140,7 +3140,8 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
       if constexpr (WW >= 7) {                                                                   \
         if constexpr (sizeof(T) == 4) {                                                          \
           if (g.fx_patch) {   /* packed fixed point, exact conversion; flagged subproblems on fp64 planes behind it */ \
-            e = launch_spread_patch3(g, sp, grid.x, horner, c, fw, batch, c_stride, fw_stride, scale, stream); \
+            if (g.stack && sp.segs) e = launch_spread_stack3(g, sp, M, horner, c, fw, batch, c_stride, fw_stride, scale, stream); \
+            else e = launch_spread_patch3(g, sp, grid.x, horner, c, fw, batch, c_stride, fw_stride, scale, stream); \
             if (e != hipSuccess) return e;                                                       \
             lds_bytes = wave3_split8_lds(g);                                                     \
             NUFFT_LAUNCH_W3S8(WW, 1) NUFFT_LAUNCH_W3S8(WW, 2)                                     \

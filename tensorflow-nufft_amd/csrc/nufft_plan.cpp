@@ -249,6 +249,8 @@ struct nufft_hip_plan_s {
   int64_t cap_sub_bound = 0;
   int* fb_list = nullptr;        // fixed-point 3-D plans: count + launch slots of the subproblems left to the fp64 planes
   int64_t cap_fb_list = 0;
+  int4* segs = nullptr;          // Geom::stack: [0].x = how many stacks, [1..] their descriptors (stack_plan_kernel)
+  int64_t cap_segs = 0;
   TapMax taps = {};              // per-tap maxima of the fitted kernel (bound3_kernel)
   int64_t workspace_bytes = 0;
   bool points_set = false;
@@ -458,12 +460,12 @@ int ensure_fixed_workspace(nufft_hip_plan p) {
 void release_workspace(nufft_hip_plan p) {
   void** bufs[] = {(void**)&p->tile_count, (void**)&p->tile_start, (void**)&p->sub_start, (void**)&p->bad_count,
                    &p->d_fine, &p->fft_work, &p->fft_tmp[0], &p->fft_tmp[1], &p->rec, &p->rec2, (void**)&p->hist, (void**)&p->tile_of,
-                   (void**)&p->rank_of, (void**)&p->cstats, (void**)&p->sub_bound, (void**)&p->fb_list};
+                   (void**)&p->rank_of, (void**)&p->cstats, (void**)&p->sub_bound, (void**)&p->fb_list, (void**)&p->segs};
   for (void** b : bufs) {
     dev_free(p, *b);
     *b = nullptr;
   }
-  p->cap = p->cap2 = p->cap_global = p->cap_tile_of = p->cap_sub_bound = p->cap_cstats = p->cap_fb_list = 0;
+  p->cap = p->cap2 = p->cap_global = p->cap_tile_of = p->cap_sub_bound = p->cap_cstats = p->cap_fb_list = p->cap_segs = 0;
   p->hist_elems = 0;
   p->workspace_bytes = 0;
   p->fixed_ws = false;
@@ -605,7 +607,18 @@ int ensure_point_capacity(nufft_hip_plan p, int64_t M, int rec_mult = 1) {
     }
   }
   if (p->g.fx_patch && (p->type == NUFFT_HIP_TYPE_1 || p->opts.spread_only)) {
-    const int64_t need_b = (int64_t)subproblem_grid_bound(p->g, M) + 1;
+    // (a plan that spreads over stacks keeps one bound per stack in the same buffer)
+    const bool stacks = stack3_wanted(p->g, M);
+    const int64_t need_b = (int64_t)std::max(subproblem_grid_bound(p->g, M), stacks ? stack_grid_bound(p->g, M) : 0u) + 1;
+    const int64_t need_g = stacks ? (int64_t)stack_grid_bound(p->g, M) + 1 : 0;
+    if (need_g > p->cap_segs) {
+      if ((rc = sync_before_regrow(p))) return rc;
+      dev_free(p, p->segs);
+      p->segs = nullptr;
+      p->cap_segs = 0;
+      if ((rc = dev_alloc(p, (void**)&p->segs, sizeof(int4) * (size_t)need_g))) return rc;
+      p->cap_segs = need_g;
+    }
     if (need_b > p->cap_sub_bound) {
       if ((rc = sync_before_regrow(p))) return rc;
       dev_free(p, p->sub_bound);
@@ -712,7 +725,15 @@ int set_points_impl(nufft_hip_plan p, int64_t M, const void* x, const void* y, c
   }
   if constexpr (sizeof(T) == 4) {
     // w = 7, 8 fixed-point plans: the bound that fixes every subproblem's step (and which of them keep fp64 planes)
-    if (p->g.fx_patch && p->sub_bound && Mtot > 0) {
+    p->g.stack = (p->g.fx_patch && p->sub_bound && p->segs && Mtot > 0 && stack3_wanted(p->g, Mtot)) ? 1 : 0;
+    if (p->g.stack) {
+      // stacks of tiles (spread_stack3_kernel): cut them, then the bound that fixes every stack's step
+      hook.begin(STAGE_SORT_CELL);
+      HIP_TRY(p, launch_stack_plan(p->g, p->tile_start, Mtot, p->segs + 1, (int*)p->segs, p->stream));
+      HIP_TRY(p, launch_bound3_stack(p->g, (const Rec<float>*)p->rec, (int)sizeof(Rec<float>), p->tile_start, p->sub_start, Mtot,
+                                     p->taps, p->segs + 1, (const int*)p->segs, p->sub_bound, p->fb_list, p->stream));
+      hook.end(STAGE_SORT_CELL);
+    } else if (p->g.fx_patch && p->sub_bound && Mtot > 0) {
       hook.begin(STAGE_SORT_CELL);
       HIP_TRY(p, launch_bound3(p->g, (const Rec<float>*)p->rec, (int)sizeof(Rec<float>), p->tile_start, p->sub_start,
                                subproblem_grid_bound(p->g, Mtot), p->taps, p->sub_bound, p->fb_list, p->stream));
@@ -751,6 +772,9 @@ SortedPoints<T> sorted_view(nufft_hip_plan p) {
   sp.cstats_blocks = p->cstats ? cstats_blocks(p->M, sp.cstats_slots) : 0;
   sp.sub_bound = p->sub_bound;
   sp.fb_list = p->fb_list;
+  sp.segs = p->g.stack ? p->segs + 1 : nullptr;
+  sp.seg_count = (const int*)p->segs;
+  sp.seg_bound = p->sub_bound;
   return sp;
 }
 
@@ -988,7 +1012,7 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
     static const int pairs[][2] = {{NUFFT_HIP_TUNE_GROUP_OFF, NUFFT_HIP_TUNE_GROUP_ON}, {NUFFT_HIP_TUNE_SPARSE_OFF, NUFFT_HIP_TUNE_SPARSE_ON},
                                    {NUFFT_HIP_TUNE_CELLSORT_OFF, NUFFT_HIP_TUNE_CELLSORT_ON}, {NUFFT_HIP_TUNE_CELLSORT3D_OFF, NUFFT_HIP_TUNE_CELLSORT3D_ON},
                                    {NUFFT_HIP_TUNE_JOINT_OFF, NUFFT_HIP_TUNE_JOINT_ON}, {NUFFT_HIP_TUNE_STAGED_OFF, NUFFT_HIP_TUNE_STAGED_ON},
-                                   {NUFFT_HIP_TUNE_SORT2_OFF, NUFFT_HIP_TUNE_SORT2_ON}};
+                                   {NUFFT_HIP_TUNE_SORT2_OFF, NUFFT_HIP_TUNE_SORT2_ON}, {NUFFT_HIP_TUNE_STACK_OFF, NUFFT_HIP_TUNE_STACK_ON}};
     for (const auto& pr : pairs)
       if ((t & pr[0]) && (t & pr[1])) return fail(NUFFT_HIP_INVALID_ARGUMENT, format("options.tuning has both bits of an OFF / ON pair (0x%x)", (unsigned)(pr[0] | pr[1])));
     if (opts_in->op_group < 0 || opts_in->op_lanes < 0) return fail(NUFFT_HIP_INVALID_ARGUMENT, "options.op_group and options.op_lanes must be >= 0");
@@ -1254,6 +1278,8 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
   g.fixed_point = 0;
   g.split_reim = 0;
   g.cell_sorted = 0;
+  g.stack = 0;
+  g.stack_len = g.stack_cap = 0;
   g.fx_patch = (patch_want && method == NUFFT_HIP_METHOD_TILE_WAVE && !g.wide && g.tile[0] == 16 && g.tile[1] == 16 &&
                 g.tile[2] == 8) ? 1 : 0;
   if (method == NUFFT_HIP_METHOD_TILE_WAVE && rank == 3 && precision == NUFFT_HIP_F32 && (w <= 7 || g.fx_patch) &&
@@ -1508,6 +1534,19 @@ int nufft_hip_debug_sort_path(nufft_hip_plan p) {
 int64_t nufft_hip_debug_sub_bounds(nufft_hip_plan p, float* out, int64_t n) {
   if (!p || p->host_only || !p->points_set) return -1;
   if (!p->g.fx_patch || !p->sub_bound) return 0;
+  if (p->g.stack) {   // one bound per stack
+    int32_t live = 0;
+    if (hipMemcpyAsync(&live, p->segs, sizeof(int32_t), hipMemcpyDeviceToHost, p->stream) != hipSuccess ||
+        hipStreamSynchronize(p->stream) != hipSuccess)
+      return -1;
+    const int64_t have = std::min<int64_t>(live, (int64_t)stack_grid_bound(p->g, p->M * p->nitems));
+    const int64_t take = std::min(n, have);
+    if (take > 0 && out &&
+        (hipMemcpyAsync(out, p->sub_bound, sizeof(float) * (size_t)take, hipMemcpyDeviceToHost, p->stream) != hipSuccess ||
+         hipStreamSynchronize(p->stream) != hipSuccess))
+      return -1;
+    return have;
+  }
   const int64_t slots = (int64_t)subproblem_grid_bound(p->g, p->M * p->nitems);
   const int64_t take = std::min(n, slots);
   if (take > 0 && out) {
@@ -1520,6 +1559,30 @@ int64_t nufft_hip_debug_sub_bounds(nufft_hip_plan p, float* out, int64_t n) {
     for (int64_t i = ss[0]; i < take; ++i) out[i] = 0.f;
   }
   return slots;
+}
+
+int nufft_hip_debug_stack_params(nufft_hip_plan p, int len, int cap) {
+  if (!p || p->host_only || len < 0 || cap < 0 || len > 32767) return NUFFT_HIP_INVALID_ARGUMENT;
+  p->g.stack_len = len;
+  p->g.stack_cap = cap;
+  p->points_set = false;   // (the next set_points cuts by the new rule; its workspace is sized for it)
+  return NUFFT_HIP_OK;
+}
+
+int64_t nufft_hip_debug_stacks(nufft_hip_plan p, int32_t* out, int64_t n) {
+  if (!p || p->host_only || !p->points_set) return -1;
+  if (!p->g.stack || !p->segs) return 0;
+  int32_t live = 0;
+  if (hipMemcpyAsync(&live, p->segs, sizeof(int32_t), hipMemcpyDeviceToHost, p->stream) != hipSuccess ||
+      hipStreamSynchronize(p->stream) != hipSuccess)
+    return -1;
+  const int64_t have = std::min<int64_t>(live, (int64_t)stack_grid_bound(p->g, p->M * p->nitems));
+  const int64_t take = std::min(n, have);
+  if (take > 0 && out &&
+      (hipMemcpyAsync(out, p->segs + 1, sizeof(int4) * (size_t)take, hipMemcpyDeviceToHost, p->stream) != hipSuccess ||
+       hipStreamSynchronize(p->stream) != hipSuccess))
+    return -1;
+  return have;
 }
 
 int nufft_hip_debug_shader_clock_mhz(void* stream, double* mhz) {

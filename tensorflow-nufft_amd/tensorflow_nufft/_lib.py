@@ -24,7 +24,7 @@ METHOD_AUTO, METHOD_TILE_GENERIC, METHOD_TILE_WAVE, METHOD_POINT_GLOBAL = 0, 1, 
 TUNE = {name: 1 << bit for bit, name in enumerate((
     'NO_FUSED', 'GROUP_OFF', 'GROUP_ON', 'SPARSE_OFF', 'SPARSE_ON', 'CELLSORT_OFF', 'CELLSORT_ON', 'CELLSORT3D_OFF',
     'CELLSORT3D_ON', 'ROCFFT', 'NO_WIDE', 'NO_LINE', 'JOINT_OFF', 'JOINT_ON', 'STAGED_OFF', 'STAGED_ON',
-    'SORT2_OFF', 'SORT2_ON', 'FXPATCH_OFF', 'QFOLD_OFF'))}
+    'SORT2_OFF', 'SORT2_ON', 'FXPATCH_OFF', 'QFOLD_OFF', 'STACK_OFF', 'STACK_ON'))}
 STAGES = ('sort_count', 'sort_scan', 'sort_scatter', 'zero', 'spread', 'fft', 'deconvolve', 'interp', 'sort_cell')
 
 
@@ -121,6 +121,8 @@ SYMBOLS = {
     'nufft_hip_debug_stop_after': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     'nufft_hip_debug_sort_path': (ctypes.c_int, [ctypes.c_void_p]),
     'nufft_hip_debug_sub_bounds': (ctypes.c_int64, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.c_int64]),
+    'nufft_hip_debug_stacks': (ctypes.c_int64, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32), ctypes.c_int64]),
+    'nufft_hip_debug_stack_params': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
     'nufft_hip_debug_shader_clock_mhz': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]),
     'nufft_hip_set_points': (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,

@@ -165,6 +165,22 @@ class Plan:
       self.lib.nufft_hip_debug_sub_bounds(self._handle, out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), n)
     return out
 
+  def stacks(self):
+    """Debug: the stacks of tiles a 3-D float w = 7 / 8 plan spreads over (int32 [n, 4]: column, z0 | nz << 16,
+    point range of a piece or -1, -1), as many rows as sub_bounds() then has entries; empty for other plans."""
+    import numpy as np
+    n = int(self.lib.nufft_hip_debug_stacks(self._handle, None, 0))
+    if n < 0:
+      self._check(1)
+    out = np.zeros((max(n, 0), 4), dtype=np.int32)
+    if n > 0:
+      self.lib.nufft_hip_debug_stacks(self._handle, out.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), n)
+    return out
+
+  def stack_params(self, length=0, cap=0):
+    """Debug: at most `length` tiles and `cap` points per stack from the next set_points on (0: the plan's rule)."""
+    self._check(self.lib.nufft_hip_debug_stack_params(self._handle, int(length), int(cap)))
+
   def stop_after(self, stage):
     """Debug: execute returns after the named stage ('spread', 'fft', 'deconvolve'); None = run all."""
     self._check(self.lib.nufft_hip_debug_stop_after(

@@ -26,6 +26,18 @@ def _dev(a):
   return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
+def _tuned(*names):
+  """tfft.Options forcing the named options.tuning bits (the op-level entry's way in)."""
+  import tensorflow_nufft
+  from tensorflow_nufft._lib import TUNE
+  o = tensorflow_nufft.Options()
+  bits = 0
+  for n in names:
+    bits |= TUNE[n]
+  o._internal = {'tuning': bits}
+  return o
+
+
 def _cases(golden, fname):
   g = golden(fname)
   for name in g['names']:
@@ -815,11 +827,12 @@ def test_3d_w8_bound_kernel_matches_its_numpy_restatement(tfft):
   # r04: 3-D float plans at w = 7 / 8 fix every subproblem's fixed-point step from a count-filter bound computed in
   # set_points (bound3_kernel). Host-logic check of that kernel against numpy on a grid with plain tile numbering,
   # uniform points (one subproblem per tile) plus a blob that must be flagged for the fp64 planes.
+  from tensorflow_nufft._lib import TUNE
   rng = np.random.default_rng(11)
   grid = [64, 64, 64]
   pts = rng.uniform(-np.pi, np.pi, (300_000, 3)).astype(np.float32)
   for tol, w in ((1e-6, 8), (1e-5, 7)):
-    plan = tfft.Plan('type_1', grid, 'forward', tol=tol)
+    plan = tfft.Plan('type_1', grid, 'forward', tol=tol, tuning=TUNE['STACK_OFF'])
     i = plan.info()
     assert i.kernel_width == w and list(i.tile_dims) == [16, 16, 8]
     plan.set_points(_dev(pts))
@@ -838,15 +851,102 @@ def test_3d_w8_bound_kernel_matches_its_numpy_restatement(tfft):
     assert live.max() < (80 if w == 8 else 800)
   # a blob of 3000 points inside one tile: its bound is far above the w = 8 limit -> negative entry
   blob = (np.array([0.3, -0.7, 1.1]) + 2e-3 * rng.standard_normal((3000, 3))).astype(np.float32)
-  plan = tfft.Plan('type_1', grid, 'forward', tol=1e-6)
+  plan = tfft.Plan('type_1', grid, 'forward', tol=1e-6, tuning=TUNE['STACK_OFF'])
   plan.set_points(_dev(np.concatenate([pts[:100_000], blob])))
   got = plan.sub_bounds()
   plan.close()
   assert (got < 0).sum() >= 1 and (got < 0).sum() <= 8
 
 
+def _stack_filter_bounds(plan, pts, stacks):
+  """numpy restatement of bound3_stack_kernel: the start-cell counts of a whole stack of tiles (consecutive in z)
+  filtered with the per-tap maxima, maximum over every cell the stack writes. Returns one bound per row of `stacks`
+  (rows that are pieces of a tile: nan)."""
+  i = plan.info()
+  w = int(i.kernel_width)
+  nf = [int(i.fine_dims[d]) for d in range(3)]        # x fastest
+  tile = [int(i.tile_dims[d]) for d in range(3)]
+  ntile = [int(i.num_tiles[d]) for d in range(3)]
+  z = -1.0 + 2.0 * np.arange(4097) / 4096.0
+  kmax = np.abs(plan.eval_kernel((z + 1.0 - w) / 2.0)).max(axis=0) * 1.001 + 1e-6     # [w]
+  x = pts.astype(np.float64)[:, ::-1]
+  cells = []
+  for d in range(3):
+    xp = (x[:, d] + np.pi) * (nf[d] / (2 * np.pi))
+    cells.append(np.ceil(xp - w / 2).astype(np.int64) % nf[d])
+  col = (cells[0] // tile[0]) + ntile[0] * (cells[1] // tile[1])
+  tz = cells[2] // tile[2]
+  out = []
+  for c, zz, p0, p1 in stacks:
+    z0, nz = int(zz) & 0xffff, int(zz) >> 16
+    if p0 >= 0:
+      out.append(np.nan)
+      continue
+    sel = (col == c) & (tz >= z0) & (tz < z0 + nz)
+    cnt = np.zeros((nz * tile[2], tile[1], tile[0]))
+    np.add.at(cnt, (cells[2][sel] - z0 * tile[2], cells[1][sel] % tile[1], cells[0][sel] % tile[0]), 1.0)
+    a = cnt
+    for ax in range(3):
+      a = np.apply_along_axis(lambda v: np.convolve(v, kmax), ax, a)
+    out.append(max(a.max() * 1.0001, 1.0))
+  return np.array(out)
+
+
+def test_3d_stack_bounds_and_cuts_match_their_numpy_restatement(tfft):
+  # r05: plans that spread over STACKS of tiles (consecutive in z, one workgroup each, the z halo carried in LDS): the
+  # cutting rule of stack_plan_kernel (every non-empty tile in exactly one stack, at most `len` tiles and `cap` points,
+  # tiles above max_subproblem_size points as pieces) and the bound of every stack (the count filter with the z pass
+  # carried across the stack's tiles) against numpy; a blob is flagged for the fp64 planes.
+  from tensorflow_nufft._lib import TUNE
+  rng = np.random.default_rng(12)
+  grid = [64, 48, 80]
+  for tol, w in ((1e-6, 8), (1e-5, 7)):
+    for M, ln, cp in ((150_000, 0, 0), (300_000, 3, 0), (400_000, 5, 4096)):
+      pts = rng.uniform(-np.pi, np.pi, (M, 3)).astype(np.float32)
+      pts[: M // 10, 0] *= 0.1      # (a denser slab: the point cap cuts there)
+      plan = tfft.Plan('type_1', grid, 'forward', tol=tol, tuning=TUNE['STACK_ON'])
+      if ln or cp:
+        plan.stack_params(ln, cp)
+      i = plan.info()
+      assert i.kernel_width == w and list(i.tile_dims) == [16, 16, 8]
+      plan.set_points(_dev(pts))
+      got, st = plan.sub_bounds(), plan.stacks()
+      want = _stack_filter_bounds(plan, pts, st)
+      msub = int(i.max_subproblem_size)
+      plan.close()
+      assert got.shape[0] == st.shape[0] > 0 and (st[:, 2] < 0).all()        # no tile above the subproblem cap here
+      # every non-empty tile in exactly one stack; lengths and point counts within the rule
+      ntile = [int(i.num_tiles[d]) for d in range(3)]
+      nf = [int(i.fine_dims[d]) for d in range(3)]
+      x = pts.astype(np.float64)[:, ::-1]
+      cz = [np.ceil((x[:, d] + np.pi) * (nf[d] / (2 * np.pi)) - w / 2).astype(np.int64) % nf[d] for d in range(3)]
+      key = ((cz[0] // 16) + ntile[0] * (cz[1] // 16)) * ntile[2] + cz[2] // 8
+      counts = np.bincount(key, minlength=ntile[0] * ntile[1] * ntile[2]).reshape(ntile[0] * ntile[1], ntile[2])
+      seen = np.zeros_like(counts)
+      len_rule = ln if ln else max(2, min(16, ntile[2], (ntile[0] * ntile[1] * ntile[2]) // 512))
+      cap_rule = max(cp if cp else 8192, msub)
+      for c, zz, _, _ in st:
+        z0, nz = int(zz) & 0xffff, int(zz) >> 16
+        assert 1 <= nz <= len_rule and z0 + nz <= ntile[2], (c, z0, nz, len_rule)
+        assert counts[c, z0] > 0 and counts[c, z0 + nz - 1] > 0             # (stacks start and end on non-empty tiles)
+        assert counts[c, z0:z0 + nz].sum() <= cap_rule
+        seen[c, z0:z0 + nz] += 1
+      assert ((seen == 1) | (counts == 0)).all() and (seen <= 1).all()
+      assert np.allclose(got, want, rtol=3e-5), np.abs(got / want - 1).max()
+      assert got.max() < (80 if w == 8 else 800)
+  blob = (np.array([0.3, -0.7, 1.1]) + 2e-3 * rng.standard_normal((2500, 3))).astype(np.float32)
+  big = (np.array([-1.3, 0.7, -2.1]) + 2e-3 * rng.standard_normal((9000, 3))).astype(np.float32)   # > max_subproblem_size: pieces
+  plan = tfft.Plan('type_1', grid, 'forward', tol=1e-6, tuning=TUNE['STACK_ON'])
+  plan.set_points(_dev(np.concatenate([pts[:100_000], blob, big])))
+  got, st = plan.sub_bounds(), plan.stacks()
+  plan.close()
+  assert (got < 0).sum() >= 1 and (st[:, 2] >= 0).sum() >= 4
+  assert (got[st[:, 2] >= 0] < 0).all()          # 2250-point pieces inside a few cells: far above the w = 8 limit
+
+
+@pytest.mark.parametrize('stack', ['STACK_OFF', 'STACK_ON'])
 @pytest.mark.parametrize('tol,bar', [(1e-6, 4e-7), (1e-5, 4e-6)])
-def test_3d_w8_w7_fixed_point_total_parity(tfft, tol, bar):
+def test_3d_w8_w7_fixed_point_total_parity(tfft, tol, bar, stack):
   # The default-tolerance 3-D transform (w = 8; and w = 7) on packed fixed point with the exact conversion
   # (spread_patch3_kernel): whole output against the fp64 oracle, against the r03 kernels (fp64 planes at w = 8),
   # through the one-call entry and set_points + execute, several transforms (strength statistics per slot).
@@ -860,17 +960,18 @@ def test_3d_w8_w7_fixed_point_total_parity(tfft, tol, bar):
   c = (rng.uniform(-.5, .5, (3, M)) + 1j * rng.uniform(-.5, .5, (3, M))).astype(np.complex64)
   c[1] *= 1e-3                         # slots of very different scale: the step follows each slot's own largest strength
   c[2, ::2] = np.conj(c[2, ::2])
-  plan = tfft.Plan('type_1', grid, 'forward', tol=tol, num_transforms=3)
+  plan = tfft.Plan('type_1', grid, 'forward', tol=tol, num_transforms=3, tuning=TUNE[stack])
   assert list(plan.info().tile_dims) == [16, 16, 8]
   plan.set_points(_dev(pts))
-  assert (plan.sub_bounds() > 0).sum() > 1000 and (plan.sub_bounds() < 0).sum() == 0
+  assert (plan.sub_bounds() > 0).sum() > (1000 if stack == 'STACK_OFF' else 500) and (plan.sub_bounds() < 0).sum() == 0
+  assert (plan.stacks().shape[0] > 0) == (stack == 'STACK_ON')
   out = plan.execute(_dev(c)).cpu().numpy()
   plan.close()
   old = tfft.Plan('type_1', grid, 'forward', tol=tol, num_transforms=3, tuning=TUNE['FXPATCH_OFF'])
   old.set_points(_dev(pts))
   ref = old.execute(_dev(c)).cpu().numpy()
   old.close()
-  one = tfft.Plan('type_1', grid, 'forward', tol=tol)
+  one = tfft.Plan('type_1', grid, 'forward', tol=tol, tuning=TUNE[stack])
   single = one.execute_with_points(_dev(pts), _dev(c[0])).cpu().numpy()
   one.close()
   for t in range(3):
@@ -883,7 +984,8 @@ def test_3d_w8_w7_fixed_point_total_parity(tfft, tol, bar):
       assert rel_l2(single, out[0]) < 3e-7
 
 
-def test_3d_w8_fixed_point_clustered_and_skewed(tfft):
+@pytest.mark.parametrize('stack', ['STACK_OFF', 'STACK_ON'])
+def test_3d_w8_fixed_point_clustered_and_skewed(tfft, stack):
   # Clustered points: subproblems whose bound is too large, and tiles with more than 16 subproblems, go to the
   # fp64-plane kernels behind the fixed-point one. One dominant strength: every subproblem takes its own pass over
   # its strengths (min of its sum and its largest x bound). All-negative / all-zero imaginary parts: the subtract path.
@@ -903,7 +1005,8 @@ def test_3d_w8_fixed_point_clustered_and_skewed(tfft):
   cases['lognormal'] = (np.exp(3 * rng.standard_normal(M)) * np.exp(2j * np.pi * rng.uniform(0, 1, M))).astype(np.complex64)
   cases['negative imaginary'] = (rng.uniform(-.5, .5, M) - 1j * rng.uniform(0, 1, M)).astype(np.complex64)
   cases['real'] = rng.uniform(-.5, .5, M).astype(np.complex64)
-  plan = tfft.Plan('type_1', grid, 'forward', tol=1e-6)
+  from tensorflow_nufft._lib import TUNE
+  plan = tfft.Plan('type_1', grid, 'forward', tol=1e-6, tuning=TUNE[stack])
   plan.set_points(_dev(pts))
   b = plan.sub_bounds()
   assert (b < 0).sum() >= 10 and (b > 0).sum() > 100, ((b < 0).sum(), (b > 0).sum())
@@ -918,9 +1021,15 @@ def test_3d_w8_fixed_point_clustered_and_skewed(tfft):
   out = tfft.spread(_dev(cases['clustered']), _dev(pts), g2, tol=1e-6).cpu().numpy()
   ref = oracle.nufft(cases['clustered'].astype(np.complex128), pts, g2, 'type_1', op='spread', tol=1e-6)
   assert rel_l2(out, ref) < 2e-6, rel_l2(out, ref)
+  sp = tfft.Plan('type_1', g2, 'forward', tol=1e-6, spread_only=True, tuning=TUNE[stack])
+  sp.set_points(_dev(pts))
+  assert (sp.stacks().shape[0] > 0) == (stack == 'STACK_ON')
+  out2 = sp.spread(_dev(cases['clustered'])).cpu().numpy()
+  sp.close()
+  assert rel_l2(out2, ref) < 2e-6, rel_l2(out2, ref)
 
 
-@pytest.mark.parametrize('mode', [0, 1])
+@pytest.mark.parametrize('mode', [0, 1, 'stacks'])
 def test_3d_very_crowded_tile_joins_its_subproblems(tfft, mode):
   # 1.5e6 points within a few cells of one spot: ~590 subproblems (2560 points each) of one tile, every one adding its
   # partial sums to the same fine-grid cells in float -- 1.2-1.3e-6 at tol 1e-6 (r04 soak seed 403; the fp64-plane
@@ -934,9 +1043,16 @@ def test_3d_very_crowded_tile_joins_its_subproblems(tfft, mode):
   c = (rng.standard_normal(M) + 1j * rng.standard_normal(M)).astype(np.complex64)
   truth = oracle.nufft(c.astype(np.complex128), pts, grid, 'type_1', 'forward', tol=1e-12, sigma=2.0)
   same = oracle.nufft(c.astype(np.complex128), pts, grid, 'type_1', 'forward', tol=1e-6, sigma=2.0)
-  plan = tfft.Plan('type_1', grid, 'forward', tol=1e-6, lds_accumulate=mode)
+  from tensorflow_nufft._lib import TUNE
+  if mode == 'stacks':   # (r05: the tile is ~590 PIECES, every one flagged as the subproblem it is)
+    plan = tfft.Plan('type_1', grid, 'forward', tol=1e-6, tuning=TUNE['STACK_ON'])
+  else:
+    plan = tfft.Plan('type_1', grid, 'forward', tol=1e-6, lds_accumulate=mode, tuning=TUNE['STACK_OFF'])
   plan.set_points(_dev(pts))
   out = plan.execute(_dev(c)).cpu().numpy()
+  if mode == 'stacks':
+    st, b = plan.stacks(), plan.sub_bounds()
+    assert (st[:, 2] >= 0).sum() > 300 and (b[st[:, 2] >= 0] < 0).all()
   nsub = M / plan.info().max_subproblem_size
   plan.close()
   err, ref_err = rel_l2(out, truth), rel_l2(same, truth)
@@ -944,7 +1060,8 @@ def test_3d_very_crowded_tile_joins_its_subproblems(tfft, mode):
   assert nsub > 300 and err <= 1.05 * ref_err + 4e-7, (err, ref_err)
 
 
-def test_3d_w8_uneven_strengths_take_the_weighted_bound(tfft):
+@pytest.mark.parametrize('stack', ['STACK_OFF', 'STACK_ON'])
+def test_3d_w8_uneven_strengths_take_the_weighted_bound(tfft, stack):
   # With the step from the transform's largest strength the quantisation adds ~1.2e-9 B (largest / rms strength):
   # 5.1e-7 for lognormal strengths at 0.75 points per fine cell (B = 37), twice the kernel's own error. Subproblems
   # whose B x largest / mean exceeds the budget bound their cells with the strength-weighted count filter instead
@@ -958,11 +1075,13 @@ def test_3d_w8_uneven_strengths_take_the_weighted_bound(tfft):
   z = rng.standard_normal(M) + 1j * rng.standard_normal(M)
   laws = {'lognormal': (z * np.exp(rng.standard_normal(M)), 1.0e-7), 'six decades': (z * 10.0 ** rng.uniform(-3, 3, M), 1.0e-7),
           'gaussian': (z, 2.8e-7)}
-  plans = {mode: tfft.Plan('type_1', grid, 'forward', tol=1e-6, lds_accumulate=mode) for mode in (0, 1)}
+  from tensorflow_nufft._lib import TUNE
+  plans = {mode: tfft.Plan('type_1', grid, 'forward', tol=1e-6, lds_accumulate=mode, tuning=TUNE[stack]) for mode in (0, 1)}
   for pl in plans.values():
     pl.set_points(_dev(pts))
   b = plans[0].sub_bounds()
-  assert (b >= 0).all() and (b > 0).sum() >= 1024   # every subproblem on the fixed-point kernel (0 = unused launch slot)
+  # every subproblem / stack on the fixed-point kernel (0 = unused launch slot)
+  assert (b >= 0).all() and (b > 0).sum() >= (1024 if stack == 'STACK_OFF' else 256)
   for name, (c, allowed) in laws.items():
     c = c.astype(np.complex64)
     truth = oracle.nufft(c.astype(np.complex128), pts, grid, 'type_1', 'forward', tol=1e-12, sigma=2.0)
