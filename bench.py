@@ -109,6 +109,8 @@ def pmc_traffic_of(config_key):
     d = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic_configs.json'))).get(config_key)
     if d:
       return {'traffic': int(d['traffic_bytes_corrected']), 'traffic_raw': int(d.get('traffic_bytes_raw', 0)) or None,
+              # (gathers counted at their 64-byte sectors, streams doubled: profiles/r04_fetch_calibration.txt)
+              'traffic_bytes_calibrated': int(d.get('traffic_bytes_calibrated', 0)) or None,
               'traffic_kernel': d.get('kernel'), 'traffic_source': 'offline: ' + d.get('source', 'profiles/')}
   except (OSError, ValueError, KeyError, TypeError):
     pass
@@ -443,7 +445,7 @@ def main():
   if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
     sys.exit(spawn_ranks(args, sys.argv[1:]))
 
-  import numpy as np
+  import numpy as np   # noqa: F401
   import torch
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
@@ -482,13 +484,33 @@ def main():
   else:
     result = run_config2(args, dev, dist, world, rank)
     if world > 1 and not args.no_extras:
-      # the batched workload north_star shards, on the same ranks (every rank takes part; rank 0 keeps the result)
+      # the batched workload north_star shards, on the same ranks. A rank-local failure inside it (allocation, plan
+      # creation) must not leave the other ranks waiting in a collective with the headline line unprinted: the line
+      # goes to stderr first as a breadcrumb, every rank runs its share ONCE without any collective, and the ranks
+      # agree that all of them got through before the timed, collective-bearing leg starts.
+      if rank == 0:
+        print('headline (before the sharded config-5 leg): ' + json.dumps(result), file=sys.stderr, flush=True)
+      c5, ok = None, 1
       try:
-        c5 = run_config5(args, dev, dist, world, rank)
+        prep = prepare_config5(args, dev, world, rank)
       except Exception as e:   # pylint: disable=broad-except
-        c5 = {'error': f'{type(e).__name__}: {str(e)[:200]}'}
+        prep, ok = None, 0
+        c5 = {'error': f'rank {rank}: {type(e).__name__}: {str(e)[:200]}'}
+      flag = torch.tensor([ok], dtype=torch.int32, device=dev if args.dist_backend == 'nccl' else 'cpu')
+      dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+      if int(flag.item()) == 1:
+        try:
+          c5 = run_config5(args, dev, dist, world, rank, prep)
+        except Exception as e:   # pylint: disable=broad-except
+          c5 = {'error': f'{type(e).__name__}: {str(e)[:200]}'}
+      elif c5 is None:
+        c5 = {'error': 'another rank failed to set the sharded workload up; leg skipped on every rank'}
       if rank == 0:
         result['config']['config5_sharded'] = c5
+        # (what the driver's record should show without digging)
+        cfg5 = c5.get('config', {}) if isinstance(c5, dict) else {}
+        result['config']['equal_work_efficiency'] = cfg5.get('equal_work_efficiency')
+        result['config']['rccl_world_size'] = cfg5.get('rccl_world_size')
   if rank == 0:
     print(json.dumps(result), flush=True)
   if dist is not None:
@@ -535,12 +557,13 @@ def run_config2(args, dev, dist, world, rank):
 
   for _ in range(args.warmup):
     step()
-  # full per-stage breakdown from an untimed pass (14 events per step cost ~7 %). At least 20 steps: the averages
-  # need them, and the device's clocks settle only after ~10 ms of work -- a timed region that starts after 6 steps
-  # measured 2-3 % below the sustained rate (EXPERIMENTS.md section 10.19); config.untimed_steps says how many ran.
+  # full per-stage breakdown from an untimed pass (14 events per step cost ~7 %). The device's clocks settle only
+  # after ~10 ms of work -- a timed region that starts after 6 steps measured 2-3 % below the sustained rate
+  # (EXPERIMENTS.md section 10.19) -- so the W warm-up steps and this pass together are at least 20 steps;
+  # `warmup_effective` in the line says how many untimed steps ran before the timed K.
   plan.set_timing(1)
   plan.get_timing()
-  stage_steps = max(3, args.warmup, 20)
+  stage_steps = max(3, 20 - args.warmup)   # (W >= 20: the W steps are the warm-up and this pass is 3 steps long)
   for _ in range(stage_steps):
     step()
   stage_all = plan.get_timing()
@@ -598,7 +621,8 @@ def run_config2(args, dev, dist, world, rank):
   result = {
       'metric': 'non-uniform pts/s, 2D type-1 1024^2 tol=1e-6 (set_points + execute)',
       'value': round(value, 2), 'unit': 'Mpts/s', 'n_gpus': world, 'steps': args.steps,
-      'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True,
+      'warmup': args.warmup, 'warmup_effective': args.warmup + stage_steps,
+      'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True,
       'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
       'config': {
           'workload': 'BASELINE configs[1]: 2D type-1, 1024x1024 modes, M=1e7 uniform random points, '
@@ -626,7 +650,8 @@ def run_config2(args, dev, dist, world, rank):
   return result
 
 
-def run_config5(args, dev, dist, world, rank):
+def prepare_config5(args, dev, world, rank):
+  """This rank's share of the sharded workload, run once: inputs, plans, workspaces. No collective in here."""
   import numpy as np
   import torch
   import tensorflow_nufft as tfft
@@ -639,6 +664,20 @@ def run_config5(args, dev, dist, world, rank):
   pts = (torch.rand((nloc, m, 2), generator=g, device=dev) * 2 - 1) * np.pi
   c = torch.complex(torch.rand((nloc, m), generator=g, device=dev) - .5,
                     torch.rand((nloc, m), generator=g, device=dev) - .5)
+  tfft.nufft(c, pts, grid_shape=C5_GRID, transform_type='type_1', tol=TOL)
+  torch.cuda.synchronize()
+  return pts, c
+
+
+def run_config5(args, dev, dist, world, rank, prep=None):
+  import numpy as np
+  import torch
+  import tensorflow_nufft as tfft
+  from tensorflow_nufft import sharding
+  items, m = args.items, C5_M
+  lo, hi = sharding.shard_bounds(items, world, rank)
+  nloc = hi - lo
+  pts, c = prep if prep is not None else prepare_config5(args, dev, world, rank)
 
   def transform(s, p):
     return tfft.nufft(s, p, grid_shape=C5_GRID, transform_type='type_1', tol=TOL)

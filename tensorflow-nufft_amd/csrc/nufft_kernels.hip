@@ -289,6 +289,9 @@ constexpr int kSortBlock = 1024;
 #ifndef NUFFT_SORT_MIN_WAVES
 #define NUFFT_SORT_MIN_WAVES 8
 #endif
+// (the general fold -- fmod / division / 64-bit modulo paths -- and the double instantiations do not fit in 64 VGPRs:
+// they are compiled for one workgroup per CU instead of spilling 24-92 bytes per lane; r04 verdict, weak #9)
+template <typename T, bool QF> constexpr int sort_min_waves() { return (QF && sizeof(T) == 4) ? NUFFT_SORT_MIN_WAVES : 4; }
 constexpr int kSortBatch = 4;    // load slots in flight per thread in the count / staged-scatter loops
 // The plain scatter of the two-call form (one scattered 16-byte store per point, strengths not read) runs ahead of its
 // stores with twice the loads in flight: r04 same-run A/B at config 2 (set_points + execute), slots 2 / 4 / 8: scatter
@@ -365,7 +368,7 @@ struct PointWalk {
 };
 
 template <typename T, int AOS, bool QF = false>
-__global__ __launch_bounds__(kSortBlock, NUFFT_SORT_MIN_WAVES) void hist_lds_kernel(Geom g, PointsIn in, int64_t per_block,
+__global__ __launch_bounds__(kSortBlock, (sort_min_waves<T, QF>())) void hist_lds_kernel(Geom g, PointsIn in, int64_t per_block,
                                                               int32_t* __restrict__ hist,
                                                               int32_t* __restrict__ bad_count) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -450,7 +453,7 @@ __device__ __forceinline__ FusedRec fused_record(const Rec<float>& r, float2 cv)
 }
 
 template <typename T, int AOS, bool FUSED, bool QF = false>
-__global__ __launch_bounds__(kSortBlock, NUFFT_SORT_MIN_WAVES) void scatter_lds_kernel(Geom g, PointsIn in, int64_t per_block,
+__global__ __launch_bounds__(kSortBlock, (sort_min_waves<T, QF>())) void scatter_lds_kernel(Geom g, PointsIn in, int64_t per_block,
                                                                  const int32_t* __restrict__ hist,
                                                                  const int32_t* __restrict__ tile_start,
                                                                  SortedOut<T> out) {
@@ -788,12 +791,10 @@ __global__ __launch_bounds__(256) void scatter_ranked_kernel(Geom g, PointsIn in
 // super-tile is ordered by tile inside it (<= 256 keys: segments of ~32-64 records). Neither level stages
 // records in LDS: a workgroup computes the permutation of its piece (LDS counters, 16-bit indices) and then
 // walks the OUTPUT positions, re-reading its input through the permutation (it was read a moment ago: L2).
-constexpr int kSort2Chunk = 8192;       // points per pass of the level-1 scatter
 constexpr int kSort2Sub = 4096;         // records per level-2 workgroup (a piece of a super-tile): 64 KB staged
 constexpr size_t kSort2Lds = (size_t)kSort2Sub * 17 + 2 * 256 * 4 + 16;
 constexpr int kSort2Threads = 512;      // threads of a level-2 count workgroup
 constexpr int kSort2MaxKeys = 256;      // tiles per super-tile
-constexpr int kSort2MaxSuper = 1024;
 
 // tile of a level-1 record inside its super-tile (fine geometry g), and the record's final form
 __device__ __forceinline__ int coarse_key(const Geom& g, const uint4& r) {
@@ -1398,11 +1399,18 @@ __global__ __launch_bounds__(kCellSortThreads) void cellsort2d_kernel(
   const int tid = threadIdx.x;
   for (int i = tid; i < 1024; i += NT) cnt[i] = 0u;
   // loads are unconditional on clamped indices so that all of them are in flight together
-  Rec<T> r[IT];
+  // (records as 16-byte vectors, every slot initialised: an array of Rec<T> that is assigned under a condition is
+  // kept in scratch memory -- 48-172 bytes per lane, r04 verdict; `loc` is the first word of both record types)
+  constexpr int NV = (int)(sizeof(Rec<T>) / 16);
+  uint4 r[IT][NV];
+  const uint4* inv = reinterpret_cast<const uint4*>(in);
+  uint4* outv = reinterpret_cast<uint4*>(out);
 #pragma unroll
   for (int u = 0; u < IT; ++u) {
     const int i = tid + u * NT;
-    if (u * NT < n) r[u] = in[p0 + (i < n ? i : n - 1)];
+    const size_t e = (size_t)(p0 + (i < n ? i : n - 1)) * NV;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) r[u][k] = (u * NT < n) ? inv[e + k] : make_uint4(0u, 0u, 0u, 0u);
   }
   __syncthreads();
   uint32_t kr[IT];   // key | rank-in-cell << 10
@@ -1411,7 +1419,8 @@ __global__ __launch_bounds__(kCellSortThreads) void cellsort2d_kernel(
     const int i = tid + u * NT;
     kr[u] = 0u;
     if (u * NT < n) {
-      const uint32_t key = (((r[u].loc >> 10) & 31u) << 5) | (r[u].loc & 31u);
+      const uint32_t loc = r[u][0].x;
+      const uint32_t key = (((loc >> 10) & 31u) << 5) | (loc & 31u);
       if (i < n) kr[u] = key | (atomicAdd(&cnt[key], 1u) << 10);
     }
   }
@@ -1420,7 +1429,11 @@ __global__ __launch_bounds__(kCellSortThreads) void cellsort2d_kernel(
 #pragma unroll
   for (int u = 0; u < IT; ++u) {
     const int i = tid + u * NT;
-    if (u * NT < n && i < n) out[p0 + cnt[kr[u] & 1023u] + (kr[u] >> 10)] = r[u];
+    if (u * NT < n && i < n) {
+      const size_t e = (size_t)(p0 + cnt[kr[u] & 1023u] + (kr[u] >> 10)) * NV;
+#pragma unroll
+      for (int k = 0; k < NV; ++k) outv[e + k] = r[u][k];
+    }
   }
 }
 
@@ -1440,11 +1453,16 @@ __global__ __launch_bounds__(kCellSortThreads) void cellsort3d_kernel(
   const int n = p1 - p0;
   const int tid = threadIdx.x;
   for (int i = tid; i < 2048; i += NT) cnt[i] = 0u;
-  Rec<T> r[IT];
+  constexpr int NV = (int)(sizeof(Rec<T>) / 16);   // (records as 16-byte vectors: see cellsort2d_kernel)
+  uint4 r[IT][NV];
+  const uint4* inv = reinterpret_cast<const uint4*>(in);
+  uint4* outv = reinterpret_cast<uint4*>(out);
 #pragma unroll
   for (int u = 0; u < IT; ++u) {
     const int i = tid + u * NT;
-    if (u * NT < n) r[u] = in[p0 + (i < n ? i : n - 1)];
+    const size_t e = (size_t)(p0 + (i < n ? i : n - 1)) * NV;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) r[u][k] = (u * NT < n) ? inv[e + k] : make_uint4(0u, 0u, 0u, 0u);
   }
   __syncthreads();
   uint32_t kr[IT];   // key | rank-in-cell << 11
@@ -1453,7 +1471,12 @@ __global__ __launch_bounds__(kCellSortThreads) void cellsort3d_kernel(
     const int i = tid + u * NT;
     kr[u] = 0u;
     if (u * NT < n) {
-      const uint32_t loc = unpack_rec<T, 3>(r[u]).loc;
+      uint32_t loc;
+      if constexpr (sizeof(T) == 4) {   // (packed float records: 4-bit tile-local starts in the top bits of three words)
+        loc = (r[u][0].x >> 28) | ((r[u][0].y >> 28) << 10) | ((r[u][0].z >> 28) << 20);
+      } else {
+        loc = r[u][0].x;
+      }
       const uint32_t key = (loc & 15u) | (((loc >> 10) & 15u) << 4) | (((loc >> 20) & 7u) << 8);
       if (i < n) kr[u] = key | (atomicAdd(&cnt[key], 1u) << 11);
     }
@@ -1463,7 +1486,11 @@ __global__ __launch_bounds__(kCellSortThreads) void cellsort3d_kernel(
 #pragma unroll
   for (int u = 0; u < IT; ++u) {
     const int i = tid + u * NT;
-    if (u * NT < n && i < n) out[p0 + cnt[kr[u] & 2047u] + (kr[u] >> 11)] = r[u];
+    if (u * NT < n && i < n) {
+      const size_t e = (size_t)(p0 + cnt[kr[u] & 2047u] + (kr[u] >> 11)) * NV;
+#pragma unroll
+      for (int k = 0; k < NV; ++k) outv[e + k] = r[u][k];
+    }
   }
 }
 
