@@ -130,10 +130,7 @@ enum {
   NUFFT_HIP_TUNE_STACK_OFF = 1 << 20,      /* 3-D float w = 7, 8 fixed point: one workgroup per STACK of tiles consecutive in z, the
                                               z halo carried in LDS instead of written out per tile (r05): never / always */
   NUFFT_HIP_TUNE_STACK_ON = 1 << 21,
-  NUFFT_HIP_TUNE_PLAIN_OFF = 1 << 22,      /* stacks: finished planes STORED into private slabs and gathered into the fine grid by a
-                                              merge kernel instead of added to it with float atomics (r05): never / wherever it exists */
-  NUFFT_HIP_TUNE_PLAIN_ON = 1 << 23,
-  NUFFT_HIP_TUNE_ALL = (1 << 24) - 1       /* every defined bit: plan creation refuses others, and both bits of a pair */
+  NUFFT_HIP_TUNE_ALL = (1 << 22) - 1       /* every defined bit: plan creation refuses others, and both bits of a pair */
 };
 
 typedef struct nufft_hip_plan_s* nufft_hip_plan;

@@ -979,64 +979,18 @@ __device__ __forceinline__ int stack_tile_index(const Geom& g, const StackColumn
 
 // One wave per tile column: cuts the column into stacks (greedy along z), two passes -- count, take a range of
 // descriptor slots with one atomic, write. The order of the descriptors depends on arrival; nothing else does.
-// Plain-store form (StackPlain::src non-null, r05): stacks that are not pieces write their planes to a private SLAB
-// with plain stores; the tables the gather into the fine grid needs are written here. src[col * ntz + tz] = {slab
-// plane of tile tz's first core plane, slab plane of the first HALO plane that lands on tile tz (the planes behind
-// the last tile of the stack that ends on the tile below), -1 = none} (preset to -1 by the launcher; a stack takes
-// nz * TZ + W - 1 planes of the pool, one atomic per column), and dirty[t0 + ntile0 (t1 + ntile1 t2)] = 1 for every
-// tile a piece's atomics reach (its own and the 7 neighbours its halo covers).
-struct StackPlain {
-  int2* src;              // [columns][ntile2]
-  unsigned char* dirty;   // [tiles], x-fastest numbering
-  unsigned char* anyhalo; // [ntile1][ntile2]: a halo lands on some tile (., t1, t2)
-  int* pool_count;        // planes handed out
-  int planes_per_tile, halo_planes;   // TZ, W - 1
-  int az_wrap;            // planes of the last tile in z that lie inside the grid (TZ when nf2 is a multiple of TZ)
-};
-__device__ __forceinline__ void stack_mark_dirty(const Geom& g, unsigned char* dirty, int t0, int t1, int t2) {
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    int tc[3] = {t0 + (k & 1), t1 + ((k >> 1) & 1), t2 + (k >> 2)};
-#pragma unroll
-    for (int d = 0; d < 3; ++d)
-      if (tc[d] >= g.ntile[d]) tc[d] = 0;
-    dirty[tc[0] + g.ntile[0] * (tc[1] + g.ntile[1] * tc[2])] = 1;
-  }
-}
 constexpr int kStackPlanWaves = 4;
 __global__ __launch_bounds__(kStackPlanWaves * 64) void stack_plan_kernel(Geom g, const int32_t* __restrict__ tile_start,
                                                                          int ncol, int cap, int len, int4* __restrict__ segs,
-                                                                         int* __restrict__ seg_count, int max_segs, StackPlain pl) {
+                                                                         int* __restrict__ seg_count, int max_segs) {
   const int lane = threadIdx.x & 63;
   const int col = blockIdx.x * kStackPlanWaves + (threadIdx.x >> 6);
   if (col >= ncol) return;
   const StackColumn cc = stack_column(g, col);
   const int ntz = g.ntile[2], S = g.max_sub;
-  int base = 0, pbase = 0;
+  int base = 0;
   for (int pass = 0; pass < 2; ++pass) {
     int nseg = 0, first = 0, last = 0, pts = 0;   // open stack: tiles [first, last], `pts` points (0: none open)
-    int planes = 0;                               // slab planes of the column's stacks so far
-    // closes the open stack [first, last] as descriptor base + nseg (pass 1: writes it and its tables)
-    auto close = [&]() {
-      const int nz = last - first + 1;
-      if (pass && base + nseg < max_segs) {
-        if (lane == 0) segs[base + nseg] = make_int4(col, first | (nz << 16), -1, -1);
-        if (pl.src) {
-          // (the .x and .y halves of an entry are written by different stacks: 4-byte stores)
-          int* sp = reinterpret_cast<int*>(pl.src + (size_t)col * ntz);
-          const int off = pbase + planes;
-          for (int k = lane; k < nz; k += 64) sp[2 * (first + k)] = off + k * pl.planes_per_tile;
-          if (lane == 0) {
-            if (last + 1 < ntz) sp[2 * (last + 1) + 1] = off + nz * pl.planes_per_tile;
-            else sp[1] = off + (nz - 1) * pl.planes_per_tile + pl.az_wrap;
-            pl.anyhalo[cc.t1 * ntz + (last + 1 < ntz ? last + 1 : 0)] = 1;
-          }
-        }
-      }
-      planes += nz * pl.planes_per_tile + pl.halo_planes;
-      ++nseg;
-      pts = 0;
-    };
     for (int zb = 0; zb < ntz; zb += 64) {
       int n = 0, b = 0;
       if (zb + lane < ntz) {
@@ -1049,16 +1003,18 @@ __global__ __launch_bounds__(kStackPlanWaves * 64) void stack_plan_kernel(Geom g
         const int ni = __shfl(n, i), bi = __shfl(b, i), tz = zb + i;   // (wave-uniform)
         if (ni == 0) continue;   // (empty tiles neither open nor end a stack; the length rule below counts them)
         const bool big = ni > S;
-        if (pts > 0 && (big || pts + ni > cap || tz - first + 1 > len)) close();
+        if (pts > 0 && (big || pts + ni > cap || tz - first + 1 > len)) {
+          if (pass && lane == 0 && base + nseg < max_segs) segs[base + nseg] = make_int4(col, first | ((last - first + 1) << 16), -1, -1);
+          ++nseg;
+          pts = 0;
+        }
         if (big) {
           const int k = (ni + S - 1) / S, sz = (ni + k - 1) / k;
-          if (pass) {
+          if (pass)
             for (int j = lane; j < k; j += 64) {
               const int a = bi + j * sz, e = a + sz < bi + ni ? a + sz : bi + ni;
               if (base + nseg + j < max_segs) segs[base + nseg + j] = make_int4(col, tz | (1 << 16), a, e);
             }
-            if (pl.dirty && lane == 0) stack_mark_dirty(g, pl.dirty, cc.t0, cc.t1, tz);
-          }
           nseg += k;
         } else {
           if (pts == 0) first = tz;
@@ -1067,15 +1023,14 @@ __global__ __launch_bounds__(kStackPlanWaves * 64) void stack_plan_kernel(Geom g
         }
       }
     }
-    if (pts > 0) close();
+    if (pts > 0) {
+      if (pass && lane == 0 && base + nseg < max_segs) segs[base + nseg] = make_int4(col, first | ((last - first + 1) << 16), -1, -1);
+      ++nseg;
+    }
     if (pass == 0) {
       if (nseg == 0) return;
-      if (lane == 0) {
-        base = atomicAdd(seg_count, nseg);
-        if (pl.src) pbase = atomicAdd(pl.pool_count, planes);
-      }
+      if (lane == 0) base = atomicAdd(seg_count, nseg);
       base = __shfl(base, 0);
-      pbase = __shfl(pbase, 0);
     }
   }
 }
@@ -1125,8 +1080,7 @@ __global__ __launch_bounds__(kBoundThreads) void bound3_stack_kernel(Geom g, con
                                                                     const int32_t* __restrict__ tile_start,
                                                                     const int32_t* __restrict__ sub_start, TapMax taps,
                                                                     const int4* __restrict__ segs, const int* __restrict__ seg_count,
-                                                                    float* __restrict__ seg_bound, int* __restrict__ fb_list,
-                                                                    unsigned char* __restrict__ dirty) {
+                                                                    float* __restrict__ seg_bound, int* __restrict__ fb_list) {
   constexpr int T = kDenseTile, L = T + W - 1, CP = T + 1, NT = kBoundThreads;
   __shared__ uint32_t cnt[TZ * T * CP];
   __shared__ float a[TZ * T * L];
@@ -1177,10 +1131,7 @@ __global__ __launch_bounds__(kBoundThreads) void bound3_stack_kernel(Geom g, con
       } else {
         for (int i = 0; i < d.nz; ++i) {   // (tiles of at most max_sub points: one subproblem each, none when empty)
           const int t = stack_tile_index(g, cc, d.z0 + i);
-          if (sub_start[t + 1] > sub_start[t]) {
-            fb_list[1 + atomicAdd(&fb_list[0], 1)] = sub_start[t];
-            if (dirty) stack_mark_dirty(g, dirty, cc.t0, cc.t1, d.z0 + i);   // (their atomics: see StackPlain)
-          }
+          if (sub_start[t + 1] > sub_start[t]) fb_list[1 + atomicAdd(&fb_list[0], 1)] = sub_start[t];
         }
       }
     } else {
@@ -1189,11 +1140,9 @@ __global__ __launch_bounds__(kBoundThreads) void bound3_stack_kernel(Geom g, con
   }
 }
 
-// The w = 7, 8 kernel over a stack. PLAIN = false: finished planes are added to the fine grid with float atomics.
-// PLAIN: a stack that is not a piece STORES them into its slab (rows of kSlabRow cells, every cell of every row:
-// the slab is not cleared between transforms); merge_stack3_kernel adds the slabs up into the fine grid.
-constexpr int kSlabRow = 24;   // cells per slab row (16 + W - 1 <= 23 used: rows start on 64-byte boundaries)
-template <int W, int TZ, int HALF, bool PLAIN>
+// The w = 7, 8 kernel over a stack: finished planes are added to the fine grid with float atomics. (A plain-store form --
+// slabs gathered by a merge kernel or by the first FFT pass -- was built and removed in r05: EXPERIMENTS.md section 11.3.)
+template <int W, int TZ, int HALF>
 __global__ NUFFT_PATCH_BOUNDS void spread_stack3_kernel(
     Geom g, SortedPoints<float> sp, const float* __restrict__ horner, const float* __restrict__ c,
     float* __restrict__ fw, int64_t c_stride, int64_t fw_stride, float scale) {
@@ -1299,10 +1248,6 @@ __global__ NUFFT_PATCH_BOUNDS void spread_stack3_kernel(
   patch3_lane_coef<W>(horner, lane, coef);
   const int o0 = col.t0 * kDenseTile, o1 = col.t1 * kDenseTile;
   float* out = fw + 2 * (int64_t)slot * fw_stride;
-  float* slab = nullptr;   // PLAIN: this stack's planes (not a piece's: several pieces share a tile)
-  if constexpr (PLAIN) {
-    if (d.p0 < 0) slab = sp.slab + 2 * ((int64_t)slot * sp.slab_stride + (int64_t)sp.src[(size_t)d.col * g.ntile[2] + d.z0].x * (L1 * kSlabRow));
-  }
   for (int i = 0; i < d.nz; ++i) {
     int p0 = d.p0, p1 = d.p1;
     if (p0 < 0) {
@@ -1355,12 +1300,7 @@ __global__ NUFFT_PATCH_BOUNDS void spread_stack3_kernel(
         const int im_sum = (int)(unsigned)(t[u] & 0xffffffffll);
         const int re_sum = (int)((t[u] - (long long)im_sum) >> 32);
         const float v = (float)(comp ? im_sum : re_sum) * step;
-        if (PLAIN && slab) {
-          const int rho = r0 + u * NW;   // plane a2, row a1 of this tile = row rho of the stack's planes from i TZ on
-          if (active) slab[2 * ((int64_t)(i * TZ * L1 + rho) * kSlabRow) + lane] = v;
-        } else if (active && v != 0.f) {
-          glb_add(&out[2 * (gbase[u] + gx) + comp], v);
-        }
+        if (active && v != 0.f) glb_add(&out[2 * (gbase[u] + gx) + comp], v);
       }
       if (!last && active && comp == 0) {   // (both lanes of a cell have read it: LDS operations of a wave complete in order)
 #pragma unroll
@@ -1382,62 +1322,6 @@ __global__ NUFFT_PATCH_BOUNDS void spread_stack3_kernel(
     lg[6] = __builtin_readcyclecounter(); lg[7] = (unsigned long long)d.nz;
   }
 #endif
-}
-
-// Gathers the slabs of a PLAIN spread into the fine grid (the stand-alone form: plans whose FFT is rocFFT, debug stops
-// behind the spread stage; otherwise the first pruned FFT pass does this while it loads, nufft_fft.hip): one workgroup
-// per tile CORE (16 x 16 x TZ cells), which receives the core planes of the stack that holds the tile and the halo
-// planes of the stack that ends on the tile below it, from its own tile column and from the three columns whose x / y
-// halo covers it: at most 8 plain reads per cell, one plain store. Tiles marked dirty (pieces, flagged stacks: atomics
-// into the fine grid) add what the fine grid holds; the others overwrite it.
-template <int W, int TZ>
-__global__ __launch_bounds__(256) void merge_stack3_kernel(Geom g, const int2* __restrict__ src, const unsigned char* __restrict__ dirty,
-                                                          const float2* __restrict__ slab, int64_t slab_stride,
-                                                          float2* __restrict__ fw, int64_t fw_stride) {
-  constexpr int T = kDenseTile, L0 = T + W - 1, L1 = T + W - 1, L2 = TZ + W - 1, PC = L1 * kSlabRow;
-  const int tid = threadIdx.x;
-  const int nt0 = g.ntile[0], nt1 = g.ntile[1], ntz = g.ntile[2];
-  const int t0 = blockIdx.x % nt0, t1 = (blockIdx.x / nt0) % nt1, t2 = blockIdx.x / (nt0 * nt1);
-  const int slot = blockIdx.y;
-  // per dimension: the neighbour whose halo reaches this tile and where this tile's first cell sits in its footprint
-  const int p0 = t0 > 0 ? t0 - 1 : nt0 - 1, ax1 = t0 > 0 ? T : g.nf[0] - T * (nt0 - 1);
-  const int p1 = t1 > 0 ? t1 - 1 : nt1 - 1, ay1 = t1 > 0 ? T : g.nf[1] - T * (nt1 - 1);
-  const int az1 = t2 > 0 ? TZ : g.nf[2] - TZ * (ntz - 1);
-  const int lx = tid & 15, ly = tid >> 4;
-  const int x = t0 * T + lx, y = t1 * T + ly;
-  if (x >= g.nf[0] || y >= g.nf[1]) return;
-  const float2* sl = slab + (int64_t)slot * slab_stride;
-  float2* out = fw + (int64_t)slot * fw_stride;
-  const bool add = dirty[blockIdx.x] != 0;
-  int64_t bc[4], bh[4];   // element of plane lz = 0 in the four columns' core / halo planes, < 0: none
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int sx = k & 1, sy = k >> 1;
-    const int ax = lx + (sx ? ax1 : 0), ay = ly + (sy ? ay1 : 0);
-    bc[k] = bh[k] = -1;
-    if (ax < L0 && ay < L1) {
-      const int2 sv = src[((sx ? p0 : t0) + nt0 * (sy ? p1 : t1)) * ntz + t2];
-      if (sv.x >= 0) bc[k] = (int64_t)sv.x * PC + ay * kSlabRow + ax;
-      if (sv.y >= 0) bh[k] = (int64_t)sv.y * PC + ay * kSlabRow + ax;
-    }
-  }
-  for (int lz = 0; lz < TZ; ++lz) {
-    const int z = t2 * TZ + lz;
-    if (z >= g.nf[2]) break;
-    float2 acc = make_float2(0.f, 0.f);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (bc[k] >= 0) { const float2 v = sl[bc[k] + (int64_t)lz * PC]; acc.x += v.x; acc.y += v.y; }
-      if (bh[k] >= 0 && lz + az1 < L2) { const float2 v = sl[bh[k] + (int64_t)lz * PC]; acc.x += v.x; acc.y += v.y; }
-    }
-    const int64_t cell = x + (int64_t)g.nf[0] * (y + (int64_t)g.nf[1] * z);
-    if (add) {
-      const float2 f = out[cell];
-      acc.x += f.x;
-      acc.y += f.y;
-    }
-    out[cell] = acc;
-  }
 }
 
 // ---- strengths of one spread launch: largest and summed max(|re c|, |im c|) per slot ----------------------------
@@ -1634,90 +1518,44 @@ bool stack3_wanted(const Geom& g, int64_t M) {
   const double cells = (double)g.nf[0] * g.nf[1] * g.nf[2] * (g.nitems > 1 ? g.nitems : 1);
   return (double)M < kStackDensity * cells;
 }
-// Plain-store form of the stack spreader (slabs + merge_stack3_kernel): where the stack form is taken at all, for one
-// point set, when every dimension has at least two tiles and a last tile that is whole or at least W - 1 cells wide
-// (the gather assumes a footprint that wraps reaches the first tile only). options.tuning PLAIN_OFF / PLAIN_ON.
-bool stack_plain_wanted(const Geom& g, int64_t M) {
-  if (!stack3_wanted(g, M) || g.nitems > 1) return false;
-  for (int d = 0; d < 3; ++d) {
-    const int rem = g.nf[d] % g.tile[d];
-    if (g.ntile[d] < 2 || (rem != 0 && rem < g.w - 1)) return false;
-  }
-  const int mode = tune_mode(g, NUFFT_HIP_TUNE_PLAIN_OFF, NUFFT_HIP_TUNE_PLAIN_ON);
-  if (mode >= 0) return mode != 0;
-  return true;
-}
-// planes of the slab pool of one transform: every tile in at most one stack, W - 1 halo planes per stack
-int64_t stack_pool_planes(const Geom& g, int64_t M) {
-  return (int64_t)g.ntiles * g.tile[2] + (int64_t)(g.w - 1) * stack_grid_bound(g, M);
-}
-int64_t stack_plane_cells(const Geom& g) { return (int64_t)(g.tile[1] + g.w - 1) * kSlabRow; }
-// tabs (plain form, else null): [ntiles] int2 src, [ntiles bytes] dirty, [ntile1 ntile2 bytes] anyhalo; seg_count[1] = planes handed out
-hipError_t launch_stack_plan(const Geom& g, const int32_t* tile_start, int64_t M, int4* segs, int* seg_count, int* tabs,
-                             hipStream_t stream) {
-  hipError_t e = hipMemsetAsync(seg_count, 0, 2 * sizeof(int), stream);
+hipError_t launch_stack_plan(const Geom& g, const int32_t* tile_start, int64_t M, int4* segs, int* seg_count, hipStream_t stream) {
+  hipError_t e = hipMemsetAsync(seg_count, 0, sizeof(int), stream);
   if (e != hipSuccess) return e;
   int cap, len;
   stack_params(g, &cap, &len);
   const int ncol = g.ntile[0] * g.ntile[1] * std::max(1, g.nitems);
-  const unsigned bound = stack_grid_bound(g, M);
-  StackPlain pl = {nullptr, nullptr, nullptr, seg_count + 1, g.tile[2], g.w - 1, g.nf[2] - g.tile[2] * (g.ntile[2] - 1)};
-  if (tabs) {
-    pl.src = reinterpret_cast<int2*>(tabs);
-    pl.dirty = reinterpret_cast<unsigned char*>(tabs + 2 * (size_t)g.ntiles);
-    pl.anyhalo = pl.dirty + g.ntiles;
-    if ((e = hipMemsetAsync(pl.src, 0xff, sizeof(int2) * (size_t)g.ntiles, stream)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(pl.dirty, 0, (size_t)g.ntiles + (size_t)g.ntile[1] * g.ntile[2], stream)) != hipSuccess) return e;
-  }
   stack_plan_kernel<<<(unsigned)((ncol + kStackPlanWaves - 1) / kStackPlanWaves), kStackPlanWaves * 64, 0, stream>>>(
-      g, tile_start, ncol, cap, len, segs, seg_count, (int)bound, pl);
+      g, tile_start, ncol, cap, len, segs, seg_count, (int)stack_grid_bound(g, M));
   return hipGetLastError();
 }
-size_t stack_tabs_bytes(const Geom& g, int64_t) { return sizeof(int2) * (size_t)g.ntiles + (size_t)g.ntiles + (size_t)g.ntile[1] * g.ntile[2]; }
 hipError_t launch_bound3_stack(const Geom& g, const Rec<float>* rec, int rec_stride, const int32_t* tile_start,
                                const int32_t* sub_start, int64_t M, const TapMax& taps, const int4* segs, const int* seg_count,
-                               float* seg_bound, int* fb_list, int* tabs, hipStream_t stream) {
+                               float* seg_bound, int* fb_list, hipStream_t stream) {
   hipError_t e = hipMemsetAsync(fb_list, 0, sizeof(int), stream);
   if (e != hipSuccess) return e;
   const unsigned grid = stack_grid_bound(g, M);
-  unsigned char* dirty = tabs ? reinterpret_cast<unsigned char*>(tabs + 2 * (size_t)g.ntiles) : nullptr;
-  if (g.w == 8) bound3_stack_kernel<8, 8><<<grid, kBoundThreads, 0, stream>>>(g, rec, rec_stride, tile_start, sub_start, taps, segs, seg_count, seg_bound, fb_list, dirty);
-  else if (g.w == 7) bound3_stack_kernel<7, 8><<<grid, kBoundThreads, 0, stream>>>(g, rec, rec_stride, tile_start, sub_start, taps, segs, seg_count, seg_bound, fb_list, dirty);
+  if (g.w == 8) bound3_stack_kernel<8, 8><<<grid, kBoundThreads, 0, stream>>>(g, rec, rec_stride, tile_start, sub_start, taps, segs, seg_count, seg_bound, fb_list);
+  else if (g.w == 7) bound3_stack_kernel<7, 8><<<grid, kBoundThreads, 0, stream>>>(g, rec, rec_stride, tile_start, sub_start, taps, segs, seg_count, seg_bound, fb_list);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }
-template <int W, bool PLAIN>
+template <int W>
 static hipError_t launch_stack3(const Geom& g, const SortedPoints<float>& sp, const float* horner, const float* c, float* fw,
                                 dim3 grid, int64_t c_stride, int64_t fw_stride, float scale, hipStream_t stream) {
   using C = PatchCfg<W, 8, kPatchHalf>;
-  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(spread_stack3_kernel<W, 8, kPatchHalf, PLAIN>),
+  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(spread_stack3_kernel<W, 8, kPatchHalf>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes);
   if (e != hipSuccess) return e;
-  spread_stack3_kernel<W, 8, kPatchHalf, PLAIN><<<grid, kPatchNW * 64, C::lds_bytes, stream>>>(g, sp, horner, c, fw, c_stride, fw_stride, scale);
+  spread_stack3_kernel<W, 8, kPatchHalf><<<grid, kPatchNW * 64, C::lds_bytes, stream>>>(g, sp, horner, c, fw, c_stride, fw_stride, scale);
   return hipGetLastError();
 }
 hipError_t launch_spread_stack3(const Geom& g, const SortedPoints<float>& sp, int64_t M, const float* horner,
                                 const float* c, float* fw, int batch, int64_t c_stride, int64_t fw_stride, float scale,
                                 hipStream_t stream) {
   const dim3 grid(stack_grid_bound(g, M), (unsigned)batch);
-  if (sp.slab) {
-    if (g.w == 8) return launch_stack3<8, true>(g, sp, horner, c, fw, grid, c_stride, fw_stride, scale, stream);
-    if (g.w == 7) return launch_stack3<7, true>(g, sp, horner, c, fw, grid, c_stride, fw_stride, scale, stream);
-    return hipErrorInvalidValue;
-  }
-  if (g.w == 8) return launch_stack3<8, false>(g, sp, horner, c, fw, grid, c_stride, fw_stride, scale, stream);
-  if (g.w == 7) return launch_stack3<7, false>(g, sp, horner, c, fw, grid, c_stride, fw_stride, scale, stream);
+  if (g.w == 8) return launch_stack3<8>(g, sp, horner, c, fw, grid, c_stride, fw_stride, scale, stream);
+  if (g.w == 7) return launch_stack3<7>(g, sp, horner, c, fw, grid, c_stride, fw_stride, scale, stream);
   return hipErrorInvalidValue;
-}
-// behind the spread launches of a plain-store plan (the stack kernel AND the fp64-plane launches for flagged stacks)
-hipError_t launch_merge_stack3(const Geom& g, const SortedPoints<float>& sp, float* fw, int batch, int64_t fw_stride, hipStream_t stream) {
-  const dim3 grid((unsigned)g.ntiles, (unsigned)batch);
-  const float2* slab = reinterpret_cast<const float2*>(sp.slab);
-  float2* out = reinterpret_cast<float2*>(fw);
-  if (g.w == 8) merge_stack3_kernel<8, 8><<<grid, 256, 0, stream>>>(g, sp.src, sp.dirty, slab, sp.slab_stride, out, fw_stride);
-  else if (g.w == 7) merge_stack3_kernel<7, 8><<<grid, 256, 0, stream>>>(g, sp.src, sp.dirty, slab, sp.slab_stride, out, fw_stride);
-  else return hipErrorInvalidValue;
-  return hipGetLastError();
 }
 int cstats_blocks(int64_t M, int slots) {
   // (workgroups per slot: 16384 strengths each, at most 1024, and at most 2^20 partial pairs over all slots)

@@ -31,8 +31,6 @@ namespace nufft_hip {
 
 namespace {
 
-inline int rank_of(const Geom& g) { return g.rank; }
-
 template <typename T> struct C2;
 template <> struct C2<float> { using type = float2; };
 template <> struct C2<double> { using type = double2; };
@@ -159,85 +157,6 @@ __device__ __forceinline__ void fft_load_line(const typename C2<T>::type* rowp, 
   }
 }
 
-// First-pass inputs of one line of a plain-store stack plan (FftMerge): element x of line (y, z) is the sum of what
-// up to four tile columns stored for it in their slabs -- the column that holds the cell and the ones whose x / y halo
-// covers it, core planes and the halo planes of a stack that ended on the tile below -- plus, on tiles that atomics
-// reached, the fine grid's cell (cleared behind the read). Tiles are 16 x 16 x 8 cells.
-// Whether a y neighbour or a halo can contribute at all is decided per LINE (ly < w - 1; any stack ending under this
-// row of tiles: FftMerge::anyhalo), so most lines issue 2 slab loads per element. The thread's 8 elements
-// (x = lt + k TL: the radix-8 first pass takes exactly these) are gathered NUFFT_MERGE_ELEMS at a time in a loop that is NOT
-// unrolled, through the thread's own slots of the line buffer: gathered straight into the 8 register pairs, the
-// table entries, addresses and cells in flight of all 8 elements spilled 200-470 bytes per lane, and that scratch
-// traffic (5.4 GB per pass at 512^3) was the whole cost of the pass.
-#ifndef NUFFT_MERGE_ELEMS
-#define NUFFT_MERGE_ELEMS 4
-#endif
-__device__ __forceinline__ void fft_load_line_merged(const FftMerge& m, const float2* __restrict__ slab, float2* fine_line,
-                                                     int64_t line, bool live, int lt, int TL, float2* mybuf, float2 (&x)[8]) {
-  if (live) {
-    // line = y + nf1 z (nf1 and nf2 need not be multiples of the tile)
-    const int z = (int)(line / m.nf1), y = (int)(line - (int64_t)z * m.nf1);
-    const int ty = y >> 4, ly = y & 15, tz = z >> 3, lz = z & 7;
-    const int cyp = ty > 0 ? ty - 1 : m.nt1 - 1;
-    const int ayp = ly + (ty > 0 ? 16 : m.ay1);
-    const bool use_y = ayp < m.L;                                   // (line-uniform)
-    const bool halo_z = lz + (tz > 0 ? 8 : m.az1) < m.LZ;
-    const int nh = (halo_z && (m.anyhalo[ty * m.ntz + tz] || (use_y && m.anyhalo[cyp * m.ntz + tz]))) ? 2 : 1;
-    const unsigned pc = (unsigned)m.plane_cells;   // (element offsets in 32 bits: a slot's slabs stay below 2^31 elements)
-    const unsigned e0 = (unsigned)lz * pc + ly * 24, e1 = (unsigned)lz * pc + ayp * 24;
-    const int row0 = (m.nt0 * ty) * m.ntz + tz, row1 = (m.nt0 * cyp) * m.ntz + tz;
-    const int* tab = reinterpret_cast<const int*>(m.src);   // entry e: tab[2 e] core plane, tab[2 e + 1] halo plane
-    const int drow = m.nt0 * (ty + m.nt1 * tz);
-    constexpr int NE = NUFFT_MERGE_ELEMS;   // elements gathered together
-#pragma nounroll
-    for (int k = 0; k < 8; k += NE) {
-      float2 acc[NE];
-      int xi[NE], lx[NE], axq[NE], txq[NE], cxp[NE];
-#pragma unroll
-      for (int j = 0; j < NE; ++j) {
-        xi[j] = lt + (k + j) * TL;
-        txq[j] = xi[j] >> 4;
-        lx[j] = xi[j] & 15;
-        cxp[j] = txq[j] > 0 ? txq[j] - 1 : m.nt0 - 1;
-        axq[j] = lx[j] + (txq[j] > 0 ? 16 : m.ax1);
-        acc[j] = make_float2(0.f, 0.f);
-      }
-      for (int h = 0; h < nh; ++h) {   // core planes, then (few lines) the halo planes
-        int p00[NE], p10[NE], p01[NE], p11[NE];   // slab planes [sx][sy]
-#pragma unroll
-        for (int j = 0; j < NE; ++j) {
-          p00[j] = tab[2 * (row0 + txq[j] * m.ntz) + h];
-          p10[j] = axq[j] < m.L ? tab[2 * (row0 + cxp[j] * m.ntz) + h] : -1;
-          p01[j] = use_y ? tab[2 * (row1 + txq[j] * m.ntz) + h] : -1;
-          p11[j] = (use_y && axq[j] < m.L) ? tab[2 * (row1 + cxp[j] * m.ntz) + h] : -1;
-        }
-#pragma unroll
-        for (int j = 0; j < NE; ++j) {
-          float2 a = make_float2(0.f, 0.f), b = a, c = a, d = a;
-          if (p00[j] >= 0) a = slab[(unsigned)p00[j] * pc + e0 + lx[j]];
-          if (p10[j] >= 0) b = slab[(unsigned)p10[j] * pc + e0 + axq[j]];
-          if (p01[j] >= 0) c = slab[(unsigned)p01[j] * pc + e1 + lx[j]];
-          if (p11[j] >= 0) d = slab[(unsigned)p11[j] * pc + e1 + axq[j]];
-          acc[j].x += (a.x + b.x) + (c.x + d.x);
-          acc[j].y += (a.y + b.y) + (c.y + d.y);
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < NE; ++j) {
-        if (m.dirty[txq[j] + drow]) {
-          const float2 f = fine_line[xi[j]];
-          acc[j].x += f.x;
-          acc[j].y += f.y;
-          fine_line[xi[j]] = make_float2(0.f, 0.f);
-        }
-        mybuf[lpad(xi[j])] = acc[j];
-      }
-    }
-  }
-#pragma unroll
-  for (int q = 0; q < 8; ++q) x[q] = live ? mybuf[lpad(lt + q * TL)] : make_float2(0.f, 0.f);   // (the thread's own stores)
-}
-
 // One Stockham pass of radix RAD on the 8 values of a thread (8 / RAD butterflies).
 template <typename T, int RAD, bool CROP, bool INPLACE = false>
 __device__ __forceinline__ void fft_pass(const typename C2<T>::type* twp, int n, const BinMap<T>& map,
@@ -343,10 +262,9 @@ __device__ __forceinline__ void fft_all_passes(const typename C2<T>::type* twp, 
 // from pass to pass (N -> nf per dimension), so its strided side should be the small input, not the
 // large output: with the scatter-out form the last 2-D pass wrote the 33.5 MB fine grid in 64-byte
 // pieces (39.6 us at 2048^2 against 21.5 us for the type-1 pass that READS those 33.5 MB).
-template <typename T, int LOGN, bool PAD, bool GATHER = false, bool MERGE = false>
-__global__ __launch_bounds__(kFftMaxThreads, 4) void fft_rotate_kernel(FftPassArgs<T> a, FftMerge mg) {
+template <typename T, int LOGN, bool PAD, bool GATHER = false>
+__global__ __launch_bounds__(kFftMaxThreads, 4) void fft_rotate_kernel(FftPassArgs<T> a) {
   static_assert(!GATHER || PAD, "the gather form is the type-2 pass");
-  static_assert(!MERGE || (!PAD && sizeof(T) == 4), "the merged load is the first type-1 pass of a float plan");
   using V = typename C2<T>::type;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int n = 1 << LOGN;
@@ -411,13 +329,7 @@ __global__ __launch_bounds__(kFftMaxThreads, 4) void fft_rotate_kernel(FftPassAr
   }
   __syncthreads();   // twiddle table (and the gathered lines)
   V v[8], vn[8];
-  [[maybe_unused]] const float2* mslab = nullptr;
-  if constexpr (MERGE) mslab = reinterpret_cast<const float2*>(mg.slab) + (int64_t)blockIdx.y * mg.slab_stride;
-  if constexpr (MERGE) {
-    // (no loads in flight across the passes here: with a second set of inputs live beside the gather's table entries
-    // and slab cells the kernel spilled 260-470 bytes per lane, and that scratch traffic -- 5.4 GB per pass at 512^3 --
-    // was the whole cost of the pass; the other workgroups of the CU cover the latency)
-  } else if constexpr (!GATHER) {
+  if constexpr (!GATHER) {
     const int64_t line = line0 + lw;
     const bool live = lw < a.R && line < a.nlines;
     fft_load_line<T, RAD0, PAD>(in + (live ? line : 0) * inlen, live, lt, TL, n, map, v, a.zero_in != 0);
@@ -428,15 +340,6 @@ __global__ __launch_bounds__(kFftMaxThreads, 4) void fft_rotate_kernel(FftPassAr
     if constexpr (GATHER) {                     // first-pass inputs come from the tile row (modes, padded by the map)
       const bool live = r < a.R && line0 + r < a.nlines;
       fft_load_line<T, RAD0, PAD>(tile + (r < a.R ? r : 0) * TS, live, lt, TL, n, map, v);
-    } else if constexpr (MERGE) {               // this group's inputs, gathered from the slabs
-      const int64_t line = line0 + r;
-      const bool live = r < a.R && line < a.nlines;
-      if (g > 0) __syncthreads();   // (the gather stores into the line buffer the previous group's last pass read from)
-      int ltg = lt;   // (opaque, as below: the gather's per-element tile columns and offsets must not be hoisted out of the loop)
-      asm volatile("" : "+v"(ltg));
-      static_assert(!MERGE || RAD0 == 8, "the merged load hands every thread the elements lt + k n / 8");
-      fft_load_line_merged(mg, mslab, const_cast<float2*>(reinterpret_cast<const float2*>(in)) + (live ? line : 0) * inlen, line, live, ltg, TL,
-                           reinterpret_cast<float2*>(mybuf), v);
     } else if (more) {                          // next group's loads are in flight during this group's passes
       const int64_t line = line0 + r + LW;
       const bool live = r + LW < a.R && line < a.nlines;
@@ -449,7 +352,7 @@ __global__ __launch_bounds__(kFftMaxThreads, 4) void fft_rotate_kernel(FftPassAr
     int ltv = lt;
     asm volatile("" : "+v"(ltv));
     fft_all_passes<T, LOGN, 0, !PAD, GATHER>(twp, map, v, mybuf, trow, ltv, r < a.R, sgn);
-    if constexpr (!GATHER && !MERGE) {
+    if constexpr (!GATHER) {
       if (more) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[q] = vn[q];
@@ -479,32 +382,17 @@ __global__ __launch_bounds__(kFftMaxThreads, 4) void fft_rotate_kernel(FftPassAr
 
 template <typename T, int LOGN>
 hipError_t launch_fft_pass(const FftPassArgs<T>& a, bool pad, bool gather, unsigned nblk, unsigned batch, size_t lds,
-                           hipStream_t stream, const FftMerge* merge = nullptr) {
+                           hipStream_t stream) {
   if (pad && a.kout != a.n) return hipErrorInvalidValue;   // a pass either pads or crops
   if (gather != pad) return hipErrorInvalidValue;          // (type 2 = padding passes in gather form, type 1 = cropping scatter-out passes)
-  const FftMerge none = {};
-  if constexpr (sizeof(T) == 4 && LOGN >= 5) {
-    if (merge) {   // first type-1 pass of a plain-store stack plan
-      if (pad) return hipErrorInvalidValue;
-      const void* fnm = reinterpret_cast<const void*>(fft_rotate_kernel<T, LOGN, false, false, true>);
-      if (lds > 64 * 1024) {
-        const hipError_t e = hipFuncSetAttribute(fnm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-      }
-      fft_rotate_kernel<T, LOGN, false, false, true><<<dim3(nblk, batch), a.LW * (a.n / 8), lds, stream>>>(a, *merge);
-      return hipGetLastError();
-    }
-  } else {
-    if (merge) return hipErrorInvalidValue;
-  }
   const void* fn = gather ? reinterpret_cast<const void*>(fft_rotate_kernel<T, LOGN, true, true>)
                           : reinterpret_cast<const void*>(fft_rotate_kernel<T, LOGN, false>);
   if (lds > 64 * 1024) {
     const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  if (gather) fft_rotate_kernel<T, LOGN, true, true><<<dim3(nblk, batch), a.LW * (a.n / 8), lds, stream>>>(a, none);
-  else fft_rotate_kernel<T, LOGN, false><<<dim3(nblk, batch), a.LW * (a.n / 8), lds, stream>>>(a, none);
+  if (gather) fft_rotate_kernel<T, LOGN, true, true><<<dim3(nblk, batch), a.LW * (a.n / 8), lds, stream>>>(a);
+  else fft_rotate_kernel<T, LOGN, false><<<dim3(nblk, batch), a.LW * (a.n / 8), lds, stream>>>(a);
   return hipGetLastError();
 }
 
@@ -581,9 +469,8 @@ int64_t pruned_fft_tmp_elems(const Geom& g) {
 template <typename T>
 hipError_t launch_pruned_fft(const Geom& g, int type, int iflag, T* fine, T* f, T* tmp0, T* tmp1,
                              const T* const rf[3], const T* const tw[3], int batch, hipStream_t stream,
-                             bool zero_fine, const FftMerge* merge) {
+                             bool zero_fine) {
   using V = typename C2<T>::type;
-  if (merge && (type != 1 || rank_of(g) != 3 || sizeof(T) != 4)) return hipErrorInvalidValue;
   const int rank = g.rank;
   const int csize = 2 * (int)sizeof(T);
   int64_t fine_elems = 1, mode_elems = 1;
@@ -631,14 +518,14 @@ hipError_t launch_pruned_fft(const Geom& g, int type, int iflag, T* fine, T* f, 
     if (nblk > 2147483647LL || batch > 65535) return hipErrorInvalidValue;
     hipError_t e = hipErrorInvalidValue;
     switch (a.n) {
-      case 16: e = launch_fft_pass<T, 4>(a, type == 2, gather, (unsigned)nblk, (unsigned)batch, lds, stream, step == 0 ? merge : nullptr); break;
-      case 32: e = launch_fft_pass<T, 5>(a, type == 2, gather, (unsigned)nblk, (unsigned)batch, lds, stream, step == 0 ? merge : nullptr); break;
-      case 64: e = launch_fft_pass<T, 6>(a, type == 2, gather, (unsigned)nblk, (unsigned)batch, lds, stream, step == 0 ? merge : nullptr); break;
-      case 128: e = launch_fft_pass<T, 7>(a, type == 2, gather, (unsigned)nblk, (unsigned)batch, lds, stream, step == 0 ? merge : nullptr); break;
-      case 256: e = launch_fft_pass<T, 8>(a, type == 2, gather, (unsigned)nblk, (unsigned)batch, lds, stream, step == 0 ? merge : nullptr); break;
-      case 512: e = launch_fft_pass<T, 9>(a, type == 2, gather, (unsigned)nblk, (unsigned)batch, lds, stream, step == 0 ? merge : nullptr); break;
-      case 1024: e = launch_fft_pass<T, 10>(a, type == 2, gather, (unsigned)nblk, (unsigned)batch, lds, stream, step == 0 ? merge : nullptr); break;
-      case 2048: e = launch_fft_pass<T, 11>(a, type == 2, gather, (unsigned)nblk, (unsigned)batch, lds, stream, step == 0 ? merge : nullptr); break;
+      case 16: e = launch_fft_pass<T, 4>(a, type == 2, gather, (unsigned)nblk, (unsigned)batch, lds, stream); break;
+      case 32: e = launch_fft_pass<T, 5>(a, type == 2, gather, (unsigned)nblk, (unsigned)batch, lds, stream); break;
+      case 64: e = launch_fft_pass<T, 6>(a, type == 2, gather, (unsigned)nblk, (unsigned)batch, lds, stream); break;
+      case 128: e = launch_fft_pass<T, 7>(a, type == 2, gather, (unsigned)nblk, (unsigned)batch, lds, stream); break;
+      case 256: e = launch_fft_pass<T, 8>(a, type == 2, gather, (unsigned)nblk, (unsigned)batch, lds, stream); break;
+      case 512: e = launch_fft_pass<T, 9>(a, type == 2, gather, (unsigned)nblk, (unsigned)batch, lds, stream); break;
+      case 1024: e = launch_fft_pass<T, 10>(a, type == 2, gather, (unsigned)nblk, (unsigned)batch, lds, stream); break;
+      case 2048: e = launch_fft_pass<T, 11>(a, type == 2, gather, (unsigned)nblk, (unsigned)batch, lds, stream); break;
       default: break;
     }
     if (e != hipSuccess) return e;
@@ -648,8 +535,8 @@ hipError_t launch_pruned_fft(const Geom& g, int type, int iflag, T* fine, T* f, 
   return hipGetLastError();
 }
 template hipError_t launch_pruned_fft<float>(const Geom&, int, int, float*, float*, float*, float*,
-                                             const float* const[3], const float* const[3], int, hipStream_t, bool, const FftMerge*);
+                                             const float* const[3], const float* const[3], int, hipStream_t, bool);
 template hipError_t launch_pruned_fft<double>(const Geom&, int, int, double*, double*, double*, double*,
-                                              const double* const[3], const double* const[3], int, hipStream_t, bool, const FftMerge*);
+                                              const double* const[3], const double* const[3], int, hipStream_t, bool);
 
 }  // namespace nufft_hip

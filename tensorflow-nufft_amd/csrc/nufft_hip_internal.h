@@ -63,7 +63,6 @@ struct Geom {
   // parameters when a debug call overrides the defaults (0: stack_params' rule)
   int stack;
   int stack_len, stack_cap;
-  int stack_plain;   // stacks store their planes in slabs, merge_stack3_kernel gathers them (set per set_points)
 };
 // OFF / ON pair of nufft_hip_options.tuning: -1 = by the plan's own rule, 0 = never, 1 = always
 inline int tune_mode(const Geom& g, int off_bit, int on_bit) { return (g.tuning & on_bit) ? 1 : ((g.tuning & off_bit) ? 0 : -1); }
@@ -122,15 +121,6 @@ struct SortedPoints {
   const int4* segs;
   const int* seg_count;
   const float* seg_bound;
-  // plain-store form of the stack spreader (null otherwise): every stack that is not a piece stores its planes in
-  // a slab (float2 [slots][slab_stride]) and the first FFT pass (or merge_stack3_kernel) gathers them into the fine
-  // grid through src[column][tile in z] = {slab plane of the tile's core planes, of the halo planes that land on it};
-  // dirty[tile, x fastest]: atomics reached the tile as well
-  float* slab;
-  int64_t slab_stride;
-  const int2* src;
-  const unsigned char* dirty;
-  const unsigned char* anyhalo;   // [ntile1][ntile2]: some column of tile row t1 has halo planes landing on tile (., t1, t2)
 };
 // Tap maxima of the fitted kernel, max over z of |P_t(z)| for every stencil cell t (with the fit's and the float
 // evaluation's margin): what bound3_kernel filters the start-cell counts with
@@ -227,26 +217,10 @@ hipError_t launch_permute(const void* src, void* dst, int elem_bytes, int ndim,
 // tw[d]: exp(iflag 2 pi i m / nf_d), m < nf_d; rf[d]: reciprocal kernel Fourier series.
 bool pruned_fft_supported(const Geom& g, int precision);
 int64_t pruned_fft_tmp_elems(const Geom& g);
-// The first type-1 pass of a plain-store stack plan (3-D float, nufft_dense3.hip) does not read the fine grid: it
-// gathers every element from the slabs the stacks stored (SortedPoints::slab / src / dirty) and adds -- and clears --
-// the fine grid only on tiles that atomics reached.
-struct FftMerge {
-  const void* slab;          // float2 [transforms][slab_stride]
-  int64_t slab_stride;
-  const int2* src;           // [columns][ntz]
-  const unsigned char* dirty;   // [tiles, x fastest]
-  const unsigned char* anyhalo; // [nt1][ntz]: a stack of some column of tile row t1 ended on the tile below (t1, ., tz)
-  int nt0, nt1, ntz;
-  int nf1;                   // fine cells in y (a line of the pass is (y, z))
-  int ax1, ay1, az1;         // where the first tile's cells sit in the footprint of the LAST tile of the dimension (wrap)
-  int L, LZ;                 // footprint of a tile: 16 + w - 1 cells in x and y, 8 + w - 1 planes
-  int plane_cells;           // float2 elements per slab plane
-};
 template <typename T>
 hipError_t launch_pruned_fft(const Geom& g, int type, int iflag, T* fine, T* f, T* tmp0, T* tmp1,
                              const T* const rf[3], const T* const tw[3], int batch, hipStream_t stream,
-                             bool zero_fine = false,   // type 1: leave `fine` zeroed (its first pass reads it all)
-                             const FftMerge* merge = nullptr);
+                             bool zero_fine = false);   // type 1: leave `fine` zeroed (its first pass reads it all)
 size_t spread_lds_bytes(const Geom& g, int method, int precision);
 size_t interp_lds_bytes(const Geom& g, int method, int precision);
 int wave_lstride(int rank);
@@ -291,16 +265,10 @@ hipError_t launch_bound3(const Geom& g, const Rec<float>* rec, int rec_stride, c
 bool stack3_wanted(const Geom& g, int64_t M);
 void stack_params(const Geom& g, int* cap, int* len);
 unsigned stack_grid_bound(const Geom& g, int64_t M);
-bool stack_plain_wanted(const Geom& g, int64_t M);
-int64_t stack_pool_planes(const Geom& g, int64_t M);   // slab planes of one transform
-int64_t stack_plane_cells(const Geom& g);              // float2 elements per slab plane
-size_t stack_tabs_bytes(const Geom& g, int64_t M);     // owner / seg_off / dirty tables of the plain form
-hipError_t launch_stack_plan(const Geom& g, const int32_t* tile_start, int64_t M, int4* segs, int* seg_count, int* tabs,
-                             hipStream_t stream);
+hipError_t launch_stack_plan(const Geom& g, const int32_t* tile_start, int64_t M, int4* segs, int* seg_count, hipStream_t stream);
 hipError_t launch_bound3_stack(const Geom& g, const Rec<float>* rec, int rec_stride, const int32_t* tile_start,
                                const int32_t* sub_start, int64_t M, const TapMax& taps, const int4* segs, const int* seg_count,
-                               float* seg_bound, int* fb_list, int* tabs, hipStream_t stream);
-hipError_t launch_merge_stack3(const Geom& g, const SortedPoints<float>& sp, float* fw, int batch, int64_t fw_stride, hipStream_t stream);
+                               float* seg_bound, int* fb_list, hipStream_t stream);
 hipError_t launch_spread_stack3(const Geom& g, const SortedPoints<float>& sp, int64_t M, const float* horner,
                                 const float* c, float* fw, int batch, int64_t c_stride, int64_t fw_stride, float scale,
                                 hipStream_t stream);

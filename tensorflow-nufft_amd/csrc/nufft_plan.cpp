@@ -245,18 +245,12 @@ struct nufft_hip_plan_s {
   int32_t *tile_count = nullptr, *tile_start = nullptr, *sub_start = nullptr, *bad_count = nullptr;
   float* cstats = nullptr;       // 3-D float fixed-point plans: {largest, summed} strength of every slot of a spread launch
   int64_t cap_cstats = 0;        //   (+ the per-workgroup partials of the reduction: sized per point count)
-  bool slab_ok = false;          // the workspace of the plain-store form exists for the current point count
   float* sub_bound = nullptr;    // Geom::fx_patch: count-filter bound per subproblem
   int64_t cap_sub_bound = 0;
   int* fb_list = nullptr;        // fixed-point 3-D plans: count + launch slots of the subproblems left to the fp64 planes
   int64_t cap_fb_list = 0;
   int4* segs = nullptr;          // Geom::stack: [0].x = how many stacks, [1..] their descriptors (stack_plan_kernel)
   int64_t cap_segs = 0;
-  int* stack_tabs = nullptr;     // Geom::stack_plain: owner / seg_off / dirty tables (launch_stack_plan)
-  int64_t cap_stack_tabs = 0;    //   (bytes)
-  void* slab = nullptr;          // Geom::stack_plain: slab pool, [slots][planes][rows][kSlabRow] complex
-  int64_t cap_slab = 0;          //   (bytes)
-  int64_t slab_stride = 0;       //   complex elements per slot
   TapMax taps = {};              // per-tap maxima of the fitted kernel (bound3_kernel)
   int64_t workspace_bytes = 0;
   bool points_set = false;
@@ -466,12 +460,12 @@ int ensure_fixed_workspace(nufft_hip_plan p) {
 void release_workspace(nufft_hip_plan p) {
   void** bufs[] = {(void**)&p->tile_count, (void**)&p->tile_start, (void**)&p->sub_start, (void**)&p->bad_count,
                    &p->d_fine, &p->fft_work, &p->fft_tmp[0], &p->fft_tmp[1], &p->rec, &p->rec2, (void**)&p->hist, (void**)&p->tile_of,
-                   (void**)&p->rank_of, (void**)&p->cstats, (void**)&p->sub_bound, (void**)&p->fb_list, (void**)&p->segs, (void**)&p->stack_tabs, &p->slab};
+                   (void**)&p->rank_of, (void**)&p->cstats, (void**)&p->sub_bound, (void**)&p->fb_list, (void**)&p->segs};
   for (void** b : bufs) {
     dev_free(p, *b);
     *b = nullptr;
   }
-  p->cap = p->cap2 = p->cap_global = p->cap_tile_of = p->cap_sub_bound = p->cap_cstats = p->cap_fb_list = p->cap_segs = p->cap_stack_tabs = p->cap_slab = 0;
+  p->cap = p->cap2 = p->cap_global = p->cap_tile_of = p->cap_sub_bound = p->cap_cstats = p->cap_fb_list = p->cap_segs = 0;
   p->hist_elems = 0;
   p->workspace_bytes = 0;
   p->fixed_ws = false;
@@ -547,7 +541,6 @@ StageHook make_hook(nufft_hip_plan p) {
   return h;
 }
 
-constexpr int64_t kSlabBytesMax = (int64_t)16 << 30;   // slab pools of the plain-store stack form, all slots together
 // Most (transform, point set) slots one spread launch of this plan covers: execute passes batch_size transforms,
 // the spread-only entry up to 32768 (spread_interp_impl)
 int spread_slots(nufft_hip_plan p) {
@@ -625,34 +618,6 @@ int ensure_point_capacity(nufft_hip_plan p, int64_t M, int rec_mult = 1) {
       p->cap_segs = 0;
       if ((rc = dev_alloc(p, (void**)&p->segs, sizeof(int4) * (size_t)need_g))) return rc;
       p->cap_segs = need_g;
-    }
-    // plain-store form: tables + one slab pool per fine grid in flight (at most kSlabBytesMax in all: beyond that the
-    // stacks keep their atomics)
-    p->slab_ok = false;
-    if (stacks && stack_plain_wanted(p->g, M) && p->type == NUFFT_HIP_TYPE_1 && !p->opts.spread_only) {
-      const int64_t stride = stack_pool_planes(p->g, M) * stack_plane_cells(p->g);
-      const int64_t need_s = stride * 8 * spread_slots(p);
-      const int64_t need_t = (int64_t)stack_tabs_bytes(p->g, M);
-      if (need_s <= kSlabBytesMax) {
-        if (need_t > p->cap_stack_tabs) {
-          if ((rc = sync_before_regrow(p))) return rc;
-          dev_free(p, p->stack_tabs);
-          p->stack_tabs = nullptr;
-          p->cap_stack_tabs = 0;
-          if ((rc = dev_alloc(p, (void**)&p->stack_tabs, (size_t)need_t))) return rc;
-          p->cap_stack_tabs = need_t;
-        }
-        if (need_s > p->cap_slab) {
-          if ((rc = sync_before_regrow(p))) return rc;
-          dev_free(p, p->slab);
-          p->slab = nullptr;
-          p->cap_slab = 0;
-          if ((rc = dev_alloc(p, &p->slab, (size_t)need_s))) return rc;
-          p->cap_slab = need_s;
-        }
-        p->slab_stride = stride;
-        p->slab_ok = true;
-      }
     }
     if (need_b > p->cap_sub_bound) {
       if ((rc = sync_before_regrow(p))) return rc;
@@ -761,14 +726,12 @@ int set_points_impl(nufft_hip_plan p, int64_t M, const void* x, const void* y, c
   if constexpr (sizeof(T) == 4) {
     // w = 7, 8 fixed-point plans: the bound that fixes every subproblem's step (and which of them keep fp64 planes)
     p->g.stack = (p->g.fx_patch && p->sub_bound && p->segs && Mtot > 0 && stack3_wanted(p->g, Mtot)) ? 1 : 0;
-    p->g.stack_plain = (p->g.stack && p->slab_ok && p->stack_tabs && p->slab) ? 1 : 0;
     if (p->g.stack) {
       // stacks of tiles (spread_stack3_kernel): cut them, then the bound that fixes every stack's step
-      int* tabs = p->g.stack_plain ? p->stack_tabs : nullptr;
       hook.begin(STAGE_SORT_CELL);
-      HIP_TRY(p, launch_stack_plan(p->g, p->tile_start, Mtot, p->segs + 1, (int*)p->segs, tabs, p->stream));
+      HIP_TRY(p, launch_stack_plan(p->g, p->tile_start, Mtot, p->segs + 1, (int*)p->segs, p->stream));
       HIP_TRY(p, launch_bound3_stack(p->g, (const Rec<float>*)p->rec, (int)sizeof(Rec<float>), p->tile_start, p->sub_start, Mtot,
-                                     p->taps, p->segs + 1, (const int*)p->segs, p->sub_bound, p->fb_list, tabs, p->stream));
+                                     p->taps, p->segs + 1, (const int*)p->segs, p->sub_bound, p->fb_list, p->stream));
       hook.end(STAGE_SORT_CELL);
     } else if (p->g.fx_patch && p->sub_bound && Mtot > 0) {
       hook.begin(STAGE_SORT_CELL);
@@ -812,17 +775,6 @@ SortedPoints<T> sorted_view(nufft_hip_plan p) {
   sp.segs = p->g.stack ? p->segs + 1 : nullptr;
   sp.seg_count = (const int*)p->segs;
   sp.seg_bound = p->sub_bound;
-  sp.slab = nullptr;
-  sp.slab_stride = 0;
-  sp.src = nullptr;
-  sp.dirty = sp.anyhalo = nullptr;
-  if (p->g.stack_plain) {
-    sp.slab = (float*)p->slab;
-    sp.slab_stride = p->slab_stride;
-    sp.src = reinterpret_cast<const int2*>(p->stack_tabs);
-    sp.dirty = reinterpret_cast<const unsigned char*>(p->stack_tabs + 2 * (size_t)p->g.ntiles);
-    sp.anyhalo = sp.dirty + p->g.ntiles;
-  }
   return sp;
 }
 
@@ -914,36 +866,6 @@ int execute_impl(nufft_hip_plan p, void* c, void* f) {
       HIP_TRY(p, launch_spread<T>(p->g, p->method, sp, p->M * p->nitems, (const T*)p->d_horner, cb, fw, nb,
                                   p->M, p->fine_elems, (T)1, p->lds_bytes, p->stream));
       hook.end(STAGE_SPREAD);
-      // plain-store stacks: the slabs are gathered by the first pruned FFT pass while it loads (the fine grid is read
-      // and cleared only where atomics reached it, and is zero elsewhere); rocFFT and the debug stops behind the
-      // spread stage get the stand-alone gather
-      bool merged = false;
-      if constexpr (sizeof(T) == 4) {
-        if (p->g.stack_plain && sp.slab) {
-          if (own && stop != STAGE_SPREAD) {
-            FftMerge mg;
-            mg.slab = sp.slab; mg.slab_stride = sp.slab_stride; mg.src = sp.src; mg.dirty = sp.dirty; mg.anyhalo = sp.anyhalo;
-            mg.nt0 = p->g.ntile[0]; mg.nt1 = p->g.ntile[1]; mg.ntz = p->g.ntile[2];
-            mg.nf1 = p->g.nf[1];
-            mg.ax1 = p->g.nf[0] - p->g.tile[0] * (p->g.ntile[0] - 1);
-            mg.ay1 = p->g.nf[1] - p->g.tile[1] * (p->g.ntile[1] - 1);
-            mg.az1 = p->g.nf[2] - p->g.tile[2] * (p->g.ntile[2] - 1);
-            mg.L = p->g.tile[0] + p->g.w - 1; mg.LZ = p->g.tile[2] + p->g.w - 1;
-            mg.plane_cells = (int)stack_plane_cells(p->g);
-            hook.begin(STAGE_FFT);
-            HIP_TRY(p, launch_pruned_fft<T>(p->g, 1, p->iflag, fw, fb, (T*)p->fft_tmp[0], (T*)p->fft_tmp[1], rf, tw,
-                                            slots, p->stream, /*zero_fine=*/true, &mg));
-            hook.end(STAGE_FFT);
-            p->fine_clear_slots = slots;
-            merged = true;
-          } else {
-            hook.begin(STAGE_SPREAD);
-            HIP_TRY(p, launch_merge_stack3(p->g, sp, (float*)fw, nb, p->fine_elems, p->stream));
-            hook.end(STAGE_SPREAD);
-          }
-        }
-      }
-      if (merged) continue;
       if (stop == STAGE_SPREAD) continue;
       if (own) {
         hook.begin(STAGE_FFT);
@@ -1090,7 +1012,7 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
     static const int pairs[][2] = {{NUFFT_HIP_TUNE_GROUP_OFF, NUFFT_HIP_TUNE_GROUP_ON}, {NUFFT_HIP_TUNE_SPARSE_OFF, NUFFT_HIP_TUNE_SPARSE_ON},
                                    {NUFFT_HIP_TUNE_CELLSORT_OFF, NUFFT_HIP_TUNE_CELLSORT_ON}, {NUFFT_HIP_TUNE_CELLSORT3D_OFF, NUFFT_HIP_TUNE_CELLSORT3D_ON},
                                    {NUFFT_HIP_TUNE_JOINT_OFF, NUFFT_HIP_TUNE_JOINT_ON}, {NUFFT_HIP_TUNE_STAGED_OFF, NUFFT_HIP_TUNE_STAGED_ON},
-                                   {NUFFT_HIP_TUNE_SORT2_OFF, NUFFT_HIP_TUNE_SORT2_ON}, {NUFFT_HIP_TUNE_STACK_OFF, NUFFT_HIP_TUNE_STACK_ON}, {NUFFT_HIP_TUNE_PLAIN_OFF, NUFFT_HIP_TUNE_PLAIN_ON}};
+                                   {NUFFT_HIP_TUNE_SORT2_OFF, NUFFT_HIP_TUNE_SORT2_ON}, {NUFFT_HIP_TUNE_STACK_OFF, NUFFT_HIP_TUNE_STACK_ON}};
     for (const auto& pr : pairs)
       if ((t & pr[0]) && (t & pr[1])) return fail(NUFFT_HIP_INVALID_ARGUMENT, format("options.tuning has both bits of an OFF / ON pair (0x%x)", (unsigned)(pr[0] | pr[1])));
     if (opts_in->op_group < 0 || opts_in->op_lanes < 0) return fail(NUFFT_HIP_INVALID_ARGUMENT, "options.op_group and options.op_lanes must be >= 0");
@@ -1356,7 +1278,7 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
   g.fixed_point = 0;
   g.split_reim = 0;
   g.cell_sorted = 0;
-  g.stack = g.stack_plain = 0;
+  g.stack = 0;
   g.stack_len = g.stack_cap = 0;
   g.fx_patch = (patch_want && method == NUFFT_HIP_METHOD_TILE_WAVE && !g.wide && g.tile[0] == 16 && g.tile[1] == 16 &&
                 g.tile[2] == 8) ? 1 : 0;

@@ -48,12 +48,11 @@ def main():
     c = torch.complex(torch.rand(M, generator=g, device='cuda') - .5, torch.rand(M, generator=g, device='cuda') - .5)
     print(f'# {n}^3 modes, M = {M:.3g} ({M / (2 * n) ** 3:.3f} per fine cell), tol {args.tol:g}, {args.dist} points', flush=True)
     ref = None
-    variants = [('STACK_OFF', TUNE['STACK_OFF'], 0, 0), ('STACK_ON', TUNE['STACK_ON'] | TUNE['PLAIN_OFF'], 0, 0),
-                ('STACK_ON+PLAIN', TUNE['STACK_ON'] | TUNE['PLAIN_ON'], 0, 0)]
+    variants = [('STACK_OFF', TUNE['STACK_OFF'], 0, 0), ('STACK_ON', TUNE['STACK_ON'], 0, 0)]
     if args.only:
       variants = [v for v in variants if v[0] == args.only]
     if args.sweep:
-      variants += [(f'PLAIN len={l} cap={cp}', TUNE['STACK_ON'] | TUNE['PLAIN_ON'], l, cp) for l in (2, 4, 8, 16, 32) for cp in (4096, 8192, 16384)]
+      variants += [(f'STACK_ON len={l} cap={cp}', TUNE['STACK_ON'], l, cp) for l in (2, 4, 8, 16, 32) for cp in (4096, 8192, 16384)]
     for name, tune, ln, cp in variants:
       plan = tfft.Plan('type_1', grid, 'forward', tol=args.tol, tuning=tune)
       if ln or cp:
