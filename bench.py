@@ -267,10 +267,29 @@ def other_configs(args, dev):
   def rnd_c(shape, g):
     return torch.complex(torch.rand(shape, generator=g, device=dev) - .5, torch.rand(shape, generator=g, device=dev) - .5)
 
-  def plan_case(name, ttype, grid, m, tol, seed, steps, stage):
+  def radial_points(m, rank, g):
+    """MRI-like trajectories in acquisition order (SURVEY 8d's secondary stress input; docs/examples/mri_app.ipynb
+    upstream): spokes through the centre, 1000 (2-D, golden-angle) / 500 (3-D kooshball, random directions) samples each."""
+    ns = 1000 if rank == 2 else 500
+    nsp = m // ns
+    s = torch.linspace(-np.pi, np.pi, ns + 1, device=dev)[:ns]
+    if rank == 2:
+      a = torch.arange(nsp, device=dev) * (np.pi * 0.6180339887)
+      d = torch.stack([torch.cos(a), torch.sin(a)], dim=1)
+    else:
+      u = torch.rand(nsp, generator=g, device=dev) * 2 - 1
+      ph = torch.rand(nsp, generator=g, device=dev) * 2 * np.pi
+      d = torch.stack([torch.sqrt(1 - u * u) * torch.cos(ph), torch.sqrt(1 - u * u) * torch.sin(ph), u], dim=1)
+    return (d[:, None, :] * s[None, :, None]).reshape(-1, rank).contiguous()
+
+  def plan_case(name, ttype, grid, m, tol, seed, steps, stage, dist='uniform'):
     g = torch.Generator(device=dev).manual_seed(seed)
     rank = len(grid)
-    pts = (torch.rand((m, rank), generator=g, device=dev) * 2 - 1) * np.pi
+    if dist == 'radial':
+      pts = radial_points(m, rank, g)
+      m = int(pts.shape[0])
+    else:
+      pts = (torch.rand((m, rank), generator=g, device=dev) * 2 - 1) * np.pi
     src = rnd_c([m] if ttype == 'type_1' else grid, g)
     plan = tfft.Plan(ttype, grid, 'forward', tol=tol, dtype=torch.complex64, device=dev)
     info = plan.info()
@@ -291,7 +310,7 @@ def other_configs(args, dev):
     out[name] = {'ms_per_step': round(ms, 4), 'Gpts_s': round(m / ms / 1e6, 2), 'dominant_kernel': stage,
                  'dominant_kernel_ms': round(k_ms, 4), 'algorithmic_bytes': algo,
                  'hbm_frac': round(algo / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                 'kernel_width': int(info.kernel_width), 'fine_grid': nf[::-1], 'steps': steps}
+                 'kernel_width': int(info.kernel_width), 'fine_grid': nf[::-1], 'steps': steps, 'points': dist}
     if ttype == 'type_1' and rank == 3 and int(info.kernel_width) <= 8:
       # the 3-D float fixed-point spreaders are bound by the LDS-atomic data path, not by HBM: ds_add_u64
       # wave-instructions per point of the kernel family (spread_dense3_kernel: one W x 3 x 3 lane block per
@@ -323,6 +342,13 @@ def other_configs(args, dev):
   # the reference harness's own 3-D case at the API's default tolerance, scaled to config 4's grid (w = 8)
   guarded('3d_type1_256_M3e7_tol1e-6',
           lambda: plan_case('3d_type1_256_M3e7_tol1e-6', 'type_1', [256, 256, 256], 30_000_000, 1e-6, 6, 5, 'spread'))
+  # radial point sets (acquisition order) at the sizes above: the uniform entries are the ones to read them against
+  guarded('radial_2d_type1_1024_M1e7',
+          lambda: plan_case('radial_2d_type1_1024_M1e7', 'type_1', GRID, M, TOL, 7, max(5, args.steps // 2), 'spread', 'radial'))
+  guarded('radial_2d_type2_1024_M1e7',
+          lambda: plan_case('radial_2d_type2_1024_M1e7', 'type_2', GRID, M, TOL, 8, max(5, args.steps // 2), 'interp', 'radial'))
+  guarded('kooshball_3d_type1_256_M3e7_tol1e-6',
+          lambda: plan_case('kooshball_3d_type1_256_M3e7_tol1e-6', 'type_1', [256, 256, 256], 30_000_000, 1e-6, 9, 5, 'spread', 'radial'))
   for k in list(out):
     if 'error' not in out[k]:
       out[k].update(pmc_traffic_of(k))
