@@ -201,135 +201,23 @@ __device__ unsigned long long g_phase_log3[kPhaseLogWgs3 * kPhaseSlots3];
 #define NUFFT_PHASE3(k) do { } while (0)
 #endif
 
-// FUSED: the records are FusedRec3 (strength behind the 16-byte record): nothing is gathered.
-// GROUP (dense point sets): the subproblem's points are counting-sorted by stencil start cell in LDS first (as
-// spread_2d_w8_group_kernel does), and consecutive points that share a start cell add their packed contributions
-// in registers (one v_lshl_add_u64 per atomic saved; the bias of the FMA conversion is taken out once per run)
-// before ONE set of ds_add_u64. Pays above ~1.2 points per fine cell (dense3_grouped below has the measurements).
+// The accumulation loop of spread_dense3_kernel: this wave's share [wbeg, wend) of the npt points starting at record
+// p0 (through perm when GROUP), see the kernel's header comment. stage: the wave's staging area (its zero slot set).
 template <int W, int TZ, bool FUSED, bool GROUP>
-__global__ __launch_bounds__(kDenseNW * 64) void spread_dense3_kernel(
-    Geom g, SortedPoints<float> sp, const float* __restrict__ horner, const float* __restrict__ c,
-    float* __restrict__ fw, int64_t c_stride, int64_t fw_stride, float scale) {
+__device__ __forceinline__ void dense3_accumulate(const SortedPoints<float>& sp, const float2* __restrict__ cc, int p0, int wbeg,
+                                                  int wend, float pre, float big_limit, const float* __restrict__ horner, int nc,
+                                                  unsigned char* stage, unsigned long long* plane, const uint16_t* perm, int lane) {
   using C = DenseCfg<W, TZ>;
-  constexpr int LS = C::L.ls, PS = C::L.ps, NW = C::NW, YB = C::YB, ZB = C::ZB, NYH = C::NYH, NZH = C::NZH;
-  constexpr int L0 = kDenseTile + W - 1, L1 = kDenseTile + W - 1, L2 = TZ + W - 1;
+  constexpr int LS = C::L.ls, PS = C::L.ps, YB = C::YB, ZB = C::ZB, NYH = C::NYH, NZH = C::NZH;
   constexpr int SLOTS = C::SLOTS, HALF = C::HALF;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  unsigned long long* plane = reinterpret_cast<unsigned long long*>(smem_raw);
-  unsigned char* stage_all = smem_raw + (size_t)C::plane_elems * 8;
-  float* red = reinterpret_cast<float*>(stage_all + C::stage_bytes);   // [2 NW]
-
-  int tb, p0, p1, slot, nsub;
-  NUFFT_PHASE3(0);
-  if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1, &slot, &nsub)) return;
-  if (nsub > g.fx_max_subs) return;   // crowded tile: the fp64-plane launches behind this one take it
-  NUFFT_PHASE3(1);
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: keeps the point loops' bounds in SGPRs)
-  const float2* cc = reinterpret_cast<const float2*>(c) + (int64_t)slot * c_stride;
   const FusedRec3* rec3 = reinterpret_cast<const FusedRec3*>(sp.rec);
-  const int npt = p1 - p0;
-  uint16_t* perm = reinterpret_cast<uint16_t*>(red + 2 * NW + 8);   // [kMaxSub] (GROUP)
-  if constexpr (GROUP) {
-    // counting sort of the subproblem by start cell: keys 4 + 4 + 3 bits (tile 16 x 16 x 8), counters in the
-    // (not yet zeroed) plane, 16-bit permutation; records stay where the global sort put them
-    constexpr int NT = NW * 64, NKEY = C::NKEY, KBITS = TZ == 8 ? 11 : 10, IT = (C::kMaxSub + NT - 1) / NT;
-    uint32_t* cnt = reinterpret_cast<uint32_t*>(plane);
-    uint32_t* wsum = reinterpret_cast<uint32_t*>(perm + C::kMaxSub);
-    for (int i = tid; i < NKEY; i += NT) cnt[i] = 0u;
-    __syncthreads();
-    uint32_t kr[IT];
-#pragma unroll
-    for (int u = 0; u < IT; ++u) {   // (loads unconditional on clamped indices: issued back to back)
-      const int i = tid + u * NT;
-      const int ic = p0 + (i < npt ? i : npt - 1);
-      uint4 w;
-      if constexpr (FUSED) w = *reinterpret_cast<const uint4*>(&rec3[ic].r);
-      else w = *reinterpret_cast<const uint4*>(&sp.rec[ic]);
-      kr[u] = (w.x >> 28) | ((w.y >> 28) << 4) | ((w.z >> 28) << 8);
-    }
-#pragma unroll
-    for (int u = 0; u < IT; ++u) {
-      const int i = tid + u * NT;
-      if (i < npt) kr[u] |= atomicAdd(&cnt[kr[u]], 1u) << KBITS;
-    }
-    __syncthreads();
-    scan_counts<NT, NKEY>(cnt, wsum, tid);
-#pragma unroll
-    for (int u = 0; u < IT; ++u) {
-      const int i = tid + u * NT;
-      if (i < npt) perm[cnt[kr[u] & (uint32_t)(NKEY - 1)] + (kr[u] >> KBITS)] = (uint16_t)i;
-    }
-    __syncthreads();
-  }
-  NUFFT_PHASE3(2);
-  for (int i = tid; i < C::plane_elems; i += NW * 64) plane[i] = 0ull;
-
-  // step of the fixed-point grid (see the header comment). The transform's largest and mean strength are known
-  // (cstats_kernel, one streaming pass before this launch): unless one strength dominates (largest > 8 x the mean)
-  // the subproblem's sum is bounded by its point COUNT x the largest strength and no pass over its own strengths --
-  // a second random gather of every c[idx], r03: 16.6 % of a workgroup's life at config 4 -- is needed.
-  // (a NaN strength makes the slot's sum NaN -- fmaxf would drop it from the maximum -- and then the step, i.e. every
-  // cell this launch writes: non-finite input gives non-finite output, as it does on the floating-point paths)
-  const float sum_g = sp.cstats[2 * slot + 1];
-  const float top_g = sum_g == sum_g ? sp.cstats[2 * slot] : sum_g;
-  const bool own_pass = top_g * (float)c_stride > 8.f * sum_g;   // (workgroup-uniform)
-  float part = 0.f, big = 0.f;
-  if (own_pass) {
-    for (int j = p0 + tid; j < p1; j += NW * 64) {
-      float2 cv;
-      if constexpr (FUSED) cv = *reinterpret_cast<const float2*>(&rec3[j].re);
-      else cv = cc[sp.rec[j].idx];
-      const float m = fmaxf(fabsf(cv.x), fabsf(cv.y));
-      part += fmaf(0.f, cv.x + cv.y, m);   // (NaN / Inf components make the sum NaN)
-      big = fmaxf(big, m);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      part += __shfl_down(part, o);
-      big = fmaxf(big, __shfl_down(big, o));
-    }
-    if (lane == 0) { red[wave] = part; red[NW + wave] = big; }
-  }
-  // this wave's staging area: zero the kx slot the idle lanes read (never written again)
-  unsigned char* stage = stage_all + (size_t)wave * (HALF / 2) * SLOTS * 16;
-  if (lane < HALF / 2) *reinterpret_cast<v4f*>(stage + (lane * SLOTS + W) * 16) = (v4f){0.f, 0.f, 0.f, 0.f};
-  __syncthreads();
-  NUFFT_PHASE3(3);
-  float bound = (float)npt * top_g, top = top_g;
-  if (own_pass) {
-    bound = 0.f; top = 0.f;
-#pragma unroll
-    for (int k = 0; k < NW; ++k) { bound += red[k]; top = fmaxf(top, red[NW + k]); }
-  }
-  const float amp = fabsf(scale) * g.fx_headroom;   // (the fitted polynomials overshoot 1 slightly)
-  const float room = 2147483000.f - (float)npt;     // 2^31 minus the rounding of every contribution
-  // Two constraints on the step: no cell may overflow 32 bits (sum rule), and the FMA conversion is exact only
-  // for |n| < 2^22 per contribution (top rule). Strengths of similar size (largest <= 8 x the mean): the larger
-  // of the two -- the top rule binds for subproblems of fewer than ~512 points and is still 2^-22 of the largest
-  // strength. One dominant strength: that step would drown the others, so it follows the mean instead, and the
-  // few strengths above 2^22 steps are added behind the loop with the exact conversion (v_cvt, any |n| < 2^31).
-  const float s_sum = bound * amp / room;
-  const bool skewed = top * (float)npt > 8.f * bound;
-  float step = fmaxf(s_sum, (skewed ? 2.f * bound / (float)npt : top) * amp * (1.f / 4194000.f));
-  if (!(top == top) || !(bound == bound)) step = top + bound;   // NaN strengths (fmaxf would drop them)
-  const float pre = step > 0.f ? scale / step : 0.f;
-  const float big_limit = 4194000.f / g.fx_headroom;   // |c| in steps above which a point waits for the exact pass
-
-  // lane constants
   const int cell_b = kLaneTab<W, TZ>.cell[lane] * 8;
   const int rd_x = kLaneTab<W, TZ>.sx[lane] * 16;
   const int rd_y = (W + 1 + kLaneTab<W, TZ>.sy[lane]) * 16;
   const int rd_z = (W + 1 + YB + kLaneTab<W, TZ>.sz[lane]) * 16;
-  const int nc = g.ncoef;
-  // (indices into the subproblem, in sorted order when GROUP)
-  const int share = (npt + NW - 1) / NW;
-  const int wbeg = wave * share;
-  const int wend = (wbeg + share < npt) ? wbeg + share : npt;
   const v2f magic = {12582912.f, 12582912.f};                 // 1.5 * 2^23
   const unsigned long long unbias = 0ull - 0x4B4000004B400000ull;
   unsigned char* plane_b = reinterpret_cast<unsigned char*>(plane);
-
   // (Loading chunk i + 1's records and strengths before chunk i's atomics was measured, r03: no gain at config 4 --
   // 7.75 ms either way, the other 23 waves of the CU already cover a wave's load latency -- and 10 % slower on a
   // sparse set, 256^3 with M = 1e7. Running the first chunk's phase 1 before the barrier the step waits behind moved
@@ -483,6 +371,129 @@ __global__ __launch_bounds__(kDenseNW * 64) void spread_dense3_kernel(
       }
     }
   }
+}
+
+// FUSED: the records are FusedRec3 (strength behind the 16-byte record): nothing is gathered.
+// GROUP (dense point sets): the subproblem's points are counting-sorted by stencil start cell in LDS first (as
+// spread_2d_w8_group_kernel does), and consecutive points that share a start cell add their packed contributions
+// in registers (one v_lshl_add_u64 per atomic saved; the bias of the FMA conversion is taken out once per run)
+// before ONE set of ds_add_u64. Pays above ~1.2 points per fine cell (dense3_grouped below has the measurements).
+template <int W, int TZ, bool FUSED, bool GROUP>
+__global__ __launch_bounds__(kDenseNW * 64) void spread_dense3_kernel(
+    Geom g, SortedPoints<float> sp, const float* __restrict__ horner, const float* __restrict__ c,
+    float* __restrict__ fw, int64_t c_stride, int64_t fw_stride, float scale) {
+  using C = DenseCfg<W, TZ>;
+  constexpr int LS = C::L.ls, PS = C::L.ps, NW = C::NW;
+  constexpr int L0 = kDenseTile + W - 1, L1 = kDenseTile + W - 1, L2 = TZ + W - 1;
+  constexpr int SLOTS = C::SLOTS, HALF = C::HALF;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned long long* plane = reinterpret_cast<unsigned long long*>(smem_raw);
+  unsigned char* stage_all = smem_raw + (size_t)C::plane_elems * 8;
+  float* red = reinterpret_cast<float*>(stage_all + C::stage_bytes);   // [2 NW]
+
+  int tb, p0, p1, slot, nsub;
+  NUFFT_PHASE3(0);
+  if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1, &slot, &nsub)) return;
+  if (nsub > g.fx_max_subs) return;   // crowded tile: the fp64-plane launches behind this one take it
+  NUFFT_PHASE3(1);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: keeps the point loops' bounds in SGPRs)
+  const float2* cc = reinterpret_cast<const float2*>(c) + (int64_t)slot * c_stride;
+  const FusedRec3* rec3 = reinterpret_cast<const FusedRec3*>(sp.rec);
+  const int npt = p1 - p0;
+  uint16_t* perm = reinterpret_cast<uint16_t*>(red + 2 * NW + 8);   // [kMaxSub] (GROUP)
+  if constexpr (GROUP) {
+    // counting sort of the subproblem by start cell: keys 4 + 4 + 3 bits (tile 16 x 16 x 8), counters in the
+    // (not yet zeroed) plane, 16-bit permutation; records stay where the global sort put them
+    constexpr int NT = NW * 64, NKEY = C::NKEY, KBITS = TZ == 8 ? 11 : 10, IT = (C::kMaxSub + NT - 1) / NT;
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(plane);
+    uint32_t* wsum = reinterpret_cast<uint32_t*>(perm + C::kMaxSub);
+    for (int i = tid; i < NKEY; i += NT) cnt[i] = 0u;
+    __syncthreads();
+    uint32_t kr[IT];
+#pragma unroll
+    for (int u = 0; u < IT; ++u) {   // (loads unconditional on clamped indices: issued back to back)
+      const int i = tid + u * NT;
+      const int ic = p0 + (i < npt ? i : npt - 1);
+      uint4 w;
+      if constexpr (FUSED) w = *reinterpret_cast<const uint4*>(&rec3[ic].r);
+      else w = *reinterpret_cast<const uint4*>(&sp.rec[ic]);
+      kr[u] = (w.x >> 28) | ((w.y >> 28) << 4) | ((w.z >> 28) << 8);
+    }
+#pragma unroll
+    for (int u = 0; u < IT; ++u) {
+      const int i = tid + u * NT;
+      if (i < npt) kr[u] |= atomicAdd(&cnt[kr[u]], 1u) << KBITS;
+    }
+    __syncthreads();
+    scan_counts<NT, NKEY>(cnt, wsum, tid);
+#pragma unroll
+    for (int u = 0; u < IT; ++u) {
+      const int i = tid + u * NT;
+      if (i < npt) perm[cnt[kr[u] & (uint32_t)(NKEY - 1)] + (kr[u] >> KBITS)] = (uint16_t)i;
+    }
+    __syncthreads();
+  }
+  NUFFT_PHASE3(2);
+  for (int i = tid; i < C::plane_elems; i += NW * 64) plane[i] = 0ull;
+
+  // step of the fixed-point grid (see the header comment). The transform's largest and mean strength are known
+  // (cstats_kernel, one streaming pass before this launch): unless one strength dominates (largest > 8 x the mean)
+  // the subproblem's sum is bounded by its point COUNT x the largest strength and no pass over its own strengths --
+  // a second random gather of every c[idx], r03: 16.6 % of a workgroup's life at config 4 -- is needed.
+  // (a NaN strength makes the slot's sum NaN -- fmaxf would drop it from the maximum -- and then the step, i.e. every
+  // cell this launch writes: non-finite input gives non-finite output, as it does on the floating-point paths)
+  const float sum_g = sp.cstats[2 * slot + 1];
+  const float top_g = sum_g == sum_g ? sp.cstats[2 * slot] : sum_g;
+  const bool own_pass = top_g * (float)c_stride > 8.f * sum_g;   // (workgroup-uniform)
+  float part = 0.f, big = 0.f;
+  if (own_pass) {
+    for (int j = p0 + tid; j < p1; j += NW * 64) {
+      float2 cv;
+      if constexpr (FUSED) cv = *reinterpret_cast<const float2*>(&rec3[j].re);
+      else cv = cc[sp.rec[j].idx];
+      const float m = fmaxf(fabsf(cv.x), fabsf(cv.y));
+      part += fmaf(0.f, cv.x + cv.y, m);   // (NaN / Inf components make the sum NaN)
+      big = fmaxf(big, m);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      part += __shfl_down(part, o);
+      big = fmaxf(big, __shfl_down(big, o));
+    }
+    if (lane == 0) { red[wave] = part; red[NW + wave] = big; }
+  }
+  // this wave's staging area: zero the kx slot the idle lanes read (never written again)
+  unsigned char* stage = stage_all + (size_t)wave * (HALF / 2) * SLOTS * 16;
+  if (lane < HALF / 2) *reinterpret_cast<v4f*>(stage + (lane * SLOTS + W) * 16) = (v4f){0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  NUFFT_PHASE3(3);
+  float bound = (float)npt * top_g, top = top_g;
+  if (own_pass) {
+    bound = 0.f; top = 0.f;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) { bound += red[k]; top = fmaxf(top, red[NW + k]); }
+  }
+  const float amp = fabsf(scale) * g.fx_headroom;   // (the fitted polynomials overshoot 1 slightly)
+  const float room = 2147483000.f - (float)npt;     // 2^31 minus the rounding of every contribution
+  // Two constraints on the step: no cell may overflow 32 bits (sum rule), and the FMA conversion is exact only
+  // for |n| < 2^22 per contribution (top rule). Strengths of similar size (largest <= 8 x the mean): the larger
+  // of the two -- the top rule binds for subproblems of fewer than ~512 points and is still 2^-22 of the largest
+  // strength. One dominant strength: that step would drown the others, so it follows the mean instead, and the
+  // few strengths above 2^22 steps are added behind the loop with the exact conversion (v_cvt, any |n| < 2^31).
+  const float s_sum = bound * amp / room;
+  const bool skewed = top * (float)npt > 8.f * bound;
+  float step = fmaxf(s_sum, (skewed ? 2.f * bound / (float)npt : top) * amp * (1.f / 4194000.f));
+  if (!(top == top) || !(bound == bound)) step = top + bound;   // NaN strengths (fmaxf would drop them)
+  const float pre = step > 0.f ? scale / step : 0.f;
+  const float big_limit = 4194000.f / g.fx_headroom;   // |c| in steps above which a point waits for the exact pass
+
+  const int nc = g.ncoef;
+  // (indices into the subproblem, in sorted order when GROUP)
+  const int share = (npt + NW - 1) / NW;
+  const int wbeg = wave * share;
+  const int wend = (wbeg + share < npt) ? wbeg + share : npt;
+  dense3_accumulate<W, TZ, FUSED, GROUP>(sp, cc, p0, wbeg, wend, pre, big_limit, horner, nc, stage, plane, perm, lane);
   __syncthreads();
   NUFFT_PHASE3(4);
 
@@ -1324,6 +1335,165 @@ __global__ NUFFT_PATCH_BOUNDS void spread_stack3_kernel(
 #endif
 }
 
+// spread_dense3_kernel (w <= 6) over a stack (r05): the same z carry as spread_stack3_kernel, without a bound kernel --
+// the step follows the r03 rules on the points that can share a cell, i.e. of two neighbouring tiles of the stack
+// (sum rule: the largest such pair x the launch's largest strength) and the 2^22 range of the FMA conversion (top rule;
+// it binds wherever stacks are taken: below 0.15 points per cell a pair holds < 512 points). One dominant strength
+// (largest > 8 x the mean): the stack's own sum and largest, as a subproblem's. Pieces of tiles with more than
+// fx_max_subs of them are the fp64-plane launches' (crowded_list_kernel lists them as the subproblems they are).
+template <int W, int TZ, bool FUSED>
+__global__ __launch_bounds__(kDenseNW * 64) void spread_dense3_stack_kernel(
+    Geom g, SortedPoints<float> sp, const float* __restrict__ horner, const float* __restrict__ c,
+    float* __restrict__ fw, int64_t c_stride, int64_t fw_stride, float scale) {
+  using C = DenseCfg<W, TZ>;
+  constexpr int LS = C::L.ls, PS = C::L.ps, NW = C::NW, NT = NW * 64, H = W - 1;
+  constexpr int L0 = kDenseTile + W - 1, L1 = kDenseTile + W - 1, L2 = TZ + W - 1;
+  constexpr int SLOTS = C::SLOTS, HALF = C::HALF;
+  static_assert(H <= TZ, "the z halo must end inside the next tile");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned long long* plane = reinterpret_cast<unsigned long long*>(smem_raw);
+  unsigned char* stage_all = smem_raw + (size_t)C::plane_elems * 8;
+  float* red = reinterpret_cast<float*>(stage_all + C::stage_bytes);   // [2 NW]
+
+  const int s = blockIdx.x;
+  if (s >= sp.seg_count[0]) return;
+  const StackDesc d = stack_load(sp.segs, s);
+  const StackColumn col = stack_column(g, d.col);
+  const int slot = col.item * (int)gridDim.y + (int)blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const float2* cc = reinterpret_cast<const float2*>(c) + (int64_t)slot * c_stride;
+  const FusedRec3* rec3 = reinterpret_cast<const FusedRec3*>(sp.rec);
+  // points of the stack, and the most that two neighbouring tiles hold together (what can share a cell)
+  int npt_all = 0, pair = 0;
+  if (d.p0 >= 0) {
+    const int t = stack_tile_index(g, col, d.z0);
+    if (sp.sub_start[t + 1] - sp.sub_start[t] > g.fx_max_subs) return;   // crowded tile: the fp64-plane launches take it
+    npt_all = pair = d.p1 - d.p0;
+  } else {
+    int prev = 0;
+    for (int i = 0; i < d.nz; ++i) {
+      const int t = stack_tile_index(g, col, d.z0 + i);
+      const int n = sp.tile_start[t + 1] - sp.tile_start[t];
+      npt_all += n;
+      pair = pair > prev + n ? pair : prev + n;
+      prev = n;
+    }
+  }
+  for (int i = tid; i < C::plane_elems; i += NT) plane[i] = 0ull;
+
+  // step of the fixed-point grid (spread_dense3_kernel's rules)
+  const float sum_g = sp.cstats[2 * slot + 1];
+  const float top_g = sum_g == sum_g ? sp.cstats[2 * slot] : sum_g;
+  const bool own_pass = top_g * (float)c_stride > 8.f * sum_g;   // (workgroup-uniform)
+  float part = 0.f, big = 0.f;
+  if (own_pass) {
+    for (int i = 0; i < d.nz; ++i) {
+      int p0 = d.p0, p1 = d.p1;
+      if (p0 < 0) {
+        const int t = stack_tile_index(g, col, d.z0 + i);
+        p0 = sp.tile_start[t];
+        p1 = sp.tile_start[t + 1];
+      }
+      for (int j = p0 + tid; j < p1; j += NT) {
+        float2 cv;
+        if constexpr (FUSED) cv = *reinterpret_cast<const float2*>(&rec3[j].re);
+        else cv = cc[sp.rec[j].idx];
+        const float m = fmaxf(fabsf(cv.x), fabsf(cv.y));
+        part += fmaf(0.f, cv.x + cv.y, m);   // (NaN / Inf components make the sum NaN)
+        big = fmaxf(big, m);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      part += __shfl_down(part, o);
+      big = fmaxf(big, __shfl_down(big, o));
+    }
+    if (lane == 0) { red[wave] = part; red[NW + wave] = big; }
+  }
+  unsigned char* stage = stage_all + (size_t)wave * (HALF / 2) * SLOTS * 16;
+  if (lane < HALF / 2) *reinterpret_cast<v4f*>(stage + (lane * SLOTS + W) * 16) = (v4f){0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  float bound = (float)pair * top_g, top = top_g;
+  float cnt = (float)pair;
+  if (own_pass) {
+    bound = 0.f; top = 0.f;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) { bound += red[k]; top = fmaxf(top, red[NW + k]); }
+    cnt = (float)npt_all;
+  }
+  const float amp = fabsf(scale) * g.fx_headroom;
+  const float room = 2147483000.f - (float)npt_all;
+  const float s_sum = bound * amp / room;
+  const bool skewed = top * cnt > 8.f * bound;
+  float step = fmaxf(s_sum, (skewed ? 2.f * bound / cnt : top) * amp * (1.f / 4194000.f));
+  if (!(top == top) || !(bound == bound)) step = top + bound;   // NaN strengths (fmaxf would drop them)
+  const float pre = step > 0.f ? scale / step : 0.f;
+  const float big_limit = 4194000.f / g.fx_headroom;
+
+  const int nc = g.ncoef;
+  const int o0 = col.t0 * kDenseTile, o1 = col.t1 * kDenseTile;
+  float* out = fw + 2 * (int64_t)slot * fw_stride;
+  for (int i = 0; i < d.nz; ++i) {
+    int p0 = d.p0, p1 = d.p1;
+    if (p0 < 0) {
+      const int t = stack_tile_index(g, col, d.z0 + i);
+      p0 = sp.tile_start[t];
+      p1 = sp.tile_start[t + 1];
+    }
+    const int npt = p1 - p0;
+    const int share = (npt + NW - 1) / NW;
+    const int wbeg = wave * share;
+    const int wend = (wbeg + share < npt) ? wbeg + share : npt;
+    dense3_accumulate<W, TZ, FUSED, false>(sp, cc, p0, wbeg, wend, pre, big_limit, horner, nc, stage, plane, nullptr, lane);
+    __syncthreads();
+    // write-out of the tile's finished planes and the move of the halo planes: as spread_stack3_kernel
+    const bool last = i == d.nz - 1;
+    const int o2 = (d.z0 + i) * TZ;
+    const int nplanes = last ? L2 : TZ;
+    constexpr int R = NUFFT_STACK_ROWS;
+    const int nrows = nplanes * L1;
+    const int e = lane < 2 * L0 ? lane : 2 * L0 - 1, a0 = e >> 1, comp = e & 1;
+    const bool active = lane < 2 * L0;
+    const int gx = wrap1(o0 + a0, g.nf[0]);
+    for (int r0 = wave; r0 < nrows; r0 += NW * R) {
+      int lrow[R], a2v[R];
+      int64_t gbase[R];
+      long long t[R], hi[R];
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        const int rho = r0 + u * NW < nrows ? r0 + u * NW : r0;
+        const int a2 = rho / L1, a1 = rho - a2 * L1;
+        a2v[u] = a2;
+        lrow[u] = a2 * PS + a1 * LS;
+        gbase[u] = (int64_t)g.nf[0] * (wrap1(o1 + a1, g.nf[1]) + (int64_t)g.nf[1] * wrap1(o2 + a2, g.nf[2]));
+        t[u] = (long long)plane[lrow[u] + a0];
+      }
+      if (!last) {
+#pragma unroll
+        for (int u = 0; u < R; ++u) hi[u] = a2v[u] < H ? (long long)plane[lrow[u] + TZ * PS + a0] : 0ll;
+      }
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        if (u > 0 && r0 + u * NW >= nrows) break;
+        const int im_sum = (int)(unsigned)(t[u] & 0xffffffffll);
+        const int re_sum = (int)((t[u] - (long long)im_sum) >> 32);
+        const float v = (float)(comp ? im_sum : re_sum) * step;
+        if (active && v != 0.f) glb_add(&out[2 * (gbase[u] + gx) + comp], v);
+      }
+      if (!last && active && comp == 0) {
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+          if (u > 0 && r0 + u * NW >= nrows) break;
+          plane[lrow[u] + a0] = (unsigned long long)hi[u];
+          if (a2v[u] < H) plane[lrow[u] + TZ * PS + a0] = 0ull;
+        }
+      }
+    }
+    if (!last) __syncthreads();
+  }
+}
+
 // ---- strengths of one spread launch: largest and summed max(|re c|, |im c|) per slot ----------------------------
 // Two stages, no atomics: a first form had every workgroup add its partial sums to the slot's two floats --
 // 4096 atomics on two addresses, serialised at ~60 ns each: 0.24 ms for a 60 us read of 3e7 strengths.
@@ -1512,11 +1682,18 @@ unsigned stack_grid_bound(const Geom& g, int64_t M) {
 // loop (VALU issue + LDS atomics) hides the write-out either way, and the bound of a stack costs 0.15 ms more than
 // the bounds of its tiles. options.tuning STACK_OFF / STACK_ON force the choice.
 bool stack3_wanted(const Geom& g, int64_t M) {
-  if (!g.fx_patch || g.ntile[2] < 2 || g.ntile[2] > 32767) return false;
+  // (w = 7, 8: spread_stack3_kernel; w <= 6 on 16 x 16 x 8 tiles: spread_dense3_stack_kernel)
+  const bool dense = g.fixed_point && !g.fx_patch && g.rank == 3 && g.w >= 2 && g.w <= 6 && g.tile[0] == kDenseTile &&
+                     g.tile[1] == kDenseTile && g.tile[2] == 8;
+  if ((!g.fx_patch && !dense) || g.ntile[2] < 2 || g.ntile[2] > 32767) return false;
   const int mode = tune_mode(g, NUFFT_HIP_TUNE_STACK_OFF, NUFFT_HIP_TUNE_STACK_ON);
   if (mode >= 0) return mode != 0;
   const double cells = (double)g.nf[0] * g.nf[1] * g.nf[2] * (g.nitems > 1 ? g.nitems : 1);
-  return (double)M < kStackDensity * cells;
+  // w <= 6 (spread_dense3_stack_kernel, same file): the fewer atomics a point costs, the longer the write-out shows --
+  // w = 6 (4 per point), 256^3 modes, spread stage: 0.075 per cell 2.93 -> 2.33 ms, 0.224: 4.06 -> 3.33, 0.298: 3.67 -> 3.84,
+  // 0.745: 7.55 -> 7.91; w = 4 (1 per point): 0.224: 2.87 -> 2.33, 0.373: 3.00 -> 2.81, 0.745: 4.50 -> 4.33
+  const double limit = g.fx_patch ? kStackDensity : (g.w >= 5 ? 0.25 : 1.0);
+  return (double)M < limit * cells;
 }
 hipError_t launch_stack_plan(const Geom& g, const int32_t* tile_start, int64_t M, int4* segs, int* seg_count, hipStream_t stream) {
   hipError_t e = hipMemsetAsync(seg_count, 0, sizeof(int), stream);
@@ -1548,6 +1725,34 @@ static hipError_t launch_stack3(const Geom& g, const SortedPoints<float>& sp, co
   if (e != hipSuccess) return e;
   spread_stack3_kernel<W, 8, kPatchHalf><<<grid, kPatchNW * 64, C::lds_bytes, stream>>>(g, sp, horner, c, fw, c_stride, fw_stride, scale);
   return hipGetLastError();
+}
+// the w <= 6 kernel over stacks
+template <int W, bool FUSED>
+static hipError_t launch_dense3_stack(const Geom& g, const SortedPoints<float>& sp, const float* horner, const float* c, float* fw,
+                                      dim3 grid, int64_t c_stride, int64_t fw_stride, float scale, hipStream_t stream) {
+  using C = DenseCfg<W, 8>;
+  constexpr size_t lds = C::lds_bytes;
+  if (lds > 64 * 1024) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(spread_dense3_stack_kernel<W, 8, FUSED>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  spread_dense3_stack_kernel<W, 8, FUSED><<<grid, C::NW * 64, lds, stream>>>(g, sp, horner, c, fw, c_stride, fw_stride, scale);
+  return hipGetLastError();
+}
+hipError_t launch_spread_dense3_stack(const Geom& g, const SortedPoints<float>& sp, int64_t M, const float* horner,
+                                      const float* c, float* fw, int batch, int64_t c_stride, int64_t fw_stride, float scale,
+                                      hipStream_t stream) {
+  const dim3 grid(stack_grid_bound(g, M), (unsigned)batch);
+#define NUFFT_D3S(WV)                                                                                                 \
+  case WV:                                                                                                            \
+    return g.fused ? launch_dense3_stack<WV, true>(g, sp, horner, c, fw, grid, c_stride, fw_stride, scale, stream)    \
+                   : launch_dense3_stack<WV, false>(g, sp, horner, c, fw, grid, c_stride, fw_stride, scale, stream);
+  switch (g.w) {
+    NUFFT_D3S(2) NUFFT_D3S(3) NUFFT_D3S(4) NUFFT_D3S(5) NUFFT_D3S(6)
+    default: return hipErrorInvalidValue;
+  }
+#undef NUFFT_D3S
 }
 hipError_t launch_spread_stack3(const Geom& g, const SortedPoints<float>& sp, int64_t M, const float* horner,
                                 const float* c, float* fw, int batch, int64_t c_stride, int64_t fw_stride, float scale,

@@ -269,6 +269,9 @@ hipError_t launch_stack_plan(const Geom& g, const int32_t* tile_start, int64_t M
 hipError_t launch_bound3_stack(const Geom& g, const Rec<float>* rec, int rec_stride, const int32_t* tile_start,
                                const int32_t* sub_start, int64_t M, const TapMax& taps, const int4* segs, const int* seg_count,
                                float* seg_bound, int* fb_list, hipStream_t stream);
+hipError_t launch_spread_dense3_stack(const Geom& g, const SortedPoints<float>& sp, int64_t M, const float* horner,
+                                      const float* c, float* fw, int batch, int64_t c_stride, int64_t fw_stride, float scale,
+                                      hipStream_t stream);
 hipError_t launch_spread_stack3(const Geom& g, const SortedPoints<float>& sp, int64_t M, const float* horner,
                                 const float* c, float* fw, int batch, int64_t c_stride, int64_t fw_stride, float scale,
                                 hipStream_t stream);

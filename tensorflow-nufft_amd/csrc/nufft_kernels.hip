@@ -3188,7 +3188,8 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
       } else if constexpr (WW <= 6) {                                                            \
         if (g.fixed_point) {                                                                     \
           if constexpr (sizeof(T) == 4) {                                                        \
-            e = launch_spread_dense3(g, sp, grid.x, Md, horner, c, fw, batch, c_stride, fw_stride, scale, stream); \
+            if (g.stack && sp.segs) e = launch_spread_dense3_stack(g, sp, M, horner, c, fw, batch, c_stride, fw_stride, scale, stream); \
+            else e = launch_spread_dense3(g, sp, grid.x, Md, horner, c, fw, batch, c_stride, fw_stride, scale, stream); \
             if (e != hipSuccess) return e;                                                       \
             if (Md > (int64_t)g.fx_max_subs * g.max_sub) {   /* a tile may be crowded: fp64 planes for those */ \
               lds_bytes = wave3_split_lds(g);                                                    \

@@ -606,11 +606,10 @@ int ensure_point_capacity(nufft_hip_plan p, int64_t M, int rec_mult = 1) {
       p->cap_fb_list = need_l;
     }
   }
-  if (p->g.fx_patch && (p->type == NUFFT_HIP_TYPE_1 || p->opts.spread_only)) {
-    // (a plan that spreads over stacks keeps one bound per stack in the same buffer)
-    const bool stacks = stack3_wanted(p->g, M);
-    const int64_t need_b = (int64_t)std::max(subproblem_grid_bound(p->g, M), stacks ? stack_grid_bound(p->g, M) : 0u) + 1;
-    const int64_t need_g = stacks ? (int64_t)stack_grid_bound(p->g, M) + 1 : 0;
+  // fixed-point 3-D plans that spread over stacks of tiles (r05): the stack descriptors
+  const bool stacks = p->g.fixed_point && p->rank == 3 && (p->type == NUFFT_HIP_TYPE_1 || p->opts.spread_only) && stack3_wanted(p->g, M);
+  if (stacks) {
+    const int64_t need_g = (int64_t)stack_grid_bound(p->g, M) + 1;
     if (need_g > p->cap_segs) {
       if ((rc = sync_before_regrow(p))) return rc;
       dev_free(p, p->segs);
@@ -619,6 +618,10 @@ int ensure_point_capacity(nufft_hip_plan p, int64_t M, int rec_mult = 1) {
       if ((rc = dev_alloc(p, (void**)&p->segs, sizeof(int4) * (size_t)need_g))) return rc;
       p->cap_segs = need_g;
     }
+  }
+  if (p->g.fx_patch && (p->type == NUFFT_HIP_TYPE_1 || p->opts.spread_only)) {
+    // (a plan that spreads over stacks keeps one bound per stack in the same buffer)
+    const int64_t need_b = (int64_t)std::max(subproblem_grid_bound(p->g, M), stacks ? stack_grid_bound(p->g, M) : 0u) + 1;
     if (need_b > p->cap_sub_bound) {
       if ((rc = sync_before_regrow(p))) return rc;
       dev_free(p, p->sub_bound);
@@ -725,8 +728,18 @@ int set_points_impl(nufft_hip_plan p, int64_t M, const void* x, const void* y, c
   }
   if constexpr (sizeof(T) == 4) {
     // w = 7, 8 fixed-point plans: the bound that fixes every subproblem's step (and which of them keep fp64 planes)
-    p->g.stack = (p->g.fx_patch && p->sub_bound && p->segs && Mtot > 0 && stack3_wanted(p->g, Mtot)) ? 1 : 0;
-    if (p->g.stack) {
+    p->g.stack = (p->g.fixed_point && p->rank == 3 && (!p->g.fx_patch || p->sub_bound) && p->segs && Mtot > 0 &&
+                  (p->type == NUFFT_HIP_TYPE_1 || p->opts.spread_only) && stack3_wanted(p->g, Mtot)) ? 1 : 0;
+    if (p->g.stack && !p->g.fx_patch) {
+      // w <= 6 (spread_dense3_stack_kernel): the stacks, and the subproblems of crowded tiles for the fp64 planes as before
+      hook.begin(STAGE_SORT_CELL);
+      HIP_TRY(p, launch_stack_plan(p->g, p->tile_start, Mtot, p->segs + 1, (int*)p->segs, p->stream));
+      hook.end(STAGE_SORT_CELL);
+      if (p->fb_list) {
+        if (M > (int64_t)p->g.fx_max_subs * p->g.max_sub) HIP_TRY(p, launch_crowded_list(p->g, p->sub_start, p->fb_list, p->stream));
+        else HIP_TRY(p, hipMemsetAsync(p->fb_list, 0, sizeof(int), p->stream));
+      }
+    } else if (p->g.stack) {
       // stacks of tiles (spread_stack3_kernel): cut them, then the bound that fixes every stack's step
       hook.begin(STAGE_SORT_CELL);
       HIP_TRY(p, launch_stack_plan(p->g, p->tile_start, Mtot, p->segs + 1, (int*)p->segs, p->stream));

@@ -1768,6 +1768,60 @@ def test_fixed_point_lds_accumulation_3d(tfft, tol):
     tfft.Plan('type_1', grid, 'forward', tol=1e-7, lds_accumulate=2)   # w = 9 (w = 8 has a fixed-point kernel since r04)
 
 
+@pytest.mark.parametrize('stack', ['STACK_OFF', 'STACK_ON'])
+@pytest.mark.parametrize('tol', [1e-2, 1e-3, 1e-4])
+def test_3d_low_tolerance_fixed_point_over_stacks_and_subproblems(tfft, tol, stack):
+  # r05: the w <= 6 fixed-point spreader over STACKS of tiles (spread_dense3_stack_kernel, the default below 0.25 /
+  # 1.0 points per fine cell) against the per-subproblem form, the fp64 oracle and double LDS accumulation: uniform
+  # strengths, one dominant strength (the stack's own pass over its strengths), a blob that makes one tile crowded
+  # (pieces of a tile, more than fx_max_subs of them: the fp64-plane launches), through set_points + execute, the
+  # one-call entry (32-byte fused records) and the spread op; grids whose last tiles are partial in every dimension.
+  import torch
+  from oracle import oracle
+  from tensorflow_nufft._lib import TUNE
+  rng = np.random.default_rng(93)
+  grid, M = [44, 60, 84], 500_000          # fine 88 x 120 x 168: last tiles of 8 / 8 / 8 cells in x / y / z
+  pts = rng.uniform(-np.pi, np.pi, (M, 3)).astype(np.float32)
+  blob = (np.array([2.9, -3.0, 0.1]) + 2e-3 * rng.standard_normal((90_000, 3))).astype(np.float32)   # wraps in x and y
+  blob = ((blob + np.pi) % (2 * np.pi) - np.pi).astype(np.float32)
+  for name, p, c in (('uniform', pts, rng.uniform(-.5, .5, M) + 1j * rng.uniform(-.5, .5, M)),
+                     ('one-huge', pts, np.where(np.arange(M) == 4321, 1e6, 1.0) * (rng.standard_normal(M) + 0.3j)),
+                     ('crowded', np.concatenate([pts[:200_000], blob]), rng.standard_normal(290_000) + 1j * rng.standard_normal(290_000))):
+    c = c.astype(np.complex64)
+    truth = oracle.nufft(c.astype(np.complex128), p, grid, 'type_1', 'forward', tol=1e-12, sigma=2.0)
+    plan = tfft.Plan('type_1', grid, 'forward', tol=tol, tuning=TUNE[stack])
+    i = plan.info()
+    assert i.kernel_width <= 6 and list(i.tile_dims) == [16, 16, 8]
+    plan.set_points(_dev(p))
+    st = plan.stacks()
+    assert (st.shape[0] > 0) == (stack == 'STACK_ON')
+    if stack == 'STACK_ON' and name == 'crowded':
+      assert (st[:, 2] >= 0).sum() > 16            # the blob's tile: pieces
+    two = plan.execute(_dev(c)).cpu().numpy()
+    one = plan.execute_with_points(_dev(p), _dev(c)).cpu().numpy()   # fused records
+    plan.close()
+    dbl = tfft.Plan('type_1', grid, 'forward', tol=tol, lds_accumulate=1)
+    dbl.set_points(_dev(p))
+    ref = dbl.execute(_dev(c)).cpu().numpy()
+    dbl.close()
+    e2, e1, ed = rel_l2(two, truth), rel_l2(one, truth), rel_l2(ref, truth)
+    assert e2 < tol and e1 < tol, (name, tol, stack, e2, e1, ed)
+    assert e2 < ed + 0.2 * tol and e1 < ed + 0.2 * tol, (name, tol, stack, e2, e1, ed)
+  # the spread op (no upsampling, scaled) on the same kernels
+  g2 = [48, 64, 40]
+  c = (rng.uniform(-.5, .5, M) + 1j * rng.uniform(-.5, .5, M)).astype(np.complex64)
+  sp = tfft.Plan('type_1', g2, 'forward', tol=tol, spread_only=True, tuning=TUNE[stack])
+  sp.set_points(_dev(pts))
+  assert (sp.stacks().shape[0] > 0) == (stack == 'STACK_ON')
+  out = sp.spread(_dev(c)).cpu().numpy()
+  sp.close()
+  dbl = tfft.Plan('type_1', g2, 'forward', tol=tol, spread_only=True, lds_accumulate=1)   # (the same kernel on fp64 planes)
+  dbl.set_points(_dev(pts))
+  ref = dbl.spread(_dev(c)).cpu().numpy()
+  dbl.close()
+  assert rel_l2(out, ref) < 0.2 * tol, rel_l2(out, ref)
+
+
 def test_radial_mri_example_shape(tfft):
   # the reference's documented use (docs/examples/mri_app.ipynb): 256^2 image, 233-view
   # radial trajectory, type-2 forward to k-space, then density-compensated type-1 backward
