@@ -574,8 +574,9 @@ hipError_t launch_dense3(const Geom& g, const SortedPoints<float>& sp, const flo
 // Every thread of the NT-thread workgroup calls it with cnt complete (barrier passed) and gets the maximum;
 // a: TZ T L floats, b: TZ L L floats, wmax: NT / 64 floats of scratch (L = T + W - 1).
 // x and y passes: cnt[TZ][T][T + 1] -> b[TZ][L][L] (a: TZ T L floats of scratch); ends with a barrier
-template <int W, int TZ, int NT>
-__device__ __forceinline__ void count_filter_xy(const uint32_t* cnt, float* a, float* b, const float (&km)[W], int tid) {
+// (NSLOT > 0: layer z goes to slot (slot0 + z) mod NSLOT of a circular buffer of NSLOT layers -- stack_filter_max)
+template <int W, int TZ, int NT, int NSLOT = 0>
+__device__ __forceinline__ void count_filter_xy(const uint32_t* cnt, float* a, float* b, const float (&km)[W], int tid, int slot0 = 0) {
   // count rows of 17 words: the x pass reads one LINE per lane, and a lane stride of 16 words would put a wave on 4 banks
   constexpr int T = kDenseTile, L = T + W - 1, CP = T + 1;
   // x: line (z, y) of T counts -> L values
@@ -596,6 +597,8 @@ __device__ __forceinline__ void count_filter_xy(const uint32_t* cnt, float* a, f
   // y: line (z, i) of T values -> L values
   for (int line = tid; line < TZ * L; line += NT) {
     const int z = line / L, i = line - z * L;
+    int zs = z;
+    if constexpr (NSLOT > 0) { zs = slot0 + z; zs = zs >= NSLOT ? zs - NSLOT : zs; }
     float in[T];
 #pragma unroll
     for (int y = 0; y < T; ++y) in[y] = a[(z * T + y) * L + i];
@@ -605,7 +608,7 @@ __device__ __forceinline__ void count_filter_xy(const uint32_t* cnt, float* a, f
 #pragma unroll
       for (int t = 0; t < W; ++t)
         if (j - t >= 0 && j - t < T) v = fmaf(km[t], in[j - t], v);
-      b[(z * L + j) * L + i] = v;
+      b[(zs * L + j) * L + i] = v;
     }
   }
   __syncthreads();
@@ -1049,29 +1052,39 @@ __global__ __launch_bounds__(kStackPlanWaves * 64) void stack_plan_kernel(Geom g
 // Filter maximum over a stack: the start-cell weights of every tile through the x and y passes of the count filter,
 // the z pass over the tile's TZ layers and the last W - 1 layers of the tile before it. add_tile(i, cnt) adds the
 // weights of the stack's i-th tile to cnt[TZ][T][T + 1] (zeroed, behind a barrier; called by every thread).
-// a: TZ T L floats, b: 2 TZ L L floats, wmax: NT / 64 floats. Returns the maximum in every thread.
+// a: TZ T L floats, b: (TZ + W - 1) L L floats, wmax: NT / 64 floats. Returns the maximum in every thread.
 template <int W, int TZ, int NT, typename AddTile>
 __device__ __forceinline__ float stack_filter_max(int nz, AddTile add_tile, uint32_t* cnt, float* a, float* b, float* wmax,
                                                   const float (&km)[W], int tid) {
-  constexpr int T = kDenseTile, L = T + W - 1, CP = T + 1, H = W - 1;
+  constexpr int T = kDenseTile, L = T + W - 1, CP = T + 1, H = W - 1, NS = TZ + H;
   static_assert(H <= TZ, "the z halo must end inside the next tile");
+  // b: a circular buffer of TZ + H layers -- tile i's layer z in slot (i TZ + z) mod NS, so that the last H layers of
+  // tile i - 1 sit in the H slots in front of tile i's (52 KB with cnt and a: three workgroups per CU; two full
+  // buffers of TZ layers made 54 KB, two per CU)
   float best = 0.f;
+  int s0 = 0;   // slot of this tile's layer 0
   for (int i = 0; i <= nz; ++i) {   // (i == nz: the halo planes behind the last tile)
-    float* cur = b + (i & 1) * (TZ * L * L);
-    const float* prev = b + ((i & 1) ^ 1) * (TZ * L * L);
     if (i < nz) {
       for (int q = tid; q < TZ * T * CP; q += NT) cnt[q] = 0u;
       __syncthreads();
       add_tile(i, cnt);
       __syncthreads();
-      count_filter_xy<W, TZ, NT>(cnt, a, cur, km, tid);
+      count_filter_xy<W, TZ, NT, NS>(cnt, a, b, km, tid, s0);
     }
     for (int line = tid; line < L * L; line += NT) {
       float in[H + TZ];   // layers TZ - H .. TZ - 1 of the previous tile, then this tile's
 #pragma unroll
-      for (int m = 0; m < H; ++m) in[m] = i > 0 ? prev[(TZ - H + m) * L * L + line] : 0.f;
+      for (int m = 0; m < H; ++m) {
+        int sl = s0 - H + m;
+        sl = sl < 0 ? sl + NS : sl;
+        in[m] = i > 0 ? b[sl * L * L + line] : 0.f;
+      }
 #pragma unroll
-      for (int z = 0; z < TZ; ++z) in[H + z] = i < nz ? cur[z * L * L + line] : 0.f;
+      for (int z = 0; z < TZ; ++z) {
+        int sl = s0 + z;
+        sl = sl >= NS ? sl - NS : sl;
+        in[H + z] = i < nz ? b[sl * L * L + line] : 0.f;
+      }
 #pragma unroll
       for (int k = 0; k < TZ; ++k) {
         if (i == nz && k >= H) break;
@@ -1081,7 +1094,10 @@ __device__ __forceinline__ float stack_filter_max(int nz, AddTile add_tile, uint
         best = fmaxf(best, v);
       }
     }
-    // (the next tile's y pass writes the buffer this z pass read as `prev` three barriers from here)
+    // (the next tile's y pass overwrites only slots this z pass is done with: the TZ slots behind its own H)
+    s0 += TZ;
+    s0 = s0 >= NS ? s0 - NS : s0;
+    if (i < nz) __syncthreads();
   }
   return workgroup_max<NT>(best, wmax, tid);
 }
@@ -1095,7 +1111,7 @@ __global__ __launch_bounds__(kBoundThreads) void bound3_stack_kernel(Geom g, con
   constexpr int T = kDenseTile, L = T + W - 1, CP = T + 1, NT = kBoundThreads;
   __shared__ uint32_t cnt[TZ * T * CP];
   __shared__ float a[TZ * T * L];
-  __shared__ float b[2 * TZ * L * L];
+  __shared__ float b[(TZ + W - 1) * L * L];   // (circular: stack_filter_max)
   __shared__ float wmax[NT / 64];
   const int s = blockIdx.x, tid = threadIdx.x;
   if (s >= seg_count[0]) return;
@@ -1198,9 +1214,9 @@ __global__ NUFFT_PATCH_BOUNDS void spread_stack3_kernel(
     constexpr int T = kDenseTile, FL = T + W - 1, CP = T + 1;
     uint32_t* cnt = reinterpret_cast<uint32_t*>(smem_raw);                 // [TZ][T][CP]
     float* fa = reinterpret_cast<float*>(cnt + TZ * T * CP);               // [TZ][T][FL]
-    float* fb = fa + TZ * T * FL;                                          // [2][TZ][FL][FL]
-    float* fmx = fb + 2 * TZ * FL * FL;                                    // [NW]
-    static_assert((size_t)(TZ * T * CP + TZ * T * FL + 2 * TZ * FL * FL + NW) * 4 <= (size_t)C::plane_elems * 8, "filter scratch");
+    float* fb = fa + TZ * T * FL;                                          // [TZ + W - 1][FL][FL] (circular)
+    float* fmx = fb + (TZ + W - 1) * FL * FL;                              // [NW]
+    static_assert((size_t)(TZ * T * CP + TZ * T * FL + (TZ + W - 1) * FL * FL + NW) * 4 <= (size_t)C::plane_elems * 8, "filter scratch");
     float wscale = 524288.f;
     if ((float)(g.max_sub + 1) * wscale > 4.0e9f) wscale = floorf(4.0e9f / (float)(g.max_sub + 1));
     const float inv = top_g > 0.f ? wscale / top_g : 0.f;
