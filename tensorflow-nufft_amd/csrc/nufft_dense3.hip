@@ -819,7 +819,11 @@ __global__ NUFFT_PATCH_BOUNDS void spread_patch3_kernel(
     static_assert((size_t)(TZ * T * CP + TZ * T * FL + TZ * FL * FL + NW) * 4 <= (size_t)C::plane_elems * 8, "filter scratch");
     for (int i = tid; i < TZ * T * CP; i += NW * 64) cnt[i] = 0u;
     __syncthreads();
-    const float inv = top_g > 0.f ? 524288.f / top_g : 0.f;
+    // (weights in units of the largest / wscale, rounded up; a start cell holds at most the subproblem's points:
+    // wscale (npt + 1) stays below 2^32 whatever max_subproblem_size the plan was given -- r04 advisor)
+    float wscale = 524288.f;
+    if ((float)(npt + 1) * wscale > 4.0e9f) wscale = floorf(4.0e9f / (float)(npt + 1));
+    const float inv = top_g > 0.f ? wscale / top_g : 0.f;
     float part = 0.f, big = 0.f;
     for (int j = p0 + tid; j < p1; j += NW * 64) {
       const PointView<float> rec = unpack_rec<float, 3>(sp.rec[j]);
@@ -844,7 +848,7 @@ __global__ NUFFT_PATCH_BOUNDS void spread_patch3_kernel(
 #pragma unroll
     for (int t = 0; t < W; ++t) km[t] = g.fx_tap[t];
     const float wb = count_filter_max<W, TZ, NW * 64>(cnt, fa, fb, fmx, km, tid);
-    cap = fminf(top * bound_b, top_g * wb * (1.0001f / 524288.f));
+    cap = fminf(top * bound_b, top_g * wb * (1.0001f / wscale));
     __syncthreads();   // (the scratch becomes the plane)
   }
   for (int i = tid; i < C::plane_elems; i += NW * 64) plane[i] = 0ull;

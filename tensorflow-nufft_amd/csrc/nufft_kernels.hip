@@ -139,6 +139,12 @@ __device__ __forceinline__ void load_coords(const PointsIn& in, int64_t i, T x[3
 }
 
 // QF (quick fold): the caller has checked quick_fold(g, in) on the host.
+// double -> int with the hardware's semantics: saturating, NaN -> 0 (defined for every input, unlike the C++ cast)
+__device__ __forceinline__ int cvt_i32_sat(double x) {
+  int r;
+  asm("v_cvt_i32_f64 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
 template <typename T, bool QF = false>
 __device__ __forceinline__ int fold_coords(const Geom& g, const PointsIn& in, const T xin[3], Rec<T>* r,
                                            bool* bad) {
@@ -166,7 +172,11 @@ __device__ __forceinline__ int fold_coords(const Geom& g, const PointsIn& in, co
       const double i0f = ceil(xs - 0.5 * (double)g.w);   // in [-w / 2, nf) for a point in range
       double zz = 2.0 * (i0f - xs) + (double)(g.w - 1);
       zz = fmin(1.0, fmax(-1.0, zz));
-      int i0 = (int)i0f;                 // (saturates; NaN -> 0)
+      // garbage coordinates (NaN, Inf, 1e30 with the range check off): the conversion is the INSTRUCTION, which
+      // saturates and maps NaN to 0, not the C++ cast, whose result is undefined out of range -- the memory safety of
+      // the scattered stores must not rest on how today's compiler lowers a cast (r04 advisor; a clamp in double cost
+      // the two hottest scatter instantiations 20-28 bytes of scratch)
+      int i0 = cvt_i32_sat(i0f);
       if (i0 < 0) i0 += nf;
       i0 = i0 < 0 ? 0 : (i0 >= nf ? nf - 1 : i0);
       tc[d] = i0 >> g.tile_shift[d];
