@@ -971,30 +971,6 @@ __global__ __launch_bounds__(kBoundThreads) void bound3_kernel(Geom g, const Rec
 // the subproblems locate_subproblem would give it, each a stack of its own (PIECES: one tile, a point range).
 // Flagged stacks (bound above Geom::fx_bound_limit, tiles of more than fx_max_subs pieces) go to the fp64-plane
 // launches behind this one as the subproblems they consist of.
-struct StackDesc {
-  int col, z0, nz, p0, p1;   // column, first tile in z, tiles; piece: its points [p0, p1), else p0 < 0
-};
-__device__ __forceinline__ StackDesc stack_load(const int4* __restrict__ segs, int s) {
-  const int4 v = segs[s];
-  StackDesc d;
-  d.col = v.x; d.z0 = v.y & 0xffff; d.nz = v.y >> 16; d.p0 = v.z; d.p1 = v.w;
-  return d;
-}
-struct StackColumn { int item, t0, t1; };
-__device__ __forceinline__ StackColumn stack_column(const Geom& g, int col) {
-  const int ncol_item = g.ntile[0] * g.ntile[1];
-  StackColumn c;
-  c.item = col / ncol_item;
-  const int r = col - c.item * ncol_item;
-  c.t1 = r / g.ntile[0];
-  c.t0 = r - c.t1 * g.ntile[0];
-  return c;
-}
-__device__ __forceinline__ int stack_tile_index(const Geom& g, const StackColumn& c, int t2) {
-  const int tc[3] = {c.t0, c.t1, t2};
-  return c.item * g.ntiles_item + tile_id(g, tc);
-}
-
 // One wave per tile column: cuts the column into stacks (greedy along z), two passes -- count, take a range of
 // descriptor slots with one atomic, write. The order of the descriptors depends on arrival; nothing else does.
 constexpr int kStackPlanWaves = 4;
@@ -1714,6 +1690,21 @@ bool stack3_wanted(const Geom& g, int64_t M) {
   // 0.745: 7.55 -> 7.91; w = 4 (1 per point): 0.224: 2.87 -> 2.33, 0.373: 3.00 -> 2.81, 0.745: 4.50 -> 4.33
   const double limit = g.fx_patch ? kStackDensity : (g.w >= 5 ? 0.25 : 1.0);
   return (double)M < limit * cells;
+}
+// The 3-D interpolation over stacks (interp_stack3_kernel, nufft_kernels.hip): the LDS-tile kernel of the wavefront
+// method in single precision at w <= 6, tiles whose depth holds the z halo. (w = 7, 8: the 66 KB tile leaves two
+// 512-thread workgroups per CU and the kernel no registers for the next tile's planes: 2.40 -> 2.43 ms at 0.022 points
+// per cell, r05 A/B; not instantiated.)
+bool stack_interp_wanted(const Geom& g, int method, int precision, int64_t M) {
+  if (g.rank != 3 || precision != NUFFT_HIP_F32 || method != NUFFT_HIP_METHOD_TILE_WAVE || g.wide || g.w > 6 ||
+      g.w - 1 > g.tile[2] || g.ntile[2] < 2 || g.ntile[2] > 32767)
+    return false;
+  const int mode = tune_mode(g, NUFFT_HIP_TUNE_STACK_OFF, NUFFT_HIP_TUNE_STACK_ON);
+  if (mode >= 0) return mode != 0;
+  const double cells = (double)g.nf[0] * g.nf[1] * g.nf[2] * (g.nitems > 1 ? g.nitems : 1);
+  // r05 A/B (256^3 modes, interp stage, subproblems -> stacks): w = 6: 0.022 points per cell 1.66 -> 1.09 ms, 0.075: 1.78 -> 1.22,
+  // 0.224: 2.36 -> 1.93, 0.373: 2.78 -> 2.65, 0.522: 3.17 -> 3.42; w = 4: 0.075: 1.39 -> 0.91, 0.224: 1.62 -> 1.39, 0.745: 4.39 -> 3.99
+  return (double)M < (g.w >= 5 ? 0.3 : 1.0) * cells;
 }
 hipError_t launch_stack_plan(const Geom& g, const int32_t* tile_start, int64_t M, int4* segs, int* seg_count, hipStream_t stream) {
   hipError_t e = hipMemsetAsync(seg_count, 0, sizeof(int), stream);

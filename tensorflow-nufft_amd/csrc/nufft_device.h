@@ -237,5 +237,30 @@ __device__ __forceinline__ double fma_sgpr(double k, double z, double t) {
   return r;
 }
 
+// ---- stacks of tiles (r05; nufft_dense3.hip has the description): descriptor decoding shared by the spread and interp kernels
+struct StackDesc {
+  int col, z0, nz, p0, p1;   // column, first tile in z, tiles; piece: its points [p0, p1), else p0 < 0
+};
+__device__ __forceinline__ StackDesc stack_load(const int4* __restrict__ segs, int s) {
+  const int4 v = segs[s];
+  StackDesc d;
+  d.col = v.x; d.z0 = v.y & 0xffff; d.nz = v.y >> 16; d.p0 = v.z; d.p1 = v.w;
+  return d;
+}
+struct StackColumn { int item, t0, t1; };
+__device__ __forceinline__ StackColumn stack_column(const Geom& g, int col) {
+  const int ncol_item = g.ntile[0] * g.ntile[1];
+  StackColumn c;
+  c.item = col / ncol_item;
+  const int r = col - c.item * ncol_item;
+  c.t1 = r / g.ntile[0];
+  c.t0 = r - c.t1 * g.ntile[0];
+  return c;
+}
+__device__ __forceinline__ int stack_tile_index(const Geom& g, const StackColumn& c, int t2) {
+  const int tc[3] = {c.t0, c.t1, t2};
+  return c.item * g.ntiles_item + tile_id(g, tc);
+}
+
 }  // namespace
 }  // namespace nufft_hip

@@ -24,7 +24,7 @@ def run(plan, pts, c, steps):
   for _ in range(steps):
     plan.set_points(pts); out = plan.execute(c)
   tm = plan.get_timing()
-  st = {k: v[0] / max(v[1], 1) * 1e3 for k, v in tm.items() if v[1]}
+  st = {k: v[0] / steps * 1e3 for k, v in tm.items() if v[1]}   # (per call: a stage may run more than once per call)
   return out, st
 
 
