@@ -705,10 +705,14 @@ __device__ __forceinline__ void horner1(const float* __restrict__ tab, float z, 
     for (int q = 0; q < W; ++q) k[q] = fmaf(k[q], z, tab[j * kMaxW + q]);
   }
 }
+// have_first: the record and strength of the wave's FIRST 64 points (lane's point wbeg + lane) were loaded by the caller
+// (spread_stack3_kernel fetches the next tile's while it writes this one's planes out).
 template <int W, int TZ, int HALF>
 __device__ __forceinline__ void patch3_accumulate(const Rec<float>* __restrict__ rec, const float2* __restrict__ cc, int wbeg,
                                                          int wend, float pre, const float* __restrict__ horner,
-                                                         const v2f (&coef)[kPatchCoef], lds_byte* plane_l, int lane) {
+                                                         const v2f (&coef)[kPatchCoef], lds_byte* plane_l, int lane,
+                                                         bool have_first = false, Rec<float> first_rec = Rec<float>(),
+                                                         float2 first_c = make_float2(0.f, 0.f)) {
   using C = PatchCfg<W, TZ, HALF>;
   constexpr int LS = C::LS, PS = C::PS;
   const int dx = lane & 7, dy = lane >> 3;
@@ -721,8 +725,9 @@ __device__ __forceinline__ void patch3_accumulate(const Rec<float>* __restrict__
 #pragma unroll
     for (int q = 0; q < 8; ++q) kz[q] = 0.f;
     if (js < wend) {
-      const PointView<float> pv = unpack_rec<float, 3>(rec[js]);
-      const float2 cv = cc[pv.idx];
+      const bool pre_loaded = have_first && base == wbeg;   // (wave-uniform)
+      const PointView<float> pv = unpack_rec<float, 3>(pre_loaded ? first_rec : rec[js]);
+      const float2 cv = pre_loaded ? first_c : cc[pv.idx];
       cre = cv.x * pre;
       cim = cv.y * pre;
       off = ((int)(pv.loc & 1023) + (int)((pv.loc >> 10) & 1023) * LS + (int)((pv.loc >> 20) & 1023) * PS) * 8;
@@ -1255,20 +1260,45 @@ __global__ NUFFT_PATCH_BOUNDS void spread_stack3_kernel(
   patch3_lane_coef<W>(horner, lane, coef);
   const int o0 = col.t0 * kDenseTile, o1 = col.t1 * kDenseTile;
   float* out = fw + 2 * (int64_t)slot * fw_stride;
-  for (int i = 0; i < d.nz; ++i) {
-    int p0 = d.p0, p1 = d.p1;
-    if (p0 < 0) {
+  // The record and the strength of every lane's first point of a tile are fetched a tile ahead: the record while the
+  // tile before is accumulated, the strength (through the record's index) before that tile's planes are written out --
+  // at a few dozen points per tile the two dependent loads at the head of a tile were ~20 % of its time.
+  auto tile_range = [&](int i, int* p0, int* p1) {
+    *p0 = d.p0; *p1 = d.p1;
+    if (d.p0 < 0) {
       const int t = stack_tile_index(g, col, d.z0 + i);
-      p0 = sp.tile_start[t];
-      p1 = sp.tile_start[t + 1];
+      *p0 = sp.tile_start[t];
+      *p1 = sp.tile_start[t + 1];
+    }
+  };
+  auto first_index = [&](int p0, int p1) {   // the lane's first point of a tile, or -1
+    const int npt = p1 - p0, share = (npt + NW - 1) / NW;
+    const int wbeg = wave * share, wend = (wbeg + share < npt) ? wbeg + share : npt;
+    return wbeg + lane < wend ? p0 + wbeg + lane : -1;
+  };
+  int q0, q1;
+  tile_range(0, &q0, &q1);
+  int jn = first_index(q0, q1);
+  Rec<float> rec_n = sp.rec[jn >= 0 ? jn : 0];   // (lanes without a point: some valid record)
+  float2 c_n = cc[jn >= 0 ? rec_n.idx : 0];
+  for (int i = 0; i < d.nz; ++i) {
+    const int p0 = q0, p1 = q1;
+    const Rec<float> rec_i = rec_n;
+    const float2 c_i = c_n;
+    const bool more = i + 1 < d.nz;
+    if (more) {
+      tile_range(i + 1, &q0, &q1);
+      jn = first_index(q0, q1);
+      rec_n = sp.rec[jn >= 0 ? jn : 0];
     }
     const int npt = p1 - p0;
     const int share = (npt + NW - 1) / NW;
     const int wbeg = wave * share;
     const int wend = (wbeg + share < npt) ? wbeg + share : npt;
     NUFFT_STACK_PH(0);
-    patch3_accumulate<W, TZ, HALF>(sp.rec + p0, cc, wbeg, wend, pre, horner, coef, (lds_byte*)plane, lane);
+    patch3_accumulate<W, TZ, HALF>(sp.rec + p0, cc, wbeg, wend, pre, horner, coef, (lds_byte*)plane, lane, true, rec_i, c_i);
     NUFFT_STACK_PH(1);
+    if (more) c_n = cc[jn >= 0 ? rec_n.idx : 0];
     __syncthreads();
     NUFFT_STACK_PH(2);
     // tile d.z0 + i is complete in its first TZ planes (the last tile of the stack: in all of them): unpack, scale
@@ -1653,7 +1683,7 @@ hipError_t launch_bound3(const Geom& g, const Rec<float>* rec, int rec_stride, c
 // points per cell: 16 tiles 313 us, 8 320, 4 334, 2 372; 256 stacks of 32 tiles 399): at least 512 stacks where the
 // tile count allows, at most 16 tiles. Points: 8192, so that workgroups stay of similar length whatever the density
 // (and never below the subproblem cap: pieces are subproblems).
-constexpr double kStackDensity = 0.15;   // points per fine cell below which a plan spreads over stacks
+constexpr double kStackDensity = 0.22;   // points per fine cell below which a w = 7, 8 plan spreads over stacks
 void stack_params(const Geom& g, int* cap, int* len) {
   int l = g.ntiles / 512;
   l = l < 2 ? 2 : (l > 16 ? 16 : l);
@@ -1673,10 +1703,11 @@ unsigned stack_grid_bound(const Geom& g, int64_t M) {
   return (unsigned)std::min<int64_t>(n, 0x7fffffff);
 }
 // The stack form pays where the tile + halo write-out is a visible part of the spread (r05, profiles/r05_stack_ab.txt,
-// spread stage, stacks against subproblems, w = 8): 256^3 modes at 0.022 points per fine cell 2.07 against 2.97 ms,
-// 0.075: 2.46 against 3.62; 0.22: 4.59 against 4.57 and 0.75: 12.7 against 12.4 -- from there the accumulation
-// loop (VALU issue + LDS atomics) hides the write-out either way, and the bound of a stack costs 0.15 ms more than
-// the bounds of its tiles. options.tuning STACK_OFF / STACK_ON force the choice.
+// spread stage, stacks against subproblems, w = 8): 256^3 modes at 0.022 points per fine cell 2.00 against 2.98 ms,
+// 0.075: 2.38 against 3.60, 0.149: 3.35 against 4.65, 0.179: 3.84 against 4.15, 0.201: 4.17 against 4.40, 0.224: 4.49 against
+// 4.58 and 0.75: 12.7 against 12.4 -- from there the accumulation loop (VALU issue + LDS atomics) hides the write-out
+// either way, and the bound of a stack costs 0.1 ms more than the bounds of its tiles.
+// options.tuning STACK_OFF / STACK_ON force the choice.
 bool stack3_wanted(const Geom& g, int64_t M) {
   // (w = 7, 8: spread_stack3_kernel; w <= 6 on 16 x 16 x 8 tiles: spread_dense3_stack_kernel)
   const bool dense = g.fixed_point && !g.fx_patch && g.rank == 3 && g.w >= 2 && g.w <= 6 && g.tile[0] == kDenseTile &&
