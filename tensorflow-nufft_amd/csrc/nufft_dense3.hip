@@ -1722,21 +1722,6 @@ bool stack3_wanted(const Geom& g, int64_t M) {
   const double limit = g.fx_patch ? kStackDensity : (g.w >= 5 ? 0.25 : 1.0);
   return (double)M < limit * cells;
 }
-// The 3-D interpolation over stacks (interp_stack3_kernel, nufft_kernels.hip): the LDS-tile kernel of the wavefront
-// method in single precision at w <= 6, tiles whose depth holds the z halo. (w = 7, 8: the 66 KB tile leaves two
-// 512-thread workgroups per CU and the kernel no registers for the next tile's planes: 2.40 -> 2.43 ms at 0.022 points
-// per cell, r05 A/B; not instantiated.)
-bool stack_interp_wanted(const Geom& g, int method, int precision, int64_t M) {
-  if (g.rank != 3 || precision != NUFFT_HIP_F32 || method != NUFFT_HIP_METHOD_TILE_WAVE || g.wide || g.w > 6 ||
-      g.w - 1 > g.tile[2] || g.ntile[2] < 2 || g.ntile[2] > 32767)
-    return false;
-  const int mode = tune_mode(g, NUFFT_HIP_TUNE_STACK_OFF, NUFFT_HIP_TUNE_STACK_ON);
-  if (mode >= 0) return mode != 0;
-  const double cells = (double)g.nf[0] * g.nf[1] * g.nf[2] * (g.nitems > 1 ? g.nitems : 1);
-  // r05 A/B (256^3 modes, interp stage, subproblems -> stacks): w = 6: 0.022 points per cell 1.66 -> 1.09 ms, 0.075: 1.78 -> 1.22,
-  // 0.224: 2.36 -> 1.93, 0.373: 2.78 -> 2.65, 0.522: 3.17 -> 3.42; w = 4: 0.075: 1.39 -> 0.91, 0.224: 1.62 -> 1.39, 0.745: 4.39 -> 3.99
-  return (double)M < (g.w >= 5 ? 0.3 : 1.0) * cells;
-}
 hipError_t launch_stack_plan(const Geom& g, const int32_t* tile_start, int64_t M, int4* segs, int* seg_count, hipStream_t stream) {
   hipError_t e = hipMemsetAsync(seg_count, 0, sizeof(int), stream);
   if (e != hipSuccess) return e;

@@ -62,7 +62,6 @@ struct Geom {
   // fx_patch plans whose spread runs over STACKS of tiles (spread_stack3_kernel; set per set_points) and the cutting
   // parameters when a debug call overrides the defaults (0: stack_params' rule)
   int stack;
-  int stack_interp;   // the 3-D interpolation runs over stacks too (interp_stack3_kernel; set per set_points)
   int stack_len, stack_cap;
 };
 // OFF / ON pair of nufft_hip_options.tuning: -1 = by the plan's own rule, 0 = never, 1 = always
@@ -264,7 +263,6 @@ hipError_t launch_bound3(const Geom& g, const Rec<float>* rec, int rec_stride, c
                          unsigned nsub_bound, const TapMax& taps, float* sub_bound, int* fb_list, hipStream_t stream);
 // stacks of tiles (r05, same file): which plans take them, the launch grid bound, cutting, bounds, spreading
 bool stack3_wanted(const Geom& g, int64_t M);
-bool stack_interp_wanted(const Geom& g, int method, int precision, int64_t M);   // 3-D type 2 / interp op
 void stack_params(const Geom& g, int* cap, int* len);
 unsigned stack_grid_bound(const Geom& g, int64_t M);
 hipError_t launch_stack_plan(const Geom& g, const int32_t* tile_start, int64_t M, int4* segs, int* seg_count, hipStream_t stream);

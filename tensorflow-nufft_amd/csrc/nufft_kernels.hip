@@ -2208,6 +2208,35 @@ __global__ __launch_bounds__(NTHREADS) void interp_point_kernel(
   // wave in 2-D, 35 in 3-D) at the head of every workgroup.
   constexpr int kRowBatch = 8;
   const int nrows = L1 * L2;
+  // 3-D tiles of 16 x 16 cells in x and y (r05): the cells are dealt to the threads one after the other instead of a
+  // row per wave -- a row is 16 + W - 1 <= 23 cells, a third of a wave, and a wave walked its ~43 rows in 5-6 batches
+  // of loads one after the other; this way a thread's ~15 cells are two batches (the row length is compile-time here:
+  // the divisions are multiplications). 3-D type 2, 256^3 modes, w = 8, interp stage: M = 3e6 2.40 -> 1.41 ms, 1e7
+  // 2.58 -> 1.58, 3e7 3.99 -> 3.10, 1e8 7.32 -> 6.77; w = 6, 1e7: 1.78 -> 1.03. (The 2-D tiles -- 39- and 71-cell rows, the
+  // latter in two sweeps -- measured the same either way, config 3 221 against 221-227 us: left on rows.)
+  auto load_flat = [&](auto lc) {
+    constexpr int LC = decltype(lc)::value;
+    const int ncell = LC * LC * L2;
+    for (int e0 = tid; e0 < ncell; e0 += kRowBatch * NT) {
+      T2 v[kRowBatch];
+      int lofs[kRowBatch];
+#pragma unroll
+      for (int u = 0; u < kRowBatch; ++u) {
+        const int e = e0 + u * NT;
+        const int ec = e < ncell ? e : ncell - 1;
+        const int a2 = RANK > 2 ? ec / (LC * LC) : 0, r = ec - a2 * (LC * LC);
+        const int a1 = r / LC, a0 = r - a1 * LC;
+        const int g2 = RANK > 2 ? wrap1(o2 + a2, g.nf[2]) : 0;
+        v[u] = in[(int64_t)g.nf[0] * (wrap1(o1 + a1, g.nf[1]) + (int64_t)g.nf[1] * g2) + wrap1(o0 + a0, g.nf[0])];
+        lofs[u] = e < ncell ? a2 * PS + a1 * LS + a0 : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < kRowBatch; ++u)
+        if (lofs[u] >= 0) tile[lofs[u]] = v[u];
+    }
+  };
+  if (RANK > 2 && g.tile[0] == 16 && g.tile[1] == 16) load_flat(std::integral_constant<int, 16 + W - 1>());
+  else
   // (rows of more than 64 cells -- the 64 x 64 tiles of 2-D type-2 plans, 71 cells with the
   // halo -- take a second sweep for the remaining columns)
   for (int c0 = 0; c0 < L0; c0 += 64) {
@@ -2278,141 +2307,6 @@ __global__ __launch_bounds__(NTHREADS) void interp_point_kernel(
     out.x = sre * scale;
     out.y = sim * scale;
     cc[rec.idx] = out;
-  }
-}
-
-// The 3-D kernel above over a STACK of tiles (r05; stacks: nufft_dense3.hip): the tile + halo of a 16 x 16 x 8 tile is
-// 23 x 23 x 15 cells at w = 8 -- 3.9 x the fine grid read per transform, and below ~0.3 points per cell that read IS the
-// kernel (256^3 modes, M = 3e6: 2.4 ms for 4.2 GB). One workgroup walks a run of tiles consecutive in z: after tile t
-// the W - 1 planes it shares with tile t + 1 move down in LDS and only the next tile's TZ new planes are read -- into
-// REGISTERS, before tile t's points are interpolated, so that their latency is behind that work (read after it, the
-// halved volume bought nothing: a sparse tile's time is the latency of its loads, not their bytes; r05 A/B).
-template <typename T, int W, int NTHREADS = kInterpThreads<3>>
-__global__ __launch_bounds__(NTHREADS, 4) void interp_stack3_kernel(
-    Geom g, SortedPoints<T> sp, const T* __restrict__ horner, T* __restrict__ c,
-    const T* __restrict__ fw, int64_t c_stride, int64_t fw_stride, T scale) {
-  using T2 = typename Pair<T>::type;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int LS = g.lstride;
-  const int L0 = g.ldim[0], L1 = g.ldim[1], L2 = g.ldim[2];
-  const int PS = LS * L1, TZ = g.tile[2], H = W - 1;
-  T2* tile = reinterpret_cast<T2*>(smem_raw);
-  const int s = blockIdx.x;
-  if (s >= sp.seg_count[0]) return;
-  const StackDesc d = stack_load(sp.segs, s);
-  const StackColumn col = stack_column(g, d.col);
-  const int slot = col.item * (int)gridDim.y + (int)blockIdx.y;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int o0 = col.t0 * g.tile[0], o1 = col.t1 * g.tile[1];
-  const T2* in = reinterpret_cast<const T2*>(fw) + (int64_t)slot * fw_stride;
-  T2* cc = reinterpret_cast<T2*>(c) + (int64_t)slot * c_stride;
-  constexpr int NT = NTHREADS;
-  constexpr int kRowBatch = 8;
-  const int nc = g.ncoef;
-  // the first tile: all its planes (rows fetched kRowBatch at a time, one lane per cell, as above)
-  {
-    const int a0c = lane < L0 ? lane : L0 - 1;
-    const int64_t gx = wrap1(o0 + a0c, g.nf[0]);
-    const int o2 = d.z0 * TZ;
-    const int nrows = L1 * L2;
-    for (int rb = wave; rb < nrows; rb += kRowBatch * (NT / 64)) {
-      T2 v[kRowBatch];
-      int lofs[kRowBatch];
-#pragma unroll
-      for (int u = 0; u < kRowBatch; ++u) {
-        const int row = rb + u * (NT / 64);
-        const int rc = row < nrows ? row : nrows - 1;
-        const int a2 = rc / L1, a1 = rc - a2 * L1;
-        v[u] = in[(int64_t)g.nf[0] * (wrap1(o1 + a1, g.nf[1]) + (int64_t)g.nf[1] * wrap1(o2 + a2, g.nf[2])) + gx];
-        lofs[u] = row < nrows ? a2 * PS + a1 * LS + lane : -1;
-      }
-#pragma unroll
-      for (int u = 0; u < kRowBatch; ++u)
-        if (lofs[u] >= 0 && lane < L0) tile[lofs[u]] = v[u];
-    }
-  }
-  __syncthreads();
-  // the TZ new planes of a following tile: cells dealt to the threads one after the other (a thread's k-th cell is
-  // cell tid + k NT of the TZ L1 L0 cells): at most kNext per thread
-  constexpr int kNext = (8 * (16 + W - 1) * (16 + W - 1) + NT - 1) / NT;   // (tiles of at most 16 x 16 x 8 cells)
-  const int ncell = TZ * L1 * L0;
-  for (int i = 0; i < d.nz; ++i) {
-    T2 nxt[kNext];
-    const bool more = i + 1 < d.nz;
-    int tq = tid;   // (opaque: the cells' addresses are computed per tile, not hoisted out of the loop and kept in registers)
-    asm volatile("" : "+v"(tq));
-    if (more) {
-      const int o2 = (d.z0 + i + 1) * TZ + H;   // (plane H of the next tile = plane L2 - TZ ... of the fine grid's z)
-#pragma unroll
-      for (int k = 0; k < kNext; ++k) {
-        int e = tq + k * NT;
-        e = e < ncell ? e : ncell - 1;
-        const int a2 = e / (L1 * L0), r = e - a2 * (L1 * L0);
-        const int a1 = r / L0, a0 = r - a1 * L0;
-        nxt[k] = in[(int64_t)g.nf[0] * (wrap1(o1 + a1, g.nf[1]) + (int64_t)g.nf[1] * wrap1(o2 + a2, g.nf[2])) + wrap1(o0 + a0, g.nf[0])];
-      }
-    }
-    int p0 = d.p0, p1 = d.p1;
-    if (p0 < 0) {
-      const int t = stack_tile_index(g, col, d.z0 + i);
-      p0 = sp.tile_start[t];
-      p1 = sp.tile_start[t + 1];
-    }
-    if (p1 > p0) {
-      Rec<T> raw = sp.rec[p0 + tid < p1 ? p0 + tid : p1 - 1];
-      for (int j = p0 + tid; j < p1; j += NT) {
-        const PointView<T> rec = unpack_rec<T, 3>(raw);
-        raw = sp.rec[j + NT < p1 ? j + NT : p1 - 1];
-        T kx[W], ky[W], kz[W];
-        hornerW<T, 3, W>(horner, nc, rec.z0, rec.z1, rec.z2, kx, ky, kz);
-        const T2* tp = tile + (int)(rec.loc & 1023) + (int)((rec.loc >> 10) & 1023) * LS + (int)((rec.loc >> 20) & 1023) * PS;
-        T sre = (T)0, sim = (T)0;
-#pragma unroll 3
-        for (int dz = 0; dz < W; ++dz) {
-          T pre = (T)0, pim = (T)0;
-#pragma unroll
-          for (int dy = 0; dy < W; ++dy) {
-            const T2* row = tp + dz * PS + dy * LS;
-            T rre = (T)0, rim = (T)0;
-#pragma unroll
-            for (int dx = 0; dx < W; ++dx) {
-              const T2 v = lds_cell(row + dx);
-              rre = fma(kx[dx], v.x, rre);
-              rim = fma(kx[dx], v.y, rim);
-            }
-            pre = fma(ky[dy], rre, pre);
-            pim = fma(ky[dy], rim, pim);
-          }
-          sre = fma(kz[dz], pre, sre);
-          sim = fma(kz[dz], pim, sim);
-        }
-        T2 out;
-        out.x = sre * scale;
-        out.y = sim * scale;
-        cc[rec.idx] = out;
-      }
-    }
-    if (more) {
-      __syncthreads();   // every point of tile i has read its cells
-      // planes TZ .. L2 - 1 are planes 0 .. H - 1 of the next tile (H <= TZ: sources and targets do not overlap)
-      for (int e = tid; e < H * L1 * LS; e += NT) {
-        const int a2 = e / (L1 * LS), r = e - a2 * (L1 * LS);
-        tile[a2 * PS + r] = tile[(a2 + TZ) * PS + r];
-      }
-      __syncthreads();
-      int ts = tid;
-      asm volatile("" : "+v"(ts));
-#pragma unroll
-      for (int k = 0; k < kNext; ++k) {
-        const int e = ts + k * NT;
-        if (e < ncell) {
-          const int a2 = e / (L1 * L0), r = e - a2 * (L1 * L0);
-          const int a1 = r / L0, a0 = r - a1 * L0;
-          tile[(H + a2) * PS + a1 * LS + a0] = nxt[k];
-        }
-      }
-      __syncthreads();
-    }
   }
 }
 
@@ -3421,15 +3315,6 @@ hipError_t launch_interp(const Geom& g, int method, const SortedPoints<T>& sp, i
         if (e != hipSuccess) return e;                                                                \
         interp_point_kernel<T, RR, WW, 512><<<grid, 512, lds, stream>>>(g, sp, horner, c, fw,         \
                                                                         c_stride, fw_stride, scale);  \
-        break;                                                                                        \
-      }                                                                                               \
-    }                                                                                                 \
-    if constexpr (RR == 3 && WW <= 6 && sizeof(T) == 4) {                                             \
-      if (g.stack_interp && sp.segs) {   /* stacks of tiles: the z halo stays in LDS */               \
-        e = ensure_lds(interp_stack3_kernel<T, WW>, lds);                                             \
-        if (e != hipSuccess) return e;                                                                \
-        interp_stack3_kernel<T, WW><<<dim3(stack_grid_bound(g, M), (unsigned)batch), kInterpThreads<3>, lds, stream>>>( \
-            g, sp, horner, c, fw, c_stride, fw_stride, scale);                                        \
         break;                                                                                        \
       }                                                                                               \
     }                                                                                                 \

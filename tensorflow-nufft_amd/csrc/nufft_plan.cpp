@@ -606,10 +606,9 @@ int ensure_point_capacity(nufft_hip_plan p, int64_t M, int rec_mult = 1) {
       p->cap_fb_list = need_l;
     }
   }
-  // fixed-point 3-D plans that spread over stacks of tiles (r05), 3-D plans that interpolate over them: the stack descriptors
+  // fixed-point 3-D plans that spread over stacks of tiles (r05): the stack descriptors
   const bool stacks = p->g.fixed_point && p->rank == 3 && (p->type == NUFFT_HIP_TYPE_1 || p->opts.spread_only) && stack3_wanted(p->g, M);
-  const bool istacks = (p->type == NUFFT_HIP_TYPE_2 || p->opts.spread_only) && stack_interp_wanted(p->g, p->method, p->precision, M);
-  if (stacks || istacks) {
+  if (stacks) {
     const int64_t need_g = (int64_t)stack_grid_bound(p->g, M) + 1;
     if (need_g > p->cap_segs) {
       if ((rc = sync_before_regrow(p))) return rc;
@@ -727,16 +726,9 @@ int set_points_impl(nufft_hip_plan p, int64_t M, const void* x, const void* y, c
                                   (Rec<T>*)p->rec, p->stream));
     hook.end(STAGE_SORT_CELL);
   }
-  // stacks of tiles (r05): 3-D fixed-point float plans spread over them, 3-D plans of both precisions interpolate over them
+  // stacks of tiles (r05): 3-D fixed-point float plans spread over them
   p->g.stack = (sizeof(T) == 4 && p->g.fixed_point && p->rank == 3 && (!p->g.fx_patch || p->sub_bound) && p->segs && Mtot > 0 &&
                 (p->type == NUFFT_HIP_TYPE_1 || p->opts.spread_only) && stack3_wanted(p->g, Mtot)) ? 1 : 0;
-  p->g.stack_interp = (p->segs && Mtot > 0 && (p->type == NUFFT_HIP_TYPE_2 || p->opts.spread_only) &&
-                       stack_interp_wanted(p->g, p->method, p->precision, Mtot)) ? 1 : 0;
-  if (p->g.stack_interp && !p->g.stack) {   // (a plan that also spreads over stacks cuts them below)
-    hook.begin(STAGE_SORT_CELL);
-    HIP_TRY(p, launch_stack_plan(p->g, p->tile_start, Mtot, p->segs + 1, (int*)p->segs, p->stream));
-    hook.end(STAGE_SORT_CELL);
-  }
   if constexpr (sizeof(T) == 4) {
     // w = 7, 8 fixed-point plans: the bound that fixes every subproblem's step (and which of them keep fp64 planes)
     if (p->g.stack && !p->g.fx_patch) {
@@ -794,7 +786,7 @@ SortedPoints<T> sorted_view(nufft_hip_plan p) {
   sp.cstats_blocks = p->cstats ? cstats_blocks(p->M, sp.cstats_slots) : 0;
   sp.sub_bound = p->sub_bound;
   sp.fb_list = p->fb_list;
-  sp.segs = (p->g.stack || p->g.stack_interp) ? p->segs + 1 : nullptr;
+  sp.segs = p->g.stack ? p->segs + 1 : nullptr;
   sp.seg_count = (const int*)p->segs;
   sp.seg_bound = p->sub_bound;
   return sp;
@@ -1300,7 +1292,7 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
   g.fixed_point = 0;
   g.split_reim = 0;
   g.cell_sorted = 0;
-  g.stack = g.stack_interp = 0;
+  g.stack = 0;
   g.stack_len = g.stack_cap = 0;
   g.fx_patch = (patch_want && method == NUFFT_HIP_METHOD_TILE_WAVE && !g.wide && g.tile[0] == 16 && g.tile[1] == 16 &&
                 g.tile[2] == 8) ? 1 : 0;
@@ -1593,7 +1585,7 @@ int nufft_hip_debug_stack_params(nufft_hip_plan p, int len, int cap) {
 
 int64_t nufft_hip_debug_stacks(nufft_hip_plan p, int32_t* out, int64_t n) {
   if (!p || p->host_only || !p->points_set) return -1;
-  if ((!p->g.stack && !p->g.stack_interp) || !p->segs) return 0;
+  if (!p->g.stack || !p->segs) return 0;
   int32_t live = 0;
   if (hipMemcpyAsync(&live, p->segs, sizeof(int32_t), hipMemcpyDeviceToHost, p->stream) != hipSuccess ||
       hipStreamSynchronize(p->stream) != hipSuccess)

@@ -1822,53 +1822,6 @@ def test_3d_low_tolerance_fixed_point_over_stacks_and_subproblems(tfft, tol, sta
   assert rel_l2(out, ref) < 0.2 * tol, rel_l2(out, ref)
 
 
-@pytest.mark.parametrize('tol', [1e-2, 1e-4])
-def test_3d_interpolation_over_stacks_equals_subproblems(tfft, tol):
-  # r05: the 3-D type-2 / interp kernel over STACKS of tiles (interp_stack3_kernel, w <= 6, single precision: the z halo
-  # stays in LDS, the next tile's planes are prefetched into registers) does the arithmetic of interp_point_kernel point
-  # for point: bit-identical results, on grids with partial last tiles, with a blob that makes one tile a run of pieces,
-  # through type-2 plans, the interp op, several transforms; and the whole thing against the fp64 oracle.
-  import torch
-  from oracle import oracle
-  from tensorflow_nufft._lib import TUNE
-  rng = np.random.default_rng(95)
-  grid, M = [44, 60, 84], 400_000
-  pts = rng.uniform(-np.pi, np.pi, (M, 3)).astype(np.float32)
-  blob = (np.array([2.9, -3.0, 0.1]) + 2e-3 * rng.standard_normal((60_000, 3))).astype(np.float32)
-  blob = ((blob + np.pi) % (2 * np.pi) - np.pi).astype(np.float32)
-  pts = np.concatenate([pts, blob])
-  f = (rng.uniform(-.5, .5, [2] + grid) + 1j * rng.uniform(-.5, .5, [2] + grid)).astype(np.complex64)
-  outs = {}
-  for stack in ('STACK_OFF', 'STACK_ON'):
-    plan = tfft.Plan('type_2', grid, 'backward', tol=tol, num_transforms=2, tuning=TUNE[stack])
-    assert plan.info().kernel_width <= 6
-    plan.set_points(_dev(pts))
-    st = plan.stacks()
-    assert (st.shape[0] > 0) == (stack == 'STACK_ON')
-    if stack == 'STACK_ON':
-      assert (st[:, 2] >= 0).sum() >= 8          # the blob's tile: pieces
-    outs[stack] = plan.execute(_dev(f)).cpu().numpy()
-    plan.close()
-  assert np.array_equal(outs['STACK_ON'], outs['STACK_OFF'])
-  truth = oracle.nufft(f[1].astype(np.complex128), pts, None, 'type_2', 'backward', tol=1e-12, sigma=2.0)
-  assert rel_l2(outs['STACK_ON'][1], truth) < tol
-  # default rule: this density takes the stacks; the interp op of a spread_only plan too
-  plan = tfft.Plan('type_2', grid, 'backward', tol=tol, num_transforms=2)
-  plan.set_points(_dev(pts))
-  assert plan.stacks().shape[0] > 0
-  assert np.array_equal(plan.execute(_dev(f)).cpu().numpy(), outs['STACK_OFF'])
-  plan.close()
-  g2 = [48, 64, 40]
-  fg = (rng.uniform(-.5, .5, g2) + 1j * rng.uniform(-.5, .5, g2)).astype(np.complex64)
-  res = {}
-  for stack in ('STACK_OFF', 'STACK_ON'):
-    sp = tfft.Plan('type_2', g2, 'backward', tol=tol, spread_only=True, tuning=TUNE[stack])
-    sp.set_points(_dev(pts))
-    res[stack] = sp.interp(_dev(fg)).cpu().numpy()
-    sp.close()
-  assert np.array_equal(res['STACK_ON'], res['STACK_OFF'])
-
-
 def test_radial_mri_example_shape(tfft):
   # the reference's documented use (docs/examples/mri_app.ipynb): 256^2 image, 233-view
   # radial trajectory, type-2 forward to k-space, then density-compensated type-1 backward
