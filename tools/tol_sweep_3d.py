@@ -43,7 +43,7 @@ def main():
   print(f'# strengths: {args.strengths}')
   truth = None
   for tol in [float(t) for t in args.tols.split(',')]:
-    variants = [('r04', 0)]
+    variants = [('r05', 0), ('per subproblem (STACK_OFF)', TUNE['STACK_OFF'])]
     if tol <= 2e-5:
       variants.append(('r03 kernels (FXPATCH_OFF)', TUNE['FXPATCH_OFF']))
     for name, tune in variants:
@@ -56,13 +56,13 @@ def main():
       tm = plan.get_timing()
       i = plan.info()
       line = (f'tol {tol:g} w={i.kernel_width} tile={list(i.tile_dims)} sub<={i.max_subproblem_size} [{name}]: ' +
-              ' '.join(f'{k}={v[0] / max(v[1], 1) * 1e3:.0f}us' for k, v in tm.items() if v[1]))
-      total = sum(v[0] / max(v[1], 1) for v in tm.values() if v[1])
+              ' '.join(f'{k}={v[0] / args.steps * 1e3:.0f}us' for k, v in tm.items() if v[1]))
+      total = sum(v[0] / args.steps for v in tm.values() if v[1])
       line += f' | all stages {total:.2f} ms'
       b = plan.sub_bounds()
       if b.size:
         live = b[b != 0]
-        line += (f' | bounds: {live.size} subproblems, B mean {np.abs(live).mean():.1f} max {np.abs(live).max():.1f}, '
+        line += (f' | bounds: {live.size} {"stacks" if plan.stacks().size else "subproblems"}, B mean {np.abs(live).mean():.1f} max {np.abs(live).max():.1f}, '
                  f'{int((live < 0).sum())} on fp64 planes')
       if tol <= 2e-5 and not args.no_oracle:
         if truth is None:
