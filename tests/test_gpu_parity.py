@@ -1822,6 +1822,70 @@ def test_3d_low_tolerance_fixed_point_over_stacks_and_subproblems(tfft, tol, sta
   assert rel_l2(out, ref) < 0.2 * tol, rel_l2(out, ref)
 
 
+def test_randomised_3d_stacks_vs_fp64_planes(tfft):
+  # r05: the spreaders over STACKS of tiles (forced on: STACK_ON) against double LDS accumulation over subproblems,
+  # 20 seeded random cases over grid (partial last tiles, fewer tile layers than a stack is long, one tile column),
+  # density, width, point distribution (uniform; blob + background: pieces of a tile; a line along z: one column
+  # holds everything; a sheet at one z: one tile layer), strengths (uniform, six decades, a few huge), transforms per
+  # call, stack length / point cap / max_subproblem_size, and entry point. Both run the same kernel table, so the bar
+  # is the fixed-point one: 0.3 tol in relative l2 (+ float rounding of the sums).
+  import os
+  import torch
+  from tensorflow_nufft._lib import TUNE
+  rng = np.random.default_rng(int(os.environ.get('NUFFT_TEST_SEED', '20261004')) + 77)
+  worst, stacked = [], 0
+  for case in range(20):
+    grid = [int(rng.integers(4, 70)) for _ in range(3)]
+    if case % 5 == 0:
+      grid[int(rng.integers(0, 3))] = int(rng.integers(4, 9))          # one tile (or one layer) in some dimension
+    tol = float(rng.choice([1e-6, 1e-5, 1e-4, 1e-3, 1e-2]))
+    ncell = 8 * grid[0] * grid[1] * grid[2]
+    M = max(1, min(int(ncell * float(rng.choice([0.004, 0.03, 0.1, 0.22, 0.6]))), 600_000))
+    dist = int(rng.integers(0, 4))
+    pts = rng.uniform(-np.pi, np.pi, (M, 3))
+    if dist == 1:
+      k = M // 3
+      pts[:k] = rng.uniform(-np.pi, np.pi, (1, 3)) + 2e-2 * rng.standard_normal((k, 3))
+    elif dist == 2:
+      pts[:, 1:] = rng.uniform(-np.pi, np.pi, (1, 2)) + 1e-2 * rng.standard_normal((M, 2))   # (array order: z is axis 0)
+    elif dist == 3:
+      pts[:, 0] = rng.uniform(-np.pi, np.pi) + 1e-2 * rng.standard_normal(M)
+    pts = ((pts + np.pi) % (2 * np.pi) - np.pi).astype(np.float32)
+    nt = int(rng.choice([1, 1, 2]))
+    c = rng.standard_normal((nt, M)) + 1j * rng.standard_normal((nt, M))
+    sk = int(rng.integers(0, 3))
+    if sk == 1:
+      c *= 10.0 ** rng.uniform(-6, 0, (nt, M))
+    elif sk == 2:
+      c[:, rng.integers(0, M, 3)] *= 1e5
+    c = c.astype(np.complex64)
+    if nt == 1:
+      c = c[0]
+    msub = int(rng.choice([0, 0, 300, 1500]))
+    kw = dict(max_subproblem_size=msub) if msub else {}
+    plan = tfft.Plan('type_1', grid, 'forward', tol=tol, num_transforms=nt, tuning=TUNE['STACK_ON'], **kw)
+    plan.stack_params(int(rng.choice([0, 0, 1, 2, 5, 16])), int(rng.choice([0, 0, 512, 3000])))
+    if rng.integers(0, 2) and nt == 1:
+      got = plan.execute_with_points(_dev(pts), _dev(c))
+      n_stacks = plan.stacks().shape[0]
+    else:
+      plan.set_points(_dev(pts))
+      n_stacks = plan.stacks().shape[0]
+      got = plan.execute(_dev(c))
+    got = got.cpu().numpy()
+    plan.close()
+    stacked += n_stacks > 0      # (none: a single tile layer in z, or a grid the fixed-point kernels do not take)
+    dbl = tfft.Plan('type_1', grid, 'forward', tol=tol, num_transforms=nt, lds_accumulate=1, **kw)
+    dbl.set_points(_dev(pts))
+    ref = dbl.execute(_dev(c)).cpu().numpy()
+    dbl.close()
+    err = rel_l2(got, ref)
+    worst.append((err / tol, case, grid, M, tol, dist, sk, nt, msub))
+    assert err < 0.3 * tol + 3e-7, worst[-1]
+  assert stacked >= 14, stacked
+  print('worst err/tol:', max(worst)[:2], 'cases over stacks:', stacked)
+
+
 def test_radial_mri_example_shape(tfft):
   # the reference's documented use (docs/examples/mri_app.ipynb): 256^2 image, 233-view
   # radial trajectory, type-2 forward to k-space, then density-compensated type-1 backward
