@@ -1524,6 +1524,9 @@ __device__ unsigned long long g_phase_log[kPhaseLogWgs * kPhaseSlots];
 #endif
 constexpr double kGroupMinDensity = 0.5;   // points per fine cell
 constexpr double kInterpSortMinDensity = 0.3;   // 3-D interp cell sort pays from here (r01: 0.075 loses, 0.75 and 1.8 win)
+#ifndef NUFFT_GROUP_EXP   // (experiment builds, tools/group_loop_experiment.sh: pieces of the main loop left out -- wrong results, timing only;
+#define NUFFT_GROUP_EXP 0 //  1 no LDS atomics, 2 no staging reads, 4 no kernel evaluation / staging writes)
+#endif
 constexpr int kGroupStage = 32; // points whose kernel values are in LDS at a time (per wave; 16 measured 12 % slower, r02)
 template <typename T> constexpr int kGroupStageOf = sizeof(T) == 8 ? 16 : kGroupStage;   // double: half, same bytes
 constexpr int kGroupBlk = 36;   // staging words per block of 4 points (8 x 4 + 4 pad)
@@ -1693,7 +1696,7 @@ __global__ __launch_bounds__(NW * 64) void spread_2d_w8_group_kernel(
 #pragma unroll 1
     for (int h = 0; h < CH; h += SC) {
       if (h >= npts) break;
-      if (lane >= h && lane < h + SC) {
+      if (!(NUFFT_GROUP_EXP & 4) && lane >= h && lane < h + SC) {
         const int sl = lane - h;
         const int sb = (sl >> 2) * kGroupBlk + (sl & 3);
 #pragma unroll
@@ -1709,9 +1712,13 @@ __global__ __launch_bounds__(NW * 64) void spread_2d_w8_group_kernel(
       const int nround = (nh + 3) & ~3;   // padded lanes hold zeros and are never tails
       T ar = (T)0, ai = (T)0;
       for (int q = 0; q < nround; q += 4) {
+#if NUFFT_GROUP_EXP & 2
+        const v4 ax4 = {(T)q, (T)1, (T)2, (T)3}, br4 = {(T)dx, (T)dy, (T)1, (T)2}, bi4 = {(T)dy, (T)dx, (T)3, (T)4};
+#else
         const v4 ax4 = *reinterpret_cast<const v4*>(kxs + (q >> 2) * kGroupBlk + 4 * dx);
         const v4 br4 = *reinterpret_cast<const v4*>(kyr + (q >> 2) * kGroupBlk + 4 * dy);
         const v4 bi4 = *reinterpret_cast<const v4*>(kyi + (q >> 2) * kGroupBlk + 4 * dy);
+#endif
         const T a[4] = {ax4.x, ax4.y, ax4.z, ax4.w};
         const T br[4] = {br4.x, br4.y, br4.z, br4.w};
         const T bi[4] = {bi4.x, bi4.y, bi4.z, bi4.w};
@@ -1724,8 +1731,12 @@ __global__ __launch_bounds__(NW * 64) void spread_2d_w8_group_kernel(
           ai = fma(a[u], bi[u], ai);
           if (t4 & (1u << u)) {
             const int o = __builtin_amdgcn_readlane(off, h + q + u) + cell;   // byte offset into the re plane
+#if NUFFT_GROUP_EXP & 1
+            if (ar == (T)123.456) plane_re[o & 255] = 1.0;
+#else
             lds_add(reinterpret_cast<double*>(smem_raw + o), (double)ar);
             lds_add(reinterpret_cast<double*>(smem_raw + o) + kWPlane, (double)ai);
+#endif
             ar = (T)0;
             ai = (T)0;
           }
