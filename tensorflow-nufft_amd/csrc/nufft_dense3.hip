@@ -191,6 +191,9 @@ __device__ __forceinline__ void horner3(const float* __restrict__ tab, int nc, f
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+#ifndef NUFFT_DENSE_EXP   // (experiment builds, tools/dense_loop_experiment.sh: pieces of dense3_accumulate left out -- wrong results, timing
+#define NUFFT_DENSE_EXP 0 //  only; 1 no LDS atomics, 2 no staging reads, 4 no kernel evaluation / staging writes)
+#endif
 
 // Phase timestamps (experiment build -DNUFFT_HIP_PHASE_LOG, tools/phase_log_experiment.sh; compiled out otherwise)
 #ifdef NUFFT_HIP_PHASE_LOG
@@ -266,7 +269,7 @@ __device__ __forceinline__ void dense3_accumulate(const SortedPoints<float>& sp,
     for (int h = 0; h < 64 / HALF; ++h) {
       if (h * HALF >= left) break;
       // stage HALF points: pair p holds points 2p, 2p + 1 of this round side by side in every 16-byte slot
-      if (lane / HALF == h) {
+      if (!(NUFFT_DENSE_EXP & 4) && lane / HALF == h) {
         unsigned char* s = stage + (((lane % HALF) >> 1) * SLOTS) * 16 + (lane & 1) * 8;
 #pragma unroll
         for (int x = 0; x < W; ++x) *reinterpret_cast<v2f*>(s + x * 16) = (v2f){kx[x] * cim, kx[x] * cre};
@@ -283,9 +286,13 @@ __device__ __forceinline__ void dense3_accumulate(const SortedPoints<float>& sp,
 #pragma unroll 4
       for (int p = 0; p < HALF / 2; ++p) {
         if (2 * p >= npts) break;
+#if NUFFT_DENSE_EXP & 2
+        const v4f rx = {(float)p, 1.f, 2.f, (float)lane}, ry = {1.f, (float)p, 3.f, 2.f}, rz = {2.f, 1.f, (float)p, 1.f};
+#else
         const v4f rx = *reinterpret_cast<const v4f*>(stage + p * SLOTS * 16 + rd_x);
         const v4f ry = *reinterpret_cast<const v4f*>(stage + p * SLOTS * 16 + rd_y);
         const v4f rz = *reinterpret_cast<const v4f*>(stage + p * SLOTS * 16 + rd_z);
+#endif
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const v2f kxc = u ? (v2f){rx.z, rx.w} : (v2f){rx.x, rx.y};
@@ -303,7 +310,11 @@ __device__ __forceinline__ void dense3_accumulate(const SortedPoints<float>& sp,
                 const float f = yh ? yz.y : yz.x;
                 const v2f fx = __builtin_elementwise_fma(kxc, (v2f){f, f}, magic);
                 const unsigned long long x = __builtin_bit_cast(unsigned long long, fx) + unbias;
+#if NUFFT_DENSE_EXP & 1
+                if (x == 0x123456789ull) *reinterpret_cast<unsigned long long*>(dst) = 1ull;
+#else
                 atomicAdd(reinterpret_cast<unsigned long long*>(dst + (yh * YB * LS + zh * ZB * PS) * 8), x);
+#endif
               }
             }
           } else {
@@ -326,7 +337,11 @@ __device__ __forceinline__ void dense3_accumulate(const SortedPoints<float>& sp,
               for (int zh = 0; zh < NZH; ++zh)
 #pragma unroll
                 for (int yh = 0; yh < NYH; ++yh) {
+#if NUFFT_DENSE_EXP & 1
+                  if (acc[zh * NYH + yh] + unb == 0x123456789ull) *reinterpret_cast<unsigned long long*>(dst) = 1ull;
+#else
                   atomicAdd(reinterpret_cast<unsigned long long*>(dst + (yh * YB * LS + zh * ZB * PS) * 8), acc[zh * NYH + yh] + unb);
+#endif
                   acc[zh * NYH + yh] = 0ull;
                 }
               nrun = 0;
