@@ -2191,6 +2191,9 @@ __device__ __forceinline__ void hornerW(const T* __restrict__ tab, int nc, T z0,
 // in 3-D, where a 46 KB tile lets only three workgroups share a CU.
 // The 64 x 64 tiles of 2-D float type-2 plans (41 KB: three workgroups per CU) take 512 as well: 12 -> 24 waves per CU,
 // config 3 interp 256 -> 241 us (r03; 1024 threads: 260).
+#ifndef NUFFT_INTERP_EXP   // (experiment builds, tools/interp_loop_experiment.sh: 1 no LDS reads, 2 no result stores, 4 no tile load,
+#define NUFFT_INTERP_EXP 0 //  8 results stored in sorted order -- wrong results, timing only)
+#endif
 template <int RANK> constexpr int kInterpThreads = RANK > 2 ? 512 : 256;
 template <typename T, int RANK, int W, int NTHREADS = kInterpThreads<RANK>>
 __global__ __launch_bounds__(NTHREADS) void interp_point_kernel(
@@ -2246,7 +2249,8 @@ __global__ __launch_bounds__(NTHREADS) void interp_point_kernel(
         if (lofs[u] >= 0) tile[lofs[u]] = v[u];
     }
   };
-  if (RANK > 2 && g.tile[0] == 16 && g.tile[1] == 16) load_flat(std::integral_constant<int, 16 + W - 1>());
+  if (NUFFT_INTERP_EXP & 4) { }
+  else if (RANK > 2 && g.tile[0] == 16 && g.tile[1] == 16) load_flat(std::integral_constant<int, 16 + W - 1>());
   else
   // (rows of more than 64 cells -- the 64 x 64 tiles of 2-D type-2 plans, 71 cells with the
   // halo -- take a second sweep for the remaining columns)
@@ -2299,7 +2303,11 @@ __global__ __launch_bounds__(NTHREADS) void interp_point_kernel(
         T rre = (T)0, rim = (T)0;
 #pragma unroll
         for (int dx = 0; dx < W; ++dx) {
+#if NUFFT_INTERP_EXP & 1
+          T2 v; v.x = (T)(dx + dy); v.y = (T)dz;
+#else
           const T2 v = lds_cell(row + dx);
+#endif
           rre = fma(kx[dx], v.x, rre);
           rim = fma(kx[dx], v.y, rim);
         }
@@ -2317,7 +2325,13 @@ __global__ __launch_bounds__(NTHREADS) void interp_point_kernel(
     T2 out;
     out.x = sre * scale;
     out.y = sim * scale;
+#if NUFFT_INTERP_EXP & 2
+    if (out.x == (T)123.456) cc[rec.idx] = out;
+#elif NUFFT_INTERP_EXP & 8
+    cc[j] = out;   // (in sorted order: coalesced)
+#else
     cc[rec.idx] = out;
+#endif
   }
 }
 
