@@ -1588,22 +1588,30 @@ def test_tiny_and_odd_grids(tfft, grid, ttype):
     assert rel_l2(out, ref) < tol, (grid, ttype, tol, rel_l2(out, ref))
 
 
-def test_set_points_and_execute_capture_into_a_hip_graph(tfft):
+@pytest.mark.parametrize('grid,M,tol', [([256, 256], 200000, 1e-6),
+                                        ([64, 64, 64], 100000, 1e-6),     # 3-D over stacks of tiles: plan, bounds, fallback list on the device
+                                        ([64, 64, 64], 100000, 1e-4),     # the low-tolerance stacks
+                                        ([48, 48, 48], 900000, 1e-6)])    # per-subproblem bounds, fixed point + fp64-plane launches
+def test_set_points_and_execute_capture_into_a_hip_graph(tfft, grid, M, tol):
   # after warm-up neither call allocates or synchronises, so the whole transform
-  # (sort, spread, rocFFT, deconvolve) can be captured once and replayed
+  # (sort, [stack plan, bounds,] spread, FFT, deconvolve) can be captured once and replayed
   import torch
   rng = np.random.default_rng(61)
-  M, grid = 200000, [256, 256]
-  pts = _dev(rng.uniform(-np.pi, np.pi, (M, 2)).astype(np.float32))
+  pts = rng.uniform(-np.pi, np.pi, (M, len(grid)))
+  if len(grid) == 3 and M > 500000:
+    pts[: M // 3] = 0.3 + 0.01 * rng.standard_normal((M // 3, 3))      # a blob: flagged subproblems
+  pts = _dev(pts.astype(np.float32))
   c1 = _dev((rng.standard_normal(M) + 1j * rng.standard_normal(M)).astype(np.complex64))
   s = torch.cuda.Stream()
   with torch.cuda.stream(s):
-    plan = tfft.Plan('type_1', grid, 'forward', tol=1e-6)
+    plan = tfft.Plan('type_1', grid, 'forward', tol=tol)
     out = torch.empty(grid, dtype=torch.complex64, device='cuda')
     cbuf = c1.clone()
     for _ in range(2):
       plan.set_points(pts); plan.execute(cbuf, out=out)
     s.synchronize()
+    if len(grid) == 3:
+      assert (plan.stacks().shape[0] > 0) == (M < 500000)
     ref1 = out.clone()
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph, stream=s):
