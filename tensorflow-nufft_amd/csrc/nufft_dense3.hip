@@ -1379,7 +1379,7 @@ __global__ NUFFT_PATCH_BOUNDS void spread_stack3_kernel(
 // spread_dense3_kernel (w <= 6) over a stack (r05): the same z carry as spread_stack3_kernel, without a bound kernel --
 // the step follows the r03 rules on the points that can share a cell, i.e. of two neighbouring tiles of the stack
 // (sum rule: the largest such pair x the launch's largest strength) and the 2^22 range of the FMA conversion (top rule;
-// it binds wherever stacks are taken: below 0.15 points per cell a pair holds < 512 points). One dominant strength
+// it binds at most of the densities stacks are taken at: below 0.12 points per cell a pair of tiles holds < 512 points). One dominant strength
 // (largest > 8 x the mean): the stack's own sum and largest, as a subproblem's. Pieces of tiles with more than
 // fx_max_subs of them are the fp64-plane launches' (crowded_list_kernel lists them as the subproblems they are).
 template <int W, int TZ, bool FUSED>
