@@ -8,7 +8,7 @@ double-precision tol 1e-9 transform of the same data.
 """
 import argparse, os, sys, time
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tensorflow-nufft_amd'))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.environ.get('NUFFT_PKG', os.path.join(ROOT, 'tensorflow-nufft_amd')))
 import numpy as np, torch
 import tensorflow_nufft as tfft
 ap = argparse.ArgumentParser()

@@ -7,7 +7,7 @@ S=/tmp/variants/$1; rm -rf $S; mkdir -p $S/obj
 cp -r tensorflow-nufft_amd/tensorflow_nufft $S/
 C=tensorflow-nufft_amd/csrc
 FL="-O3 -std=c++17 -fPIC -Iinclude -I$C --offload-arch=gfx950 -munsafe-fp-atomics"
-base=$(basename $2 .hip)
+base=$(basename $2 .hip); base=$(basename $base .cpp)   # (.hip or .cpp translation unit)
 /opt/rocm/bin/hipcc $FL $3 -c $C/$2 -o $S/obj/$base.o || exit 1
 OBJS=""
 for o in nufft_kernels nufft_dense3 nufft_wide nufft_line nufft_fft nufft_plan nufft_op; do
