@@ -1527,7 +1527,13 @@ constexpr double kInterpSortMinDensity = 0.3;   // 3-D interp cell sort pays fro
 #ifndef NUFFT_GROUP_EXP   // (experiment builds, tools/group_loop_experiment.sh: pieces of the main loop left out -- wrong results, timing only;
 #define NUFFT_GROUP_EXP 0 //  1 no LDS atomics, 2 no staging reads, 4 no kernel evaluation / staging writes)
 #endif
-constexpr int kGroupStage = 32; // points whose kernel values are in LDS at a time (per wave; 16 measured 12 % slower, r02)
+#ifndef NUFFT_GROUP_STAGE   // (experiment builds: tools/group_shape_experiment.sh)
+#define NUFFT_GROUP_STAGE 32
+#endif
+#ifndef NUFFT_GROUP_NW
+#define NUFFT_GROUP_NW 12
+#endif
+constexpr int kGroupStage = NUFFT_GROUP_STAGE; // points whose kernel values are in LDS at a time (per wave; 16 measured 12 % slower, r02)
 template <typename T> constexpr int kGroupStageOf = sizeof(T) == 8 ? 16 : kGroupStage;   // double: half, same bytes
 constexpr int kGroupBlk = 36;   // staging words per block of 4 points (8 x 4 + 4 pad)
 template <int CH> constexpr int kGroupStageWave = 3 * (CH / 4) * kGroupBlk;   // words per wave (kx, ky re, ky im)
@@ -2862,7 +2868,7 @@ static bool wave8_use_group(const Geom& g, int64_t M) {
 // Defaults from the r01 sweeps (tools/sweep_w8.py, tools/sweep_w8_group.py): 4 x 64
 // for the per-point kernel, 12 x 64 for the cell-grouped one (79 KB of LDS: two
 // workgroups = 24 waves per CU, 3 per SIMD each; 8 x 64 = 16 waves per CU was 8 % slower).
-static int wave8_nw(bool grouped) { return grouped ? 12 : 4; }
+static int wave8_nw(bool grouped) { return grouped ? NUFFT_GROUP_NW : 4; }
 static int wave8_ch(bool) { return 64; }
 constexpr int kW2NW = 4, kW2CH = 64;   // launch shape of spread_wave2_kernel (others measured no better)
 static size_t group_lds(int nw, int ch, bool presorted, int precision = NUFFT_HIP_F32) {
@@ -3129,7 +3135,7 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
             NUFFT_CASE_W8G(6) NUFFT_CASE_W8G(7)
             case 8:
               switch (shape) {
-                NUFFT_LAUNCH_W8G(8, 12, 64)
+                NUFFT_LAUNCH_W8G(8, NUFFT_GROUP_NW, 64)
                 default: return hipErrorInvalidValue;
               }
               break;
