@@ -1535,6 +1535,164 @@ __global__ __launch_bounds__(kDenseNW * 64) void spread_dense3_stack_kernel(
   }
 }
 
+// ---- the fp64-plane fallback of the w = 7, 8 plans, cell-grouped (r05) ----------------------------------------------
+// What set_points leaves to the fp64 planes are subproblems whose count-filter bound is above what the tolerance allows:
+// dense clusters -- a kooshball's centre, hundreds of points per start cell. spread_wave3_kernel (one launch per
+// component) adds every point's 2 x W plane values with LDS atomics: 0.3 ns per point and launch, 1.75 ms for the 2.9e6
+// points of a 256^3 kooshball at M = 3e7 (profiles/r05_kooshball_kernels.txt), a fifth of the transform. Here the
+// subproblem's points are counting-sorted by start cell in LDS (4096 at a time; planes persist across the segments),
+// every lane evaluates its own (dx, dy) taps as patch3_accumulate does, and a run of points that share a start cell is
+// summed in float registers -- W packed FMAs per point -- before ONE set of 2 W ds_add_f64: both fp64 planes in one
+// launch (133 KB, one workgroup of 16 waves per CU; the list is short). Runs of one point cost what the old kernel did.
+constexpr int kFbNW = 16, kFbSeg = 4096, kFbKeys = kDenseTile * kDenseTile * 8;
+constexpr int kFbJoinFrom = 64, kFbJoinMax = 8;   // (as spread_wave3_body: subproblems of a very crowded tile joined per workgroup)
+template <int W> struct FbCfg {
+  using P = PatchCfg<W, 8, 8>;
+  static constexpr int PE = P::plane_elems;   // per component, with the idle lanes' room behind it
+  static constexpr size_t lds_bytes = (size_t)2 * PE * 8 + kFbKeys * 4 + kFbSeg * 2 + 16 * 4 + 64;
+};
+template <int W>
+__device__ __forceinline__ void spread_group3_f64_body(const Geom& g, const SortedPoints<float>& sp, const float* __restrict__ horner,
+                                                       const float* __restrict__ c, float* __restrict__ fw, int64_t c_stride,
+                                                       int64_t fw_stride, float scale, int sub) {
+  using C = PatchCfg<W, 8, 8>;
+  constexpr int LS = C::LS, PS = C::PS, L0 = C::L0, L1 = C::L1, L2 = C::L2, PE = FbCfg<W>::PE;
+  constexpr int NW = kFbNW, NT = NW * 64, IT = kFbSeg / NT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* plane_re = reinterpret_cast<double*>(smem_raw);
+  double* plane_im = plane_re + PE;
+  uint32_t* cnt = reinterpret_cast<uint32_t*>(plane_im + PE);   // [kFbKeys]
+  uint16_t* perm = reinterpret_cast<uint16_t*>(cnt + kFbKeys);  // [kFbSeg]
+  uint32_t* wsum = reinterpret_cast<uint32_t*>(perm + kFbSeg);  // [16]
+  int tb, p0, p1, slot, nsub, chunk, tile_end;
+  if (!locate_subproblem(g, sp.tile_start, sp.sub_start, sub, &tb, &p0, &p1, &slot, &nsub, &chunk, &tile_end)) return;
+  if (nsub > kFbJoinFrom) {   // (float atomics of hundreds of write-outs into the same cells: see spread_wave3_body)
+    int join = (nsub + kFbJoinFrom - 1) / kFbJoinFrom;
+    if (join > kFbJoinMax) join = kFbJoinMax;
+    if (chunk % join) return;
+    const long long end = (long long)p0 + (long long)join * (p1 - p0);
+    p1 = end < (long long)tile_end ? (int)end : tile_end;
+  }
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < 2 * PE; i += NT) plane_re[i] = 0.0;
+  const float2* cc = reinterpret_cast<const float2*>(c) + (int64_t)slot * c_stride;
+  const int rstride = g.fused ? (int)sizeof(FusedRec3) : (int)sizeof(Rec<float>);
+  v2f coef[kPatchCoef];
+  patch3_lane_coef<W>(horner, lane, coef);
+  const int dx = lane & 7, dy = lane >> 3;
+  const int cell_b = (dy * LS + dx) * 8;
+  for (int seg0 = p0; seg0 < p1; seg0 += kFbSeg) {
+    const int n = p1 - seg0 < kFbSeg ? p1 - seg0 : kFbSeg;
+    // counting sort of the segment by start cell (4 + 4 + 3 bits of the packed record)
+    for (int i = tid; i < kFbKeys; i += NT) cnt[i] = 0u;
+    __syncthreads();
+    uint32_t kr[IT];
+#pragma unroll
+    for (int u = 0; u < IT; ++u) {
+      const int i = tid + u * NT;
+      const uint4 w = *reinterpret_cast<const uint4*>(&rec_at(sp.rec, seg0 + (i < n ? i : n - 1), rstride));
+      kr[u] = (w.x >> 28) | ((w.y >> 28) << 4) | ((w.z >> 28) << 8);
+    }
+#pragma unroll
+    for (int u = 0; u < IT; ++u) {
+      const int i = tid + u * NT;
+      if (i < n) kr[u] |= atomicAdd(&cnt[kr[u]], 1u) << 11;
+    }
+    __syncthreads();
+    scan_counts<NT, kFbKeys>(cnt, wsum, tid);
+#pragma unroll
+    for (int u = 0; u < IT; ++u) {
+      const int i = tid + u * NT;
+      if (i < n) perm[cnt[kr[u] & (uint32_t)(kFbKeys - 1)] + (kr[u] >> 11)] = (uint16_t)i;
+    }
+    __syncthreads();
+    const int share = (n + NW - 1) / NW;
+    const int wbeg = wave * share;
+    const int wend = (wbeg + share < n) ? wbeg + share : n;
+    for (int base = wbeg; base < wend; base += 64) {
+      // phase 1: one point per lane
+      const int js = base + lane;
+      int off = -8;
+      float kz[8], z0 = 0.f, z1 = 0.f, cre = 0.f, cim = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) kz[q] = 0.f;
+      if (js < wend) {
+        const PointView<float> pv = unpack_rec<float, 3>(rec_at(sp.rec, seg0 + (int)perm[js], rstride));
+        const float2 cv = cc[pv.idx];
+        cre = cv.x * scale;
+        cim = cv.y * scale;
+        off = ((int)(pv.loc & 1023) + (int)((pv.loc >> 10) & 1023) * LS + (int)((pv.loc >> 20) & 1023) * PS) * 8;
+        z0 = pv.z0;
+        z1 = pv.z1;
+        float h2[W];
+        horner1<W>(horner, pv.z2, h2);
+#pragma unroll
+        for (int q = 0; q < W; ++q) kz[q] = h2[q];
+      }
+      // a point ends a run when the next one starts in another cell (or the chunk / the wave's share ends)
+      const int off_next = __shfl_down(off, 1);
+      const unsigned long long tailm = __ballot(js < wend && (lane == 63 || js == wend - 1 || off_next != off));
+      int left = wend - base;
+      if (left > 64) left = 64;
+      v2f acc[W];
+#pragma unroll
+      for (int dz = 0; dz < W; ++dz) acc[dz] = (v2f){0.f, 0.f};
+      // phase 2: a pass per point -- the lane's taps, then its (dx, dy) column of the W planes into the run's sums
+      for (int q = 0; q < left; ++q) {
+        const v2f zz = {bcast_lane(z0, q), bcast_lane(z1, q)};
+        v2f k = coef[kPatchCoef - 1];
+#pragma unroll
+        for (int j = kPatchCoef - 2; j >= 0; --j) k = __builtin_elementwise_fma(k, zz, coef[j]);
+        const float kxy = k.x * k.y;
+        const v2f wc = (v2f){kxy, kxy} * (v2f){bcast_lane(cre, q), bcast_lane(cim, q)};
+#pragma unroll
+        for (int dz = 0; dz < W; ++dz) {
+          const float kzq = bcast_lane(kz[dz], q);
+          acc[dz] = __builtin_elementwise_fma(wc, (v2f){kzq, kzq}, acc[dz]);
+        }
+        if ((tailm >> q) & 1ull) {   // wave-uniform
+          const int o = __builtin_amdgcn_readlane(off, q) + cell_b;
+          double* pr = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(plane_re) + o);
+#pragma unroll
+          for (int dz = 0; dz < W; ++dz) {
+            lds_add(pr + dz * PS, (double)acc[dz].x);
+            lds_add(pr + dz * PS + PE, (double)acc[dz].y);
+            acc[dz] = (v2f){0.f, 0.f};
+          }
+        }
+      }
+    }
+    __syncthreads();   // (the next segment's sort reuses the counters and the permutation)
+  }
+  // write-out: both planes into the periodic fine grid
+  int t0, t1, t2;
+  tile_coords(g, tb, &t0, &t1, &t2);
+  const int o0 = t0 * kDenseTile, o1 = t1 * kDenseTile, o2 = t2 * 8;
+  float* out = fw + 2 * (int64_t)slot * fw_stride;
+  for (RowWalk r(wave, L1); r.a2 < L2; r.advance(NW, L1)) {
+    const int g1 = wrap1(o1 + r.a1, g.nf[1]);
+    const int g2 = wrap1(o2 + r.a2, g.nf[2]);
+    const int64_t rowbase = (int64_t)g.nf[0] * (g1 + (int64_t)g.nf[1] * g2);
+    const int lrow = r.a2 * PS + r.a1 * LS;
+    if (lane < 2 * L0) {
+      const int a0 = lane >> 1, comp = lane & 1;
+      const float v = (float)plane_re[lrow + a0 + comp * PE];
+      if (v != 0.f) glb_add(&out[2 * (rowbase + wrap1(o0 + a0, g.nf[0])) + comp], v);
+    }
+  }
+}
+// a small persistent grid walks the list of subproblems that set_points left to the fp64 planes (entries follow the count)
+template <int W>
+__global__ __launch_bounds__(kFbNW * 64) void spread_group3_f64_kernel(
+    Geom g, SortedPoints<float> sp, const float* __restrict__ horner, const float* __restrict__ c,
+    float* __restrict__ fw, int64_t c_stride, int64_t fw_stride, float scale) {
+  const int n = sp.fb_list[0];
+  for (int it = blockIdx.x; it < n; it += gridDim.x) {
+    spread_group3_f64_body<W>(g, sp, horner, c, fw, c_stride, fw_stride, scale, sp.fb_list[1 + it]);
+    __syncthreads();   // (the next subproblem zeroes the planes this one's write-out reads)
+  }
+}
 // ---- strengths of one spread launch: largest and summed max(|re c|, |im c|) per slot ----------------------------
 // Two stages, no atomics: a first form had every workgroup add its partial sums to the slot's two floats --
 // 4096 atomics on two addresses, serialised at ~60 ns each: 0.24 ms for a 60 us read of 3e7 strengths.
@@ -1674,6 +1832,23 @@ static hipError_t launch_patch3(const Geom& g, const SortedPoints<float>& sp, co
   spread_patch3_kernel<W, 8, kPatchHalf><<<grid, kPatchNW * 64, C::lds_bytes, stream>>>(g, sp, horner, c, fw, c_stride, fw_stride, scale);
   return hipGetLastError();
 }
+hipError_t launch_spread_group3_fallback(const Geom& g, const SortedPoints<float>& sp, unsigned nsub_bound, const float* horner,
+                                         const float* c, float* fw, int batch, int64_t c_stride, int64_t fw_stride, float scale,
+                                         hipStream_t stream) {
+  if (!sp.fb_list) return hipErrorInvalidValue;
+  const dim3 grid(std::min(nsub_bound, 1024u), (unsigned)batch);
+#define NUFFT_FB(WV)                                                                                                          \
+  {                                                                                                                           \
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(spread_group3_f64_kernel<WV>),                     \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)FbCfg<WV>::lds_bytes);          \
+    if (e != hipSuccess) return e;                                                                                            \
+    spread_group3_f64_kernel<WV><<<grid, kFbNW * 64, FbCfg<WV>::lds_bytes, stream>>>(g, sp, horner, c, fw, c_stride, fw_stride, scale); \
+  }
+  if (g.w == 8) NUFFT_FB(8) else if (g.w == 7) NUFFT_FB(7) else return hipErrorInvalidValue;
+#undef NUFFT_FB
+  return hipGetLastError();
+}
+
 hipError_t launch_spread_patch3(const Geom& g, const SortedPoints<float>& sp, unsigned nsub_bound, const float* horner,
                                 const float* c, float* fw, int batch, int64_t c_stride, int64_t fw_stride, float scale,
                                 hipStream_t stream) {

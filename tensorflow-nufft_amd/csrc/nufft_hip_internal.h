@@ -277,6 +277,10 @@ hipError_t launch_spread_stack3(const Geom& g, const SortedPoints<float>& sp, in
                                 hipStream_t stream);
 // the other fixed-point plans: fb_list from the tiles with more than fx_max_subs subproblems
 hipError_t launch_crowded_list(const Geom& g, const int32_t* sub_start, int* fb_list, hipStream_t stream);
+// the cell-grouped fp64-plane launch for the subproblems on fb_list of a w = 7, 8 fixed-point plan (nufft_dense3.hip)
+hipError_t launch_spread_group3_fallback(const Geom& g, const SortedPoints<float>& sp, unsigned nsub_bound, const float* horner,
+                                         const float* c, float* fw, int batch, int64_t c_stride, int64_t fw_stride, float scale,
+                                         hipStream_t stream);
 // strengths of one spread launch: cstats[slot] = {max, sum} of max(|re c|, |im c|) over the slot's M points;
 // the buffer holds cstats_floats(M, slots) floats (the results, then per-workgroup partial pairs)
 hipError_t launch_cstats(const float* c, int64_t M, int slots, int nblk, int max_slots, int64_t c_stride, float* cstats, hipStream_t stream);

@@ -3240,8 +3240,13 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
             if (g.stack && sp.segs) e = launch_spread_stack3(g, sp, M, horner, c, fw, batch, c_stride, fw_stride, scale, stream); \
             else e = launch_spread_patch3(g, sp, grid.x, horner, c, fw, batch, c_stride, fw_stride, scale, stream); \
             if (e != hipSuccess) return e;                                                       \
-            lds_bytes = wave3_split8_lds(g);                                                     \
-            NUFFT_LAUNCH_W3S8(WW, 1) NUFFT_LAUNCH_W3S8(WW, 2)                                     \
+            if (!(g.tuning & NUFFT_HIP_TUNE_FBGROUP_OFF)) {   /* r05: cell-grouped, both planes in one launch */ \
+              e = launch_spread_group3_fallback(g, sp, grid.x, horner, c, fw, batch, c_stride, fw_stride, scale, stream); \
+              if (e != hipSuccess) return e;                                                     \
+            } else {                                                                             \
+              lds_bytes = wave3_split8_lds(g);                                                   \
+              NUFFT_LAUNCH_W3S8(WW, 1) NUFFT_LAUNCH_W3S8(WW, 2)                                   \
+            }                                                                                    \
           } else if constexpr (WW == 7) { return hipErrorInvalidValue;                           \
           } else if (!g.split_reim) { return hipErrorInvalidValue;                               \
           } else if (wave3_joint_wanted(g, Md)) {   /* thin point sets: both planes, one write-out */   \
