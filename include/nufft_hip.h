@@ -131,8 +131,9 @@ enum {
                                               z, the z halo carried in LDS instead of written out per tile (r05; by default below
                                               0.22 / 0.25 / 1.0 points per fine cell at w = 7, 8 / 5, 6 / <= 4): never / always */
   NUFFT_HIP_TUNE_STACK_ON = 1 << 21,
-  NUFFT_HIP_TUNE_FBGROUP_OFF = 1 << 22,    /* 3-D float w = 7, 8: the subproblems left to the fp64 planes on the r04 kernel (one launch per
-                                              component, an atomic per point and plane) instead of the cell-grouped one (r05) */
+  NUFFT_HIP_TUNE_FBGROUP_OFF = 1 << 22,    /* 3-D float fixed-point plans: the subproblems left to the fp64 planes (bound above the limit,
+                                              crowded tiles) on the r04 kernel (one launch per component, an atomic per point and
+                                              plane) instead of the cell-grouped one (r05) */
   NUFFT_HIP_TUNE_ALL = (1 << 23) - 1       /* every defined bit: plan creation refuses others, and both bits of a pair */
 };
 

@@ -1535,8 +1535,9 @@ __global__ __launch_bounds__(kDenseNW * 64) void spread_dense3_stack_kernel(
   }
 }
 
-// ---- the fp64-plane fallback of the w = 7, 8 plans, cell-grouped (r05) ----------------------------------------------
-// What set_points leaves to the fp64 planes are subproblems whose count-filter bound is above what the tolerance allows:
+// ---- the fp64-plane fallback of the fixed-point plans on 16 x 16 x 8 tiles, cell-grouped (r05) ------------------------
+// What set_points leaves to the fp64 planes are subproblems whose count-filter bound is above what the tolerance allows
+// (w = 7, 8) and the subproblems of tiles with more than fx_max_subs of them (w <= 6):
 // dense clusters -- a kooshball's centre, hundreds of points per start cell. spread_wave3_kernel (one launch per
 // component) adds every point's 2 x W plane values with LDS atomics: 0.3 ns per point and launch, 1.75 ms for the 2.9e6
 // points of a 256^3 kooshball at M = 3e7 (profiles/r05_kooshball_kernels.txt), a fifth of the transform. Here the
@@ -1547,16 +1548,19 @@ __global__ __launch_bounds__(kDenseNW * 64) void spread_dense3_stack_kernel(
 constexpr int kFbNW = 16, kFbSeg = 4096, kFbKeys = kDenseTile * kDenseTile * 8;
 constexpr int kFbJoinFrom = 64, kFbJoinMax = 8;   // (as spread_wave3_body: subproblems of a very crowded tile joined per workgroup)
 template <int W> struct FbCfg {
-  using P = PatchCfg<W, 8, 8>;
-  static constexpr int PE = P::plane_elems;   // per component, with the idle lanes' room behind it
+  static constexpr int LS = kPatchLS, L0 = kDenseTile + W - 1, L1 = kDenseTile + W - 1, L2 = 8 + W - 1, PS = LS * L1;
+  // per component; lanes outside the W x W patch (zero taps) add 0 at their natural 8 x 8 patch address: up to row 22, column
+  // 22 of the last plane, i.e. up to 22 * 24 + 22 - PS + 1 elements behind it
+  static constexpr int pad = (22 * LS + 22 - PS + 1) > 64 ? (22 * LS + 22 - PS + 1) : 64;
+  static constexpr int PE = (PS * L2 + pad + 1) & ~1;
   static constexpr size_t lds_bytes = (size_t)2 * PE * 8 + kFbKeys * 4 + kFbSeg * 2 + 16 * 4 + 64;
 };
 template <int W>
 __device__ __forceinline__ void spread_group3_f64_body(const Geom& g, const SortedPoints<float>& sp, const float* __restrict__ horner,
                                                        const float* __restrict__ c, float* __restrict__ fw, int64_t c_stride,
                                                        int64_t fw_stride, float scale, int sub) {
-  using C = PatchCfg<W, 8, 8>;
-  constexpr int LS = C::LS, PS = C::PS, L0 = C::L0, L1 = C::L1, L2 = C::L2, PE = FbCfg<W>::PE;
+  using C = FbCfg<W>;
+  constexpr int LS = C::LS, PS = C::PS, L0 = C::L0, L1 = C::L1, L2 = C::L2, PE = C::PE;
   constexpr int NW = kFbNW, NT = NW * 64, IT = kFbSeg / NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* plane_re = reinterpret_cast<double*>(smem_raw);
@@ -1844,7 +1848,16 @@ hipError_t launch_spread_group3_fallback(const Geom& g, const SortedPoints<float
     if (e != hipSuccess) return e;                                                                                            \
     spread_group3_f64_kernel<WV><<<grid, kFbNW * 64, FbCfg<WV>::lds_bytes, stream>>>(g, sp, horner, c, fw, c_stride, fw_stride, scale); \
   }
-  if (g.w == 8) NUFFT_FB(8) else if (g.w == 7) NUFFT_FB(7) else return hipErrorInvalidValue;
+  switch (g.w) {
+    case 8: NUFFT_FB(8) break;
+    case 7: NUFFT_FB(7) break;
+    case 6: NUFFT_FB(6) break;
+    case 5: NUFFT_FB(5) break;
+    case 4: NUFFT_FB(4) break;
+    case 3: NUFFT_FB(3) break;
+    case 2: NUFFT_FB(2) break;
+    default: return hipErrorInvalidValue;
+  }
 #undef NUFFT_FB
   return hipGetLastError();
 }

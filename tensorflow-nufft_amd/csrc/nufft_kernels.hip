@@ -3267,8 +3267,13 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
             else e = launch_spread_dense3(g, sp, grid.x, Md, horner, c, fw, batch, c_stride, fw_stride, scale, stream); \
             if (e != hipSuccess) return e;                                                       \
             if (Md > (int64_t)g.fx_max_subs * g.max_sub) {   /* a tile may be crowded: fp64 planes for those */ \
-              lds_bytes = wave3_split_lds(g);                                                    \
-              NUFFT_LAUNCH_W3S(WW, 8, 1) NUFFT_LAUNCH_W3S(WW, 8, 2)                               \
+              if (!(g.tuning & NUFFT_HIP_TUNE_FBGROUP_OFF) && g.ncoef <= 10) {   /* r05: cell-grouped, both planes */ \
+                e = launch_spread_group3_fallback(g, sp, grid.x, horner, c, fw, batch, c_stride, fw_stride, scale, stream); \
+                if (e != hipSuccess) return e;                                                   \
+              } else {                                                                           \
+                lds_bytes = wave3_split_lds(g);                                                  \
+                NUFFT_LAUNCH_W3S(WW, 8, 1) NUFFT_LAUNCH_W3S(WW, 8, 2)                             \
+              }                                                                                  \
             }                                                                                    \
           } else { return hipErrorInvalidValue; }                                                \
         } else { NUFFT_LAUNCH_W3(WW, 8, false) }                                                 \

@@ -1894,14 +1894,15 @@ def test_randomised_3d_stacks_vs_fp64_planes(tfft):
   print('worst err/tol:', max(worst)[:2], 'cases over stacks:', stacked)
 
 
-@pytest.mark.parametrize('tol', [1e-6, 1e-5])
+@pytest.mark.parametrize('tol', [1e-6, 1e-5, 1e-4, 1e-3, 1e-2])
 def test_3d_grouped_fp64_fallback_matches_the_per_point_one(tfft, tol):
   # r05: the subproblems a w = 7, 8 plan leaves to the fp64 planes (count-filter bound above what the tolerance allows)
   # run on spread_group3_f64_kernel -- counting sort by start cell in LDS, runs of equal cells summed in registers, both
   # planes in one launch -- instead of two launches of the per-point kernel (options.tuning FBGROUP_OFF). Point sets:
   # a blob inside one tile (> 64 subproblems of that tile: joined per workgroup, several 4096-point segments), a blob
   # across a tile corner with a uniform background, coincident points, over subproblems and (sparse background) over
-  # stacks; one and three transforms. Both against the fp64 oracle, and against each other.
+  # stacks; one and three transforms; the w <= 6 plans' crowded tiles take the same kernel. Both against the fp64 oracle, and
+  # against each other.
   import torch
   from oracle import oracle
   from tensorflow_nufft._lib import TUNE
@@ -1914,7 +1915,7 @@ def test_3d_grouped_fp64_fallback_matches_the_per_point_one(tfft, tol):
                                              np.array([0.31, -0.2, 0.12]) + 4e-3 * rng.standard_normal((200_000, 3))])),
       'blob on a corner': wrap(np.concatenate([rng.uniform(-np.pi, np.pi, (400_000, 3)),
                                                np.array([np.pi, np.pi, -np.pi]) + 3e-2 * rng.standard_normal((150_000, 3))])),
-      'coincident': wrap(np.concatenate([rng.uniform(-np.pi, np.pi, (20_000, 3)), np.tile([[1.0, -2.0, 0.5]], (30_000, 1))])),
+      'coincident': wrap(np.concatenate([rng.uniform(-np.pi, np.pi, (20_000, 3)), np.tile([[1.0, -2.0, 0.5]], (80_000, 1))])),
   }
   for name, pts in cases.items():
     M = pts.shape[0]
@@ -1927,10 +1928,10 @@ def test_3d_grouped_fp64_fallback_matches_the_per_point_one(tfft, tol):
       outs = {}
       for vname, tune in (('grouped', 0), ('per point', TUNE['FBGROUP_OFF'])):
         plan = tfft.Plan('type_1', grid, 'forward', tol=tol, num_transforms=nt, tuning=tune)
-        assert plan.info().kernel_width in (7, 8)
         plan.set_points(_dev(pts))
-        b = plan.sub_bounds()
-        assert (b < 0).sum() > 0, (name, 'nothing on the fp64 planes')
+        if plan.info().kernel_width >= 7:
+          assert (plan.sub_bounds() < 0).sum() > 0, (name, 'nothing on the fp64 planes')
+        # (w <= 6: the tiles with more than 16 subproblems of 4096 points -- every case here has one -- are the fp64 planes')
         outs[vname] = plan.execute(_dev(c)).cpu().numpy().reshape(truth.shape)
         plan.close()
       for vname, out in outs.items():
