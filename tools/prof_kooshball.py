@@ -1,3 +1,5 @@
+# rocprofv3 target: the 256^3 kooshball at the default tolerance, M = 3e7, four one-call type-1 transforms (profiles/r05_kooshball_kernels*.txt):
+#   rocprofv3 --kernel-trace --stats -d gpurun_out/prof_koosh -o run --output-format csv -- python3 tools/prof_kooshball.py
 import os, sys
 ROOT='/root/repo'
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tensorflow-nufft_amd'))
