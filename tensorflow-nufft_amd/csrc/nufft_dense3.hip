@@ -1558,7 +1558,7 @@ template <int W> struct FbCfg {
 template <int W>
 __device__ __forceinline__ void spread_group3_f64_body(const Geom& g, const SortedPoints<float>& sp, const float* __restrict__ horner,
                                                        const float* __restrict__ c, float* __restrict__ fw, int64_t c_stride,
-                                                       int64_t fw_stride, float scale, int sub) {
+                                                       int64_t fw_stride, float scale, int sub, int y, int batch) {
   using C = FbCfg<W>;
   constexpr int LS = C::LS, PS = C::PS, L0 = C::L0, L1 = C::L1, L2 = C::L2, PE = C::PE;
   constexpr int NW = kFbNW, NT = NW * 64, IT = kFbSeg / NT;
@@ -1570,6 +1570,7 @@ __device__ __forceinline__ void spread_group3_f64_body(const Geom& g, const Sort
   uint32_t* wsum = reinterpret_cast<uint32_t*>(perm + kFbSeg);  // [16]
   int tb, p0, p1, slot, nsub, chunk, tile_end;
   if (!locate_subproblem(g, sp.tile_start, sp.sub_start, sub, &tb, &p0, &p1, &slot, &nsub, &chunk, &tile_end)) return;
+  slot = slot * batch + y;   // (the launch is one workgroup row: `slot` came back as the item; transform y of `batch`)
   if (nsub > kFbJoinFrom) {   // (float atomics of hundreds of write-outs into the same cells: see spread_wave3_body)
     int join = (nsub + kFbJoinFrom - 1) / kFbJoinFrom;
     if (join > kFbJoinMax) join = kFbJoinMax;
@@ -1690,11 +1691,20 @@ __device__ __forceinline__ void spread_group3_f64_body(const Geom& g, const Sort
 template <int W>
 __global__ __launch_bounds__(kFbNW * 64) void spread_group3_f64_kernel(
     Geom g, SortedPoints<float> sp, const float* __restrict__ horner, const float* __restrict__ c,
-    float* __restrict__ fw, int64_t c_stride, int64_t fw_stride, float scale) {
-  const int n = sp.fb_list[0];
-  for (int it = blockIdx.x; it < n; it += gridDim.x) {
-    spread_group3_f64_body<W>(g, sp, horner, c, fw, c_stride, fw_stride, scale, sp.fb_list[1 + it]);
-    __syncthreads();   // (the next subproblem zeroes the planes this one's write-out reads)
+    float* __restrict__ fw, int64_t c_stride, int64_t fw_stride, float scale, int batch) {
+  // (entries cost anything from nothing -- joined subproblems exit -- to a dozen segments: the workgroups draw (entry,
+  // transform) pairs from a counter; dealt in strides, a grid of one workgroup per CU ran 6-10 % longer, r05)
+  __shared__ int next_it;
+  const int n = sp.fb_list[0] * batch;
+  for (;;) {
+    if (threadIdx.x == 0) next_it = atomicAdd(sp.fb_ticket, 1);
+    __syncthreads();
+    const int it = next_it;
+    __syncthreads();   // (everyone has read it before thread 0 draws again; also: the next subproblem zeroes the planes
+                       //  this one's write-out reads)
+    if (it >= n) break;
+    const int e = it / batch;
+    spread_group3_f64_body<W>(g, sp, horner, c, fw, c_stride, fw_stride, scale, sp.fb_list[1 + e], it - e * batch, batch);
   }
 }
 // ---- strengths of one spread launch: largest and summed max(|re c|, |im c|) per slot ----------------------------
@@ -1839,14 +1849,16 @@ static hipError_t launch_patch3(const Geom& g, const SortedPoints<float>& sp, co
 hipError_t launch_spread_group3_fallback(const Geom& g, const SortedPoints<float>& sp, unsigned nsub_bound, const float* horner,
                                          const float* c, float* fw, int batch, int64_t c_stride, int64_t fw_stride, float scale,
                                          hipStream_t stream) {
-  if (!sp.fb_list) return hipErrorInvalidValue;
-  const dim3 grid(std::min(nsub_bound, 1024u), (unsigned)batch);
+  if (!sp.fb_list || !sp.fb_ticket) return hipErrorInvalidValue;
+  const hipError_t e0 = hipMemsetAsync(sp.fb_ticket, 0, sizeof(int), stream);
+  if (e0 != hipSuccess) return e0;
+  const dim3 grid((unsigned)std::min<uint64_t>((uint64_t)nsub_bound * (unsigned)batch, 1024u), 1u);
 #define NUFFT_FB(WV)                                                                                                          \
   {                                                                                                                           \
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(spread_group3_f64_kernel<WV>),                     \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)FbCfg<WV>::lds_bytes);          \
     if (e != hipSuccess) return e;                                                                                            \
-    spread_group3_f64_kernel<WV><<<grid, kFbNW * 64, FbCfg<WV>::lds_bytes, stream>>>(g, sp, horner, c, fw, c_stride, fw_stride, scale); \
+    spread_group3_f64_kernel<WV><<<grid, kFbNW * 64, FbCfg<WV>::lds_bytes, stream>>>(g, sp, horner, c, fw, c_stride, fw_stride, scale, batch); \
   }
   switch (g.w) {
     case 8: NUFFT_FB(8) break;

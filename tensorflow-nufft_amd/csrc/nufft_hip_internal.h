@@ -114,6 +114,7 @@ struct SortedPoints {
   int cstats_slots;           // cstats_slots: the partial pairs start behind that many result pairs)
   const float* sub_bound;     // Geom::fx_patch: [subproblem grid + 1] count-filter bound of every subproblem, negative =
                               // left to the fp64-plane kernels
+  int* fb_ticket;             // (one int: the work counter of the persistent fp64-plane launch, zeroed before it)
   const int* fb_list;         // fixed-point plans: fb_list[0] = how many subproblems set_points left to the fp64-plane
                               // kernels, fb_list[1..] = their launch slots (bound3_kernel / crowded_list_kernel)
   // Geom::stack: the stacks stack_plan_kernel cut ({column, z0 | nz << 16, piece's points or -1}), how many, and

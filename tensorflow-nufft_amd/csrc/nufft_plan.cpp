@@ -786,6 +786,7 @@ SortedPoints<T> sorted_view(nufft_hip_plan p) {
   sp.cstats_blocks = p->cstats ? cstats_blocks(p->M, sp.cstats_slots) : 0;
   sp.sub_bound = p->sub_bound;
   sp.fb_list = p->fb_list;
+  sp.fb_ticket = p->bad_count ? p->bad_count + 2 : nullptr;   // (bad_count[0]: the range check's flag; [2]: this counter)
   sp.segs = p->g.stack ? p->segs + 1 : nullptr;
   sp.seg_count = (const int*)p->segs;
   sp.seg_bound = p->sub_bound;
