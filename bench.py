@@ -471,6 +471,12 @@ def main():
   if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
     sys.exit(spawn_ranks(args, sys.argv[1:]))
 
+  # The JSON line must be the only (and last) thing on stdout. Libraries below write there through C stdio -- RCCL's version
+  # banner is flushed at process exit, i.e. BEHIND anything Python printed -- so file descriptor 1 is pointed at stderr for the
+  # life of the process and the line goes out through a private duplicate of the real stdout.
+  sys.stdout.flush()
+  json_fd = os.dup(1)
+  os.dup2(2, 1)
   import numpy as np   # noqa: F401
   import torch
   world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -538,7 +544,8 @@ def main():
         result['config']['equal_work_efficiency'] = cfg5.get('equal_work_efficiency')
         result['config']['rccl_world_size'] = cfg5.get('rccl_world_size')
   if rank == 0:
-    print(json.dumps(result), flush=True)
+    os.write(json_fd, (json.dumps(result) + '\n').encode())
+  os.close(json_fd)
   if dist is not None:
     dist.destroy_process_group()
 

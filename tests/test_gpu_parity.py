@@ -2926,6 +2926,25 @@ def test_bench_spawns_its_own_ranks():
   assert d['scaling'] == 'strong' and d['value'] > 0
 
 
+def test_bench_json_line_is_all_of_stdout_under_rccl():
+  # RCCL writes its version banner to stdout through C stdio and a pipe delivers it at process exit, BEHIND anything Python
+  # printed (r05: `bench.py ... | tail -1` showed "Librccl path : ..." instead of the line). bench.py points file descriptor 1
+  # at stderr and writes the line through a duplicate of the real stdout: the line is the only thing there.
+  import json
+  import os
+  import subprocess
+  import sys
+  from conftest import ROOT
+  env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
+  r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--force-dist', '--steps', '2', '--warmup', '1',
+                      '--points', '300000', '--no-cpu-baseline', '--no-extras'],
+                     capture_output=True, text=True, env=env, timeout=600)
+  assert r.returncode == 0, r.stderr[-2000:]
+  out = r.stdout.strip().splitlines()
+  assert len(out) == 1 and out[0].startswith('{'), r.stdout[-2000:]
+  assert json.loads(out[0])['n_gpus'] == 1
+
+
 def test_bench_under_the_drivers_launcher():
   # The driver's N > 1 command line: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
   # 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from
