@@ -45,7 +45,10 @@ namespace nufft_hip {
 namespace {
 
 constexpr int kDenseTile = 16;   // tile edge in x and y (the plan's 3-D tiles: 16 x 16 x 8)
-constexpr int kDenseNW = 12;     // waves per workgroup (two workgroups per CU)
+#ifndef NUFFT_DENSE_NW   // (experiment builds)
+#define NUFFT_DENSE_NW 12
+#endif
+constexpr int kDenseNW = NUFFT_DENSE_NW;     // waves per workgroup (two workgroups per CU)
 
 // ---- compile-time lane layout -------------------------------------------------------------------
 
