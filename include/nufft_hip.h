@@ -134,7 +134,9 @@ enum {
   NUFFT_HIP_TUNE_FBGROUP_OFF = 1 << 22,    /* 3-D float fixed-point plans: the subproblems left to the fp64 planes (bound above the limit,
                                               crowded tiles) on the r04 kernel (one launch per component, an atomic per point and
                                               plane) instead of the cell-grouped one (r05) */
-  NUFFT_HIP_TUNE_ALL = (1 << 23) - 1       /* every defined bit: plan creation refuses others, and both bits of a pair */
+  NUFFT_HIP_TUNE_MIXFFT_OFF = 1 << 23,     /* fine-grid dimensions that are not powers of two (or exceed 2048): rocFFT + deconvolve kernel
+                                              instead of the mixed-radix pruned passes (r06); power-of-two grids keep their passes */
+  NUFFT_HIP_TUNE_ALL = (1 << 24) - 1       /* every defined bit: plan creation refuses others, and both bits of a pair */
 };
 
 typedef struct nufft_hip_plan_s* nufft_hip_plan;

@@ -433,6 +433,350 @@ int fft_pass_shape(int n, int kout, int csize, int64_t nlines, int* lw_out, size
   return best;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Mixed-radix passes (r06): every even fine-grid size 2^a 3^b 5^c the reference's
+// next_smooth_int picks (nufft_util.cc:119-133; plan: nufft_plan.h:803-863, cuFFT plan
+// nufft_plan.cu.cc:2227-2285), not only the powers of two. Same data flow as above -- one
+// dimension per launch, output transposed, crop x 1/phi_hat (type 1) / zero-pad (type 2) fused,
+// the first type-1 pass zeroing the fine grid -- but the line transform is a Stockham autosort
+// over a RUNTIME list of radices out of {2, 3, 4, 5, 6, 8, 10} (6 and 10 as Good-Thomas prime-factor
+// butterflies: index permutations known at compile time, no inner twiddles). A pass reads from one
+// LDS line buffer and writes the other (one barrier per pass); its butterflies -- n / radix per line,
+// over the LW lines in flight -- are dealt to the workgroup's threads as one flat range, so every
+// radix fills the threads whatever n / radix is. The first pass of a type-1 line reads global memory
+// directly (consecutive lanes, consecutive 8-byte elements), the last one writes the cropped, scaled
+// modes into the tile [R][kout + 1] that leaves transposed; type 2 mirrors it (tile of gathered mode
+// lines in, last pass writes whole fine-grid lines).
+// ------------------------------------------------------------------------------------------
+constexpr int kMixThreads = 256;
+constexpr int kMixMaxPass = 6;
+constexpr int kMixMaxN = 4096;
+
+template <typename V, typename T>
+__device__ __forceinline__ void dft3(V& v0, V& v1, V& v2, T sgn) {
+  const T s = (T)0.86602540378443864676;
+  const V t1 = cadd(v1, v2);
+  V t2; t2.x = v0.x - (T)0.5 * t1.x; t2.y = v0.y - (T)0.5 * t1.y;
+  V d = csub(v1, v2);
+  d.x *= s; d.y *= s;
+  const V id = mul_i<V, T>(d, sgn);
+  v0 = cadd(v0, t1);
+  v1 = cadd(t2, id);
+  v2 = csub(t2, id);
+}
+template <typename V, typename T>
+__device__ __forceinline__ void dft5(V& v0, V& v1, V& v2, V& v3, V& v4, T sgn) {
+  const T c1 = (T)0.30901699437494742410, c2 = (T)-0.80901699437494742410;
+  const T s1 = (T)0.95105651629515357212, s2 = (T)0.58778525229247312917;
+  const V a1 = cadd(v1, v4), a2 = cadd(v2, v3), b1 = csub(v1, v4), b2 = csub(v2, v3);
+  V r1, r2, i1, i2;
+  r1.x = v0.x + c1 * a1.x + c2 * a2.x; r1.y = v0.y + c1 * a1.y + c2 * a2.y;
+  r2.x = v0.x + c2 * a1.x + c1 * a2.x; r2.y = v0.y + c2 * a1.y + c1 * a2.y;
+  i1.x = s1 * b1.x + s2 * b2.x; i1.y = s1 * b1.y + s2 * b2.y;
+  i2.x = s2 * b1.x - s1 * b2.x; i2.y = s2 * b1.y - s1 * b2.y;
+  const V j1 = mul_i<V, T>(i1, sgn), j2 = mul_i<V, T>(i2, sgn);
+  v0.x += a1.x + a2.x; v0.y += a1.y + a2.y;
+  v1 = cadd(r1, j1); v4 = csub(r1, j1);
+  v2 = cadd(r2, j2); v3 = csub(r2, j2);
+}
+
+// DFT of RAD values in registers, natural order in and out.
+template <typename V, typename T, int RAD>
+__device__ __forceinline__ void dft_small(V (&v)[RAD], T sgn) {
+  if constexpr (RAD == 2) {
+    dft2<V, T>(v[0], v[1]);
+  } else if constexpr (RAD == 3) {
+    dft3<V, T>(v[0], v[1], v[2], sgn);
+  } else if constexpr (RAD == 4) {
+    dft4<V, T>(v[0], v[1], v[2], v[3], sgn);
+  } else if constexpr (RAD == 5) {
+    dft5<V, T>(v[0], v[1], v[2], v[3], v[4], sgn);
+  } else if constexpr (RAD == 8) {
+    dft8<V, T>(v, sgn);
+  } else if constexpr (RAD == 6) {
+    // Good-Thomas 2 x 3: input (3 n1 + 2 n2) mod 6, output (3 k1 + 4 k2) mod 6
+    V a0 = v[0], a1 = v[2], a2 = v[4];   // n1 = 0
+    V b0 = v[3], b1 = v[5], b2 = v[1];   // n1 = 1
+    dft3<V, T>(a0, a1, a2, sgn);
+    dft3<V, T>(b0, b1, b2, sgn);
+    v[0] = cadd(a0, b0); v[3] = csub(a0, b0);
+    v[4] = cadd(a1, b1); v[1] = csub(a1, b1);
+    v[2] = cadd(a2, b2); v[5] = csub(a2, b2);
+  } else if constexpr (RAD == 10) {
+    // Good-Thomas 2 x 5: input (5 n1 + 2 n2) mod 10, output (5 k1 + 6 k2) mod 10
+    V a0 = v[0], a1 = v[2], a2 = v[4], a3 = v[6], a4 = v[8];   // n1 = 0
+    V b0 = v[5], b1 = v[7], b2 = v[9], b3 = v[1], b4 = v[3];   // n1 = 1
+    dft5<V, T>(a0, a1, a2, a3, a4, sgn);
+    dft5<V, T>(b0, b1, b2, b3, b4, sgn);
+    v[0] = cadd(a0, b0); v[5] = csub(a0, b0);
+    v[6] = cadd(a1, b1); v[1] = csub(a1, b1);
+    v[2] = cadd(a2, b2); v[7] = csub(a2, b2);
+    v[8] = cadd(a3, b3); v[3] = csub(a3, b3);
+    v[4] = cadd(a4, b4); v[9] = csub(a4, b4);
+  } else {
+    static_assert(RAD == 2, "radix not implemented");
+  }
+}
+
+// q = j / d for j < 2^16, d < 2^12 with m = floor((2^32 - 1) / d) + 1 (d > 1)
+__device__ __forceinline__ unsigned magic_of(unsigned d) { return 0xFFFFFFFFu / d + 1u; }
+
+template <typename T>
+struct MixCtx {
+  using V = typename C2<T>::type;
+  const V* gin;        // type 1: the first line in flight (global, n elements each)
+  V* gout;             // type 2: the first line in flight (global, n elements each)
+  const V* src;        // LDS line buffers [LW][LB] (padded layout) this pass reads / writes
+  V* dst;
+  V* tile;             // type 1: cropped output rows [R][TS]; type 2: gathered mode rows
+  const V* tw;         // LDS, n / 2 twiddles
+  const T* rf;         // LDS, reciprocal Fourier series of the kept modes
+  int n, K, LB, TS, cur, row0, zero_in;
+  T sgn;
+};
+
+// One pass of radix RAD over the `cur` lines in flight. `first`: inputs from global memory (type 1)
+// or from the tile of mode rows through the zero-padding map (type 2); `last`: outputs to the tile of
+// cropped modes (type 1) or to global memory (type 2).
+template <typename T, int RAD, bool T2>
+__device__ __forceinline__ void mix_pass(const MixCtx<T>& c, int Ns, bool first, bool last) {
+  using V = typename C2<T>::type;
+  const int n = c.n;
+  const int nb = n / RAD;
+  const unsigned m_nb = magic_of((unsigned)nb);
+  const unsigned m_ns = Ns > 1 ? magic_of((unsigned)Ns) : 0u;
+  const int tstep = nb / Ns;   // n / (Ns RAD)
+  const int total = c.cur * nb;
+  const int half = n >> 1;
+  for (int b = threadIdx.x; b < total; b += blockDim.x) {
+    const int l = nb > 1 ? (int)__umulhi((unsigned)b, m_nb) : b;
+    const int j = b - l * nb;
+    V v[RAD];
+    if (first) {
+      if constexpr (T2) {
+        const V* row = c.tile + (c.row0 + l) * c.TS;
+#pragma unroll
+        for (int t = 0; t < RAD; ++t) {
+          int ak = 0;
+          const int idx = bin_to_mode_index(j + t * nb, n, c.K, &ak);
+          V y; y.x = (T)0; y.y = (T)0;
+          if (idx >= 0) {
+            const V z = row[idx];
+            const T sc = c.rf[ak];
+            y.x = z.x * sc; y.y = z.y * sc;
+          }
+          v[t] = y;
+        }
+      } else {
+        const V* row = c.gin + (int64_t)l * n;
+#pragma unroll
+        for (int t = 0; t < RAD; ++t) v[t] = row[j + t * nb];
+        if (c.zero_in) {
+          V zero; zero.x = (T)0; zero.y = (T)0;
+          V* w = const_cast<V*>(row);
+#pragma unroll
+          for (int t = 0; t < RAD; ++t) w[j + t * nb] = zero;
+        }
+      }
+    } else {
+      const V* row = c.src + l * c.LB;
+#pragma unroll
+      for (int t = 0; t < RAD; ++t) v[t] = row[lpad(j + t * nb)];
+    }
+    int k = 0;
+    if (Ns > 1) {
+      k = j - (int)__umulhi((unsigned)j, m_ns) * Ns;
+      const int base = k * tstep;
+#pragma unroll
+      for (int t = 1; t < RAD; ++t) {
+        int ti = t * base;                 // < n
+        const bool neg = ti >= half;
+        if (neg) ti -= half;
+        V w = c.tw[ti];
+        if (neg) { w.x = -w.x; w.y = -w.y; }
+        v[t] = cmul<V, T>(v[t], w);
+      }
+    }
+    dft_small<V, T, RAD>(v, c.sgn);
+    const int o = (j - k) * RAD + k;
+    if (last) {
+      if constexpr (T2) {
+        V* row = c.gout + (int64_t)l * n;
+#pragma unroll
+        for (int t = 0; t < RAD; ++t) row[o + t * Ns] = v[t];
+      } else {
+        V* row = c.tile + (c.row0 + l) * c.TS;
+#pragma unroll
+        for (int t = 0; t < RAD; ++t) {
+          int ak = 0;
+          const int idx = bin_to_mode_index(o + t * Ns, n, c.K, &ak);
+          if (idx >= 0) {
+            const T sc = c.rf[ak];
+            V y; y.x = v[t].x * sc; y.y = v[t].y * sc;
+            row[idx] = y;
+          }
+        }
+      }
+    } else {
+      V* row = c.dst + l * c.LB;
+#pragma unroll
+      for (int t = 0; t < RAD; ++t) row[lpad(o + t * Ns)] = v[t];
+    }
+  }
+}
+
+// T2 = false: type-1 pass (lines of n points in, kout modes out, transposed). T2 = true: type-2 pass
+// (kin modes in, interleaved [element][line]; whole lines of n points out).
+template <typename T, bool T2>
+__global__ __launch_bounds__(kMixThreads) void fft_mixed_kernel(FftPassArgs<T> a) {
+  using V = typename C2<T>::type;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int n = a.n;
+  const int K = T2 ? a.kin : a.kout;        // kept modes of this dimension
+  const int LB = lpad_len(n);
+  const int TS = K + 1;
+  const int LW = a.LW, R = a.R;
+  V* buf0 = reinterpret_cast<V*>(smem_raw);                 // [LW][LB]
+  V* buf1 = buf0 + (size_t)LW * LB;                         // [LW][LB]
+  V* tile = buf1 + (size_t)LW * LB;                         // [R][TS]
+  V* twl = tile + (size_t)R * TS;                           // [n / 2]
+  T* rfl = reinterpret_cast<T*>(twl + (n >> 1));            // [K / 2 + 1]
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  for (int i = tid; i < (n >> 1); i += nthr) twl[i] = a.tw[i];
+  for (int i = tid; i <= (K >> 1); i += nthr) rfl[i] = a.rf[i];
+  const int64_t line0 = (int64_t)blockIdx.x * R;
+  const V* in = a.in + (int64_t)blockIdx.y * a.in_batch;
+  V* __restrict__ out = a.out + (int64_t)blockIdx.y * a.out_batch;
+  const int64_t nl = a.nlines;
+  const int rows = (int)(nl - line0 < R ? nl - line0 : R);   // live lines of this workgroup
+  if constexpr (T2) {
+    // tile[r][m] = in[m nlines + line0 + r]: consecutive lanes take the R lines of one element
+    const int rs = __builtin_ctz(R);          // R is a power of two
+    for (int e = tid; e < (K << rs); e += nthr) {
+      const int m = e >> rs, r = e & (R - 1);
+      if (r < rows) tile[r * TS + m] = in[(int64_t)m * nl + line0 + r];
+    }
+  }
+  __syncthreads();
+  MixCtx<T> c;
+  c.tile = tile; c.tw = twl; c.rf = rfl;
+  c.n = n; c.K = K; c.LB = LB; c.TS = TS; c.zero_in = a.zero_in;
+  c.sgn = (T)a.sgn;
+  for (int g = 0; g < rows; g += LW) {
+    c.cur = rows - g < LW ? rows - g : LW;
+    c.row0 = g;
+    c.gin = T2 ? nullptr : in + (line0 + g) * n;
+    c.gout = T2 ? out + (line0 + g) * n : nullptr;
+    int Ns = 1;
+    for (int p = 0; p < a.npass; ++p) {
+      const int rad = (int)((a.radpack >> (5 * p)) & 31u);
+      c.src = (p & 1) ? buf0 : buf1;
+      c.dst = (p & 1) ? buf1 : buf0;
+      const bool first = p == 0, last = p == a.npass - 1;
+      switch (rad) {
+        case 2: mix_pass<T, 2, T2>(c, Ns, first, last); break;
+        case 3: mix_pass<T, 3, T2>(c, Ns, first, last); break;
+        case 4: mix_pass<T, 4, T2>(c, Ns, first, last); break;
+        case 5: mix_pass<T, 5, T2>(c, Ns, first, last); break;
+        case 6: mix_pass<T, 6, T2>(c, Ns, first, last); break;
+        case 8: mix_pass<T, 8, T2>(c, Ns, first, last); break;
+        case 10: mix_pass<T, 10, T2>(c, Ns, first, last); break;
+        default: break;
+      }
+      Ns *= rad;
+      __syncthreads();
+    }
+  }
+  if constexpr (!T2) {
+    // ---- tile -> out[bin][line]: R consecutive lines per bin
+    const int rs = __builtin_ctz(R);
+    for (int e = tid; e < (K << rs); e += nthr) {
+      const int bin = e >> rs, r = e & (R - 1);
+      if (r < rows) out[(int64_t)bin * nl + line0 + r] = tile[r * TS + bin];
+    }
+  }
+}
+
+// Radices of the passes of an n-point line, fewest passes first, then the largest smallest radix;
+// largest radix first (the first pass multiplies no twiddles). 0: n is not 2^a 3^b 5^c.
+int mix_factor(int n, unsigned* radpack) {
+  static const int kRad[] = {10, 8, 6, 5, 4, 3, 2};
+  int best[kMixMaxPass], bestn = 0, cur[kMixMaxPass];
+  // depth-first over non-increasing radix lists
+  struct Rec {
+    static void go(int rem, int depth, int maxi, int* cur, int* best, int* bestn) {
+      if (rem == 1) {
+        bool better = *bestn == 0 || depth < *bestn;
+        if (!better && depth == *bestn) {
+          // same number of passes: prefer the larger smallest radix, then the larger largest
+          if (cur[depth - 1] != best[depth - 1]) better = cur[depth - 1] > best[depth - 1];
+          else better = cur[0] > best[0];
+        }
+        if (better) { *bestn = depth; for (int i = 0; i < depth; ++i) best[i] = cur[i]; }
+        return;
+      }
+      if (depth >= kMixMaxPass || (*bestn && depth >= *bestn)) return;
+      for (int i = maxi; i < 7; ++i) {
+        if (rem % kRad[i]) continue;
+        cur[depth] = kRad[i];
+        go(rem / kRad[i], depth + 1, i, cur, best, bestn);
+      }
+    }
+  };
+  Rec::go(n, 0, 0, cur, best, &bestn);
+  if (!bestn) return 0;
+  unsigned pk = 0;
+  for (int i = 0; i < bestn; ++i) pk |= (unsigned)best[i] << (5 * i);
+  *radpack = pk;
+  return bestn;
+}
+
+// Lines per workgroup (R, a power of two), lines in flight (LW) and dynamic LDS of one mixed-radix pass
+// with K kept modes; 0: not supported.
+int mix_pass_shape(int n, int K, int csize, int64_t nlines, int* lw_out, size_t* lds) {
+  unsigned pk;
+  if (n < 4 || n > kMixMaxN || (n & 1) || K > n || !mix_factor(n, &pk)) return 0;
+  int best = 0, best_lw = 0, tier = 0;
+  size_t best_lds = 0;
+  for (int R = 16; R >= 2; R /= 2) {
+    if (R * csize < 32) break;                                       // output segments of at least 32 bytes
+    int LW = (8 * kMixThreads + n - 1) / n;                          // about one radix-8 butterfly per thread and pass
+    if (LW > R) LW = R;
+    size_t bytes = 0;
+    for (; LW >= 1; --LW) {
+      bytes = (2 * (size_t)LW * lpad_len(n) + (size_t)R * (K + 1) + (size_t)n / 2) * csize + ((size_t)K / 2 + 1) * (csize / 2);
+      if (bytes <= 160 * 1024) break;
+    }
+    if (LW < 1) continue;
+    const int64_t wgs = (nlines + R - 1) / R;
+    const bool seg64 = R * csize >= 64;
+    const int t = (wgs >= 512 && bytes <= 80 * 1024 && seg64) ? 4 : (wgs >= 256 && seg64) ? 3 : (wgs >= 256 ? 2 : 1);
+    if (t > tier) { tier = t; best = R; best_lw = LW; best_lds = bytes; }
+  }
+  if (!best) return 0;
+  *lw_out = best_lw;
+  *lds = best_lds;
+  return best;
+}
+
+template <typename T>
+hipError_t launch_mixed_pass(FftPassArgs<T> a, bool t2, unsigned nblk, unsigned batch, size_t lds, hipStream_t stream) {
+  a.npass = mix_factor(a.n, &a.radpack);
+  if (!a.npass) return hipErrorInvalidValue;
+  const void* fn = t2 ? reinterpret_cast<const void*>(fft_mixed_kernel<T, true>)
+                      : reinterpret_cast<const void*>(fft_mixed_kernel<T, false>);
+  if (lds > 64 * 1024) {
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  if (t2) fft_mixed_kernel<T, true><<<dim3(nblk, batch), kMixThreads, lds, stream>>>(a);
+  else fft_mixed_kernel<T, false><<<dim3(nblk, batch), kMixThreads, lds, stream>>>(a);
+  return hipGetLastError();
+}
+
+inline bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+
 }  // namespace
 
 bool pruned_fft_supported(const Geom& g, int precision) {
@@ -442,6 +786,11 @@ bool pruned_fft_supported(const Geom& g, int precision) {
     size_t lds;
     int lw;
     if (g.nmodes[d] > g.nf[d]) return false;
+    if (!is_pow2(g.nf[d]) || g.nf[d] > 2048) {
+      // r06: mixed-radix passes for the other smooth sizes
+      if ((g.tuning & NUFFT_HIP_TUNE_MIXFFT_OFF) || !mix_pass_shape(g.nf[d], g.nmodes[d], csize, 1 << 20, &lw, &lds)) return false;
+      continue;
+    }
     // type 1 crops to nmodes, type 2 writes all nf bins: both shapes must fit
     if (!fft_pass_shape(g.nf[d], g.nmodes[d], csize, 1 << 20, &lw, &lds)) return false;
     if (!fft_pass_shape(g.nf[d], g.nf[d], csize, 1 << 20, &lw, &lds)) return false;
@@ -512,11 +861,20 @@ hipError_t launch_pruned_fft(const Geom& g, int type, int iflag, T* fine, T* f, 
     a.radpack = 0;
     size_t lds = 0;
     a.LW = 1;
-    a.R = fft_pass_shape(a.n, a.kout, csize, lines, &a.LW, &lds, gather);
+    const bool mixed = !is_pow2(a.n) || a.n > 2048;
+    a.R = mixed ? mix_pass_shape(a.n, type == 1 ? a.kout : a.kin, csize, lines, &a.LW, &lds)
+                : fft_pass_shape(a.n, a.kout, csize, lines, &a.LW, &lds, gather);
     if (a.R == 0) return hipErrorInvalidValue;
     const int64_t nblk = (lines + a.R - 1) / a.R;
     if (nblk > 2147483647LL || batch > 65535) return hipErrorInvalidValue;
     hipError_t e = hipErrorInvalidValue;
+    if (mixed) {
+      e = launch_mixed_pass<T>(a, type == 2, (unsigned)nblk, (unsigned)batch, lds, stream);
+      if (e != hipSuccess) return e;
+      src = dst;
+      src_batch = a.out_batch;
+      continue;
+    }
     switch (a.n) {
       case 16: e = launch_fft_pass<T, 4>(a, type == 2, gather, (unsigned)nblk, (unsigned)batch, lds, stream); break;
       case 32: e = launch_fft_pass<T, 5>(a, type == 2, gather, (unsigned)nblk, (unsigned)batch, lds, stream); break;

@@ -3127,3 +3127,94 @@ def test_randomised_power_of_two_grids_vs_oracle(tfft):
         same = oracle.nufft(s1.astype(np.complex128), p1, gs, ttype, fd, tol=tol, sigma=2.0)
         ref_err = np.linalg.norm(same - truth) / den
         assert err <= 1.05 * ref_err + (1e-6 if not f64 else 1e-13), (case, rank, grid, f64, tol, M, ttype, fd, B, b, err, ref_err)   # (seed 81: 9.4 tol for the oracle too)
+
+
+def _smooth_sizes(lo, hi):
+  """Mode counts N whose fine grid 2 N is even and 5-smooth but not a power of two."""
+  out = []
+  for n in range(lo, hi + 1):
+    m = 2 * n
+    if m & (m - 1) == 0:
+      continue
+    for p in (2, 3, 5):
+      while m % p == 0:
+        m //= p
+    if m == 1:
+      out.append(n)
+  return out
+
+
+def test_randomised_smooth_grids_vs_oracle(tfft):
+  # r06: fine grids 2^a 3^b 5^c that are NOT powers of two (what the reference's next_smooth_int picks for most MRI
+  # matrix sizes, nufft_util.cc:119-133) take the mixed-radix pruned passes (fft_mixed_kernel: radices 2-10, crop /
+  # zero-pad and the deconvolution fused, nufft_fft.hip). Mixed with power-of-two dimensions in one grid, odd mode
+  # counts (the fine grid is then the next smooth size, not 2 N), ranks 1-3, both precisions, types and signs, some
+  # batched with per-item points. Truth: fp64 oracle (its FFT is numpy's) at sigma 2, tol 1e-12.
+  from oracle import oracle
+  import os
+  rng = np.random.default_rng(int(os.environ.get('NUFFT_TEST_SEED', '20261006')))
+  sizes = {1: _smooth_sizes(6, 1300) + [7, 11, 13, 101, 487, 1999], 2: _smooth_sizes(6, 200) + [16, 64, 7, 33, 77, 123],
+           3: _smooth_sizes(6, 50) + [8, 16, 32, 7, 13, 23]}
+  for case in range(48):
+    rank = int(rng.integers(1, 4))
+    grid = [int(rng.choice(sizes[rank])) for _ in range(rank)]
+    f64 = bool(rng.integers(0, 3) == 0)
+    tol = float(rng.choice([1e-9, 1e-6]) if f64 else rng.choice([1e-6, 1e-4, 1e-2]))
+    M = int(rng.choice([1, 50, 3000, 40000]))
+    ttype = 'type_1' if rng.integers(0, 2) else 'type_2'
+    fd = 'forward' if rng.integers(0, 2) else 'backward'
+    B = int(rng.choice([0, 0, 3]))
+    rdt, cdt = (np.float64, np.complex128) if f64 else (np.float32, np.complex64)
+    lead = [B] if B else []
+    pts = rng.uniform(-np.pi, np.pi, lead + [M, rank]).astype(rdt)
+    if ttype == 'type_1':
+      src = (rng.uniform(-.5, .5, lead + [M]) + 1j * rng.uniform(-.5, .5, lead + [M])).astype(cdt)
+      gs = grid
+    else:
+      src = (rng.uniform(-.5, .5, lead + grid) + 1j * rng.uniform(-.5, .5, lead + grid)).astype(cdt)
+      gs = None
+    out = tfft.nufft(_dev(src), _dev(pts), grid_shape=gs, transform_type=ttype, fft_direction=fd, tol=tol).cpu().numpy()
+    alt = tfft.nufft(_dev(src), _dev(pts), grid_shape=gs, transform_type=ttype, fft_direction=fd, tol=tol,
+                     options=_tuned('MIXFFT_OFF')).cpu().numpy()
+    # second opinion, same spreader: rocFFT + deconvolve kernel differ from the fused passes by FFT rounding only
+    d = np.linalg.norm(out - alt) / max(np.linalg.norm(alt), 1e-300)
+    assert d < (2e-6 if not f64 else 1e-13), (case, rank, grid, f64, tol, M, ttype, fd, B, d)
+    for b in range(max(B, 1)):
+      s1, p1, o1 = (src[b], pts[b], out[b]) if B else (src, pts, out)
+      truth = oracle.nufft(s1.astype(np.complex128), p1, gs, ttype, fd, tol=1e-12, sigma=2.0)
+      den = np.linalg.norm(truth)
+      if ttype == 'type_2' and M < 100:     # few outputs: measure against the uncancelled magnitude
+        den = max(den, np.sqrt(M) * np.linalg.norm(s1) * 1e-3)
+      err = np.linalg.norm(o1 - truth) / den
+      if err >= tol:   # (see test_randomised_geometry_sweep_vs_oracle: the bar is the reference rule at the same tol)
+        same = oracle.nufft(s1.astype(np.complex128), p1, gs, ttype, fd, tol=tol, sigma=2.0)
+        ref_err = np.linalg.norm(same - truth) / den
+        assert err <= 1.05 * ref_err + (1e-6 if not f64 else 1e-13), (case, rank, grid, f64, tol, M, ttype, fd, B, b, err, ref_err)
+
+
+@pytest.mark.parametrize('n', [18, 20, 24, 30, 36, 48, 50, 60, 90, 100, 150, 162, 240, 250, 270, 384, 400, 480, 486, 500, 640, 750,
+                               960, 972, 1000, 1250, 1280, 1458, 1536, 1620, 1920, 2000, 2250, 2560, 3000, 3072, 3750, 4096])
+def test_every_radix_list_of_the_mixed_passes(tfft, n):
+  # one fine-grid length per radix list the factoriser produces (2 ... 6 passes, every radix, lengths up to the LDS
+  # limit): a 2-D transform [n / 2 modes x 12] in both types against rocFFT + deconvolve on the same spread / interp
+  # kernels, and a 1-D type 1 against the oracle
+  from oracle import oracle
+  rng = np.random.default_rng(n)
+  N = n // 2
+  M = 20000
+  pts = rng.uniform(-np.pi, np.pi, (M, 2)).astype(np.float32)
+  c = (rng.uniform(-.5, .5, M) + 1j * rng.uniform(-.5, .5, M)).astype(np.complex64)
+  f = (rng.uniform(-.5, .5, (N, 12)) + 1j * rng.uniform(-.5, .5, (N, 12))).astype(np.complex64)
+  for ttype, src, gs in (('type_1', c, [N, 12]), ('type_2', f, None)):
+    for fd in ('forward', 'backward'):
+      own = tfft.nufft(_dev(src), _dev(pts), grid_shape=gs, transform_type=ttype, fft_direction=fd).cpu().numpy()
+      alt = tfft.nufft(_dev(src), _dev(pts), grid_shape=gs, transform_type=ttype, fft_direction=fd,
+                       options=_tuned('MIXFFT_OFF')).cpu().numpy()
+      assert rel_l2(own, alt) < 1.5e-6, (n, ttype, fd, rel_l2(own, alt))
+  p1 = pts[:4000, :1]
+  out = tfft.nufft(_dev(c[:4000]), _dev(p1), grid_shape=[N], transform_type='type_1').cpu().numpy()
+  truth = oracle.nufft(c[:4000].astype(np.complex128), p1, [N], 'type_1', 'forward', tol=1e-12, sigma=2.0)
+  assert rel_l2(out, truth) < 1.5e-6, (n, rel_l2(out, truth))
+  outd = tfft.nufft(_dev(c[:4000].astype(np.complex128)), _dev(p1.astype(np.float64)), grid_shape=[N], transform_type='type_1',
+                    tol=1e-12).cpu().numpy()
+  assert rel_l2(outd, truth) < 1e-11, (n, rel_l2(outd, truth))
