@@ -441,15 +441,15 @@ int fft_pass_shape(int n, int kout, int csize, int64_t nlines, int* lw_out, size
 // dimension per launch, output transposed, crop x 1/phi_hat (type 1) / zero-pad (type 2) fused,
 // the first type-1 pass zeroing the fine grid -- but the line transform is a Stockham autosort
 // over a RUNTIME list of radices out of {2, 3, 4, 5, 6, 8, 10} (6 and 10 as Good-Thomas prime-factor
-// butterflies: index permutations known at compile time, no inner twiddles). A pass reads from one
-// LDS line buffer and writes the other (one barrier per pass); its butterflies -- n / radix per line,
-// over the LW lines in flight -- are dealt to the workgroup's threads as one flat range, so every
-// radix fills the threads whatever n / radix is. The first pass of a type-1 line reads global memory
-// directly (consecutive lanes, consecutive 8-byte elements), the last one writes the cropped, scaled
-// modes into the tile [R][kout + 1] that leaves transposed; type 2 mirrors it (tile of gathered mode
-// lines in, last pass writes whole fine-grid lines).
+// butterflies: index permutations known at compile time, no inner twiddles). The R lines of a workgroup
+// are transformed IN PLACE in LDS, all at once: a pass's butterflies -- n / radix per line over the R
+// lines -- are dealt to the threads as one flat range (every radix fills the threads whatever n / radix
+// is); a thread reads its butterflies into registers, the workgroup meets, it writes them back. The
+// first pass of a type-1 line reads global memory directly (consecutive lanes, consecutive 8-byte
+// elements), the last one writes the cropped, scaled modes as rows [R][kout + 1] into the same LDS,
+// which leave transposed; type 2 mirrors it (rows of gathered modes in, the last pass writes whole
+// fine-grid lines). R n elements of LDS per workgroup: several workgroups share a CU.
 // ------------------------------------------------------------------------------------------
-constexpr int kMixThreads = 256;
 constexpr int kMixMaxPass = 6;
 constexpr int kMixMaxN = 4096;
 
@@ -525,37 +525,45 @@ __device__ __forceinline__ unsigned magic_of(unsigned d) { return 0xFFFFFFFFu / 
 template <typename T>
 struct MixCtx {
   using V = typename C2<T>::type;
-  const V* gin;        // type 1: the first line in flight (global, n elements each)
-  V* gout;             // type 2: the first line in flight (global, n elements each)
-  const V* src;        // LDS line buffers [LW][LB] (padded layout) this pass reads / writes
-  V* dst;
-  V* tile;             // type 1: cropped output rows [R][TS]; type 2: gathered mode rows
+  const V* gin;        // type 1: the workgroup's first line (global, n elements each)
+  V* gout;             // type 2: the workgroup's first line (global, n elements each)
+  V* buf;              // LDS lines [R][LB] (padded layout), transformed in place; the rows of kept modes
+                       // ([R][TS]: type-2 input, type-1 output) live in the same memory
   const V* tw;         // LDS, n / 2 twiddles
   const T* rf;         // LDS, reciprocal Fourier series of the kept modes
-  int n, K, LB, TS, cur, row0, zero_in;
+  int n, K, LB, TS, rows, zero_in;
   T sgn;
 };
 
-// One pass of radix RAD over the `cur` lines in flight. `first`: inputs from global memory (type 1)
-// or from the tile of mode rows through the zero-padding map (type 2); `last`: outputs to the tile of
-// cropped modes (type 1) or to global memory (type 2).
-template <typename T, int RAD, bool T2>
+// One pass of radix RAD over the workgroup's lines, in place: every thread takes its butterflies' inputs into
+// registers (at most VPT values rounded up to whole butterflies), the workgroup meets, every thread writes its
+// outputs. `first`: inputs from global memory (type 1) or from the rows of modes through the zero-padding map
+// (type 2); `last`: outputs to the rows of cropped modes (type 1) or to global memory (type 2).
+template <typename T, int RAD, int VPT, bool T2>
 __device__ __forceinline__ void mix_pass(const MixCtx<T>& c, int Ns, bool first, bool last) {
   using V = typename C2<T>::type;
+  constexpr int ITER = (VPT + RAD - 1) / RAD;
   const int n = c.n;
   const int nb = n / RAD;
   const unsigned m_nb = magic_of((unsigned)nb);
-  const unsigned m_ns = Ns > 1 ? magic_of((unsigned)Ns) : 0u;
-  const int tstep = nb / Ns;   // n / (Ns RAD)
-  const int total = c.cur * nb;
-  const int half = n >> 1;
-  for (int b = threadIdx.x; b < total; b += blockDim.x) {
+  const int total = c.rows * nb;
+  V v[ITER][RAD];
+  int jj[ITER], ll[ITER];
+  // (opaque copy of the thread index: the passes sit in a loop, and the compiler would otherwise hoist every
+  // radix's index arithmetic and addresses out of it and spill them)
+  int tidv = threadIdx.x;
+  asm volatile("" : "+v"(tidv));
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    const int b = tidv + it * blockDim.x;
     const int l = nb > 1 ? (int)__umulhi((unsigned)b, m_nb) : b;
     const int j = b - l * nb;
-    V v[RAD];
+    jj[it] = j;
+    ll[it] = b < total ? l : -1;
+    if (b >= total) continue;
     if (first) {
       if constexpr (T2) {
-        const V* row = c.tile + (c.row0 + l) * c.TS;
+        const V* row = c.buf + l * c.TS;
 #pragma unroll
         for (int t = 0; t < RAD; ++t) {
           int ak = 0;
@@ -566,12 +574,12 @@ __device__ __forceinline__ void mix_pass(const MixCtx<T>& c, int Ns, bool first,
             const T sc = c.rf[ak];
             y.x = z.x * sc; y.y = z.y * sc;
           }
-          v[t] = y;
+          v[it][t] = y;
         }
       } else {
         const V* row = c.gin + (int64_t)l * n;
 #pragma unroll
-        for (int t = 0; t < RAD; ++t) v[t] = row[j + t * nb];
+        for (int t = 0; t < RAD; ++t) v[it][t] = row[j + t * nb];
         if (c.zero_in) {
           V zero; zero.x = (T)0; zero.y = (T)0;
           V* w = const_cast<V*>(row);
@@ -580,10 +588,19 @@ __device__ __forceinline__ void mix_pass(const MixCtx<T>& c, int Ns, bool first,
         }
       }
     } else {
-      const V* row = c.src + l * c.LB;
+      const V* row = c.buf + l * c.LB;
 #pragma unroll
-      for (int t = 0; t < RAD; ++t) v[t] = row[lpad(j + t * nb)];
+      for (int t = 0; t < RAD; ++t) v[it][t] = row[lpad(j + t * nb)];
     }
+  }
+  if (!first || T2) __syncthreads();   // every input of the pass is in registers
+  const unsigned m_ns = Ns > 1 ? magic_of((unsigned)Ns) : 0u;
+  const int tstep = nb / Ns;   // n / (Ns RAD)
+  const int half = n >> 1;
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    const int l = ll[it], j = jj[it];
+    if (l < 0) continue;
     int k = 0;
     if (Ns > 1) {
       k = j - (int)__umulhi((unsigned)j, m_ns) * Ns;
@@ -595,52 +612,51 @@ __device__ __forceinline__ void mix_pass(const MixCtx<T>& c, int Ns, bool first,
         if (neg) ti -= half;
         V w = c.tw[ti];
         if (neg) { w.x = -w.x; w.y = -w.y; }
-        v[t] = cmul<V, T>(v[t], w);
+        v[it][t] = cmul<V, T>(v[it][t], w);
       }
     }
-    dft_small<V, T, RAD>(v, c.sgn);
+    dft_small<V, T, RAD>(v[it], c.sgn);
     const int o = (j - k) * RAD + k;
     if (last) {
       if constexpr (T2) {
         V* row = c.gout + (int64_t)l * n;
 #pragma unroll
-        for (int t = 0; t < RAD; ++t) row[o + t * Ns] = v[t];
+        for (int t = 0; t < RAD; ++t) row[o + t * Ns] = v[it][t];
       } else {
-        V* row = c.tile + (c.row0 + l) * c.TS;
+        V* row = c.buf + l * c.TS;
 #pragma unroll
         for (int t = 0; t < RAD; ++t) {
           int ak = 0;
           const int idx = bin_to_mode_index(o + t * Ns, n, c.K, &ak);
           if (idx >= 0) {
             const T sc = c.rf[ak];
-            V y; y.x = v[t].x * sc; y.y = v[t].y * sc;
+            V y; y.x = v[it][t].x * sc; y.y = v[it][t].y * sc;
             row[idx] = y;
           }
         }
       }
     } else {
-      V* row = c.dst + l * c.LB;
+      V* row = c.buf + l * c.LB;
 #pragma unroll
-      for (int t = 0; t < RAD; ++t) row[lpad(o + t * Ns)] = v[t];
+      for (int t = 0; t < RAD; ++t) row[lpad(o + t * Ns)] = v[it][t];
     }
   }
+  if (!(last && T2)) __syncthreads();
 }
 
 // T2 = false: type-1 pass (lines of n points in, kout modes out, transposed). T2 = true: type-2 pass
-// (kin modes in, interleaved [element][line]; whole lines of n points out).
-template <typename T, bool T2>
-__global__ __launch_bounds__(kMixThreads) void fft_mixed_kernel(FftPassArgs<T> a) {
+// (kin modes in, interleaved [element][line]; whole lines of n points out). blockDim.x >= R n / VPT.
+template <typename T, int VPT, bool T2>
+__global__ __launch_bounds__(kFftMaxThreads) void fft_mixed_kernel(FftPassArgs<T> a) {
   using V = typename C2<T>::type;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int n = a.n;
   const int K = T2 ? a.kin : a.kout;        // kept modes of this dimension
   const int LB = lpad_len(n);
   const int TS = K + 1;
-  const int LW = a.LW, R = a.R;
-  V* buf0 = reinterpret_cast<V*>(smem_raw);                 // [LW][LB]
-  V* buf1 = buf0 + (size_t)LW * LB;                         // [LW][LB]
-  V* tile = buf1 + (size_t)LW * LB;                         // [R][TS]
-  V* twl = tile + (size_t)R * TS;                           // [n / 2]
+  const int R = a.R;
+  V* buf = reinterpret_cast<V*>(smem_raw);                  // [R][LB]
+  V* twl = buf + (size_t)R * LB;                            // [n / 2]
   T* rfl = reinterpret_cast<T*>(twl + (n >> 1));            // [K / 2 + 1]
   const int tid = threadIdx.x, nthr = blockDim.x;
   for (int i = tid; i < (n >> 1); i += nthr) twl[i] = a.tw[i];
@@ -650,50 +666,42 @@ __global__ __launch_bounds__(kMixThreads) void fft_mixed_kernel(FftPassArgs<T> a
   V* __restrict__ out = a.out + (int64_t)blockIdx.y * a.out_batch;
   const int64_t nl = a.nlines;
   const int rows = (int)(nl - line0 < R ? nl - line0 : R);   // live lines of this workgroup
+  const int rs = __builtin_ctz(R);                            // R is a power of two
   if constexpr (T2) {
-    // tile[r][m] = in[m nlines + line0 + r]: consecutive lanes take the R lines of one element
-    const int rs = __builtin_ctz(R);          // R is a power of two
+    // rows of modes: buf[r][m] = in[m nlines + line0 + r]: consecutive lanes take the R lines of one element
     for (int e = tid; e < (K << rs); e += nthr) {
       const int m = e >> rs, r = e & (R - 1);
-      if (r < rows) tile[r * TS + m] = in[(int64_t)m * nl + line0 + r];
+      if (r < rows) buf[r * TS + m] = in[(int64_t)m * nl + line0 + r];
     }
+    __syncthreads();
   }
-  __syncthreads();
   MixCtx<T> c;
-  c.tile = tile; c.tw = twl; c.rf = rfl;
-  c.n = n; c.K = K; c.LB = LB; c.TS = TS; c.zero_in = a.zero_in;
+  c.buf = buf; c.tw = twl; c.rf = rfl;
+  c.n = n; c.K = K; c.LB = LB; c.TS = TS; c.zero_in = a.zero_in; c.rows = rows;
   c.sgn = (T)a.sgn;
-  for (int g = 0; g < rows; g += LW) {
-    c.cur = rows - g < LW ? rows - g : LW;
-    c.row0 = g;
-    c.gin = T2 ? nullptr : in + (line0 + g) * n;
-    c.gout = T2 ? out + (line0 + g) * n : nullptr;
-    int Ns = 1;
-    for (int p = 0; p < a.npass; ++p) {
-      const int rad = (int)((a.radpack >> (5 * p)) & 31u);
-      c.src = (p & 1) ? buf0 : buf1;
-      c.dst = (p & 1) ? buf1 : buf0;
-      const bool first = p == 0, last = p == a.npass - 1;
-      switch (rad) {
-        case 2: mix_pass<T, 2, T2>(c, Ns, first, last); break;
-        case 3: mix_pass<T, 3, T2>(c, Ns, first, last); break;
-        case 4: mix_pass<T, 4, T2>(c, Ns, first, last); break;
-        case 5: mix_pass<T, 5, T2>(c, Ns, first, last); break;
-        case 6: mix_pass<T, 6, T2>(c, Ns, first, last); break;
-        case 8: mix_pass<T, 8, T2>(c, Ns, first, last); break;
-        case 10: mix_pass<T, 10, T2>(c, Ns, first, last); break;
-        default: break;
-      }
-      Ns *= rad;
-      __syncthreads();
+  c.gin = T2 ? nullptr : in + line0 * n;
+  c.gout = T2 ? out + line0 * n : nullptr;
+  int Ns = 1;
+  for (int p = 0; p < a.npass; ++p) {
+    const int rad = (int)((a.radpack >> (5 * p)) & 31u);
+    const bool first = p == 0, last = p == a.npass - 1;
+    switch (rad) {
+      case 2: mix_pass<T, 2, VPT, T2>(c, Ns, first, last); break;
+      case 3: mix_pass<T, 3, VPT, T2>(c, Ns, first, last); break;
+      case 4: mix_pass<T, 4, VPT, T2>(c, Ns, first, last); break;
+      case 5: mix_pass<T, 5, VPT, T2>(c, Ns, first, last); break;
+      case 6: mix_pass<T, 6, VPT, T2>(c, Ns, first, last); break;
+      case 8: mix_pass<T, 8, VPT, T2>(c, Ns, first, last); break;
+      case 10: mix_pass<T, 10, VPT, T2>(c, Ns, first, last); break;
+      default: break;
     }
+    Ns *= rad;
   }
   if constexpr (!T2) {
-    // ---- tile -> out[bin][line]: R consecutive lines per bin
-    const int rs = __builtin_ctz(R);
+    // ---- rows of modes -> out[bin][line]: R consecutive lines per bin
     for (int e = tid; e < (K << rs); e += nthr) {
       const int bin = e >> rs, r = e & (R - 1);
-      if (r < rows) out[(int64_t)bin * nl + line0 + r] = tile[r * TS + bin];
+      if (r < rows) out[(int64_t)bin * nl + line0 + r] = buf[r * TS + bin];
     }
   }
 }
@@ -732,47 +740,56 @@ int mix_factor(int n, unsigned* radpack) {
   return bestn;
 }
 
-// Lines per workgroup (R, a power of two), lines in flight (LW) and dynamic LDS of one mixed-radix pass
-// with K kept modes; 0: not supported.
-int mix_pass_shape(int n, int K, int csize, int64_t nlines, int* lw_out, size_t* lds) {
+// Lines per workgroup (R, a power of two), threads, values per thread (8 / 16) and dynamic LDS of one mixed-radix
+// pass with K kept modes; 0: not supported. The R lines are all in flight: R n elements of LDS and R n / 8 (or / 16)
+// threads, so that several workgroups share a CU (the loads of one overlap the passes of another).
+int mix_pass_shape(int n, int K, int csize, int64_t nlines, int* threads, int* vpt_out, size_t* lds) {
   unsigned pk;
   if (n < 4 || n > kMixMaxN || (n & 1) || K > n || !mix_factor(n, &pk)) return 0;
-  int best = 0, best_lw = 0, tier = 0;
+  int best = 0, best_thr = 0, best_vpt = 0, tier = 0;
   size_t best_lds = 0;
-  for (int R = 16; R >= 2; R /= 2) {
-    if (R * csize < 32) break;                                       // output segments of at least 32 bytes
-    int LW = (8 * kMixThreads + n - 1) / n;                          // about one radix-8 butterfly per thread and pass
-    if (LW > R) LW = R;
-    size_t bytes = 0;
-    for (; LW >= 1; --LW) {
-      bytes = (2 * (size_t)LW * lpad_len(n) + (size_t)R * (K + 1) + (size_t)n / 2) * csize + ((size_t)K / 2 + 1) * (csize / 2);
-      if (bytes <= 160 * 1024) break;
-    }
-    if (LW < 1) continue;
+  for (int R = 16; R >= 1; R /= 2) {
+    if (R * csize < 32 && best) break;                               // output segments of at least 32 bytes where anything else fits
+    const size_t bytes = ((size_t)R * lpad_len(n) + (size_t)n / 2) * csize + ((size_t)K / 2 + 1) * (csize / 2);
+    if (bytes > 160 * 1024) continue;
+    int vpt = 8;
+    int thr = (int)(((int64_t)R * n + 8 * 64 - 1) / (8 * 64)) * 64;
+    if (thr > kFftMaxThreads) { vpt = 16; thr = (int)(((int64_t)R * n + 16 * 64 - 1) / (16 * 64)) * 64; }
+    if (thr > kFftMaxThreads) continue;
     const int64_t wgs = (nlines + R - 1) / R;
+    const int per_cu = std::min((int)(160 * 1024 / bytes), 1536 / thr);   // (72-80 VGPRs: six waves per SIMD)
     const bool seg64 = R * csize >= 64;
-    const int t = (wgs >= 512 && bytes <= 80 * 1024 && seg64) ? 4 : (wgs >= 256 && seg64) ? 3 : (wgs >= 256 ? 2 : 1);
-    if (t > tier) { tier = t; best = R; best_lw = LW; best_lds = bytes; }
+    const int t = (wgs >= 512 && per_cu >= 2 && seg64) ? 4 : (wgs >= 256 && seg64) ? 3 : (wgs >= 256 ? 2 : 1);
+    if (t > tier) { tier = t; best = R; best_thr = thr; best_vpt = vpt; best_lds = bytes; }
   }
   if (!best) return 0;
-  *lw_out = best_lw;
+  *threads = best_thr;
+  *vpt_out = best_vpt;
   *lds = best_lds;
   return best;
 }
 
-template <typename T>
-hipError_t launch_mixed_pass(FftPassArgs<T> a, bool t2, unsigned nblk, unsigned batch, size_t lds, hipStream_t stream) {
-  a.npass = mix_factor(a.n, &a.radpack);
-  if (!a.npass) return hipErrorInvalidValue;
-  const void* fn = t2 ? reinterpret_cast<const void*>(fft_mixed_kernel<T, true>)
-                      : reinterpret_cast<const void*>(fft_mixed_kernel<T, false>);
+template <typename T, int VPT>
+hipError_t launch_mixed_pass_v(const FftPassArgs<T>& a, bool t2, unsigned nblk, unsigned batch, int threads, size_t lds,
+                               hipStream_t stream) {
+  const void* fn = t2 ? reinterpret_cast<const void*>(fft_mixed_kernel<T, VPT, true>)
+                      : reinterpret_cast<const void*>(fft_mixed_kernel<T, VPT, false>);
   if (lds > 64 * 1024) {
     const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  if (t2) fft_mixed_kernel<T, true><<<dim3(nblk, batch), kMixThreads, lds, stream>>>(a);
-  else fft_mixed_kernel<T, false><<<dim3(nblk, batch), kMixThreads, lds, stream>>>(a);
+  if (t2) fft_mixed_kernel<T, VPT, true><<<dim3(nblk, batch), threads, lds, stream>>>(a);
+  else fft_mixed_kernel<T, VPT, false><<<dim3(nblk, batch), threads, lds, stream>>>(a);
   return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_mixed_pass(FftPassArgs<T> a, bool t2, unsigned nblk, unsigned batch, int threads, int vpt, size_t lds,
+                             hipStream_t stream) {
+  a.npass = mix_factor(a.n, &a.radpack);
+  if (!a.npass) return hipErrorInvalidValue;
+  return vpt == 8 ? launch_mixed_pass_v<T, 8>(a, t2, nblk, batch, threads, lds, stream)
+                  : launch_mixed_pass_v<T, 16>(a, t2, nblk, batch, threads, lds, stream);
 }
 
 inline bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
@@ -788,7 +805,8 @@ bool pruned_fft_supported(const Geom& g, int precision) {
     if (g.nmodes[d] > g.nf[d]) return false;
     if (!is_pow2(g.nf[d]) || g.nf[d] > 2048) {
       // r06: mixed-radix passes for the other smooth sizes
-      if ((g.tuning & NUFFT_HIP_TUNE_MIXFFT_OFF) || !mix_pass_shape(g.nf[d], g.nmodes[d], csize, 1 << 20, &lw, &lds)) return false;
+      int vpt;
+      if ((g.tuning & NUFFT_HIP_TUNE_MIXFFT_OFF) || !mix_pass_shape(g.nf[d], g.nmodes[d], csize, 1 << 20, &lw, &vpt, &lds)) return false;
       continue;
     }
     // type 1 crops to nmodes, type 2 writes all nf bins: both shapes must fit
@@ -862,14 +880,15 @@ hipError_t launch_pruned_fft(const Geom& g, int type, int iflag, T* fine, T* f, 
     size_t lds = 0;
     a.LW = 1;
     const bool mixed = !is_pow2(a.n) || a.n > 2048;
-    a.R = mixed ? mix_pass_shape(a.n, type == 1 ? a.kout : a.kin, csize, lines, &a.LW, &lds)
+    int mix_threads = 0, mix_vpt = 0;
+    a.R = mixed ? mix_pass_shape(a.n, type == 1 ? a.kout : a.kin, csize, lines, &mix_threads, &mix_vpt, &lds)
                 : fft_pass_shape(a.n, a.kout, csize, lines, &a.LW, &lds, gather);
     if (a.R == 0) return hipErrorInvalidValue;
     const int64_t nblk = (lines + a.R - 1) / a.R;
     if (nblk > 2147483647LL || batch > 65535) return hipErrorInvalidValue;
     hipError_t e = hipErrorInvalidValue;
     if (mixed) {
-      e = launch_mixed_pass<T>(a, type == 2, (unsigned)nblk, (unsigned)batch, lds, stream);
+      e = launch_mixed_pass<T>(a, type == 2, (unsigned)nblk, (unsigned)batch, mix_threads, mix_vpt, lds, stream);
       if (e != hipSuccess) return e;
       src = dst;
       src_batch = a.out_batch;
