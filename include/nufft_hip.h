@@ -40,7 +40,18 @@
 extern "C" {
 #endif
 
-#define NUFFT_HIP_ABI_VERSION 3
+/* ABI history (additive since 1: a host built against version n runs on any library >= n and can ask
+ * nufft_hip_abi_version() for what it needs):
+ *   1  plan_create / set_points / execute / spread / interp / destroy, plan_get_info, last_error, default_options,
+ *      op_shape / op_compute
+ *   2  plan_create_host, plan_create_ex with allocator callbacks, plan_set_allocator, plan_release_workspace,
+ *      op_compute_ex, execute_with_points, plan_set_stream, timing, plan cache controls, debug_stop_after /
+ *      copy_fine_grid / fseries / eval_kernel / sort_path, plans with several point sets
+ *   3  options.tuning (validated bits), options_from_proto, op_desc_from_attrs, plan_describe
+ *   4  (r06) nufft_hip_build_info. Entries that arrived under version 3's number in r04 / r05 and are guaranteed from
+ *      4 on: debug_sub_bounds, debug_shader_clock_mhz, debug_stacks, debug_stack_params; tuning bits FXPATCH_OFF,
+ *      QFOLD_OFF, STACK_OFF / STACK_ON, FBGROUP_OFF, and r06's MIXFFT_OFF */
+#define NUFFT_HIP_ABI_VERSION 4
 
 /* Status codes. They map onto the tensorflow::errors the reference returns. */
 enum {
@@ -168,6 +179,11 @@ typedef struct nufft_hip_plan_info {
 } nufft_hip_plan_info;
 
 int nufft_hip_abi_version(void);
+/* What this binary is, as one line of key=value pairs separated by ';':
+ * "abi=4;source=<16 hex digits: SHA-256 over the library's sources>;arch=gfx950;experiment=none". A library built with
+ * any of the experiment macros of csrc/nufft_experiment.h (kernel shapes changed, or pieces of a main loop left out
+ * for timing: wrong results) reports them after "experiment=" -- a host or test can refuse it. Static storage. (ABI 4) */
+const char* nufft_hip_build_info(void);
 void nufft_hip_default_options(nufft_hip_options* opts);
 
 /* = Plan::initialize. grid_dims has `rank` entries, x fastest. `stream` is a

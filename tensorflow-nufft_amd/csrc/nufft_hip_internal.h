@@ -3,6 +3,8 @@
 #ifndef NUFFT_HIP_INTERNAL_H_
 #define NUFFT_HIP_INTERNAL_H_
 
+#include "nufft_experiment.h"   // (first: refuses experiment macros without -DNUFFT_EXPERIMENT_BUILD)
+
 #include <hip/hip_runtime.h>
 
 #include <cstdint>

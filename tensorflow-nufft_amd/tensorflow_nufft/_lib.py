@@ -98,6 +98,7 @@ class OpDesc(ctypes.Structure):
 # Every symbol include/nufft_hip.h declares (tests check the export list).
 SYMBOLS = {
     'nufft_hip_abi_version': (ctypes.c_int, []),
+    'nufft_hip_build_info': (ctypes.c_char_p, []),
     'nufft_hip_default_options': (None, [ctypes.POINTER(OptionsStruct)]),
     'nufft_hip_plan_create': (ctypes.c_int, [
         ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int,

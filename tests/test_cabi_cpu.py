@@ -35,7 +35,54 @@ def test_library_exports_every_declared_symbol():
   missing = [n for n in sorted(declared) if not hasattr(handle, n)]
   assert not missing, missing
   assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
-  assert _lib.lib().nufft_hip_abi_version() == 3
+  assert _lib.lib().nufft_hip_abi_version() == 4
+
+
+def _source_digest():
+  import hashlib
+  import subprocess
+  csrc = os.path.join(ROOT, 'tensorflow-nufft_amd', 'csrc')
+  # the Makefile's own list, in its order
+  r = subprocess.run(['make', '-s', '-C', csrc, '--eval', 'print-src: ; @echo $(SRC)', 'print-src'], capture_output=True, text=True)
+  assert r.returncode == 0, r.stderr
+  h = hashlib.sha256()
+  for name in r.stdout.split():
+    h.update(open(os.path.join(csrc, name), 'rb').read())
+  return h.hexdigest()[:16]
+
+
+def test_shipped_library_is_a_product_build_of_this_tree():
+  # (r05 verdict / advisor) The kernels carry experiment switches -- knock-out builds that drop the atomics, the staging
+  # reads, the result stores ("wrong results, timing only"), shape overrides, the phase log. csrc/nufft_experiment.h
+  # refuses them without -DNUFFT_EXPERIMENT_BUILD, and nufft_hip_build_info() reports what a binary was built with:
+  # the library the tests and the bench load must report none, the header's ABI version, and the digest of the
+  # sources in this tree (a stale build fails here, not in a confusing parity test).
+  info = dict(kv.split('=', 1) for kv in _lib.lib().nufft_hip_build_info().decode().split(';'))
+  assert info['experiment'] == 'none', info
+  assert info['abi'] == '4' and info['arch'] == 'gfx950', info
+  assert info['source'] == _source_digest(), (info, 'libnufft_hip.so is older than csrc/: run make -C tensorflow-nufft_amd/csrc')
+
+
+def test_experiment_macros_need_the_experiment_flag(tmp_path):
+  # a stray -DNUFFT_GROUP_EXP=1 (or any other switch of nufft_experiment.h) must not compile into a product build,
+  # and an experiment build says so
+  import subprocess
+  csrc = os.path.join(ROOT, 'tensorflow-nufft_amd', 'csrc')
+  base = ['/opt/rocm/bin/hipcc', '-std=c++17', '-I' + os.path.join(ROOT, 'include'), '-I' + csrc, '-x', 'c++', '-fsyntax-only',
+          os.path.join(csrc, 'nufft_build_info.cpp')]
+  for macro in ('NUFFT_GROUP_EXP=1', 'NUFFT_DENSE_EXP=2', 'NUFFT_INTERP_EXP=8', 'NUFFT_GROUP_NW=8', 'NUFFT_DENSE_NW=8', 'NUFFT_PATCH_NW=16',
+                'NUFFT_PATCH_MINW=2', 'NUFFT_STACK_ROWS=2', 'NUFFT_BOUND_THREADS=256', 'NUFFT_FX_BOUND_LIMIT=1e9', 'NUFFT_HIP_NO_PRELOAD',
+                'NUFFT_HIP_PHASE_LOG', 'NUFFT_GROUP_STAGE=16', 'NUFFT_MIX_SHAPE_ENV'):
+    r = subprocess.run(base + ['-D' + macro], capture_output=True, text=True)
+    assert r.returncode != 0 and 'NUFFT_EXPERIMENT_BUILD' in r.stderr, (macro, r.stderr[-300:])
+  exe = str(tmp_path / 'info')
+  src = str(tmp_path / 'main.cpp')
+  open(src, 'w').write('#include <cstdio>\nextern "C" const char* nufft_hip_build_info(void);\nint main() { std::puts(nufft_hip_build_info()); }\n')
+  r = subprocess.run(['g++', '-std=c++17', '-I' + os.path.join(ROOT, 'include'), '-I' + csrc, '-DNUFFT_EXPERIMENT_BUILD', '-DNUFFT_GROUP_EXP=1',
+                      '-DNUFFT_HIP_PHASE_LOG', os.path.join(csrc, 'nufft_build_info.cpp'), src, '-o', exe], capture_output=True, text=True)
+  assert r.returncode == 0, r.stderr
+  out = subprocess.run([exe], capture_output=True, text=True).stdout
+  assert 'experiment=yes,NUFFT_GROUP_EXP=1,NUFFT_HIP_PHASE_LOG' in out, out
 
 
 def test_default_options_and_struct_layout():

@@ -168,6 +168,36 @@ def test_fine_grid_after_fft_matches_oracle(grid):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('grid', [[96, 128], [24, 40, 32], [60, 50], [45, 64], [250], [20, 18, 25]])
+def test_fused_fft_passes_equal_fft_then_deconvolve(grid):
+  # The product path has no fine grid "after the FFT": its passes crop and deconvolve as they go (power-of-two
+  # dimensions: fft_rotate_kernel; the other smooth sizes, r06: fft_mixed_kernel). The stage pair they replace is
+  # the reference's FFT (nufft_plan.cc:411-427) followed by deconvolve_*d dir 1 (nufft_plan.cc:722-760):
+  # f[k] = FFT(fw)[k mod nf] / prod_d phihat_d[|k_d|] -- built here from the oracle's spread stage, numpy's FFT and
+  # the oracle's Fourier series.
+  from tensorflow_nufft.plan import Plan
+  rank = len(grid)
+  pts, c = _inputs(rank, 30_000, 8)
+  plan = Plan('type_1', grid, fft_direction='backward', tol=1e-6)
+  i = plan.info()
+  w = int(i.kernel_width)
+  nf = [int(i.fine_dims[rank - 1 - d]) for d in range(rank)]
+  plan.set_points(_dev(pts))
+  got = plan.execute(_dev(c)).cpu().numpy().astype(np.complex128)
+  plan.close()
+  fw, _ = oracle.spread_stage(c.astype(np.complex128), pts.astype(np.float64), grid, tol=1e-6, sigma=2.0, w=w)
+  F = oracle.fft(fw, +1)
+  ks = [np.arange(-(n // 2), -(n // 2) + n) for n in grid]
+  ph = [oracle.fseries(nf[d], tol=1e-6, sigma=2.0, w=w) for d in range(rank)]
+  fac = [1.0 / ph[d][np.abs(ks[d])] for d in range(rank)]
+  scale = fac[0]
+  for d in range(1, rank):
+    scale = np.multiply.outer(scale, fac[d])
+  ref = F[np.ix_(*[ks[d] % nf[d] for d in range(rank)])] * scale
+  assert rel_l2(got, ref) < 1e-6, rel_l2(got, ref)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('grid', [[10, 16], [9, 12], [6, 8, 10]])
 def test_fine_grid_after_amplify_matches_definition(grid):
   # type-2 step 1 (reference deconvolve_*d with dir 2, nufft_plan.cc:765-778; GPU Amplify*

@@ -6,8 +6,9 @@ FL="-O3 -std=c++17 -fPIC -Iinclude -I$C --offload-arch=gfx950 -munsafe-fp-atomic
 for nt in 256 384 512; do
   S=/tmp/bound_$nt; rm -rf $S; mkdir -p $S/pkg
   cp -r tensorflow-nufft_amd/tensorflow_nufft $S/pkg/
-  /opt/rocm/bin/hipcc $FL -DNUFFT_BOUND_THREADS=$nt -c $C/nufft_dense3.hip -o $S/d.o || exit 1
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $S/pkg/tensorflow_nufft/libnufft_hip.so $C/_obj/nufft_kernels.o \
+  /opt/rocm/bin/hipcc $FL -DNUFFT_EXPERIMENT_BUILD -DNUFFT_BOUND_THREADS=$nt -c $C/nufft_dense3.hip -o $S/d.o || exit 1
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -Iinclude -I$C -DNUFFT_EXPERIMENT_BUILD -DNUFFT_BOUND_THREADS=$nt -DNUFFT_SOURCE_DIGEST=experiment -x c++ -c $C/nufft_build_info.cpp -o /tmp/nufft_build_info_exp.o || exit 1   # (the variant says what it is: nufft_hip_build_info)
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC /tmp/nufft_build_info_exp.o -o $S/pkg/tensorflow_nufft/libnufft_hip.so $C/_obj/nufft_kernels.o \
     $S/d.o $C/_obj/nufft_wide.o $C/_obj/nufft_line.o $C/_obj/nufft_fft.o $C/_obj/nufft_plan.o $C/_obj/nufft_op.o \
     -L/opt/rocm/lib -lrocfft -Wl,-rpath,/opt/rocm/lib || exit 1
   python3 - $S/pkg $nt <<'PY'

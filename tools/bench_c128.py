@@ -1,0 +1,28 @@
+"""r06: complex128 transforms beside their complex64 twins (same grid, M, tolerance where float reaches it), per-stage
+HIP-event times -> profiles/r06_c128.txt. The reference registers complex128 kernels for all three ops
+(nufft_kernels.cc:624-706)."""
+import os, sys
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tools'))
+import torch
+from bench_nonpow2 import run
+
+if __name__ == '__main__':
+  print(torch.cuda.get_device_name(0))
+  c64, c128 = torch.complex64, torch.complex128
+  which = sys.argv[1:] or ['2d', '3d']
+  if '2d' in which:
+    for tt in ('type_1', 'type_2'):
+      run(tt, [1024, 1024], 10_000_000, 1e-6, 5, dtype=c64)
+      run(tt, [1024, 1024], 10_000_000, 1e-6, 5, dtype=c128)
+      run(tt, [1024, 1024], 10_000_000, 1e-9, 5, dtype=c128)
+      run(tt, [1024, 1024], 10_000_000, 1e-12, 5, dtype=c128)
+  if '3d' in which:
+    for tt in ('type_1', 'type_2'):
+      for M in (10_000_000, 30_000_000):
+        run(tt, [256, 256, 256], M, 1e-6, 3, dtype=c64)
+        run(tt, [256, 256, 256], M, 1e-6, 3, dtype=c128)
+        run(tt, [256, 256, 256], M, 1e-9, 3, dtype=c128)
+      run(tt, [128, 128, 128], 20_000_000, 1e-4, 3, dtype=c64)
+      run(tt, [128, 128, 128], 20_000_000, 1e-4, 3, dtype=c128)
+      run(tt, [128, 128, 128], 10_000_000, 1e-12, 3, dtype=c128)

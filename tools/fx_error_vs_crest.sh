@@ -8,8 +8,9 @@ if [ "$1" = build ]; then
   mkdir -p tools/_exp
   C=tensorflow-nufft_amd/csrc
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -Iinclude -I$C -Wall -Wno-unused-result --offload-arch=gfx950 -munsafe-fp-atomics \
-      -DNUFFT_FX_BOUND_LIMIT=1e9 -x hip -c $C/nufft_plan.cpp -o tools/_exp/nufft_plan_nolimit.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/_exp/libnufft_hip_nolimit.so $C/_obj/nufft_kernels.o $C/_obj/nufft_dense3.o \
+      -DNUFFT_EXPERIMENT_BUILD -DNUFFT_FX_BOUND_LIMIT=1e9 -x hip -c $C/nufft_plan.cpp -o tools/_exp/nufft_plan_nolimit.o
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -Iinclude -I$C -DNUFFT_EXPERIMENT_BUILD -DNUFFT_FX_BOUND_LIMIT=1e9 -DNUFFT_SOURCE_DIGEST=experiment -x c++ -c $C/nufft_build_info.cpp -o /tmp/nufft_build_info_exp.o || exit 1   # (the variant says what it is: nufft_hip_build_info)
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC /tmp/nufft_build_info_exp.o -o tools/_exp/libnufft_hip_nolimit.so $C/_obj/nufft_kernels.o $C/_obj/nufft_dense3.o \
       $C/_obj/nufft_wide.o $C/_obj/nufft_line.o $C/_obj/nufft_fft.o tools/_exp/nufft_plan_nolimit.o $C/_obj/nufft_op.o \
       -L/opt/rocm/lib -lrocfft -Wl,-rpath,/opt/rocm/lib
   exit 0

@@ -7,9 +7,10 @@ S=/tmp/phaselog; rm -rf $S; mkdir -p $S/obj $S/pkg
 cp -r tensorflow-nufft_amd/tensorflow_nufft $S/pkg/
 C=tensorflow-nufft_amd/csrc
 FL="-O3 -std=c++17 -fPIC -Iinclude -I$C --offload-arch=gfx950 -munsafe-fp-atomics"
-/opt/rocm/bin/hipcc $FL -DNUFFT_HIP_PHASE_LOG -c $C/nufft_kernels.hip -o $S/obj/k.o || exit 1
-/opt/rocm/bin/hipcc $FL -DNUFFT_HIP_PHASE_LOG -c $C/nufft_dense3.hip -o $S/obj/d.o || exit 1
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $S/pkg/tensorflow_nufft/libnufft_hip.so $S/obj/k.o \
+/opt/rocm/bin/hipcc $FL -DNUFFT_EXPERIMENT_BUILD -DNUFFT_HIP_PHASE_LOG -c $C/nufft_kernels.hip -o $S/obj/k.o || exit 1
+/opt/rocm/bin/hipcc $FL -DNUFFT_EXPERIMENT_BUILD -DNUFFT_HIP_PHASE_LOG -c $C/nufft_dense3.hip -o $S/obj/d.o || exit 1
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -Iinclude -I$C -DNUFFT_EXPERIMENT_BUILD -DNUFFT_HIP_PHASE_LOG -DNUFFT_SOURCE_DIGEST=experiment -x c++ -c $C/nufft_build_info.cpp -o /tmp/nufft_build_info_exp.o || exit 1   # (the variant says what it is: nufft_hip_build_info)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC /tmp/nufft_build_info_exp.o -o $S/pkg/tensorflow_nufft/libnufft_hip.so $S/obj/k.o \
   $S/obj/d.o $C/_obj/nufft_wide.o $C/_obj/nufft_line.o $C/_obj/nufft_fft.o $C/_obj/nufft_plan.o $C/_obj/nufft_op.o \
   -L/opt/rocm/lib -lrocfft -Wl,-rpath,/opt/rocm/lib || exit 1
 python3 - $S/pkg <<'PY'
