@@ -1902,6 +1902,7 @@ hipError_t launch_bound3(const Geom& g, const Rec<float>* rec, int rec_stride, c
 // tile count allows, at most 16 tiles. Points: 8192, so that workgroups stay of similar length whatever the density
 // (and never below the subproblem cap: pieces are subproblems).
 constexpr double kStackDensity = 0.22;   // points per fine cell below which a w = 7, 8 plan spreads over stacks
+constexpr double kStack64Density = 2.0;  // the same for double-precision plans (r06)
 void stack_params(const Geom& g, int* cap, int* len) {
   int l = g.ntiles / 512;
   l = l < 2 ? 2 : (l > 16 ? 16 : l);
@@ -1930,10 +1931,13 @@ bool stack3_wanted(const Geom& g, int64_t M) {
   // (w = 7, 8: spread_stack3_kernel; w <= 6 on 16 x 16 x 8 tiles: spread_dense3_stack_kernel)
   const bool dense = g.fixed_point && !g.fx_patch && g.rank == 3 && g.w >= 2 && g.w <= 6 && g.tile[0] == kDenseTile &&
                      g.tile[1] == kDenseTile && g.tile[2] == 8;
-  if ((!g.fx_patch && !dense) || g.ntile[2] < 2 || g.ntile[2] > 32767) return false;
+  if ((!g.fx_patch && !dense && !g.fp64_stack) || g.ntile[2] < 2 || g.ntile[2] > 32767) return false;
   const int mode = tune_mode(g, NUFFT_HIP_TUNE_STACK_OFF, NUFFT_HIP_TUNE_STACK_ON);
   if (mode >= 0) return mode != 0;
   const double cells = (double)g.nf[0] * g.nf[1] * g.nf[2] * (g.nitems > 1 ? g.nitems : 1);
+  // double precision (spread_wave3_stack_kernel, nufft_kernels.hip): the depth-4 tiles write 5.7 x the fine grid per
+  // subproblem, and a workgroup per ~1000 fine cells zeroes 97 KB of planes first
+  if (g.fp64_stack) return (double)M < kStack64Density * cells;
   // w <= 6 (spread_dense3_stack_kernel, same file): the fewer atomics a point costs, the longer the write-out shows --
   // w = 6 (4 per point), 256^3 modes, spread stage: 0.075 per cell 2.93 -> 2.33 ms, 0.224: 4.06 -> 3.33, 0.298: 3.67 -> 3.84,
   // 0.745: 7.55 -> 7.91; w = 4 (1 per point): 0.224: 2.87 -> 2.33, 0.373: 3.00 -> 2.81, 0.745: 4.50 -> 4.33

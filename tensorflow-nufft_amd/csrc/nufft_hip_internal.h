@@ -65,6 +65,7 @@ struct Geom {
   // parameters when a debug call overrides the defaults (0: stack_params' rule)
   int stack;
   int stack_len, stack_cap;
+  int fp64_stack;   // r06: double-precision 3-D plan on 16 x 16 x 4 (w = 7, 8) / 16 x 16 x 8 (w <= 6) tiles (fp64 planes): spread_wave3_stack_kernel may walk stacks
 };
 // OFF / ON pair of nufft_hip_options.tuning: -1 = by the plan's own rule, 0 = never, 1 = always
 inline int tune_mode(const Geom& g, int off_bit, int on_bit) { return (g.tuning & on_bit) ? 1 : ((g.tuning & off_bit) ? 0 : -1); }

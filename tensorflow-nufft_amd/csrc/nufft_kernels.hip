@@ -2132,6 +2132,141 @@ __global__ __launch_bounds__(NW * 64) void spread_wave3_kernel(
   spread_wave3_body<T, W, TZ, NW, CH, FX, COMP>(g, sp, horner, c, fw, c_stride, fw_stride, scale, (int)blockIdx.x, false);
 }
 
+// ------------------------- spread: 3-D fp64 planes over STACKS of tiles (r06; double precision)
+//
+// A subproblem of spread_wave3_kernel writes its tile + halo to the fine grid: (16 + W - 1)^2 (TZ + W - 1) cells for a
+// 16 x 16 x TZ tile -- 5.7 x the tile at W = 8 on the depth-4 tiles of the double-precision plans (an LDS cell is 16
+// bytes there), as global fp64 atomics. Below ~1 point per fine cell that write-out, the zero-fill of 97 KB of
+// planes and the launch of one workgroup per ~76 points (256^3 modes, M = 1e7) ARE the double-precision 3-D
+// spreader: 10.1 ms against 2.4 ms for the float transform (profiles/r06_c128_before.txt). The stacks that r05 cut for
+// the float fixed-point kernels (nufft_dense3.hip, stack_plan_kernel: runs of tiles of one (x, y) column,
+// consecutive in z) serve here unchanged: one workgroup walks a stack, after tile t its TZ finished planes are
+// written out, the W - 1 halo planes move down by TZ to be the first planes of tile t + 1 (a chain of up to
+// ceil((TZ + W - 1) / TZ) planes per (y, x) column, moved by the one lane that also writes the column out) and the
+// freed planes are zeroed. Cells written per tile: 23 x 23 x (4 + 7 / nz) instead of 23 x 23 x 11.
+// Pieces (tiles above max_sub points, cut as locate_subproblem would) are stacks of one tile and a point range.
+template <typename T, int W, int TZ, int NW, int CH>
+__global__ __launch_bounds__(NW * 64) void spread_wave3_stack_kernel(
+    Geom g, SortedPoints<T> sp, const T* __restrict__ horner, const T* __restrict__ c,
+    T* __restrict__ fw, int64_t c_stride, int64_t fw_stride, T scale) {
+  using T2 = typename Pair<T>::type;
+  constexpr int LS = 24, L0 = 16 + W - 1, L1 = 16 + W - 1, L2 = TZ + W - 1;
+  constexpr int PS = LS * L1;
+  constexpr int plane = PS * L2;
+  constexpr int PAD = kWave3Pad<W>;
+  constexpr int SW = W <= 6 ? 6 : 8;                                  // staging row length
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* plane_re = reinterpret_cast<double*>(smem_raw);
+  double* plane_im = plane_re + plane;
+  T* stage_all = reinterpret_cast<T*>(plane_re + 2 * plane + PAD);
+  const int s = blockIdx.x;
+  if (s >= sp.seg_count[0]) return;
+  const StackDesc d = stack_load(sp.segs, s);
+  const StackColumn col = stack_column(g, d.col);
+  const int slot = col.item * (int)gridDim.y + (int)blockIdx.y;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < 2 * plane + PAD; i += NW * 64) plane_re[i] = 0.0;
+  const T2* cc = reinterpret_cast<const T2*>(c) + (int64_t)slot * c_stride;
+  const int nc = g.ncoef;
+  T* kxs = stage_all + wave * (CH * 2 * SW);   // [CH][SW]
+  T* kys = kxs + CH * SW;                      // [CH][SW]
+  const int dx = lane & 7, dy = lane >> 3;
+  const bool active = dx < W && dy < W;
+  const int cell = dy * LS + dx;
+  const int o0 = col.t0 * 16, o1 = col.t1 * 16;
+  T* out = fw + 2 * (int64_t)slot * fw_stride;
+  __syncthreads();
+  for (int i = 0; i < d.nz; ++i) {
+    int p0 = d.p0, p1 = d.p1;
+    if (p0 < 0) {
+      const int t = stack_tile_index(g, col, d.z0 + i);
+      p0 = sp.tile_start[t];
+      p1 = sp.tile_start[t + 1];
+    }
+    const int npt = p1 - p0;
+    const int share = (npt + NW - 1) / NW;
+    const int wbeg = p0 + wave * share;
+    const int wend = (wbeg + share < p1) ? wbeg + share : p1;
+    // ---- the tile's points into the planes (the loop of spread_wave3_body, fp64 planes, both components)
+    for (int base = wbeg; base < wend; base += CH) {
+      const int j = base + lane;
+      int off = 0;
+      T kz[W];
+      T cre = (T)0, cim = (T)0;
+#pragma unroll
+      for (int q = 0; q < W; ++q) kz[q] = (T)0;
+      if (lane < CH) {
+        T kx[W], ky[W];
+#pragma unroll
+        for (int q = 0; q < W; ++q) { kx[q] = (T)0; ky[q] = (T)0; }
+        if (j < wend) {
+          const PointView<T> rec = unpack_rec<T, 3>(sp.rec[j]);
+          const T2 cv = cc[rec.idx];
+          cre = cv.x * scale;
+          cim = cv.y * scale;
+          off = (int)(rec.loc & 1023) + (int)((rec.loc >> 10) & 1023) * LS + (int)((rec.loc >> 20) & 1023) * PS;
+          T h0[8], h1[8], h2[8];
+          horner8<T, 3>(horner, nc, rec.z0, rec.z1, rec.z2, h0, h1, h2);
+#pragma unroll
+          for (int q = 0; q < W; ++q) { kx[q] = h0[q]; ky[q] = h1[q]; kz[q] = h2[q]; }
+        }
+#pragma unroll
+        for (int q = 0; q < W; ++q) {
+          kxs[lane * SW + q] = kx[q];
+          kys[lane * SW + q] = ky[q];
+        }
+      }
+      int npts = wend - base;
+      if (npts > CH) npts = CH;
+      T kx_n = kxs[dx], ky_n = kys[dy];
+      for (int q = 0; q < npts; ++q) {
+        const T a = active ? kx_n * ky_n : (T)0;   // (lanes outside the patch add 0 at their natural patch address)
+        const int qn = (q + 1 < npts) ? q + 1 : q;
+        kx_n = kxs[qn * SW + dx];
+        ky_n = kys[qn * SW + dy];
+        const int o = __builtin_amdgcn_readlane(off, q) + cell;
+        const T ar = a * bcast_lane(cre, q);
+        const T ai = a * bcast_lane(cim, q);
+        double* pr = plane_re + o;
+        double* pi = plane_im + o;
+#pragma unroll
+        for (int dz = 0; dz < W; ++dz) {
+          const T kzq = bcast_lane(kz[dz], q);
+          lds_add(pr + dz * PS, (double)(ar * kzq));
+          lds_add(pi + dz * PS, (double)(ai * kzq));
+        }
+      }
+    }
+    __syncthreads();
+    // ---- tile d.z0 + i is complete in its first TZ planes (the last tile of the stack: in all of them)
+    const bool last = i == d.nz - 1;
+    const int o2 = (d.z0 + i) * TZ;
+    const int nrows = (last ? L2 : TZ) * L1;
+    const int e = lane < 2 * L0 ? lane : 2 * L0 - 1, a0 = e >> 1, comp = e & 1;
+    const bool lane_on = lane < 2 * L0;
+    const int gx = wrap1(o0 + a0, g.nf[0]);
+    double* pl = comp ? plane_im : plane_re;
+    for (int rho = wave; rho < nrows; rho += NW) {
+      const int a2 = rho / L1, a1 = rho - a2 * L1;
+      const int lrow = a2 * PS + a1 * LS + a0;
+      const int64_t gbase = (int64_t)g.nf[0] * (wrap1(o1 + a1, g.nf[1]) + (int64_t)g.nf[1] * wrap1(o2 + a2, g.nf[2]));
+      constexpr int CHAIN = (L2 + TZ - 1) / TZ;   // planes a2, a2 + TZ, ... of this (y, x) column
+      double v[CHAIN];
+#pragma unroll
+      for (int m = 0; m < CHAIN; ++m) v[m] = (m == 0 || (!last && a2 + m * TZ < L2)) ? pl[lrow + m * TZ * PS] : 0.0;
+      if (lane_on && v[0] != 0.0) glb_add(&out[2 * (gbase + gx) + comp], (T)v[0]);
+      if (!last && lane_on) {
+#pragma unroll
+        for (int m = 0; m < CHAIN; ++m)
+          if (a2 + m * TZ < L2) pl[lrow + m * TZ * PS] = m + 1 < CHAIN ? v[m + 1] : 0.0;
+      }
+    }
+    if (!last) __syncthreads();
+  }
+}
+
 // Fixed-point plans of the r01-r03 kernels (w <= 6 dense, w = 7 on depth-4 tiles): the subproblems of every tile with more
 // than fx_max_subs of them, as a list for the persistent fp64-plane launches (run in set_points; list[0] = count, zeroed
 // by the launcher)
@@ -3276,6 +3411,14 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
               }                                                                                  \
             }                                                                                    \
           } else { return hipErrorInvalidValue; }                                                \
+        } else if (g.stack && sp.segs) {   /* r06: double precision over stacks of tiles */        \
+          if constexpr (sizeof(T) == 8) {                                                        \
+            const dim3 sgrid(stack_grid_bound(g, M), grid.y);                                    \
+            e = ensure_lds(spread_wave3_stack_kernel<T, WW, 8, 8, 32>, lds_bytes);                \
+            if (e != hipSuccess) return e;                                                       \
+            spread_wave3_stack_kernel<T, WW, 8, 8, 32><<<sgrid, 8 * 64, lds_bytes, stream>>>(     \
+                g, sp, horner, c, fw, c_stride, fw_stride, scale);                               \
+          } else { return hipErrorInvalidValue; }                                                \
         } else { NUFFT_LAUNCH_W3(WW, 8, false) }                                                 \
       } else { return hipErrorInvalidValue; }                                                    \
     } else if (g.tile[2] == 4) {                                                                 \
@@ -3290,6 +3433,14 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
       } else if (g.split_reim) {                                                                 \
         if constexpr (sizeof(T) == 4) { NUFFT_LAUNCH_W3S(WW, 4, 1) NUFFT_LAUNCH_W3S(WW, 4, 2) }   \
         else { return hipErrorInvalidValue; }                                                    \
+      } else if (g.stack && sp.segs) {   /* r06: double precision over stacks of tiles */          \
+        if constexpr (sizeof(T) == 8) {                                                          \
+          const dim3 sgrid(stack_grid_bound(g, M), grid.y);                                      \
+          e = ensure_lds(spread_wave3_stack_kernel<T, WW, 4, 8, 32>, lds_bytes);                  \
+          if (e != hipSuccess) return e;                                                         \
+          spread_wave3_stack_kernel<T, WW, 4, 8, 32><<<sgrid, 8 * 64, lds_bytes, stream>>>(       \
+              g, sp, horner, c, fw, c_stride, fw_stride, scale);                                 \
+        } else { return hipErrorInvalidValue; }                                                  \
       } else { NUFFT_LAUNCH_W3(WW, 4, false) }                                                   \
     } else { return hipErrorInvalidValue; }                                                      \
     break;

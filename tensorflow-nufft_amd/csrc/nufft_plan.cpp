@@ -607,7 +607,7 @@ int ensure_point_capacity(nufft_hip_plan p, int64_t M, int rec_mult = 1) {
     }
   }
   // fixed-point 3-D plans that spread over stacks of tiles (r05): the stack descriptors
-  const bool stacks = p->g.fixed_point && p->rank == 3 && (p->type == NUFFT_HIP_TYPE_1 || p->opts.spread_only) && stack3_wanted(p->g, M);
+  const bool stacks = (p->g.fixed_point || p->g.fp64_stack) && p->rank == 3 && (p->type == NUFFT_HIP_TYPE_1 || p->opts.spread_only) && stack3_wanted(p->g, M);
   if (stacks) {
     const int64_t need_g = (int64_t)stack_grid_bound(p->g, M) + 1;
     if (need_g > p->cap_segs) {
@@ -728,7 +728,19 @@ int set_points_impl(nufft_hip_plan p, int64_t M, const void* x, const void* y, c
   }
   // stacks of tiles (r05): 3-D fixed-point float plans spread over them
   p->g.stack = (sizeof(T) == 4 && p->g.fixed_point && p->rank == 3 && (!p->g.fx_patch || p->sub_bound) && p->segs && Mtot > 0 &&
-                (p->type == NUFFT_HIP_TYPE_1 || p->opts.spread_only) && stack3_wanted(p->g, Mtot)) ? 1 : 0;
+                (p->type == NUFFT_HIP_TYPE_1 || p->opts.spread_only) && stack3_wanted(p->g, Mtot) &&
+                p->cap_segs >= (int64_t)stack_grid_bound(p->g, Mtot) + 1 &&   // (r05 advisor: the descriptor buffer is this large, not merely present)
+                (!p->g.fx_patch || p->cap_sub_bound >= (int64_t)stack_grid_bound(p->g, Mtot) + 1)) ? 1 : 0;
+  if constexpr (sizeof(T) == 8) {
+    // r06: double-precision fp64 planes over the same stacks (spread_wave3_stack_kernel)
+    p->g.stack = (p->g.fp64_stack && p->segs && Mtot > 0 && (p->type == NUFFT_HIP_TYPE_1 || p->opts.spread_only) &&
+                  p->cap_segs >= (int64_t)stack_grid_bound(p->g, Mtot) + 1 && stack3_wanted(p->g, Mtot)) ? 1 : 0;
+    if (p->g.stack) {
+      hook.begin(STAGE_SORT_CELL);
+      HIP_TRY(p, launch_stack_plan(p->g, p->tile_start, Mtot, p->segs + 1, (int*)p->segs, p->stream));
+      hook.end(STAGE_SORT_CELL);
+    }
+  }
   if constexpr (sizeof(T) == 4) {
     // w = 7, 8 fixed-point plans: the bound that fixes every subproblem's step (and which of them keep fp64 planes)
     if (p->g.stack && !p->g.fx_patch) {
@@ -1300,6 +1312,8 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
   if (method == NUFFT_HIP_METHOD_TILE_WAVE && rank == 3 && precision == NUFFT_HIP_F32 && (w <= 7 || g.fx_patch) &&
       p->opts.lds_accumulate != 1 && (w <= 6 || g.fx_patch || g.tile[2] == 4))
     g.fixed_point = 1;
+  g.fp64_stack = (method == NUFFT_HIP_METHOD_TILE_WAVE && rank == 3 && precision == NUFFT_HIP_F64 && !g.wide && w >= 2 && w <= 8 &&
+                  g.tile[0] == 16 && g.tile[1] == 16 && g.tile[2] == (w <= 6 ? 8 : 4)) ? 1 : 0;
   if (p->opts.lds_accumulate == 2 && !g.fixed_point) {
     delete p;
     return fail(NUFFT_HIP_INVALID_ARGUMENT,

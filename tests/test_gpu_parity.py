@@ -1839,6 +1839,7 @@ def test_randomised_3d_stacks_vs_fp64_planes(tfft):
   # is the fixed-point one: 0.3 tol in relative l2 (+ float rounding of the sums).
   import os
   import torch
+  from oracle import oracle
   from tensorflow_nufft._lib import TUNE
   rng = np.random.default_rng(int(os.environ.get('NUFFT_TEST_SEED', '20261004')) + 77)
   worst, stacked = [], 0
@@ -1890,6 +1891,16 @@ def test_randomised_3d_stacks_vs_fp64_planes(tfft):
     err = rel_l2(got, ref)
     worst.append((err / tol, case, grid, M, tol, dist, sk, nt, msub))
     assert err < 0.3 * tol + 3e-7, worst[-1]
+    # r06 (r05 verdict): and PARITY -- both against the fp64 oracle at sigma 2, tol 1e-12, under the bar of the other
+    # randomised tests (the transform's tolerance, or the reference rule's own error at that tolerance where it is larger)
+    for b in range(nt):
+      c1, g1, r1 = (c[b], got[b], ref[b]) if nt > 1 else (c, got, ref)
+      truth = oracle.nufft(c1.astype(np.complex128), pts, grid, 'type_1', 'forward', tol=1e-12, sigma=2.0)
+      for name, o1 in (('stacks', g1), ('fp64 planes', r1)):
+        e = rel_l2(o1, truth)
+        if e >= tol:
+          same = oracle.nufft(c1.astype(np.complex128), pts, grid, 'type_1', 'forward', tol=tol, sigma=2.0)
+          assert e <= 1.05 * rel_l2(same, truth) + 1e-6, (name, e, rel_l2(same, truth), worst[-1])
   assert stacked >= 14, stacked
   print('worst err/tol:', max(worst)[:2], 'cases over stacks:', stacked)
 
@@ -3218,3 +3229,74 @@ def test_every_radix_list_of_the_mixed_passes(tfft, n):
   outd = tfft.nufft(_dev(c[:4000].astype(np.complex128)), _dev(p1.astype(np.float64)), grid_shape=[N], transform_type='type_1',
                     tol=1e-12).cpu().numpy()
   assert rel_l2(outd, truth) < 1e-11, (n, rel_l2(outd, truth))
+
+
+
+@pytest.mark.parametrize('tol', [1e-6, 1e-4, 1e-2])
+def test_double_precision_3d_spread_over_stacks(tfft, tol):
+  # r06: complex128 3-D type 1 / spread at w <= 8 walks the stacks of tiles r05 cut for the float kernels
+  # (spread_wave3_stack_kernel: fp64 planes, the z halo carried in LDS, planes moved down by the tile depth 4 < w - 1:
+  # chains of up to three planes). Forced on and off against the fp64 oracle and each other: uniform points, a blob
+  # that makes pieces of one tile, a line along z (one column holds everything), a grid with partial last tiles in
+  # every dimension and one with a single tile layer but for one; several transforms per call; per-item point sets
+  # (composite tiles); stack length 1, 2, 5 and the default; the spread op.
+  from oracle import oracle
+  from tensorflow_nufft._lib import TUNE
+  rng = np.random.default_rng(606)
+  for grid, M, dist, nt, slen in (([44, 60, 84], 300_000, 0, 1, 0), ([44, 60, 84], 200_000, 1, 2, 2), ([20, 24, 70], 60_000, 2, 1, 5),
+                                  ([9, 33, 12], 20_000, 0, 1, 1), ([64, 64, 64], 150_000, 0, 3, 0), ([6, 6, 40], 3000, 0, 1, 0)):
+    pts = rng.uniform(-np.pi, np.pi, (M, 3))
+    if dist == 1:
+      k = M // 3
+      pts[:k] = np.array([2.9, -3.0, 0.1]) + 2e-3 * rng.standard_normal((k, 3))
+    elif dist == 2:
+      pts[:, 1:] = rng.uniform(-np.pi, np.pi, (1, 2)) + 1e-2 * rng.standard_normal((M, 2))
+    pts = (pts + np.pi) % (2 * np.pi) - np.pi
+    c = rng.standard_normal((nt, M)) + 1j * rng.standard_normal((nt, M))
+    if nt == 1:
+      c = c[0]
+    outs = {}
+    for stack in ('STACK_ON', 'STACK_OFF'):
+      import torch
+      plan = tfft.Plan('type_1', grid, 'forward', tol=tol, num_transforms=nt, dtype=torch.complex128, tuning=TUNE[stack])
+      td = int(plan.info().tile_dims[2])
+      full = list(plan.info().tile_dims) == [16, 16, 4 if plan.info().kernel_width >= 7 else 8]   # (tiny grids shrink the tile: no stacks there)
+      if slen:
+        plan.stack_params(slen, 0)
+      plan.set_points(_dev(pts))
+      layers = (int(plan.info().fine_dims[2]) + td - 1) // td    # tile layers in z
+      assert (plan.stacks().shape[0] > 0) == (stack == 'STACK_ON' and layers >= 2 and full), (grid, stack, plan.stacks().shape)
+      if stack == 'STACK_ON' and dist == 1:
+        assert (plan.stacks()[:, 2] >= 0).sum() > 4     # the blob's tile: pieces
+      outs[stack] = plan.execute(_dev(c)).cpu().numpy()
+      plan.close()
+    assert rel_l2(outs['STACK_ON'], outs['STACK_OFF']) < 1e-12, (grid, rel_l2(outs['STACK_ON'], outs['STACK_OFF']))
+    for b in range(nt):
+      c1, o1 = (c[b], outs['STACK_ON'][b]) if nt > 1 else (c, outs['STACK_ON'])
+      truth = oracle.nufft(c1, pts, grid, 'type_1', 'forward', tol=1e-12, sigma=2.0)
+      e = rel_l2(o1, truth)
+      if e >= tol:
+        same = oracle.nufft(c1, pts, grid, 'type_1', 'forward', tol=tol, sigma=2.0)
+        assert e <= 1.05 * rel_l2(same, truth), (grid, tol, e, rel_l2(same, truth))
+  # per-item points through the op (plans with several point sets: composite tile columns)
+  B, M, grid = 3, 40_000, [24, 40, 32]
+  pts = rng.uniform(-np.pi, np.pi, (B, M, 3))
+  c = rng.standard_normal((B, M)) + 1j * rng.standard_normal((B, M))
+  on = tfft.nufft(_dev(c), _dev(pts), grid_shape=grid, transform_type='type_1', tol=tol, options=_tuned('STACK_ON')).cpu().numpy()
+  off = tfft.nufft(_dev(c), _dev(pts), grid_shape=grid, transform_type='type_1', tol=tol, options=_tuned('STACK_OFF')).cpu().numpy()
+  assert rel_l2(on, off) < 1e-12, rel_l2(on, off)
+  truth = oracle.nufft(c[1], pts[1], grid, 'type_1', 'forward', tol=1e-12, sigma=2.0)
+  assert rel_l2(on[1], truth) < 3 * tol
+  # the spread op
+  import torch
+  g2, M = [48, 64, 40], 100_000
+  pts = rng.uniform(-np.pi, np.pi, (M, 3))
+  c = rng.standard_normal(M) + 1j * rng.standard_normal(M)
+  res = {}
+  for stack in ('STACK_ON', 'STACK_OFF'):
+    sp = tfft.Plan('type_1', g2, 'forward', tol=tol, spread_only=True, dtype=torch.complex128, tuning=TUNE[stack])
+    sp.set_points(_dev(pts))
+    assert (sp.stacks().shape[0] > 0) == (stack == 'STACK_ON')
+    res[stack] = sp.spread(_dev(c)).cpu().numpy()
+    sp.close()
+  assert rel_l2(res['STACK_ON'], res['STACK_OFF']) < 1e-12

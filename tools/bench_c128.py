@@ -26,3 +26,14 @@ if __name__ == '__main__':
       run(tt, [128, 128, 128], 20_000_000, 1e-4, 3, dtype=c64)
       run(tt, [128, 128, 128], 20_000_000, 1e-4, 3, dtype=c128)
       run(tt, [128, 128, 128], 10_000_000, 1e-12, 3, dtype=c128)
+  if 'tile' in which:   # experiment: deeper tiles for the double-precision 3-D interpolation
+    for td in ([16, 16, 4], [16, 16, 8], [16, 8, 8], [8, 8, 8]):
+      print('tile_dims', td)
+      run('type_2', [256, 256, 256], 10_000_000, 1e-6, 3, dtype=c128, tile_dims=td)
+      run('type_2', [256, 256, 256], 30_000_000, 1e-6, 3, dtype=c128, tile_dims=td)
+  if 'stack' in which:
+    from tensorflow_nufft._lib import TUNE
+    for M in (3_000_000, 10_000_000, 30_000_000, 100_000_000, 300_000_000):
+      for tol in (1e-6, 1e-4):
+        run('type_1', [256, 256, 256], M, tol, 3, dtype=c128, tuning=TUNE['STACK_ON'])
+        run('type_1', [256, 256, 256], M, tol, 3, dtype=c128, tuning=TUNE['STACK_OFF'])

@@ -35,7 +35,7 @@ def run(ttype, grid, M, tol, steps, dtype=torch.complex64, **kw):
   cells = float(np.prod(nf)) if nf else float('nan')
   tag = 'x'.join(str(n) for n in grid)
   print(f'{ttype[-1]} {tag:>14} nf={nf} M={M:.0e} tol={tol:g} {"c128" if dtype == torch.complex128 else "c64"} '
-        f'{"rocfft" if kw.get("tuning") else "own   "}: {dt*1e3:8.3f} ms/step {dt/M*1e9:7.3f} ns/pt | fft+deconv {fft_us:8.1f} us '
+        f'{"tuning=%x" % kw.get("tuning") if kw.get("tuning") else "default "}: {dt*1e3:8.3f} ms/step {dt/M*1e9:7.3f} ns/pt | fft+deconv {fft_us:8.1f} us '
         f'= {fft_us*1e3/cells:6.3f} ns/cell | ' + ' '.join(f'{k}={v:.0f}' for k, v in st.items()), flush=True)
   plan.close(); del pts, src; torch.cuda.empty_cache()
 
