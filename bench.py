@@ -82,6 +82,18 @@ def algorithmic_spread_bytes(m, nf, rank):
   return m * (4 * rank + 8) + 8 * cells
 
 
+def algorithmic_step_bytes(m, nf, nmodes, rank):
+  # SURVEY.md section 8(d), "Whole type-1 transform": the spread bytes + the sort (read d 4 M coordinates; the records are
+  # physically reordered: (4 d + 8) M written and read again) + the FFT (2 x 8 nf^d per pass, one pass per dimension) +
+  # the deconvolution (8 N^d read + 8 N^d written).  cfg2: 193.6 + 400 + 134.2 + 16.8 = 744.6 MB.
+  cells, modes = 1, 1
+  for n in nf:
+    cells *= n
+  for n in nmodes:
+    modes *= n
+  return (algorithmic_spread_bytes(m, nf, rank) + 4 * rank * m + 2 * (4 * rank + 8) * m + 2 * 8 * cells * rank + 16 * modes)
+
+
 # dominant kernel of the headline config (2-D, w = 8, float, >= 0.5 points per fine cell)
 SPREAD_KERNEL = 'spread_2d_w8_group_kernel'
 
@@ -282,18 +294,23 @@ def other_configs(args, dev):
       d = torch.stack([torch.sqrt(1 - u * u) * torch.cos(ph), torch.sqrt(1 - u * u) * torch.sin(ph), u], dim=1)
     return (d[:, None, :] * s[None, :, None]).reshape(-1, rank).contiguous()
 
-  def plan_case(name, ttype, grid, m, tol, seed, steps, stage, dist='uniform'):
+  def plan_case(name, ttype, grid, m, tol, seed, steps, stage, dist='uniform', cdtype=torch.complex64, also=()):
     g = torch.Generator(device=dev).manual_seed(seed)
     rank = len(grid)
+    rdtype = torch.float32 if cdtype == torch.complex64 else torch.float64
     if dist == 'radial':
       pts = radial_points(m, rank, g)
       m = int(pts.shape[0])
     else:
-      pts = (torch.rand((m, rank), generator=g, device=dev) * 2 - 1) * np.pi
-    src = rnd_c([m] if ttype == 'type_1' else grid, g)
-    plan = tfft.Plan(ttype, grid, 'forward', tol=tol, dtype=torch.complex64, device=dev)
+      pts = (torch.rand((m, rank), generator=g, device=dev, dtype=rdtype) * 2 - 1) * np.pi
+      if dist == 'blob':   # uniform background + 20 % of the points in a Gaussian blob of sigma = 3 fine cells (tools/ab_fallback_group.py)
+        k = m // 5
+        pts[:k] = 0.4 + torch.randn((k, rank), generator=g, device=dev, dtype=rdtype) * (3 * np.pi / grid[0])
+        pts = pts[torch.randperm(m, device=dev, generator=g)].contiguous()
+    src = rnd_c([m] if ttype == 'type_1' else grid, g).to(cdtype)
+    plan = tfft.Plan(ttype, grid, 'forward', tol=tol, dtype=cdtype, device=dev)
     info = plan.info()
-    res = torch.empty(grid if ttype == 'type_1' else [m], dtype=torch.complex64, device=dev)
+    res = torch.empty(grid if ttype == 'type_1' else [m], dtype=cdtype, device=dev)
     step = lambda: plan.execute_with_points(pts, src, out=res)
     for _ in range(2):
       step()
@@ -307,11 +324,22 @@ def other_configs(args, dev):
     k_ms = tm[stage][0] / max(tm[stage][1], 1)
     nf = [int(info.fine_dims[d]) for d in range(rank)]
     algo = algorithmic_spread_bytes(m, nf, rank)   # (type 2: the fine grid is read, the results written: same count)
+    if cdtype == torch.complex128:
+      algo *= 2                                    # (the fp64 form of SURVEY 8(d): M (8 d + 16) + 16 nf^d)
     out[name] = {'ms_per_step': round(ms, 4), 'Gpts_s': round(m / ms / 1e6, 2), 'dominant_kernel': stage,
                  'dominant_kernel_ms': round(k_ms, 4), 'algorithmic_bytes': algo,
                  'hbm_frac': round(algo / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                 'kernel_width': int(info.kernel_width), 'fine_grid': nf[::-1], 'steps': steps, 'points': dist}
-    if ttype == 'type_1' and rank == 3 and int(info.kernel_width) <= 8:
+                 'kernel_width': int(info.kernel_width), 'fine_grid': nf[::-1], 'steps': steps, 'points': dist,
+                 'dtype': 'f64' if cdtype == torch.complex128 else 'f32'}
+    for st in also:   # further stages of the same pass (timing level 2 covers the dominant kernel only: a third pass)
+      if st not in tm or not tm[st][1]:
+        plan.set_timing(1); plan.get_timing()
+        for _ in range(steps):
+          step()
+        tm = plan.get_timing()
+        plan.set_timing(False)
+      out[name][st + '_ms'] = round(sum(tm[k][0] / max(tm[k][1], 1) for k in ([st] if st != 'fft' else ['fft', 'deconvolve', 'zero']) if k in tm), 4)
+    if ttype == 'type_1' and rank == 3 and int(info.kernel_width) <= 8 and cdtype == torch.complex64:
       # the 3-D float fixed-point spreaders are bound by the LDS-atomic data path, not by HBM: ds_add_u64
       # wave-instructions per point of the kernel family (spread_dense3_kernel: one W x 3 x 3 lane block per
       # instruction, 1 at w <= 4 and 4 at w = 5, 6; spread_patch3_kernel: one 8 x 8 (x, y) patch per z plane, w of them)
@@ -349,9 +377,45 @@ def other_configs(args, dev):
           lambda: plan_case('radial_2d_type2_1024_M1e7', 'type_2', GRID, M, TOL, 8, max(5, args.steps // 2), 'interp', 'radial'))
   guarded('kooshball_3d_type1_256_M3e7_tol1e-6',
           lambda: plan_case('kooshball_3d_type1_256_M3e7_tol1e-6', 'type_1', [256, 256, 256], 30_000_000, 1e-6, 9, 5, 'spread', 'radial'))
+  # r06 (r05 verdict): what r05 / r06 built, under the driver's clock -- stacks of tiles (w = 8 and w = 6), the 3-D type-2
+  # tile loader, the cell-grouped fp64 fallback on a clustered set, a fine grid that is not a power of two (mixed-radix
+  # pruned passes; `fft_ms` = FFT + deconvolve + zero stages), a complex128 transform (fp64 planes over stacks)
+  guarded('3d_type1_256_M1e7_tol1e-6_stacks',
+          lambda: plan_case('3d_type1_256_M1e7_tol1e-6_stacks', 'type_1', [256, 256, 256], 10_000_000, 1e-6, 10, 5, 'spread', also=('fft',)))
+  guarded('3d_type1_256_M1e7_tol1e-4_dense_stacks',
+          lambda: plan_case('3d_type1_256_M1e7_tol1e-4_dense_stacks', 'type_1', [256, 256, 256], 10_000_000, 1e-4, 11, 5, 'spread'))
+  guarded('3d_type2_256_M1e7_tol1e-6',
+          lambda: plan_case('3d_type2_256_M1e7_tol1e-6', 'type_2', [256, 256, 256], 10_000_000, 1e-6, 12, 5, 'interp'))
+  guarded('uniform_plus_blob_3d_type1_256_M3e7_tol1e-6',
+          lambda: plan_case('uniform_plus_blob_3d_type1_256_M3e7_tol1e-6', 'type_1', [256, 256, 256], 30_000_000, 1e-6, 13, 3, 'spread', 'blob'))
+  guarded('nonpow2_3d_type1_240_M1e7_tol1e-6',
+          lambda: plan_case('nonpow2_3d_type1_240_M1e7_tol1e-6', 'type_1', [240, 240, 240], 10_000_000, 1e-6, 14, 5, 'spread', also=('fft',)))
+  guarded('nonpow2_2d_type1_960_M1e7_tol1e-6',
+          lambda: plan_case('nonpow2_2d_type1_960_M1e7_tol1e-6', 'type_1', [960, 960], M, TOL, 15, 5, 'spread', also=('fft',)))
+  guarded('c128_3d_type1_256_M1e7_tol1e-6',
+          lambda: plan_case('c128_3d_type1_256_M1e7_tol1e-6', 'type_1', [256, 256, 256], 10_000_000, 1e-6, 16, 3, 'spread', cdtype=torch.complex128))
   for k in list(out):
     if 'error' not in out[k]:
       out[k].update(pmc_traffic_of(k))
+
+  # the reference harness's own cases (NUFFTOpsBenchmark.cases, nufft_ops_test.py:732-741: its first 2-D case and its
+  # two 3-D ones), through tfft.nufft at the API's default tolerance like the harness: ms per call, HIP events
+  def op_case(name, source_shape, points_shape, ttype, grid):
+    g = torch.Generator(device=dev).manual_seed(17)
+    src = rnd_c(source_shape, g)
+    pts = (torch.rand(points_shape, generator=g, device=dev) - .5) * (2.0 * np.pi)
+    call = lambda: tfft.nufft(src, pts, grid_shape=grid, transform_type=ttype)
+    for _ in range(3):
+      call()
+    ms = _event_timed(call, 20)
+    npts = 1
+    for v in points_shape[:-1]:
+      npts *= v
+    out[name] = {'ms_per_call': round(ms, 4), 'Gpts_s': round(npts / ms / 1e6, 3), 'through': 'tfft.nufft (op-level entry, cached plan)',
+                 'source_shape': source_shape, 'points_shape': points_shape}
+  guarded('refharness_2d_type2_256_M2e5', lambda: op_case('refharness_2d_type2_256_M2e5', [256, 256], [200000, 2], 'type_2', None))
+  guarded('refharness_3d_type2_128_M8e5', lambda: op_case('refharness_3d_type2_128_M8e5', [128, 128, 128], [800000, 3], 'type_2', None))
+  guarded('refharness_3d_type1_128_M8e5', lambda: op_case('refharness_3d_type1_128_M8e5', [800000], [800000, 3], 'type_1', [128, 128, 128]))
   try:
     out.update(config5_one_gpu(args, dev))
   except Exception as e:   # pylint: disable=broad-except
@@ -677,6 +741,16 @@ def run_config2(args, dev, dist, world, rank):
                   'pipe and its per-tile phases, not by HBM (EXPERIMENTS.md section 4): roofline.lds is the bound '
                   'that tracks it.',
       },
+  }
+  step_bytes = algorithmic_step_bytes(m, nf, GRID, 2)
+  step_gbs = step_bytes / (ms_per_step * 1e-3) / 1e9
+  result['step_roofline'] = {
+      'bound': 'hbm', 'achieved': round(step_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(step_gbs / HBM_PEAK_GBS, 4),
+      'algorithmic_bytes': step_bytes, 'ms': round(ms_per_step, 4),
+      'note': 'the whole step (sort + spread + FFT passes with the deconvolution fused) on SURVEY.md 8(d)\'s whole-type-1-transform '
+              'bytes: spread M (4 d + 8) + 8 nf^d, sort 4 d M read + (4 d + 8) M written and read again, FFT 2 x 8 nf^d per dimension, '
+              'deconvolution 16 N^d. The sort is ~40 % of the step and its scatter is bound by write transactions (one 16-byte record per '
+              'fabric write), the spread by the LDS pipe: neither by HBM bytes.',
   }
   if world == 1 and not args.no_cpu_baseline:
     result['cpu_baseline'] = cpu_baseline(args)

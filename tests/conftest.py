@@ -15,6 +15,7 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
   config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu)')
+  config.addinivalue_line('markers', 'sizecap: GPU tests on fine grids of 2^30 cells (tens of GB; skip with -m "gpu and not sizecap")')
 
 
 def pytest_collection_modifyitems(config, items):
