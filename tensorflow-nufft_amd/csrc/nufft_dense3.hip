@@ -1937,7 +1937,9 @@ bool stack3_wanted(const Geom& g, int64_t M) {
   const double cells = (double)g.nf[0] * g.nf[1] * g.nf[2] * (g.nitems > 1 ? g.nitems : 1);
   // double precision (spread_wave3_stack_kernel, nufft_kernels.hip): the depth-4 tiles write 5.7 x the fine grid per
   // subproblem, and a workgroup per ~1000 fine cells zeroes 97 KB of planes first
-  if (g.fp64_stack) return (double)M < kStack64Density * cells;
+  // (w = 9..16, spread_wide_kernel<..., STACK>: 256^3 modes, tol 1e-9, 0.075 points per fine cell 37.6 -> 17.3 ms, 0.22: 41.4 -> 35.2;
+  // 128^3 modes, tol 1e-12, 0.6 and 1.8 per cell: 17.4 -> 17.7, 47.7 -> 48.8: profiles/r06_c128_widestack.txt)
+  if (g.fp64_stack) return (double)M < (g.wide ? 0.5 : kStack64Density) * cells;
   // w <= 6 (spread_dense3_stack_kernel, same file): the fewer atomics a point costs, the longer the write-out shows --
   // w = 6 (4 per point), 256^3 modes, spread stage: 0.075 per cell 2.93 -> 2.33 ms, 0.224: 4.06 -> 3.33, 0.298: 3.67 -> 3.84,
   // 0.745: 7.55 -> 7.91; w = 4 (1 per point): 0.224: 2.87 -> 2.33, 0.373: 3.00 -> 2.81, 0.745: 4.50 -> 4.33

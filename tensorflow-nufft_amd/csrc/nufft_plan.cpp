@@ -731,8 +731,8 @@ int set_points_impl(nufft_hip_plan p, int64_t M, const void* x, const void* y, c
                 (p->type == NUFFT_HIP_TYPE_1 || p->opts.spread_only) && stack3_wanted(p->g, Mtot) &&
                 p->cap_segs >= (int64_t)stack_grid_bound(p->g, Mtot) + 1 &&   // (r05 advisor: the descriptor buffer is this large, not merely present)
                 (!p->g.fx_patch || p->cap_sub_bound >= (int64_t)stack_grid_bound(p->g, Mtot) + 1)) ? 1 : 0;
-  if constexpr (sizeof(T) == 8) {
-    // r06: double-precision fp64 planes over the same stacks (spread_wave3_stack_kernel)
+  if (sizeof(T) == 8 || p->g.wide) {
+    // r06: the fp64-plane kernels over the same stacks (double: spread_wave3_stack_kernel; w = 9..16: spread_wide_kernel)
     p->g.stack = (p->g.fp64_stack && p->segs && Mtot > 0 && (p->type == NUFFT_HIP_TYPE_1 || p->opts.spread_only) &&
                   p->cap_segs >= (int64_t)stack_grid_bound(p->g, Mtot) + 1 && stack3_wanted(p->g, Mtot)) ? 1 : 0;
     if (p->g.stack) {
@@ -1314,6 +1314,11 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
     g.fixed_point = 1;
   g.fp64_stack = (method == NUFFT_HIP_METHOD_TILE_WAVE && rank == 3 && precision == NUFFT_HIP_F64 && !g.wide && w >= 2 && w <= 8 &&
                   g.tile[0] == 16 && g.tile[1] == 16 && g.tile[2] == (w <= 6 ? 8 : 4)) ? 1 : 0;
+  if (method == NUFFT_HIP_METHOD_TILE_WAVE && rank == 3 && g.wide) {   // w = 9..16 (either precision): spread_wide_kernel<..., STACK>
+    int wt[3];
+    wide_spread_tile(3, w, wt);
+    g.fp64_stack = (g.tile[0] == wt[0] && g.tile[1] == wt[1] && g.tile[2] == wt[2]) ? 1 : 0;
+  }
   if (p->opts.lds_accumulate == 2 && !g.fixed_point) {
     delete p;
     return fail(NUFFT_HIP_INVALID_ARGUMENT,

@@ -65,10 +65,16 @@ __device__ __forceinline__ void horner16(const T* __restrict__ tab, int nc, T z,
 }
 
 // COMP: 0 = both components (two planes), 1 / 2 = real / imaginary part only (one plane).
-template <typename T, int RANK, int W, int COMP>
+// STACK (r06, 3-D): the workgroup walks a STACK of tiles consecutive in z (stack_plan_kernel, nufft_dense3.hip) instead
+// of one subproblem: after every tile its T2 finished planes are written out, the W - 1 halo planes move down by T2
+// (chains of ceil((T2 + W - 1) / T2) planes per (y, x) column) and the freed planes are zeroed. The tile + halo of a
+// subproblem is 10.8 x the tile at W = 10 (25 x 17 x 13 cells for 16 x 8 x 4) and all of it goes to the fine grid as
+// global fp64 atomics, per component: 256^3 modes, M = 1e7, tol 1e-9 spent 37 ms there (profiles/r06_c128_before.txt).
+template <typename T, int RANK, int W, int COMP, bool STACK = false>
 __global__ __launch_bounds__(kWideNW * 64) void spread_wide_kernel(
     Geom g, SortedPoints<T> sp, const T* __restrict__ horner, const T* __restrict__ c,
     T* __restrict__ fw, int64_t c_stride, int64_t fw_stride, T scale) {
+  static_assert(!STACK || (RANK == 3 && COMP != 0), "stacks: the 3-D one-component launches");
   using G = WideGeo<RANK, W>;
   using T2 = typename Pair<T>::type;
   constexpr int NW = kWideNW, CH = kWideCH<T, RANK>, WR = G::WR, RP = kWideRP<T>;
@@ -78,8 +84,17 @@ __global__ __launch_bounds__(kWideNW * 64) void spread_wide_kernel(
   double* plane_re = reinterpret_cast<double*>(smem_raw);
   double* plane_im = plane_re + (NPL == 2 ? G::plane : 0);
   T* stage_all = reinterpret_cast<T*>(plane_re + NPL * G::plane + G::pad);
-  int tb, p0, p1, slot;
-  if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1, &slot)) return;
+  int tb = 0, p0 = 0, p1 = 0, slot = 0;
+  StackDesc sd = {0, 0, 1, 0, 0};
+  StackColumn scol = {0, 0, 0};
+  if constexpr (STACK) {
+    if ((int)blockIdx.x >= sp.seg_count[0]) return;
+    sd = stack_load(sp.segs, blockIdx.x);
+    scol = stack_column(g, sd.col);
+    slot = scol.item * (int)gridDim.y + (int)blockIdx.y;
+  } else {
+    if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1, &slot)) return;
+  }
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -94,6 +109,16 @@ __global__ __launch_bounds__(kWideNW * 64) void spread_wide_kernel(
   // Horner phase: lane = (point of the chunk, dimension)
   const int hq = lane & (CH - 1), hd = lane / CH;
   const T2* cc = reinterpret_cast<const T2*>(c) + (int64_t)slot * c_stride;
+  T* out = fw + 2 * (int64_t)slot * fw_stride;
+  for (int ti = 0; ti < (STACK ? sd.nz : 1); ++ti) {
+  if constexpr (STACK) {
+    p0 = sd.p0; p1 = sd.p1;
+    if (p0 < 0) {
+      const int t = stack_tile_index(g, scol, sd.z0 + ti);
+      p0 = sp.tile_start[t];
+      p1 = sp.tile_start[t + 1];
+    }
+  }
   const int npt = p1 - p0;
   const int share = (npt + NW - 1) / NW;
   const int wbeg = p0 + wave * share;
@@ -185,12 +210,37 @@ __global__ __launch_bounds__(kWideNW * 64) void spread_wide_kernel(
     }
   }
   __syncthreads();
+  if constexpr (STACK) {
+    // tile sd.z0 + ti is complete in its first T2 planes (the last tile of the stack: in all of them)
+    const bool last = ti == sd.nz - 1;
+    const int o0 = scol.t0 * G::T0, o1 = scol.t1 * G::T1, o2 = (sd.z0 + ti) * G::T2;
+    const int nrows = (last ? G::L2 : G::T2) * G::L1;
+    const int a0 = lane < G::L0 ? lane : G::L0 - 1;
+    const bool lane_on = lane < G::L0;
+    const int gx = wrap1(o0 + a0, g.nf[0]);
+    for (int rho = wave; rho < nrows; rho += NW) {
+      const int a2 = rho / G::L1, a1 = rho - a2 * G::L1;
+      const int lrow = a2 * PS + a1 * LS + a0;
+      const int64_t gbase = (int64_t)g.nf[0] * (wrap1(o1 + a1, g.nf[1]) + (int64_t)g.nf[1] * wrap1(o2 + a2, g.nf[2]));
+      constexpr int CHAIN = (G::L2 + G::T2 - 1) / G::T2;   // planes a2, a2 + T2, ... of this (y, x) column
+      double v[CHAIN];
+#pragma unroll
+      for (int m = 0; m < CHAIN; ++m) v[m] = (m == 0 || (!last && a2 + m * G::T2 < G::L2)) ? plane_re[lrow + m * G::T2 * PS] : 0.0;
+      if (lane_on && v[0] != 0.0) glb_add(&out[2 * (gbase + gx) + (COMP - 1)], (T)v[0]);
+      if (!last && lane_on) {
+#pragma unroll
+        for (int m = 0; m < CHAIN; ++m)
+          if (a2 + m * G::T2 < G::L2) plane_re[lrow + m * G::T2 * PS] = m + 1 < CHAIN ? v[m + 1] : 0.0;
+      }
+    }
+    if (!last) __syncthreads();
+    continue;
+  }
 
   // write-out: add the tile to the periodic fine grid
   int t0, t1, t2;
   tile_coords(g, tb, &t0, &t1, &t2);
   const int o0 = t0 * G::T0, o1 = t1 * G::T1, o2 = t2 * G::T2;
-  T* out = fw + 2 * (int64_t)slot * fw_stride;
   for (RowWalk rw(wave, G::L1); rw.a2 < G::L2; rw.advance(NW, G::L1)) {
     const int g1 = wrap1(o1 + rw.a1, g.nf[1]);
     const int g2 = RANK > 2 ? wrap1(o2 + rw.a2, g.nf[2]) : 0;
@@ -209,6 +259,7 @@ __global__ __launch_bounds__(kWideNW * 64) void spread_wide_kernel(
       }
     }
   }
+  }   // (tiles of the stack; one pass otherwise)
 }
 
 // ------------------------------------------------------------ interp, widths 9..16
@@ -396,10 +447,27 @@ hipError_t launch_one(const Geom& g, dim3 grid, const SortedPoints<T>& sp, const
   return hipGetLastError();
 }
 
+template <typename T, int W, int COMP>
+hipError_t launch_one_stack(const Geom& g, dim3 grid, const SortedPoints<T>& sp, const T* horner, const T* c, T* fw,
+                            int64_t c_stride, int64_t fw_stride, T scale, hipStream_t stream) {
+  using G = WideGeo<3, W>;
+  constexpr size_t lds = sizeof(double) * (G::plane + G::pad) + sizeof(T) * kWideNW * kWideCH<T, 3> * 2 * kWideRP<T>;
+  hipError_t e = wide_ensure_lds(spread_wide_kernel<T, 3, W, COMP, true>, lds);
+  if (e != hipSuccess) return e;
+  spread_wide_kernel<T, 3, W, COMP, true><<<grid, kWideNW * 64, lds, stream>>>(g, sp, horner, c, fw, c_stride, fw_stride, scale);
+  return hipGetLastError();
+}
+
 template <typename T, int W>
 hipError_t launch_w(const Geom& g, dim3 grid, const SortedPoints<T>& sp, const T* horner, const T* c, T* fw,
-                    int64_t c_stride, int64_t fw_stride, T scale, hipStream_t stream) {
+                    int64_t c_stride, int64_t fw_stride, T scale, hipStream_t stream, int64_t M) {
   if (g.rank == 2) return launch_one<T, 2, W, 0>(g, grid, sp, horner, c, fw, c_stride, fw_stride, scale, stream);
+  if (g.stack && sp.segs) {   // r06: stacks of tiles
+    const dim3 sgrid(stack_grid_bound(g, M), grid.y);
+    hipError_t e = launch_one_stack<T, W, 1>(g, sgrid, sp, horner, c, fw, c_stride, fw_stride, scale, stream);
+    if (e != hipSuccess) return e;
+    return launch_one_stack<T, W, 2>(g, sgrid, sp, horner, c, fw, c_stride, fw_stride, scale, stream);
+  }
   hipError_t e = launch_one<T, 3, W, 1>(g, grid, sp, horner, c, fw, c_stride, fw_stride, scale, stream);
   if (e != hipSuccess) return e;
   return launch_one<T, 3, W, 2>(g, grid, sp, horner, c, fw, c_stride, fw_stride, scale, stream);
@@ -474,7 +542,7 @@ hipError_t launch_spread_wide(const Geom& g, const SortedPoints<T>& sp, int64_t 
   if (M == 0) return hipSuccess;
   dim3 grid((unsigned)((int64_t)g.ntiles + M / g.max_sub), (unsigned)batch);
 #define NUFFT_WIDE_CASE(WW) \
-  case WW: return launch_w<T, WW>(g, grid, sp, horner, c, fw, c_stride, fw_stride, scale, stream);
+  case WW: return launch_w<T, WW>(g, grid, sp, horner, c, fw, c_stride, fw_stride, scale, stream, M);
   switch (g.w) {
     NUFFT_WIDE_CASE(9) NUFFT_WIDE_CASE(10) NUFFT_WIDE_CASE(11) NUFFT_WIDE_CASE(12)
     NUFFT_WIDE_CASE(13) NUFFT_WIDE_CASE(14) NUFFT_WIDE_CASE(15) NUFFT_WIDE_CASE(16)

@@ -3232,7 +3232,7 @@ def test_every_radix_list_of_the_mixed_passes(tfft, n):
 
 
 
-@pytest.mark.parametrize('tol', [1e-6, 1e-4, 1e-2])
+@pytest.mark.parametrize('tol', [1e-14, 1e-12, 1e-9, 1e-6, 1e-4, 1e-2])
 def test_double_precision_3d_spread_over_stacks(tfft, tol):
   # r06: complex128 3-D type 1 / spread at w <= 8 walks the stacks of tiles r05 cut for the float kernels
   # (spread_wave3_stack_kernel: fp64 planes, the z halo carried in LDS, planes moved down by the tile depth 4 < w - 1:
@@ -3260,7 +3260,9 @@ def test_double_precision_3d_spread_over_stacks(tfft, tol):
       import torch
       plan = tfft.Plan('type_1', grid, 'forward', tol=tol, num_transforms=nt, dtype=torch.complex128, tuning=TUNE[stack])
       td = int(plan.info().tile_dims[2])
-      full = list(plan.info().tile_dims) == [16, 16, 4 if plan.info().kernel_width >= 7 else 8]   # (tiny grids shrink the tile: no stacks there)
+      kw_ = int(plan.info().kernel_width)   # (w = 9..16: spread_wide_kernel<..., STACK> on its own tiles)
+      want_tile = [16, 16, 8] if kw_ <= 6 else [16, 16, 4] if kw_ <= 8 else [16, 8, 4] if kw_ <= 12 else [8, 8, 4] if kw_ <= 15 else [8, 8, 2]
+      full = list(plan.info().tile_dims) == want_tile   # (tiny grids shrink the tile: no stacks there)
       if slen:
         plan.stack_params(slen, 0)
       plan.set_points(_dev(pts))
@@ -3276,8 +3278,8 @@ def test_double_precision_3d_spread_over_stacks(tfft, tol):
       truth = oracle.nufft(c1, pts, grid, 'type_1', 'forward', tol=1e-12, sigma=2.0)
       e = rel_l2(o1, truth)
       if e >= tol:
-        same = oracle.nufft(c1, pts, grid, 'type_1', 'forward', tol=tol, sigma=2.0)
-        assert e <= 1.05 * rel_l2(same, truth), (grid, tol, e, rel_l2(same, truth))
+        same = oracle.nufft(c1, pts, grid, 'type_1', 'forward', tol=max(tol, 1e-13), sigma=2.0)
+        assert e <= 1.05 * rel_l2(same, truth) + 2e-12, (grid, tol, e, rel_l2(same, truth))
   # per-item points through the op (plans with several point sets: composite tile columns)
   B, M, grid = 3, 40_000, [24, 40, 32]
   pts = rng.uniform(-np.pi, np.pi, (B, M, 3))
@@ -3286,7 +3288,7 @@ def test_double_precision_3d_spread_over_stacks(tfft, tol):
   off = tfft.nufft(_dev(c), _dev(pts), grid_shape=grid, transform_type='type_1', tol=tol, options=_tuned('STACK_OFF')).cpu().numpy()
   assert rel_l2(on, off) < 1e-12, rel_l2(on, off)
   truth = oracle.nufft(c[1], pts[1], grid, 'type_1', 'forward', tol=1e-12, sigma=2.0)
-  assert rel_l2(on[1], truth) < 3 * tol
+  assert rel_l2(on[1], truth) < max(3 * tol, 2e-12)
   # the spread op
   import torch
   g2, M = [48, 64, 40], 100_000

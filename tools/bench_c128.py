@@ -31,6 +31,12 @@ if __name__ == '__main__':
       print('tile_dims', td)
       run('type_2', [256, 256, 256], 10_000_000, 1e-6, 3, dtype=c128, tile_dims=td)
       run('type_2', [256, 256, 256], 30_000_000, 1e-6, 3, dtype=c128, tile_dims=td)
+  if 'widestack' in which:
+    from tensorflow_nufft._lib import TUNE
+    for M in (10_000_000, 30_000_000):
+      for grid, tol in (([256] * 3, 1e-9), ([128] * 3, 1e-12)):
+        run('type_1', grid, M, tol, 3, dtype=c128, tuning=TUNE['STACK_ON'])
+        run('type_1', grid, M, tol, 3, dtype=c128, tuning=TUNE['STACK_OFF'])
   if 'stack' in which:
     from tensorflow_nufft._lib import TUNE
     for M in (3_000_000, 10_000_000, 30_000_000, 100_000_000, 300_000_000):
