@@ -138,9 +138,10 @@ enum {
   NUFFT_HIP_TUNE_QFOLD_OFF = 1 << 19,      /* LDS-histogram sorts: the general coordinate fold (fmod / division / 64-bit modulo
                                               paths compiled in) although the plan's tiles are powers of two and the points'
                                               range is STRICT or EXTENDED -- same results, for A/B runs */
-  NUFFT_HIP_TUNE_STACK_OFF = 1 << 20,      /* 3-D float fixed-point spreading (w <= 8): one workgroup per STACK of tiles consecutive in
-                                              z, the z halo carried in LDS instead of written out per tile (r05; by default below
-                                              0.22 / 0.25 / 1.0 points per fine cell at w = 7, 8 / 5, 6 / <= 4): never / always */
+  NUFFT_HIP_TUNE_STACK_OFF = 1 << 20,      /* 3-D spreading: one workgroup per STACK of tiles consecutive in z, the z halo carried in
+                                              LDS instead of written out per tile (r05, float fixed point: by default below 0.22 /
+                                              0.25 / 1.0 points per fine cell at w = 7, 8 / 5, 6 / <= 4; r06, double precision w <= 8:
+                                              below 2.0, w = 9..16 either precision: below 0.5): never / always */
   NUFFT_HIP_TUNE_STACK_ON = 1 << 21,
   NUFFT_HIP_TUNE_FBGROUP_OFF = 1 << 22,    /* 3-D float fixed-point plans: the subproblems left to the fp64 planes (bound above the limit,
                                               crowded tiles) on the r04 kernel (one launch per component, an atomic per point and
@@ -286,9 +287,10 @@ int nufft_hip_debug_sort_path(nufft_hip_plan plan);
  * spread is at most B largest strengths), < 0 = left to the double-precision LDS planes, 0 = unused launch slot.
  * Returns the number of launch slots (<= n copied), 0 for other plans, negative on error. */
 int64_t nufft_hip_debug_sub_bounds(nufft_hip_plan plan, float* out, int64_t n);
-/* 3-D float fixed-point plans spreading over STACKS of tiles (r05; options.tuning STACK_OFF for the per-subproblem
- * form): nufft_hip_debug_sub_bounds then reports one bound per stack (w = 7, 8; no unused slots), and this entry the stacks
- * themselves, four int32 each: {tile column (t0 + ntile0 * t1, + columns per point set * set), z0 | nz << 16 = first
+/* 3-D plans spreading over STACKS of tiles (r05: float fixed-point plans; r06: double-precision plans and w = 9..16;
+ * options.tuning STACK_OFF for the per-subproblem form). Float w = 7, 8: nufft_hip_debug_sub_bounds then reports one
+ * bound per stack (no unused slots); float w <= 6, double precision and w = 9..16 cut stacks without per-stack bounds
+ * (sub_bounds returns 0 entries there). This entry returns the stacks themselves, four int32 each: {tile column (t0 + ntile0 * t1, + columns per point set * set), z0 | nz << 16 = first
  * tile in z and how many, p0, p1 = the point range of a piece of a tile with more than max_subproblem_size points,
  * -1 otherwise}. Returns the number of stacks (<= n copied), 0 for other plans, negative on error. Synchronises. */
 int64_t nufft_hip_debug_stacks(nufft_hip_plan plan, int32_t* out, int64_t n);

@@ -1589,6 +1589,7 @@ __device__ __forceinline__ void spread_group3_f64_body(const Geom& g, const Sort
   v2f coef[kPatchCoef];
   patch3_lane_coef<W>(horner, lane, coef);
   const int dx = lane & 7, dy = lane >> 3;
+  const bool in_patch = dx < W && dy < W;
   const int cell_b = (dy * LS + dx) * 8;
   for (int seg0 = p0; seg0 < p1; seg0 += kFbSeg) {
     const int n = p1 - seg0 < kFbSeg ? p1 - seg0 : kFbSeg;
@@ -1653,7 +1654,9 @@ __device__ __forceinline__ void spread_group3_f64_body(const Geom& g, const Sort
 #pragma unroll
         for (int j = kPatchCoef - 2; j >= 0; --j) k = __builtin_elementwise_fma(k, zz, coef[j]);
         const float kxy = k.x * k.y;
-        const v2f wc = (v2f){kxy, kxy} * (v2f){bcast_lane(cre, q), bcast_lane(cim, q)};
+        // (lanes outside the W x W patch have zero taps: their product is forced to 0 rather than computed, so that a NaN /
+        // Inf strength stays inside its stencil as on the per-point kernels -- r05 advisor)
+        const v2f wc = in_patch ? (v2f){kxy, kxy} * (v2f){bcast_lane(cre, q), bcast_lane(cim, q)} : (v2f){0.f, 0.f};
 #pragma unroll
         for (int dz = 0; dz < W; ++dz) {
           const float kzq = bcast_lane(kz[dz], q);
@@ -1855,12 +1858,20 @@ hipError_t launch_spread_group3_fallback(const Geom& g, const SortedPoints<float
   if (!sp.fb_list || !sp.fb_ticket) return hipErrorInvalidValue;
   const hipError_t e0 = hipMemsetAsync(sp.fb_ticket, 0, sizeof(int), stream);
   if (e0 != hipSuccess) return e0;
-  const dim3 grid((unsigned)std::min<uint64_t>((uint64_t)nsub_bound * (unsigned)batch, 1024u), 1u);
+  // (r05 advisor) ~150 KB of LDS: one workgroup per CU, so a grid beyond the CU count only queues on the ticket -- fixed latency
+  // on small transforms whose list is empty, the common case
+  static int ncu = 0;
+  if (ncu == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    ncu = v;
+  }
+  const dim3 grid((unsigned)std::min<uint64_t>((uint64_t)nsub_bound * (unsigned)batch, (uint64_t)ncu), 1u);
 #define NUFFT_FB(WV)                                                                                                          \
   {                                                                                                                           \
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(spread_group3_f64_kernel<WV>),                     \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)FbCfg<WV>::lds_bytes);          \
-    if (e != hipSuccess) return e;                                                                                            \
+    if (e != hipSuccess) { (void)hipGetLastError(); return hipErrorNotSupported; }   /* a part with less LDS: the caller takes the per-point launches */ \
     spread_group3_f64_kernel<WV><<<grid, kFbNW * 64, FbCfg<WV>::lds_bytes, stream>>>(g, sp, horner, c, fw, c_stride, fw_stride, scale, batch); \
   }
   switch (g.w) {
@@ -1904,7 +1915,7 @@ hipError_t launch_bound3(const Geom& g, const Rec<float>* rec, int rec_stride, c
 constexpr double kStackDensity = 0.22;   // points per fine cell below which a w = 7, 8 plan spreads over stacks
 constexpr double kStack64Density = 2.0;  // the same for double-precision plans (r06)
 void stack_params(const Geom& g, int* cap, int* len) {
-  int l = g.ntiles / 512;
+  int l = (g.ntile[0] * g.ntile[1] * g.ntile[2] * (g.nitems > 1 ? g.nitems : 1)) / 512;   // (the tiles that exist: ntiles counts the ids, padded under the super-tile numbering)
   l = l < 2 ? 2 : (l > 16 ? 16 : l);
   if (l > g.ntile[2]) l = g.ntile[2];
   *len = g.stack_len > 0 ? g.stack_len : l;

@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "nufft_hip_internal.h"
 
@@ -748,7 +749,12 @@ int mix_pass_shape(int n, int K, int csize, int64_t nlines, int* threads, int* v
   if (n < 4 || n > kMixMaxN || (n & 1) || K > n || !mix_factor(n, &pk)) return 0;
   int best = 0, best_thr = 0, best_vpt = 0, tier = 0;
   size_t best_lds = 0;
+  int force_r = 0;
+#ifdef NUFFT_MIX_SHAPE_ENV   // (experiment builds, tools/exp_mixfft_shape.py: lines per workgroup from the environment)
+  if (const char* ev = getenv("NUFFT_MIX_R")) force_r = atoi(ev);
+#endif
   for (int R = 16; R >= 1; R /= 2) {
+    if (force_r && R != force_r) continue;
     if (R * csize < 32 && best) break;                               // output segments of at least 32 bytes where anything else fits
     const size_t bytes = ((size_t)R * lpad_len(n) + (size_t)n / 2) * csize + ((size_t)K / 2 + 1) * (csize / 2);
     if (bytes > 160 * 1024) continue;

@@ -3375,10 +3375,12 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
             if (g.stack && sp.segs) e = launch_spread_stack3(g, sp, M, horner, c, fw, batch, c_stride, fw_stride, scale, stream); \
             else e = launch_spread_patch3(g, sp, grid.x, horner, c, fw, batch, c_stride, fw_stride, scale, stream); \
             if (e != hipSuccess) return e;                                                       \
+            e = hipErrorNotSupported;                                                            \
             if (!(g.tuning & NUFFT_HIP_TUNE_FBGROUP_OFF)) {   /* r05: cell-grouped, both planes in one launch */ \
               e = launch_spread_group3_fallback(g, sp, grid.x, horner, c, fw, batch, c_stride, fw_stride, scale, stream); \
-              if (e != hipSuccess) return e;                                                     \
-            } else {                                                                             \
+              if (e != hipSuccess && e != hipErrorNotSupported) return e;                        \
+            }                                                                                    \
+            if (e == hipErrorNotSupported) {   /* (forced off, or a part without room for its 150 KB of LDS) */ \
               lds_bytes = wave3_split8_lds(g);                                                   \
               NUFFT_LAUNCH_W3S8(WW, 1) NUFFT_LAUNCH_W3S8(WW, 2)                                   \
             }                                                                                    \
@@ -3402,10 +3404,12 @@ hipError_t launch_spread(const Geom& g, int method, const SortedPoints<T>& sp, i
             else e = launch_spread_dense3(g, sp, grid.x, Md, horner, c, fw, batch, c_stride, fw_stride, scale, stream); \
             if (e != hipSuccess) return e;                                                       \
             if (Md > (int64_t)g.fx_max_subs * g.max_sub) {   /* a tile may be crowded: fp64 planes for those */ \
+              e = hipErrorNotSupported;                                                          \
               if (!(g.tuning & NUFFT_HIP_TUNE_FBGROUP_OFF) && g.ncoef <= 10) {   /* r05: cell-grouped, both planes */ \
                 e = launch_spread_group3_fallback(g, sp, grid.x, horner, c, fw, batch, c_stride, fw_stride, scale, stream); \
-                if (e != hipSuccess) return e;                                                   \
-              } else {                                                                           \
+                if (e != hipSuccess && e != hipErrorNotSupported) return e;                      \
+              }                                                                                  \
+              if (e == hipErrorNotSupported) {                                                   \
                 lds_bytes = wave3_split_lds(g);                                                  \
                 NUFFT_LAUNCH_W3S(WW, 8, 1) NUFFT_LAUNCH_W3S(WW, 8, 2)                             \
               }                                                                                  \

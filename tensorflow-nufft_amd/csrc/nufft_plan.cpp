@@ -1236,12 +1236,16 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
     int64_t nsuper = 1;
     int key_bits = 0;
     for (int d = 0; d < 3 && ok; ++d) {
-      ok = g.tile_shift[d] >= 0 && g.tile_shift[d] <= 6 && g.nf[d] % 64 == 0;
-      nsuper *= g.nf[d] / 64;
+      ok = g.tile_shift[d] >= 0 && g.tile_shift[d] <= 6;
+      nsuper *= (g.nf[d] + 63) / 64;
       key_bits += 6 - g.tile_shift[d];
     }
     if (ok && nsuper <= 1024 && key_bits <= 8 && key_bits > 0) {
-      for (int d = 0; d < 3; ++d) { g.sup_shift[d] = 6 - g.tile_shift[d]; g.nsup[d] = g.nf[d] / 64; }
+      // r06: fine grids that are not multiples of 64 cells too (the smooth sizes: 480, 400, 384 ...): the last super-tile of
+      // a dimension is partial, and the tile ids of the cells it lacks exist but stay empty -- the tile tables are sized by
+      // the padded count (240^3 modes: 65536 ids for 54000 tiles; sort 523 -> see profiles/r06_sort2_partial.txt)
+      for (int d = 0; d < 3; ++d) { g.sup_shift[d] = 6 - g.tile_shift[d]; g.nsup[d] = (g.nf[d] + 63) / 64; }
+      g.ntiles = g.ntiles_item = (int)(nsuper << key_bits);
     }
   }
   if (!wide && spread_lds_bytes(g, NUFFT_HIP_METHOD_TILE_GENERIC, precision) > 160 * 1024) {

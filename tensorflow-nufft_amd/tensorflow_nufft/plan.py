@@ -166,8 +166,10 @@ class Plan:
     return out
 
   def stacks(self):
-    """Debug: the stacks of tiles a 3-D float w = 7 / 8 plan spreads over (int32 [n, 4]: column, z0 | nz << 16,
-    point range of a piece or -1, -1), as many rows as sub_bounds() then has entries; empty for other plans."""
+    """Debug: the stacks of tiles a 3-D plan spreads over (int32 [n, 4]: column, z0 | nz << 16, point range of a
+    piece or -1, -1); empty for plans that spread per subproblem. Float w = 7 / 8 plans: as many rows as
+    sub_bounds() then has entries (one count-filter bound per stack); float w <= 6 plans and the double-precision /
+    w = 9..16 plans (r06) cut stacks too but keep no per-stack bounds: sub_bounds() is empty there."""
     import numpy as np
     n = int(self.lib.nufft_hip_debug_stacks(self._handle, None, 0))
     if n < 0:

@@ -3302,3 +3302,63 @@ def test_double_precision_3d_spread_over_stacks(tfft, tol):
     res[stack] = sp.spread(_dev(c)).cpu().numpy()
     sp.close()
   assert rel_l2(res['STACK_ON'], res['STACK_OFF']) < 1e-12
+
+
+@pytest.mark.parametrize('tol', [1e-6, 1e-4])
+def test_two_level_sort_with_partial_super_tiles(tfft, tol):
+  # r06: the two-level sort also where the fine grid is NOT a multiple of 64 cells per dimension -- the smooth sizes
+  # most matrix sizes give (fine 240 x 200 x 144 here: 4 x 4 x 3 super-tiles, the last of each dimension 48 / 8 / 16
+  # cells wide; tile ids of the cells it lacks exist and stay empty). Forced on, against the one-level sort and the
+  # oracle, both types, stacks on and off (tile columns / tile ids under the padded numbering), a cluster that sits
+  # in the partial super-tiles (the corner at +pi), the spread op.
+  import torch
+  from oracle import oracle
+  from tensorflow_nufft import _lib
+  rng = np.random.default_rng(44)
+  grid = [72, 100, 120]   # array order: x is the last dimension
+  M = 250000
+  pts = rng.uniform(-np.pi, np.pi, (M, 3)).astype(np.float32)
+  pts[:60000] = (np.pi - np.abs(0.15 * rng.standard_normal((60000, 3)))).astype(np.float32)   # the last super-tiles
+  c = (rng.uniform(-.5, .5, M) + 1j * rng.uniform(-.5, .5, M)).astype(np.complex64)
+  f = (rng.uniform(-.5, .5, grid) + 1j * rng.uniform(-.5, .5, grid)).astype(np.complex64)
+  truth1 = oracle.nufft(c.astype(np.complex128), pts, grid, 'type_1', 'forward', tol=1e-10)
+  truth2 = oracle.nufft(f.astype(np.complex128), pts, None, 'type_2', 'backward', tol=1e-10)
+  outs = {}
+  for name in ('SORT2_OFF', 'SORT2_ON'):
+    for stack in ('STACK_OFF', 'STACK_ON'):
+      p1 = tfft.Plan('type_1', grid, 'forward', tol=tol, tuning=_lib.TUNE[name] | _lib.TUNE[stack])
+      assert [int(v) for v in p1.info().fine_dims] == [240, 200, 144]
+      p1.set_points(_dev(pts))
+      assert p1.sort_path() == (3 if name == 'SORT2_ON' else 1 if p1.sort_path() == 1 else 0), p1.sort_path()
+      assert (p1.stacks().shape[0] > 0) == (stack == 'STACK_ON')
+      o1 = p1.execute(_dev(c)).cpu().numpy()
+      p1.close()
+      assert rel_l2(o1, truth1) < tol, (name, stack, rel_l2(o1, truth1))
+      outs[name, stack] = o1
+    p2 = tfft.Plan('type_2', grid, 'backward', tol=tol, tuning=_lib.TUNE[name])
+    p2.set_points(_dev(pts))
+    assert (p2.sort_path() == 3) == (name == 'SORT2_ON')
+    o2 = p2.execute(_dev(f)).cpu().numpy()
+    p2.close()
+    assert rel_l2(o2, truth2) < tol, (name, rel_l2(o2, truth2))
+    outs[name, 't2'] = o2
+  assert np.array_equal(outs['SORT2_ON', 't2'], outs['SORT2_OFF', 't2'])     # type 2 reads: same records per tile, bitwise equal
+  # (type 1 sums in another order, on level-1 records whose Horner arguments keep 26 bits, with other subproblem cuts and so
+  # other fixed-point steps: float rounding of two results that each sit ~2e-7 from the truth)
+  assert rel_l2(outs['SORT2_ON', 'STACK_OFF'], outs['SORT2_OFF', 'STACK_OFF']) < 0.1 * tol + 3e-7
+  assert rel_l2(outs['SORT2_ON', 'STACK_ON'], outs['SORT2_OFF', 'STACK_ON']) < 0.1 * tol + 3e-7
+  # by default: from 1.5 x 2^20 points on a grid with more tiles than the LDS-counter sort takes
+  g2, M2 = [168, 180, 200], 1_700_000      # fine 400 x 360 x 336 (x last): 25 x 23 x 42 = 24150 tiles, 7 x 6 x 6 super-tiles
+  p = (torch.rand((M2, 3), device='cuda') * 2 - 1) * np.pi
+  plan = tfft.Plan('type_1', g2, 'forward', tol=1e-6)
+  plan.set_points(p)
+  assert plan.sort_path() == 3, plan.sort_path()
+  cc = torch.complex(torch.rand(M2, device='cuda') - .5, torch.rand(M2, device='cuda') - .5)
+  got = plan.execute(cc)
+  plan.close()
+  alt = tfft.Plan('type_1', g2, 'forward', tol=1e-6, tuning=_lib.TUNE['SORT2_OFF'])
+  alt.set_points(p)
+  assert alt.sort_path() in (0, 1)
+  ref = alt.execute(cc)
+  alt.close()
+  assert float(torch.linalg.norm(got - ref) / torch.linalg.norm(ref)) < 4e-7
