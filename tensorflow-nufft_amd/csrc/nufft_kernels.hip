@@ -2881,13 +2881,23 @@ hipError_t launch_sort(const Geom& g, const PointsIn& in_arg, const SortWork& w,
       {
         SortedOut<T> l1;
         l1.rec = reinterpret_cast<Rec<T>*>(tmp_rec);
-        const size_t slds = kStagedLds<T, 1024>;
+        // (r06: up to 4096 super-tiles -- fine grids up to 1024^3 -- on the staged kernel's 4096-destination form: 6144 records
+        // per pass, 1.5 per destination, so the level-1 writes are single records again; what is left of the gain is level 2's)
+        const bool big1 = g1.ntiles > 1024;
+        const size_t slds = big1 ? kStagedLds<T, 4096> : kStagedLds<T, 1024>;
 #define NUFFT_SORT2_LEVEL1(AOSV, QFV)                                                                                   \
   do {                                                                                                                  \
-    e = ensure_lds(scatter_staged_kernel<T, AOSV, false, 1024, true, QFV>, slds);                                       \
-    if (e != hipSuccess) return e;                                                                                      \
-    scatter_staged_kernel<T, AOSV, false, 1024, true, QFV><<<nblk, kSortBlock, slds, stream>>>(g1, in, per_block, hist1, \
-                                                                                               c_start, l1);           \
+    if (big1) {                                                                                                         \
+      e = ensure_lds(scatter_staged_kernel<T, AOSV, false, 4096, true, QFV>, slds);                                     \
+      if (e != hipSuccess) return e;                                                                                    \
+      scatter_staged_kernel<T, AOSV, false, 4096, true, QFV><<<nblk, kSortBlock, slds, stream>>>(g1, in, per_block, hist1, \
+                                                                                                 c_start, l1);         \
+    } else {                                                                                                            \
+      e = ensure_lds(scatter_staged_kernel<T, AOSV, false, 1024, true, QFV>, slds);                                     \
+      if (e != hipSuccess) return e;                                                                                    \
+      scatter_staged_kernel<T, AOSV, false, 1024, true, QFV><<<nblk, kSortBlock, slds, stream>>>(g1, in, per_block, hist1, \
+                                                                                                 c_start, l1);         \
+    }                                                                                                                   \
   } while (0)
         if (aos == 3) {
           if (qf) NUFFT_SORT2_LEVEL1(3, true); else NUFFT_SORT2_LEVEL1(3, false);

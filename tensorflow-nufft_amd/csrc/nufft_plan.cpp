@@ -1227,7 +1227,7 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
   g.sub_small = 0;
   // Tile numbering. 3-D float plans with more tiles than the LDS-counter sort takes number them by super-tiles of
   // 64^3 fine cells, which the two-level sort (launch_sort, mode 3) sorts by first: every dimension a multiple of
-  // 64 cells, at most 1024 super-tiles of at most 256 tiles each, one point set.
+  // 64 cells, at most 4096 super-tiles (r06; 1024 before) of at most 256 tiles each, one point set.
   for (int d = 0; d < 3; ++d) { g.sup_shift[d] = 0; g.nsup[d] = g.ntile[d]; }
   {
     const int mode = tune_mode(g_tuning_probe(p->opts.tuning), NUFFT_HIP_TUNE_SORT2_OFF, NUFFT_HIP_TUNE_SORT2_ON);
@@ -1240,7 +1240,7 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
       nsuper *= (g.nf[d] + 63) / 64;
       key_bits += 6 - g.tile_shift[d];
     }
-    if (ok && nsuper <= 1024 && key_bits <= 8 && key_bits > 0) {
+    if (ok && nsuper <= 4096 && key_bits <= 8 && key_bits > 0) {
       // r06: fine grids that are not multiples of 64 cells too (the smooth sizes: 480, 400, 384 ...): the last super-tile of
       // a dimension is partial, and the tile ids of the cells it lacks exist but stay empty -- the tile tables are sized by
       // the padded count (240^3 modes: 65536 ids for 54000 tiles; sort 523 -> see profiles/r06_sort2_partial.txt)

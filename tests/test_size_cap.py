@@ -3,7 +3,7 @@
 
 The reference plan accepts fine grids of up to kMaxArraySize = 2e9 elements (nufft_plan.h:62, 843-848); 288 GB of HBM
 is where such grids become usable. Here: fine grids of 2^30 cells -- 3-D 512^3 modes (1024^3 fine, 8.6 GB in complex64,
-524 288 tiles: past the two-level sort's 1024 super-tiles, the global-counter sort) and 2-D 16384^2 modes (32768^2 fine: rocFFT, > 10^6 tiles: the global-counter sort)
+524 288 tiles in 4096 super-tiles: the two-level sort at its limit) and 2-D 16384^2 modes (32768^2 fine: rocFFT, > 10^6 tiles: the global-counter sort)
 -- where the interleaved float index 2 * cell passes 2^31 in the last rows / planes. Nothing of this size fits an
 oracle run; the checks are size independent: dense fp64 NUDFTs of all points on a few hundred modes taken from every
 corner of the mode box (type 1), of all modes at a few hundred points planted next to the domain's ends and drawn
@@ -57,7 +57,7 @@ def test_3d_512_modes_on_a_1024_cubed_fine_grid():
   assert [int(v) for v in info.fine_dims] == [1024, 1024, 1024]
   assert int(info.num_tiles[0]) * int(info.num_tiles[1]) * int(info.num_tiles[2]) == 524288
   plan.set_points(pts)
-  assert plan.sort_path() == 2          # global counters: 4096 super-tiles of 64^3 cells are more than the 1024 the two-level sort stages (sort path 3 ends at 640^3 fine cells)
+  assert plan.sort_path() == 3          # two levels: 4096 super-tiles of 64^3 cells (the staged kernel's 4096-destination form), then tiles
   Ac = plan.execute(c)
   # ---- type 1 against the definition on 7^3 modes from every corner, edge and the centre of the mode box
   idx, ks = _mode_sets(N, 'cuda')
