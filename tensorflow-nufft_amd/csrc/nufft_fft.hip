@@ -406,7 +406,17 @@ int fft_pass_shape(int n, int kout, int csize, int64_t nlines, int* lw_out, size
   int best = 0, best_lw = 0;
   size_t best_lds = 0;
   int tier = 0;
-  for (int R = 16; R >= 2; R /= 2) {
+  int force_r = 0;
+#ifdef NUFFT_MIX_SHAPE_ENV   // (experiment builds: lines per workgroup of the power-of-two passes from the environment)
+  if (const char* ev = getenv(gather ? "NUFFT_FFT_R_GATHER" : "NUFFT_FFT_R")) force_r = atoi(ev);
+#endif
+  // Type-2 (gather) passes over very many lines read R lines x 8 bytes per element of a line, the elements nlines x 8
+  // bytes apart: from ~2 MB between them every run sits on a page of its own and the longest run that fits wins
+  // (r06, profiles/r06_fft_gather_r.txt: 1024^3 fine, R = 8 -> 16: 12.4 -> 9.3 ms; 512^3, R = 8 -> 32: 1.05 -> 0.97 ms)
+  const bool far = gather && nlines * (int64_t)csize >= ((int64_t)2 << 20);
+  for (int R = 32; R >= 2; R /= 2) {
+    if (R > 16 && force_r != R && !far) continue;
+    if (force_r && R != force_r) continue;
     if (R * csize < 32) break;                                     // output segments of at least 32 bytes
     int LW = kFftMaxThreads / TL;
     if (LW > R) LW = R;
@@ -425,7 +435,8 @@ int fft_pass_shape(int n, int kout, int csize, int64_t nlines, int* lw_out, size
     // tier 4: >= 512 workgroups that fit two to a CU, 64-byte segments; tier 3: >= 256 workgroups
     // and 64-byte segments; tier 2: >= 256 workgroups; tier 1: feasible
     const bool seg64 = R * csize >= 64;
-    const int t = (wgs >= 512 && bytes <= 80 * 1024 && seg64) ? 4 : (wgs >= 256 && seg64) ? 3 : (wgs >= 256 ? 2 : 1);
+    int t = (wgs >= 512 && bytes <= 80 * 1024 && seg64) ? 4 : (wgs >= 256 && seg64) ? 3 : (wgs >= 256 ? 2 : 1);
+    if (far && wgs >= 512) t = 5;   // (the first, i.e. longest, feasible R)
     if (t > tier) { tier = t; best = R; best_lw = LW; best_lds = bytes; }
   }
   if (!best) return 0;
@@ -744,7 +755,7 @@ int mix_factor(int n, unsigned* radpack) {
 // Lines per workgroup (R, a power of two), threads, values per thread (8 / 16) and dynamic LDS of one mixed-radix
 // pass with K kept modes; 0: not supported. The R lines are all in flight: R n elements of LDS and R n / 8 (or / 16)
 // threads, so that several workgroups share a CU (the loads of one overlap the passes of another).
-int mix_pass_shape(int n, int K, int csize, int64_t nlines, int* threads, int* vpt_out, size_t* lds) {
+int mix_pass_shape(int n, int K, int csize, int64_t nlines, int* threads, int* vpt_out, size_t* lds, bool gather = false) {
   unsigned pk;
   if (n < 4 || n > kMixMaxN || (n & 1) || K > n || !mix_factor(n, &pk)) return 0;
   int best = 0, best_thr = 0, best_vpt = 0, tier = 0;
@@ -765,6 +776,9 @@ int mix_pass_shape(int n, int K, int csize, int64_t nlines, int* threads, int* v
     const int64_t wgs = (nlines + R - 1) / R;
     const int per_cu = std::min((int)(160 * 1024 / bytes), 1536 / thr);   // (72-80 VGPRs: six waves per SIMD)
     const bool seg64 = R * csize >= 64;
+    // (the far-apart-gather rule of fft_pass_shape does not carry over: one workgroup of R = 16 lines per CU instead of
+    // three of 8 lost more than the longer runs gained -- 640^3 fine type 2 2.65 -> 2.96 ms, 768^3 3.7 -> 5.2 ms; `gather` unused)
+    (void)gather;
     const int t = (wgs >= 512 && per_cu >= 2 && seg64) ? 4 : (wgs >= 256 && seg64) ? 3 : (wgs >= 256 ? 2 : 1);
     if (t > tier) { tier = t; best = R; best_thr = thr; best_vpt = vpt; best_lds = bytes; }
   }
@@ -887,7 +901,7 @@ hipError_t launch_pruned_fft(const Geom& g, int type, int iflag, T* fine, T* f, 
     a.LW = 1;
     const bool mixed = !is_pow2(a.n) || a.n > 2048;
     int mix_threads = 0, mix_vpt = 0;
-    a.R = mixed ? mix_pass_shape(a.n, type == 1 ? a.kout : a.kin, csize, lines, &mix_threads, &mix_vpt, &lds)
+    a.R = mixed ? mix_pass_shape(a.n, type == 1 ? a.kout : a.kin, csize, lines, &mix_threads, &mix_vpt, &lds, gather)
                 : fft_pass_shape(a.n, a.kout, csize, lines, &a.LW, &lds, gather);
     if (a.R == 0) return hipErrorInvalidValue;
     const int64_t nblk = (lines + a.R - 1) / a.R;
