@@ -758,7 +758,8 @@ int mix_factor(int n, unsigned* radpack) {
 int mix_pass_shape(int n, int K, int csize, int64_t nlines, int* threads, int* vpt_out, size_t* lds, bool gather = false) {
   unsigned pk;
   if (n < 4 || n > kMixMaxN || (n & 1) || K > n || !mix_factor(n, &pk)) return 0;
-  int best = 0, best_thr = 0, best_vpt = 0, tier = 0;
+  int best = 0, best_thr = 0, best_vpt = 0;
+  double tier = 0.0;
   size_t best_lds = 0;
   int force_r = 0;
 #ifdef NUFFT_MIX_SHAPE_ENV   // (experiment builds, tools/exp_mixfft_shape.py: lines per workgroup from the environment)
@@ -779,7 +780,9 @@ int mix_pass_shape(int n, int K, int csize, int64_t nlines, int* threads, int* v
     // (the far-apart-gather rule of fft_pass_shape does not carry over: one workgroup of R = 16 lines per CU instead of
     // three of 8 lost more than the longer runs gained -- 640^3 fine type 2 2.65 -> 2.96 ms, 768^3 3.7 -> 5.2 ms; `gather` unused)
     (void)gather;
-    const int t = (wgs >= 512 && per_cu >= 2 && seg64) ? 4 : (wgs >= 256 && seg64) ? 3 : (wgs >= 256 ? 2 : 1);
+    // (fewer workgroups than CUs: the more the better -- the second pass of a 1920^2 grid has 960 lines, and eight of them per
+    // workgroup left half the chip idle: 22 us for 22 MB, profiles/r06_configs_kernel_stats.txt)
+    const double t = (wgs >= 512 && per_cu >= 2 && seg64) ? 4.0 : (wgs >= 256 && seg64) ? 3.0 : (wgs >= 256 ? 2.0 : 1.0 + 0.9 * (double)wgs / 256.0);
     if (t > tier) { tier = t; best = R; best_thr = thr; best_vpt = vpt; best_lds = bytes; }
   }
   if (!best) return 0;
