@@ -50,7 +50,7 @@ extern "C" {
  *   3  options.tuning (validated bits), options_from_proto, op_desc_from_attrs, plan_describe
  *   4  (r06) nufft_hip_build_info. Entries that arrived under version 3's number in r04 / r05 and are guaranteed from
  *      4 on: debug_sub_bounds, debug_shader_clock_mhz, debug_stacks, debug_stack_params; tuning bits FXPATCH_OFF,
- *      QFOLD_OFF, STACK_OFF / STACK_ON, FBGROUP_OFF, and r06's MIXFFT_OFF */
+ *      QFOLD_OFF, STACK_OFF / STACK_ON, FBGROUP_OFF, and r06's MIXFFT_OFF, ISPLIT_OFF / ISPLIT_ON */
 #define NUFFT_HIP_ABI_VERSION 4
 
 /* Status codes. They map onto the tensorflow::errors the reference returns. */
@@ -148,7 +148,10 @@ enum {
                                               plane) instead of the cell-grouped one (r05) */
   NUFFT_HIP_TUNE_MIXFFT_OFF = 1 << 23,     /* fine-grid dimensions that are not powers of two (or exceed 2048): rocFFT + deconvolve kernel
                                               instead of the mixed-radix pruned passes (r06); power-of-two grids keep their passes */
-  NUFFT_HIP_TUNE_ALL = (1 << 24) - 1       /* every defined bit: plan creation refuses others, and both bits of a pair */
+  NUFFT_HIP_TUNE_ISPLIT_OFF = 1 << 24,     /* 3-D interpolation: eight lanes per point (each sums one z plane of the stencil) instead of
+                                              a thread per point (r06; by default at w = 7, 8 while a tile holds < 64 points on average): never / always */
+  NUFFT_HIP_TUNE_ISPLIT_ON = 1 << 25,
+  NUFFT_HIP_TUNE_ALL = (1 << 26) - 1       /* every defined bit: plan creation refuses others, and both bits of a pair */
 };
 
 typedef struct nufft_hip_plan_s* nufft_hip_plan;

@@ -2336,10 +2336,24 @@ __device__ __forceinline__ void hornerW(const T* __restrict__ tab, int nc, T z0,
 #define NUFFT_INTERP_EXP 0 //  8 results stored in sorted order -- wrong results, timing only)
 #endif
 template <int RANK> constexpr int kInterpThreads = RANK > 2 ? 512 : 256;
-template <typename T, int RANK, int W, int NTHREADS = kInterpThreads<RANK>>
+constexpr double kSplitPointsPerTile = 64.0;   // (r06; see interp_point_kernel SPLIT and profiles/r06_interp_split_ab.txt)
+// STACK (r06; 3-D, 16 x 16 x TZ tiles, double precision): the workgroup walks a STACK of tiles consecutive in z
+// (stack_plan_kernel, nufft_dense3.hip) instead of one subproblem -- the w - 1 planes a tile shares with the next one
+// move down in LDS and only TZ new planes are read. On 16-byte cells the tiles are 16 x 16 x 4 and tile + halo is 5.7 x
+// the tile, read per subproblem by the one workgroup a CU holds (93 KB): 7.8 ms for 256^3 modes at M = 1e7 against 1.55 ms
+// in float (profiles/r06_c128_before.txt). (The float kernel's stack form lost to the flat loader at three workgroups
+// per CU: EXPERIMENTS.md 11.7.)
+// SPLIT (r06; 3-D): EIGHT lanes per point, lane s summing z plane s of the stencil (w x w cells), the partial sums
+// combined over the eight lanes. A thread per point leaves a tile with 20-150 points on one or two waves of the
+// workgroup, each walking w^3 dependent cell reads and FMAs alone (512 at w = 8: ~3.5 us in double) -- below ~0.3 points
+// per cell that latency, not the tile read, was the kernel (complex128, 256^3 modes: interp 7.2-7.8 ms from M = 3e6 to
+// 1e7, unchanged by halving the reads with stacks: profiles/r06_c128_interp_stack_ab.txt).
+template <typename T, int RANK, int W, int NTHREADS = kInterpThreads<RANK>, bool STACK = false, bool SPLIT = false>
 __global__ __launch_bounds__(NTHREADS) void interp_point_kernel(
     Geom g, SortedPoints<T> sp, const T* __restrict__ horner, T* __restrict__ c,
     const T* __restrict__ fw, int64_t c_stride, int64_t fw_stride, T scale) {
+  static_assert(!STACK || RANK == 3, "stacks: 3-D");
+  static_assert(!SPLIT || RANK == 3, "eight lanes per point: 3-D");
   using T2 = typename Pair<T>::type;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int LS = g.lstride;
@@ -2347,14 +2361,25 @@ __global__ __launch_bounds__(NTHREADS) void interp_point_kernel(
   const int L2 = RANK > 2 ? g.ldim[2] : 1;
   const int PS = LS * L1;
   T2* tile = reinterpret_cast<T2*>(smem_raw);
-  int tb, p0, p1, slot;
-  if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1, &slot)) return;
+  int tb = 0, p0 = 0, p1 = 0, slot = 0;
+  int t0 = 0, t1 = 0, t2 = 0;
+  StackDesc sd = {0, 0, 1, 0, 0};
+  StackColumn scol = {0, 0, 0};
+  if constexpr (STACK) {
+    if ((int)blockIdx.x >= sp.seg_count[0]) return;
+    sd = stack_load(sp.segs, blockIdx.x);
+    scol = stack_column(g, sd.col);
+    slot = scol.item * (int)gridDim.y + (int)blockIdx.y;
+    t0 = scol.t0; t1 = scol.t1; t2 = sd.z0;
+  } else {
+    if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1, &slot)) return;
+    tile_coords(g, tb, &t0, &t1, &t2);
+  }
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  int t0, t1, t2;
-  tile_coords(g, tb, &t0, &t1, &t2);
-  const int o0 = t0 * g.tile[0], o1 = t1 * g.tile[1], o2 = t2 * g.tile[2];
+  const int o0 = t0 * g.tile[0], o1 = t1 * g.tile[1];
+  int o2 = t2 * g.tile[2];
   const T2* in = reinterpret_cast<const T2*>(fw) + (int64_t)slot * fw_stride;
   constexpr int NT = NTHREADS;
   // Tile rows (L0 <= 39 cells: one lane per cell) are fetched kRowBatch at a time: the
@@ -2369,9 +2394,9 @@ __global__ __launch_bounds__(NTHREADS) void interp_point_kernel(
   // the divisions are multiplications). 3-D type 2, 256^3 modes, w = 8, interp stage: M = 3e6 2.40 -> 1.41 ms, 1e7
   // 2.58 -> 1.58, 3e7 3.99 -> 3.10, 1e8 7.32 -> 6.77; w = 6, 1e7: 1.78 -> 1.03. (The 2-D tiles -- 39- and 71-cell rows, the
   // latter in two sweeps -- measured the same either way, config 3 221 against 221-227 us: left on rows.)
-  auto load_flat = [&](auto lc) {
+  auto load_flat = [&](auto lc, int plane0) {   // planes [plane0, L2) of the tile at (o0, o1, o2)
     constexpr int LC = decltype(lc)::value;
-    const int ncell = LC * LC * L2;
+    const int ncell = LC * LC * (L2 - plane0);
     for (int e0 = tid; e0 < ncell; e0 += kRowBatch * NT) {
       T2 v[kRowBatch];
       int lofs[kRowBatch];
@@ -2379,7 +2404,8 @@ __global__ __launch_bounds__(NTHREADS) void interp_point_kernel(
       for (int u = 0; u < kRowBatch; ++u) {
         const int e = e0 + u * NT;
         const int ec = e < ncell ? e : ncell - 1;
-        const int a2 = RANK > 2 ? ec / (LC * LC) : 0, r = ec - a2 * (LC * LC);
+        const int a2r = RANK > 2 ? ec / (LC * LC) : 0, r = ec - a2r * (LC * LC);
+        const int a2 = a2r + plane0;
         const int a1 = r / LC, a0 = r - a1 * LC;
         const int g2 = RANK > 2 ? wrap1(o2 + a2, g.nf[2]) : 0;
         v[u] = in[(int64_t)g.nf[0] * (wrap1(o1 + a1, g.nf[1]) + (int64_t)g.nf[1] * g2) + wrap1(o0 + a0, g.nf[0])];
@@ -2390,8 +2416,204 @@ __global__ __launch_bounds__(NTHREADS) void interp_point_kernel(
         if (lofs[u] >= 0) tile[lofs[u]] = v[u];
     }
   };
+  T2* cc = reinterpret_cast<T2*>(c) + (int64_t)slot * c_stride;
+  const int nc = g.ncoef;
+  // index of the first record a thread reads of a tile's points (clamped)
+  auto first_index = [&](int q0, int q1) {
+    const int j = SPLIT ? q0 + (tid >> 3) : q0 + tid;
+    return j < q1 ? j : (q1 > q0 ? q1 - 1 : 0);   // (an empty tile: any valid record)
+  };
+  // the points [p0, p1) of the tile in LDS; `first` = sp.rec[first_index(p0, p1)], loaded by the caller (a tile ahead on stacks)
+  auto do_points = [&](int p0, int p1, const Rec<T> first) {
+    if (p1 <= p0) return;
+    if constexpr (SPLIT) {
+      const int sl = tid & 7;                  // the z plane of the stencil this lane sums
+      const int sq = sl < W ? sl : 0;
+      constexpr int NP = NT / 8;               // points per pass of the workgroup
+      for (int j0 = p0; j0 < p1; j0 += NP) {
+        const int j = j0 + (tid >> 3);
+        const bool live = j < p1;
+        const PointView<T> rec = unpack_rec<T, RANK>(j0 == p0 ? first : sp.rec[live ? j : p1 - 1]);
+        // tap sl of the three kernel polynomials; the x and y taps of the other seven lanes come by shuffle
+        T k0 = horner[(nc - 1) * kMaxW + sq], k1 = k0, k2 = k0;
+        for (int k = nc - 2; k >= 0; --k) {
+          const T t = horner[k * kMaxW + sq];
+          k0 = fma(k0, rec.z0, t);
+          k1 = fma(k1, rec.z1, t);
+          k2 = fma(k2, rec.z2, t);
+        }
+        if (sl >= W) k2 = (T)0;                // (lanes past the width re-read plane 0 with weight 0)
+        T kx[W], ky[W];
+#pragma unroll
+        for (int q = 0; q < W; ++q) {
+          kx[q] = __shfl(k0, q, 8);
+          ky[q] = __shfl(k1, q, 8);
+        }
+        const T2* tp = tile + (int)(rec.loc & 1023) + (int)((rec.loc >> 10) & 1023) * LS +
+                       ((int)((rec.loc >> 20) & 1023) + sq) * PS;
+        T pre = (T)0, pim = (T)0;
+#pragma unroll
+        for (int dy = 0; dy < W; ++dy) {
+          const T2* row = tp + dy * LS;
+          T rre = (T)0, rim = (T)0;
+#pragma unroll
+          for (int dx = 0; dx < W; ++dx) {
+            const T2 v = lds_cell(row + dx);
+            rre = fma(kx[dx], v.x, rre);
+            rim = fma(kx[dx], v.y, rim);
+          }
+          pre = fma(ky[dy], rre, pre);
+          pim = fma(ky[dy], rim, pim);
+        }
+        T sre = k2 * pre, sim = k2 * pim;
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+          sre += __shfl_xor(sre, o, 8);
+          sim += __shfl_xor(sim, o, 8);
+        }
+        if (sl == 0 && live) {
+          T2 out;
+          out.x = sre * scale;
+          out.y = sim * scale;
+          cc[rec.idx] = out;
+        }
+      }
+      return;
+    }
+
+  // the next record is requested (on a clamped index, outside any branch) before this
+    // point's ~300 dependent instructions, so its HBM latency is off the critical path
+    Rec<T> raw = first;
+    for (int j = p0 + tid; j < p1; j += NT) {
+      const PointView<T> rec = unpack_rec<T, RANK>(raw);
+      raw = sp.rec[j + NT < p1 ? j + NT : p1 - 1];
+      T kx[W], ky[W], kz[W];
+      hornerW<T, RANK, W>(horner, nc, rec.z0, rec.z1, rec.z2, kx, ky, kz);
+      const T2* tp = tile + (int)(rec.loc & 1023) + (int)((rec.loc >> 10) & 1023) * LS +
+                     (RANK > 2 ? (int)((rec.loc >> 20) & 1023) * PS : 0);
+      T sre = (T)0, sim = (T)0;
+      // (3-D: three z-planes per unrolled body. Fully unrolled -- 216 to 512 cell reads -- the kernel held 114 VGPRs and
+      // up: two workgroups per CU at w = 6, spills at w = 7, 8; this way 75-79: M = 3e7 at w = 8 7.7 -> 4.0 ms, r03)
+#pragma unroll 3
+      for (int dz = 0; dz < (RANK > 2 ? W : 1); ++dz) {
+        T pre = (T)0, pim = (T)0;
+#pragma unroll
+        for (int dy = 0; dy < W; ++dy) {
+          const T2* row = tp + dz * PS + dy * LS;
+          T rre = (T)0, rim = (T)0;
+#pragma unroll
+          for (int dx = 0; dx < W; ++dx) {
+#if NUFFT_INTERP_EXP & 1
+            T2 v; v.x = (T)(dx + dy); v.y = (T)dz;
+#else
+            const T2 v = lds_cell(row + dx);
+#endif
+            rre = fma(kx[dx], v.x, rre);
+            rim = fma(kx[dx], v.y, rim);
+          }
+          pre = fma(ky[dy], rre, pre);
+          pim = fma(ky[dy], rim, pim);
+        }
+        if (RANK > 2) {
+          sre = fma(kz[dz], pre, sre);
+          sim = fma(kz[dz], pim, sim);
+        } else {
+          sre = pre;
+          sim = pim;
+        }
+      }
+      T2 out;
+      out.x = sre * scale;
+      out.y = sim * scale;
+#if NUFFT_INTERP_EXP & 2
+      if (out.x == (T)123.456) cc[rec.idx] = out;
+#elif NUFFT_INTERP_EXP & 8
+      cc[j] = out;   // (in sorted order: coalesced)
+#else
+      cc[rec.idx] = out;
+#endif
+    }
+  };
+  if constexpr (STACK) {
+    // ---- a stack of tiles, pipelined: every tile's point range is read up front, the next tile's new planes and
+    // first records are requested BEFORE this tile's points are interpolated (r05's lesson from the float stack kernels:
+    // a sparse tile's time is the latency of its dependent loads -- range, then record, then planes -- not their bytes)
+    constexpr int LC = 16 + W - 1;
+    constexpr int TZ = W <= 6 ? 8 : 4;                      // (the host launches this form on such tiles only)
+    constexpr int NPF = (LC * LC * TZ + NT - 1) / NT;       // cells of a tile's new planes per thread
+    constexpr int kRng = 64;
+    __shared__ int rng[2 * kRng];
+    if (sd.p0 < 0) {
+      for (int i = tid; i < sd.nz && i < kRng; i += NT) {
+        const int t = stack_tile_index(g, scol, sd.z0 + i);
+        rng[2 * i] = sp.tile_start[t];
+        rng[2 * i + 1] = sp.tile_start[t + 1];
+      }
+    }
+    auto range_of = [&](int i, int* q0, int* q1) {
+      if (sd.p0 >= 0) { *q0 = sd.p0; *q1 = sd.p1; return; }   // a piece: one tile, its own points
+      if (i < kRng) { *q0 = rng[2 * i]; *q1 = rng[2 * i + 1]; return; }
+      const int t = stack_tile_index(g, scol, sd.z0 + i);
+      *q0 = sp.tile_start[t];
+      *q1 = sp.tile_start[t + 1];
+    };
+    o2 = sd.z0 * TZ;
+    load_flat(std::integral_constant<int, LC>(), 0);
+    __syncthreads();
+    int q0, q1;
+    range_of(0, &q0, &q1);
+    Rec<T> first = sp.rec[first_index(q0, q1)];
+    for (int ti = 0; ti < sd.nz; ++ti) {
+      const bool more = ti + 1 < sd.nz;
+      const int c0 = q0, c1 = q1;
+      const Rec<T> first_now = first;
+      // the next tile's new planes, NPF cells per thread, in NAMED registers (as an array indexed by an unrolled loop they
+      // went to scratch memory: 80-128 bytes per lane); requested unconditionally -- behind the last tile the planes it
+      // already holds are read again and dropped
+      T2 pf0, pf1, pf2, pf3, pf4, pf5, pf6, pf7;
+      static_assert(NPF <= 8, "prefetch registers");
+      const int tn = more ? ti + 1 : ti;
+      range_of(tn, &q0, &q1);
+      first = sp.rec[first_index(q0, q1)];
+      const int o2n = (sd.z0 + tn) * TZ + (L2 - TZ);   // first new plane of the next tile, fine-grid z before wrapping
+      auto pf_src = [&](int u) {
+        const int e = tid + u * NT;
+        const int ec = e < LC * LC * TZ ? e : LC * LC * TZ - 1;
+        const int a2 = ec / (LC * LC), r = ec - a2 * (LC * LC);
+        const int a1 = r / LC, a0 = r - a1 * LC;
+        return in[(int64_t)g.nf[0] * (wrap1(o1 + a1, g.nf[1]) + (int64_t)g.nf[1] * wrap1(o2n + a2, g.nf[2])) + wrap1(o0 + a0, g.nf[0])];
+      };
+#define NUFFT_PF_LOAD(u) if constexpr (u < NPF) pf##u = pf_src(u); else pf##u = T2();
+      NUFFT_PF_LOAD(0) NUFFT_PF_LOAD(1) NUFFT_PF_LOAD(2) NUFFT_PF_LOAD(3) NUFFT_PF_LOAD(4) NUFFT_PF_LOAD(5) NUFFT_PF_LOAD(6) NUFFT_PF_LOAD(7)
+#undef NUFFT_PF_LOAD
+      do_points(c0, c1, first_now);
+      if (!more) break;
+      __syncthreads();   // every thread is done with this tile's planes
+      // planes TZ .. L2 - 1 move down by TZ: one thread per (y, x) column and residue of the plane index, upwards
+      for (int e = tid; e < LC * LC * TZ; e += NT) {
+        const int a2 = e / (LC * LC), r = e - a2 * (LC * LC);
+        const int a1 = r / LC, a0 = r - a1 * LC;
+        T2* col = tile + a1 * LS + a0;
+        for (int q = a2; q + TZ < L2; q += TZ) col[q * PS] = col[(q + TZ) * PS];
+      }
+      __syncthreads();   // (the new planes land where the moved ones were read)
+      auto pf_dst = [&](int u, const T2& v) {
+        const int e = tid + u * NT;
+        if (e < LC * LC * TZ) {
+          const int a2 = e / (LC * LC), r = e - a2 * (LC * LC);
+          const int a1 = r / LC, a0 = r - a1 * LC;
+          tile[(L2 - TZ + a2) * PS + a1 * LS + a0] = v;
+        }
+      };
+#define NUFFT_PF_STORE(u) if constexpr (u < NPF) pf_dst(u, pf##u);
+      NUFFT_PF_STORE(0) NUFFT_PF_STORE(1) NUFFT_PF_STORE(2) NUFFT_PF_STORE(3) NUFFT_PF_STORE(4) NUFFT_PF_STORE(5) NUFFT_PF_STORE(6) NUFFT_PF_STORE(7)
+#undef NUFFT_PF_STORE
+      __syncthreads();
+    }
+    return;
+  }
   if (NUFFT_INTERP_EXP & 4) { }
-  else if (RANK > 2 && g.tile[0] == 16 && g.tile[1] == 16) load_flat(std::integral_constant<int, 16 + W - 1>());
+  else if (RANK > 2 && g.tile[0] == 16 && g.tile[1] == 16) load_flat(std::integral_constant<int, 16 + W - 1>(), 0);
   else
   // (rows of more than 64 cells -- the 64 x 64 tiles of 2-D type-2 plans, 71 cells with the
   // halo -- take a second sweep for the remaining columns)
@@ -2419,61 +2641,7 @@ __global__ __launch_bounds__(NTHREADS) void interp_point_kernel(
     }
   }
   __syncthreads();
-
-  const int nc = g.ncoef;
-  T2* cc = reinterpret_cast<T2*>(c) + (int64_t)slot * c_stride;
-  // the next record is requested (on a clamped index, outside any branch) before this
-  // point's ~300 dependent instructions, so its HBM latency is off the critical path
-  Rec<T> raw = sp.rec[p0 + tid < p1 ? p0 + tid : p1 - 1];
-  for (int j = p0 + tid; j < p1; j += NT) {
-    const PointView<T> rec = unpack_rec<T, RANK>(raw);
-    raw = sp.rec[j + NT < p1 ? j + NT : p1 - 1];
-    T kx[W], ky[W], kz[W];
-    hornerW<T, RANK, W>(horner, nc, rec.z0, rec.z1, rec.z2, kx, ky, kz);
-    const T2* tp = tile + (int)(rec.loc & 1023) + (int)((rec.loc >> 10) & 1023) * LS +
-                   (RANK > 2 ? (int)((rec.loc >> 20) & 1023) * PS : 0);
-    T sre = (T)0, sim = (T)0;
-    // (3-D: three z-planes per unrolled body. Fully unrolled -- 216 to 512 cell reads -- the kernel held 114 VGPRs and
-    // up: two workgroups per CU at w = 6, spills at w = 7, 8; this way 75-79: M = 3e7 at w = 8 7.7 -> 4.0 ms, r03)
-#pragma unroll 3
-    for (int dz = 0; dz < (RANK > 2 ? W : 1); ++dz) {
-      T pre = (T)0, pim = (T)0;
-#pragma unroll
-      for (int dy = 0; dy < W; ++dy) {
-        const T2* row = tp + dz * PS + dy * LS;
-        T rre = (T)0, rim = (T)0;
-#pragma unroll
-        for (int dx = 0; dx < W; ++dx) {
-#if NUFFT_INTERP_EXP & 1
-          T2 v; v.x = (T)(dx + dy); v.y = (T)dz;
-#else
-          const T2 v = lds_cell(row + dx);
-#endif
-          rre = fma(kx[dx], v.x, rre);
-          rim = fma(kx[dx], v.y, rim);
-        }
-        pre = fma(ky[dy], rre, pre);
-        pim = fma(ky[dy], rim, pim);
-      }
-      if (RANK > 2) {
-        sre = fma(kz[dz], pre, sre);
-        sim = fma(kz[dz], pim, sim);
-      } else {
-        sre = pre;
-        sim = pim;
-      }
-    }
-    T2 out;
-    out.x = sre * scale;
-    out.y = sim * scale;
-#if NUFFT_INTERP_EXP & 2
-    if (out.x == (T)123.456) cc[rec.idx] = out;
-#elif NUFFT_INTERP_EXP & 8
-    cc[j] = out;   // (in sorted order: coalesced)
-#else
-    cc[rec.idx] = out;
-#endif
-  }
+  do_points(p0, p1, sp.rec[first_index(p0, p1)]);
 }
 
 // ------------------------------------------------ interp: generic tile path
@@ -3513,6 +3681,14 @@ hipError_t launch_interp(const Geom& g, int method, const SortedPoints<T>& sp, i
   if (method == NUFFT_HIP_METHOD_TILE_WAVE) {
     const size_t lds = interp_lds_bytes(g, method, (int)sizeof(T));
     hipError_t e = hipSuccess;
+    // 3-D: eight lanes per point while a tile holds fewer points than kSplitPointsPerTile on average (options.tuning
+    // ISPLIT_OFF / ISPLIT_ON force the choice)
+    bool split3 = false;
+    if (g.rank == 3) {
+      const int mode = tune_mode(g, NUFFT_HIP_TUNE_ISPLIT_OFF, NUFFT_HIP_TUNE_ISPLIT_ON);
+      const double tiles = (double)g.ntile[0] * g.ntile[1] * g.ntile[2] * (g.nitems > 1 ? g.nitems : 1);
+      split3 = mode >= 0 ? mode != 0 : (g.w >= 7 && (double)M < kSplitPointsPerTile * tiles);
+    }
 #define NUFFT_LAUNCH_IP(RR, WW)                                                                       \
   case RR * 100 + WW:                                                                                 \
     if constexpr (RR == 2 && sizeof(T) == 4) {                                                        \
@@ -3521,6 +3697,32 @@ hipError_t launch_interp(const Geom& g, int method, const SortedPoints<T>& sp, i
         if (e != hipSuccess) return e;                                                                \
         interp_point_kernel<T, RR, WW, 512><<<grid, 512, lds, stream>>>(g, sp, horner, c, fw,         \
                                                                         c_stride, fw_stride, scale);  \
+        break;                                                                                        \
+      }                                                                                               \
+    }                                                                                                 \
+    if constexpr (RR == 3 && sizeof(T) == 8) {                                                        \
+      if (g.stack && sp.segs && g.tile[0] == 16 && g.tile[1] == 16) {   /* r06: over stacks of tiles */ \
+        const dim3 sgrid(stack_grid_bound(g, M), grid.y);                                             \
+        if (split3) {                                                                                 \
+          e = ensure_lds(interp_point_kernel<T, RR, WW, kInterpThreads<RR>, true, true>, lds);        \
+          if (e != hipSuccess) return e;                                                              \
+          interp_point_kernel<T, RR, WW, kInterpThreads<RR>, true, true><<<sgrid, kInterpThreads<RR>, lds, stream>>>( \
+              g, sp, horner, c, fw, c_stride, fw_stride, scale);                                      \
+        } else {                                                                                      \
+          e = ensure_lds(interp_point_kernel<T, RR, WW, kInterpThreads<RR>, true>, lds);              \
+          if (e != hipSuccess) return e;                                                              \
+          interp_point_kernel<T, RR, WW, kInterpThreads<RR>, true><<<sgrid, kInterpThreads<RR>, lds, stream>>>( \
+              g, sp, horner, c, fw, c_stride, fw_stride, scale);                                      \
+        }                                                                                             \
+        break;                                                                                        \
+      }                                                                                               \
+    }                                                                                                 \
+    if constexpr (RR == 3) {                                                                          \
+      if (split3) {   /* r06: eight lanes per point on tiles that hold few points */                   \
+        e = ensure_lds(interp_point_kernel<T, RR, WW, kInterpThreads<RR>, false, true>, lds);         \
+        if (e != hipSuccess) return e;                                                                \
+        interp_point_kernel<T, RR, WW, kInterpThreads<RR>, false, true><<<grid, kInterpThreads<RR>, lds, stream>>>( \
+            g, sp, horner, c, fw, c_stride, fw_stride, scale);                                        \
         break;                                                                                        \
       }                                                                                               \
     }                                                                                                 \

@@ -607,7 +607,9 @@ int ensure_point_capacity(nufft_hip_plan p, int64_t M, int rec_mult = 1) {
     }
   }
   // fixed-point 3-D plans that spread over stacks of tiles (r05): the stack descriptors
-  const bool stacks = (p->g.fixed_point || p->g.fp64_stack) && p->rank == 3 && (p->type == NUFFT_HIP_TYPE_1 || p->opts.spread_only) && stack3_wanted(p->g, M);
+  // (type-2 plans: the double-precision w <= 8 interpolation walks stacks too, r06)
+  const bool t2_stacks = p->g.fp64_stack && !p->g.wide && p->precision == NUFFT_HIP_F64;
+  const bool stacks = (p->g.fixed_point || p->g.fp64_stack) && p->rank == 3 && (p->type == NUFFT_HIP_TYPE_1 || p->opts.spread_only || t2_stacks) && stack3_wanted(p->g, M);
   if (stacks) {
     const int64_t need_g = (int64_t)stack_grid_bound(p->g, M) + 1;
     if (need_g > p->cap_segs) {
@@ -733,7 +735,7 @@ int set_points_impl(nufft_hip_plan p, int64_t M, const void* x, const void* y, c
                 (!p->g.fx_patch || p->cap_sub_bound >= (int64_t)stack_grid_bound(p->g, Mtot) + 1)) ? 1 : 0;
   if (sizeof(T) == 8 || p->g.wide) {
     // r06: the fp64-plane kernels over the same stacks (double: spread_wave3_stack_kernel; w = 9..16: spread_wide_kernel)
-    p->g.stack = (p->g.fp64_stack && p->segs && Mtot > 0 && (p->type == NUFFT_HIP_TYPE_1 || p->opts.spread_only) &&
+    p->g.stack = (p->g.fp64_stack && p->segs && Mtot > 0 && (p->type == NUFFT_HIP_TYPE_1 || p->opts.spread_only || (sizeof(T) == 8 && !p->g.wide)) &&
                   p->cap_segs >= (int64_t)stack_grid_bound(p->g, Mtot) + 1 && stack3_wanted(p->g, Mtot)) ? 1 : 0;
     if (p->g.stack) {
       hook.begin(STAGE_SORT_CELL);
@@ -1039,7 +1041,8 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
     static const int pairs[][2] = {{NUFFT_HIP_TUNE_GROUP_OFF, NUFFT_HIP_TUNE_GROUP_ON}, {NUFFT_HIP_TUNE_SPARSE_OFF, NUFFT_HIP_TUNE_SPARSE_ON},
                                    {NUFFT_HIP_TUNE_CELLSORT_OFF, NUFFT_HIP_TUNE_CELLSORT_ON}, {NUFFT_HIP_TUNE_CELLSORT3D_OFF, NUFFT_HIP_TUNE_CELLSORT3D_ON},
                                    {NUFFT_HIP_TUNE_JOINT_OFF, NUFFT_HIP_TUNE_JOINT_ON}, {NUFFT_HIP_TUNE_STAGED_OFF, NUFFT_HIP_TUNE_STAGED_ON},
-                                   {NUFFT_HIP_TUNE_SORT2_OFF, NUFFT_HIP_TUNE_SORT2_ON}, {NUFFT_HIP_TUNE_STACK_OFF, NUFFT_HIP_TUNE_STACK_ON}};
+                                   {NUFFT_HIP_TUNE_SORT2_OFF, NUFFT_HIP_TUNE_SORT2_ON}, {NUFFT_HIP_TUNE_STACK_OFF, NUFFT_HIP_TUNE_STACK_ON},
+                                   {NUFFT_HIP_TUNE_ISPLIT_OFF, NUFFT_HIP_TUNE_ISPLIT_ON}};
     for (const auto& pr : pairs)
       if ((t & pr[0]) && (t & pr[1])) return fail(NUFFT_HIP_INVALID_ARGUMENT, format("options.tuning has both bits of an OFF / ON pair (0x%x)", (unsigned)(pr[0] | pr[1])));
     if (opts_in->op_group < 0 || opts_in->op_lanes < 0) return fail(NUFFT_HIP_INVALID_ARGUMENT, "options.op_group and options.op_lanes must be >= 0");

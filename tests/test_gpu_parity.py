@@ -2361,8 +2361,9 @@ def test_3d_interp_on_cell_sorted_records(tfft):
     tm = plan.get_timing()
     # (3-D double at w = 8 does not fit LDS: generic path, no cell sort; w = 9 takes the wide kernels, which need no cell order)
     wave = plan.info().spread_method == 2 and plan.info().kernel_width <= 8
+    stacked = plan.stacks().shape[0] > 0     # (r06: double-precision type-2 plans also cut stacks of tiles, timed under the same stage)
     plan.close()
-    assert tm['sort_cell'][1] == (1 if wave else 0), tm
+    assert tm['sort_cell'][1] == (1 if wave else 0) + (1 if stacked else 0), tm
     assert rel_l2(out, truth) < tol, rel_l2(out, truth)
 
 
@@ -2450,8 +2451,8 @@ def test_tuning_bits_give_the_same_transforms(tmp_path):
 
   ref = run(str(tmp_path / 'base.npz'), 0)
   for bits in (('NO_FUSED', 'GROUP_OFF', 'SPARSE_OFF', 'CELLSORT_OFF', 'CELLSORT3D_OFF', 'ROCFFT', 'NO_WIDE', 'NO_LINE',
-                'JOINT_OFF', 'STAGED_OFF', 'SORT2_OFF'),
-               ('GROUP_ON', 'SPARSE_OFF', 'CELLSORT_ON', 'CELLSORT3D_ON', 'JOINT_ON', 'STAGED_ON', 'SORT2_ON'),
+                'JOINT_OFF', 'STAGED_OFF', 'SORT2_OFF', 'ISPLIT_OFF'),
+               ('GROUP_ON', 'SPARSE_OFF', 'CELLSORT_ON', 'CELLSORT3D_ON', 'JOINT_ON', 'STAGED_ON', 'SORT2_ON', 'ISPLIT_ON', 'MIXFFT_OFF'),
                ('SPARSE_ON', 'NO_FUSED'), ('QFOLD_OFF',)):
     tuning = 0
     for b in bits:
@@ -3362,3 +3363,117 @@ def test_two_level_sort_with_partial_super_tiles(tfft, tol):
   ref = alt.execute(cc)
   alt.close()
   assert float(torch.linalg.norm(got - ref) / torch.linalg.norm(ref)) < 4e-7
+
+
+@pytest.mark.parametrize('tol', [1e-6, 1e-4, 1e-2])
+def test_double_precision_3d_interp_over_stacks(tfft, tol):
+  # r06: complex128 3-D type 2 / interp at w <= 8 walks the stacks too (interp_point_kernel<..., STACK>: the planes a tile
+  # shares with the next one move down in LDS, only the tile depth's worth of new planes is read). Forced on and off:
+  # bitwise equal (the same cells in the same order per point), and against the fp64 oracle; uniform points, a blob
+  # (pieces of a tile), a line along z, partial last tiles, several transforms, stack lengths 1 / 2 / 5 / default,
+  # per-item points through the op, the interp op.
+  import torch
+  from oracle import oracle
+  from tensorflow_nufft._lib import TUNE
+  rng = np.random.default_rng(707)
+  for grid, M, dist, nt, slen in (([44, 60, 84], 300_000, 0, 1, 0), ([44, 60, 84], 200_000, 1, 2, 2), ([20, 24, 70], 60_000, 2, 1, 5),
+                                  ([9, 33, 12], 20_000, 0, 1, 1), ([64, 64, 64], 150_000, 0, 3, 0)):
+    pts = rng.uniform(-np.pi, np.pi, (M, 3))
+    if dist == 1:
+      k = M // 3
+      pts[:k] = np.array([2.9, -3.0, 0.1]) + 2e-3 * rng.standard_normal((k, 3))
+    elif dist == 2:
+      pts[:, 1:] = rng.uniform(-np.pi, np.pi, (1, 2)) + 1e-2 * rng.standard_normal((M, 2))
+    pts = (pts + np.pi) % (2 * np.pi) - np.pi
+    f = rng.standard_normal([nt] + grid) + 1j * rng.standard_normal([nt] + grid)
+    if nt == 1:
+      f = f[0]
+    outs = {}
+    for stack in ('STACK_ON', 'STACK_OFF'):
+      plan = tfft.Plan('type_2', grid, 'backward', tol=tol, num_transforms=nt, dtype=torch.complex128, tuning=TUNE[stack])
+      kw_ = int(plan.info().kernel_width)
+      full = list(plan.info().tile_dims) == ([16, 16, 8] if kw_ <= 6 else [16, 16, 4])
+      if slen:
+        plan.stack_params(slen, 0)
+      plan.set_points(_dev(pts))
+      assert (plan.stacks().shape[0] > 0) == (stack == 'STACK_ON' and full), (grid, stack, plan.stacks().shape)
+      outs[stack] = plan.execute(_dev(f)).cpu().numpy()
+      plan.close()
+    assert np.array_equal(outs['STACK_ON'], outs['STACK_OFF']), (grid, rel_l2(outs['STACK_ON'], outs['STACK_OFF']))
+    for b in range(nt):
+      f1, o1 = (f[b], outs['STACK_ON'][b]) if nt > 1 else (f, outs['STACK_ON'])
+      truth = oracle.nufft(f1, pts, None, 'type_2', 'backward', tol=1e-12, sigma=2.0)
+      e = rel_l2(o1, truth)
+      if e >= tol:
+        same = oracle.nufft(f1, pts, None, 'type_2', 'backward', tol=tol, sigma=2.0)
+        assert e <= 1.05 * rel_l2(same, truth), (grid, tol, e, rel_l2(same, truth))
+  B, M, grid = 3, 40_000, [24, 40, 32]
+  pts = rng.uniform(-np.pi, np.pi, (B, M, 3))
+  f = rng.standard_normal([B] + grid) + 1j * rng.standard_normal([B] + grid)
+  on = tfft.nufft(_dev(f), _dev(pts), transform_type='type_2', tol=tol, options=_tuned('STACK_ON')).cpu().numpy()
+  off = tfft.nufft(_dev(f), _dev(pts), transform_type='type_2', tol=tol, options=_tuned('STACK_OFF')).cpu().numpy()
+  assert np.array_equal(on, off)
+  truth = oracle.nufft(f[2], pts[2], None, 'type_2', 'forward', tol=1e-12, sigma=2.0)
+  assert rel_l2(on[2], truth) < 3 * tol
+  g2, M = [48, 64, 40], 100_000
+  pts = rng.uniform(-np.pi, np.pi, (M, 3))
+  f = rng.standard_normal(g2) + 1j * rng.standard_normal(g2)
+  res = {}
+  for stack in ('STACK_ON', 'STACK_OFF'):
+    sp = tfft.Plan('type_2', g2, 'forward', tol=tol, spread_only=True, dtype=torch.complex128, tuning=TUNE[stack])
+    sp.set_points(_dev(pts))
+    res[stack] = sp.interp(_dev(f)).cpu().numpy()
+    sp.close()
+  assert np.array_equal(res['STACK_ON'], res['STACK_OFF'])
+
+
+
+@pytest.mark.parametrize('f64', [False, True])
+@pytest.mark.parametrize('tol', [1e-6, 1e-5, 1e-4, 1e-3, 1e-2])
+def test_3d_interp_eight_lanes_per_point(tfft, tol, f64):
+  # r06: the 3-D interpolation with EIGHT lanes per point (interp_point_kernel<..., SPLIT>: lane s sums z plane s of the
+  # stencil, taps shared by shuffle, the eight partial sums combined) -- the default while a tile holds fewer than 192
+  # points on average. Forced on and off against each other and the fp64 oracle: widths 4-8 (lanes past the width carry
+  # weight 0), both precisions, sparse and dense tiles, a blob (tiles with thousands of points: many passes), partial
+  # last tiles, several transforms, the interp op; double precision also over stacks.
+  import torch
+  from oracle import oracle
+  from tensorflow_nufft._lib import TUNE
+  rng = np.random.default_rng(808)
+  rdt, cdt, tdt = (np.float64, np.complex128, torch.complex128) if f64 else (np.float32, np.complex64, torch.complex64)
+  for grid, M, dist, nt in (([44, 60, 84], 40_000, 0, 1), ([44, 60, 84], 300_000, 1, 2), ([9, 33, 12], 5_000, 0, 1), ([40, 40, 40], 700_000, 0, 1)):
+    pts = rng.uniform(-np.pi, np.pi, (M, 3))
+    if dist == 1:
+      k = M // 3
+      pts[:k] = np.array([2.9, -3.0, 0.1]) + 2e-3 * rng.standard_normal((k, 3))
+    pts = ((pts + np.pi) % (2 * np.pi) - np.pi).astype(rdt)
+    f = (rng.standard_normal([nt] + grid) + 1j * rng.standard_normal([nt] + grid)).astype(cdt)
+    if nt == 1:
+      f = f[0]
+    outs = {}
+    for name in ('ISPLIT_ON', 'ISPLIT_OFF'):
+      for stack in (('STACK_OFF', 'STACK_ON') if f64 else ('STACK_OFF',)):
+        plan = tfft.Plan('type_2', grid, 'backward', tol=tol, num_transforms=nt, dtype=tdt, tuning=TUNE[name] | TUNE[stack])
+        plan.set_points(_dev(pts))
+        outs[name, stack] = plan.execute(_dev(f)).cpu().numpy()
+        plan.close()
+    ref = outs['ISPLIT_OFF', 'STACK_OFF']
+    for key, o in outs.items():
+      assert rel_l2(o, ref) < (2e-6 if not f64 else 1e-13), (grid, key, rel_l2(o, ref))
+    for b in range(nt):
+      f1, o1 = (f[b], outs['ISPLIT_ON', 'STACK_OFF'][b]) if nt > 1 else (f, outs['ISPLIT_ON', 'STACK_OFF'])
+      truth = oracle.nufft(f1.astype(np.complex128), pts, None, 'type_2', 'backward', tol=1e-12, sigma=2.0)
+      e = rel_l2(o1, truth)
+      if e >= tol:
+        same = oracle.nufft(f1.astype(np.complex128), pts, None, 'type_2', 'backward', tol=tol, sigma=2.0)
+        assert e <= 1.05 * rel_l2(same, truth) + (1e-6 if not f64 else 1e-13), (grid, tol, e, rel_l2(same, truth))
+  g2, M = [48, 64, 40], 30_000
+  pts = rng.uniform(-np.pi, np.pi, (M, 3)).astype(rdt)
+  f = (rng.standard_normal(g2) + 1j * rng.standard_normal(g2)).astype(cdt)
+  res = {}
+  for name in ('ISPLIT_ON', 'ISPLIT_OFF'):
+    sp = tfft.Plan('type_2', g2, 'forward', tol=tol, spread_only=True, dtype=tdt, tuning=TUNE[name])
+    sp.set_points(_dev(pts))
+    res[name] = sp.interp(_dev(f)).cpu().numpy()
+    sp.close()
+  assert rel_l2(res['ISPLIT_ON'], res['ISPLIT_OFF']) < (2e-6 if not f64 else 1e-13)

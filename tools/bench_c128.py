@@ -31,6 +31,19 @@ if __name__ == '__main__':
       print('tile_dims', td)
       run('type_2', [256, 256, 256], 10_000_000, 1e-6, 3, dtype=c128, tile_dims=td)
       run('type_2', [256, 256, 256], 30_000_000, 1e-6, 3, dtype=c128, tile_dims=td)
+  if 'isplit' in which:
+    from tensorflow_nufft._lib import TUNE
+    for dt, tols in (((c128, (1e-6, 1e-4)),) if 'c128only' in which else ((c128, (1e-6, 1e-4)), (c64, (1e-6, 1e-4)))):
+      for M in (1_000_000, 3_000_000, 10_000_000, 30_000_000, 100_000_000):
+        for tol in tols:
+          run('type_2', [256, 256, 256], M, tol, 3, dtype=dt, tuning=TUNE['ISPLIT_ON'])
+          run('type_2', [256, 256, 256], M, tol, 3, dtype=dt, tuning=TUNE['ISPLIT_OFF'])
+  if 'istack' in which:
+    from tensorflow_nufft._lib import TUNE
+    for M in (3_000_000, 10_000_000, 30_000_000, 100_000_000):
+      for tol in (1e-6, 1e-4):
+        run('type_2', [256, 256, 256], M, tol, 3, dtype=c128, tuning=TUNE['STACK_ON'])
+        run('type_2', [256, 256, 256], M, tol, 3, dtype=c128, tuning=TUNE['STACK_OFF'])
   if 'widestack' in which:
     from tensorflow_nufft._lib import TUNE
     for M in (10_000_000, 30_000_000):
