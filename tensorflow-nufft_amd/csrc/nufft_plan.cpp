@@ -608,7 +608,7 @@ int ensure_point_capacity(nufft_hip_plan p, int64_t M, int rec_mult = 1) {
   }
   // fixed-point 3-D plans that spread over stacks of tiles (r05): the stack descriptors
   // (type-2 plans: the double-precision w <= 8 interpolation walks stacks too, r06)
-  const bool t2_stacks = p->g.fp64_stack && !p->g.wide && p->precision == NUFFT_HIP_F64;
+  const bool t2_stacks = p->g.fp64_stack && (p->g.wide || p->precision == NUFFT_HIP_F64);   // (and the w = 9..16 interpolation)
   const bool stacks = (p->g.fixed_point || p->g.fp64_stack) && p->rank == 3 && (p->type == NUFFT_HIP_TYPE_1 || p->opts.spread_only || t2_stacks) && stack3_wanted(p->g, M);
   if (stacks) {
     const int64_t need_g = (int64_t)stack_grid_bound(p->g, M) + 1;
@@ -735,7 +735,7 @@ int set_points_impl(nufft_hip_plan p, int64_t M, const void* x, const void* y, c
                 (!p->g.fx_patch || p->cap_sub_bound >= (int64_t)stack_grid_bound(p->g, Mtot) + 1)) ? 1 : 0;
   if (sizeof(T) == 8 || p->g.wide) {
     // r06: the fp64-plane kernels over the same stacks (double: spread_wave3_stack_kernel; w = 9..16: spread_wide_kernel)
-    p->g.stack = (p->g.fp64_stack && p->segs && Mtot > 0 && (p->type == NUFFT_HIP_TYPE_1 || p->opts.spread_only || (sizeof(T) == 8 && !p->g.wide)) &&
+    p->g.stack = (p->g.fp64_stack && p->segs && Mtot > 0 &&   // (type 1, type 2 and the spread / interp ops alike: every kernel family here walks stacks)
                   p->cap_segs >= (int64_t)stack_grid_bound(p->g, Mtot) + 1 && stack3_wanted(p->g, Mtot)) ? 1 : 0;
     if (p->g.stack) {
       hook.begin(STAGE_SORT_CELL);

@@ -296,10 +296,15 @@ __device__ __forceinline__ T row_sum16(T v) {
   return v;
 }
 
-template <typename T, int RANK, int W>
+// STACK (r06, 3-D): the workgroup walks a STACK of tiles consecutive in z (stack_plan_kernel, nufft_dense3.hip): the planes a
+// tile shares with the next one move down in LDS, the next tile's T2 new planes are requested into registers before this
+// tile's points (the pipelined form of interp_point_kernel<..., STACK>, nufft_kernels.hip). Tile + halo is 10.8 x the tile
+// at W = 10 (25 x 17 x 13 cells for 16 x 8 x 4), read per subproblem: 256^3 modes, tol 1e-9, M = 1e7: 15.3 ms.
+template <typename T, int RANK, int W, bool STACK = false>
 __global__ __launch_bounds__(kWideNW * 64) void interp_wide_kernel(
     Geom g, SortedPoints<T> sp, const T* __restrict__ horner, T* __restrict__ c,
     const T* __restrict__ fw, int64_t c_stride, int64_t fw_stride, T scale) {
+  static_assert(!STACK || RANK == 3, "stacks: 3-D");
   using G = WideGeo<RANK, W>;
   using T2 = typename Pair<T>::type;
   constexpr int NW = kWideNW, NQ = kWideIQ<RANK>, CH = 4 * NQ, RP = kWideRP<T>;
@@ -308,13 +313,23 @@ __global__ __launch_bounds__(kWideNW * 64) void interp_wide_kernel(
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T2* tile = reinterpret_cast<T2*>(smem_raw);
   T* stage_all = reinterpret_cast<T*>(tile + cells + 16);
-  int tb, p0, p1, slot;
-  if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1, &slot)) return;
+  int tb = 0, p0 = 0, p1 = 0, slot = 0;
+  int t0 = 0, t1 = 0, t2 = 0;
+  StackDesc sd = {0, 0, 1, 0, 0};
+  StackColumn scol = {0, 0, 0};
+  if constexpr (STACK) {
+    if ((int)blockIdx.x >= sp.seg_count[0]) return;
+    sd = stack_load(sp.segs, blockIdx.x);
+    scol = stack_column(g, sd.col);
+    slot = scol.item * (int)gridDim.y + (int)blockIdx.y;
+    t0 = scol.t0; t1 = scol.t1; t2 = sd.z0;
+  } else {
+    if (!locate_subproblem(g, sp.tile_start, sp.sub_start, blockIdx.x, &tb, &p0, &p1, &slot)) return;
+    tile_coords(g, tb, &t0, &t1, &t2);
+  }
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  int t0, t1, t2;
-  tile_coords(g, tb, &t0, &t1, &t2);
   const int o0 = t0 * G::T0, o1 = t1 * G::T1, o2 = t2 * G::T2;
   const T2* in = reinterpret_cast<const T2*>(fw) + (int64_t)slot * fw_stride;
   // tile + halo -> LDS: cells are dealt to threads in flat order (rows are only 24-47 cells long: a
@@ -354,77 +369,141 @@ __global__ __launch_bounds__(kWideNW * 64) void interp_wide_kernel(
   const bool in_x = dx < W;
   const int hq = lane % CH, hd = lane / CH;       // Horner phase: lane = (point of the chunk, dimension)
   T2* cc = reinterpret_cast<T2*>(c) + (int64_t)slot * c_stride;
+  auto do_points = [&](int p0, int p1) {
   const int npt = p1 - p0;
-  const int share = (npt + NW - 1) / NW;
-  const int wbeg = p0 + wave * share;
-  const int wend = (wbeg + share < p1) ? wbeg + share : p1;
+    const int share = (npt + NW - 1) / NW;
+    const int wbeg = p0 + wave * share;
+    const int wend = (wbeg + share < p1) ? wbeg + share : p1;
 
-  for (int base = wbeg; base < wend; base += CH) {
-    int off = 0, idx = 0;
-    if (hd < RANK) {
-      T kv[16];
+    for (int base = wbeg; base < wend; base += CH) {
+      int off = 0, idx = 0;
+      if (hd < RANK) {
+        T kv[16];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) kv[q] = (T)0;
-      const int j = base + hq;
-      if (j < wend) {
-        const PointView<T> rec = unpack_rec<T, RANK>(sp.rec[j]);
-        const T z = hd == 0 ? rec.z0 : (hd == 1 ? rec.z1 : rec.z2);
-        horner16<T>(horner, nc, z, kv);
-        idx = rec.idx;
-        off = (int)(rec.loc & 1023) + (int)((rec.loc >> 10) & 1023) * LS +
-              (RANK > 2 ? (int)((rec.loc >> 20) & 1023) * PS : 0);
-      }
-      T* dst = kst + (hd * CH + hq) * RP;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) dst[q] = kv[q];
-    }
-#pragma unroll 1
-    for (int qq = 0; qq < NQ; ++qq) {
-      const int p = 4 * qq + pr;   // this lane row's point of the chunk (lane p, dimension 0, holds off / idx)
-      if (base + 4 * qq >= wend) break;
-      const int offp = __shfl(off, p);
-      const int idxp = __shfl(idx, p);
-      const T a0 = kst[p * RP + dx];
-      const T a = in_x ? a0 : (T)0;
-      T ky[W];
-#pragma unroll
-      for (int q = 0; q < W; ++q) ky[q] = kst[(CH + p) * RP + q];
-      const T2* tp = tile + offp + dx;
-      T sre = (T)0, sim = (T)0;
-      if (RANK == 2) {
-#pragma unroll
-        for (int dy = 0; dy < W; ++dy) {
-          const T2 v = lds_cell(tp + dy * LS);
-          const T wgt = a * ky[dy];
-          sre = fma(wgt, v.x, sre);
-          sim = fma(wgt, v.y, sim);
+        for (int q = 0; q < 16; ++q) kv[q] = (T)0;
+        const int j = base + hq;
+        if (j < wend) {
+          const PointView<T> rec = unpack_rec<T, RANK>(sp.rec[j]);
+          const T z = hd == 0 ? rec.z0 : (hd == 1 ? rec.z1 : rec.z2);
+          horner16<T>(horner, nc, z, kv);
+          idx = rec.idx;
+          off = (int)(rec.loc & 1023) + (int)((rec.loc >> 10) & 1023) * LS +
+                (RANK > 2 ? (int)((rec.loc >> 20) & 1023) * PS : 0);
         }
-      } else {
-        T kz[W];
+        T* dst = kst + (hd * CH + hq) * RP;
 #pragma unroll
-        for (int q = 0; q < W; ++q) kz[q] = kst[(2 * CH + p) * RP + q];
+        for (int q = 0; q < 16; ++q) dst[q] = kv[q];
+      }
+#pragma unroll 1
+      for (int qq = 0; qq < NQ; ++qq) {
+        const int p = 4 * qq + pr;   // this lane row's point of the chunk (lane p, dimension 0, holds off / idx)
+        if (base + 4 * qq >= wend) break;
+        const int offp = __shfl(off, p);
+        const int idxp = __shfl(idx, p);
+        const T a0 = kst[p * RP + dx];
+        const T a = in_x ? a0 : (T)0;
+        T ky[W];
 #pragma unroll
-        for (int dz = 0; dz < W; ++dz) {
-          const T az = a * kz[dz];
+        for (int q = 0; q < W; ++q) ky[q] = kst[(CH + p) * RP + q];
+        const T2* tp = tile + offp + dx;
+        T sre = (T)0, sim = (T)0;
+        if (RANK == 2) {
 #pragma unroll
           for (int dy = 0; dy < W; ++dy) {
-            const T2 v = lds_cell(tp + dz * PS + dy * LS);
-            const T wgt = az * ky[dy];
+            const T2 v = lds_cell(tp + dy * LS);
+            const T wgt = a * ky[dy];
             sre = fma(wgt, v.x, sre);
             sim = fma(wgt, v.y, sim);
           }
+        } else {
+          T kz[W];
+#pragma unroll
+          for (int q = 0; q < W; ++q) kz[q] = kst[(2 * CH + p) * RP + q];
+#pragma unroll
+          for (int dz = 0; dz < W; ++dz) {
+            const T az = a * kz[dz];
+#pragma unroll
+            for (int dy = 0; dy < W; ++dy) {
+              const T2 v = lds_cell(tp + dz * PS + dy * LS);
+              const T wgt = az * ky[dy];
+              sre = fma(wgt, v.x, sre);
+              sim = fma(wgt, v.y, sim);
+            }
+          }
+        }
+        sre = row_sum16(sre);
+        sim = row_sum16(sim);
+        if (dx == 15 && base + p < wend) {
+          T2 out;
+          out.x = sre * scale;
+          out.y = sim * scale;
+          cc[idxp] = out;
         }
       }
-      sre = row_sum16(sre);
-      sim = row_sum16(sim);
-      if (dx == 15 && base + p < wend) {
-        T2 out;
-        out.x = sre * scale;
-        out.y = sim * scale;
-        cc[idxp] = out;
+    }
+  };
+  if constexpr (STACK) {
+    constexpr int NT = NW * 64;
+    constexpr int NEWC = PS * G::T2;                         // cells of a tile's new planes
+    constexpr int NPF = (NEWC + NT - 1) / NT;
+    static_assert(NPF <= 8, "prefetch registers");
+    constexpr int kRng = 64;
+    __shared__ int rng[2 * kRng];
+    if (sd.p0 < 0) {
+      for (int i = tid; i < sd.nz && i < kRng; i += NT) {
+        const int t = stack_tile_index(g, scol, sd.z0 + i);
+        rng[2 * i] = sp.tile_start[t];
+        rng[2 * i + 1] = sp.tile_start[t + 1];
       }
     }
+    __syncthreads();
+    auto range_of = [&](int i, int* q0, int* q1) {
+      if (sd.p0 >= 0) { *q0 = sd.p0; *q1 = sd.p1; return; }   // a piece: one tile, its own points
+      if (i < kRng) { *q0 = rng[2 * i]; *q1 = rng[2 * i + 1]; return; }
+      const int t = stack_tile_index(g, scol, sd.z0 + i);
+      *q0 = sp.tile_start[t];
+      *q1 = sp.tile_start[t + 1];
+    };
+    for (int ti = 0; ti < sd.nz; ++ti) {
+      const bool more = ti + 1 < sd.nz;
+      int c0, c1;
+      range_of(ti, &c0, &c1);
+      // the next tile's new planes in named registers (see interp_point_kernel); behind the last tile the planes it already
+      // holds are read again and dropped
+      T2 pf0, pf1, pf2, pf3, pf4, pf5, pf6, pf7;
+      const int o2n = (sd.z0 + (more ? ti + 1 : ti)) * G::T2 + (L2 - G::T2);
+      auto pf_src = [&](int u) {
+        const int e = tid + u * NT;
+        const int ec = e < NEWC ? e : NEWC - 1;
+        const int rowi = ec / L0, a0 = ec - rowi * L0;
+        const int a2 = rowi / L1, a1 = rowi - a2 * L1;
+        return in[(int64_t)g.nf[0] * (wrap1(o1 + a1, g.nf[1]) + (int64_t)g.nf[1] * wrap1(o2n + a2, g.nf[2])) + wrap1(o0 + a0, g.nf[0])];
+      };
+#define NUFFT_PF_LOAD(u) if constexpr (u < NPF) pf##u = pf_src(u); else pf##u = T2();
+      NUFFT_PF_LOAD(0) NUFFT_PF_LOAD(1) NUFFT_PF_LOAD(2) NUFFT_PF_LOAD(3) NUFFT_PF_LOAD(4) NUFFT_PF_LOAD(5) NUFFT_PF_LOAD(6) NUFFT_PF_LOAD(7)
+#undef NUFFT_PF_LOAD
+      do_points(c0, c1);
+      if (!more) break;
+      __syncthreads();   // every thread is done with this tile's planes
+      // planes T2 .. L2 - 1 move down by T2: one thread per (y, x) cell and residue of the plane index, upwards
+      for (int e = tid; e < NEWC; e += NT) {
+        const int a2 = e / PS, r = e - a2 * PS;
+        T2* col = tile + r;
+        for (int q = a2; q + G::T2 < L2; q += G::T2) col[q * PS] = col[(q + G::T2) * PS];
+      }
+      __syncthreads();   // (the new planes land where the moved ones were read)
+      auto pf_dst = [&](int u, const T2& v) {
+        const int e = tid + u * NT;
+        if (e < NEWC) tile[(L2 - G::T2) * PS + e] = v;
+      };
+#define NUFFT_PF_STORE(u) if constexpr (u < NPF) pf_dst(u, pf##u);
+      NUFFT_PF_STORE(0) NUFFT_PF_STORE(1) NUFFT_PF_STORE(2) NUFFT_PF_STORE(3) NUFFT_PF_STORE(4) NUFFT_PF_STORE(5) NUFFT_PF_STORE(6) NUFFT_PF_STORE(7)
+#undef NUFFT_PF_STORE
+      __syncthreads();
+    }
+    return;
   }
+  do_points(p0, p1);
 }
 
 template <typename K>
@@ -512,6 +591,22 @@ hipError_t launch_interp_wide(const Geom& g, const SortedPoints<T>& sp, int64_t 
   dim3 grid((unsigned)((int64_t)g.ntiles + M / g.max_sub), (unsigned)batch);
   const size_t lds = wide_interp_lds_bytes(g.rank, g.w, (int)sizeof(T));
   hipError_t e = hipSuccess;
+  if (g.rank == 3 && g.stack && sp.segs) {   // r06: over stacks of tiles
+    const dim3 sgrid(stack_grid_bound(g, M), (unsigned)batch);
+#define NUFFT_WIDE_IPS(WW)                                                                           \
+  case WW:                                                                                           \
+    e = wide_ensure_lds(interp_wide_kernel<T, 3, WW, true>, lds);                                    \
+    if (e != hipSuccess) return e;                                                                   \
+    interp_wide_kernel<T, 3, WW, true><<<sgrid, kWideNW * 64, lds, stream>>>(g, sp, horner, c, fw, c_stride, fw_stride, scale); \
+    break;
+    switch (g.w) {
+      NUFFT_WIDE_IPS(9) NUFFT_WIDE_IPS(10) NUFFT_WIDE_IPS(11) NUFFT_WIDE_IPS(12)
+      NUFFT_WIDE_IPS(13) NUFFT_WIDE_IPS(14) NUFFT_WIDE_IPS(15) NUFFT_WIDE_IPS(16)
+      default: return hipErrorInvalidValue;
+    }
+#undef NUFFT_WIDE_IPS
+    return hipGetLastError();
+  }
 #define NUFFT_WIDE_IP(RR, WW)                                                                        \
   case RR * 100 + WW:                                                                                \
     e = wide_ensure_lds(interp_wide_kernel<T, RR, WW>, lds);                                         \

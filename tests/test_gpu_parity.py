@@ -3365,7 +3365,7 @@ def test_two_level_sort_with_partial_super_tiles(tfft, tol):
   assert float(torch.linalg.norm(got - ref) / torch.linalg.norm(ref)) < 4e-7
 
 
-@pytest.mark.parametrize('tol', [1e-6, 1e-4, 1e-2])
+@pytest.mark.parametrize('tol', [1e-14, 1e-12, 1e-9, 1e-6, 1e-4, 1e-2])
 def test_double_precision_3d_interp_over_stacks(tfft, tol):
   # r06: complex128 3-D type 2 / interp at w <= 8 walks the stacks too (interp_point_kernel<..., STACK>: the planes a tile
   # shares with the next one move down in LDS, only the tile depth's worth of new planes is read). Forced on and off:
@@ -3392,7 +3392,7 @@ def test_double_precision_3d_interp_over_stacks(tfft, tol):
     for stack in ('STACK_ON', 'STACK_OFF'):
       plan = tfft.Plan('type_2', grid, 'backward', tol=tol, num_transforms=nt, dtype=torch.complex128, tuning=TUNE[stack])
       kw_ = int(plan.info().kernel_width)
-      full = list(plan.info().tile_dims) == ([16, 16, 8] if kw_ <= 6 else [16, 16, 4])
+      full = list(plan.info().tile_dims) == ([16, 16, 8] if kw_ <= 6 else [16, 16, 4] if kw_ <= 8 else [16, 8, 4] if kw_ <= 12 else [8, 8, 4] if kw_ <= 15 else [8, 8, 2])   # (w = 9..16: interp_wide_kernel<..., STACK>)
       if slen:
         plan.stack_params(slen, 0)
       plan.set_points(_dev(pts))
@@ -3405,8 +3405,8 @@ def test_double_precision_3d_interp_over_stacks(tfft, tol):
       truth = oracle.nufft(f1, pts, None, 'type_2', 'backward', tol=1e-12, sigma=2.0)
       e = rel_l2(o1, truth)
       if e >= tol:
-        same = oracle.nufft(f1, pts, None, 'type_2', 'backward', tol=tol, sigma=2.0)
-        assert e <= 1.05 * rel_l2(same, truth), (grid, tol, e, rel_l2(same, truth))
+        same = oracle.nufft(f1, pts, None, 'type_2', 'backward', tol=max(tol, 1e-13), sigma=2.0)
+        assert e <= 1.05 * rel_l2(same, truth) + 2e-12, (grid, tol, e, rel_l2(same, truth))
   B, M, grid = 3, 40_000, [24, 40, 32]
   pts = rng.uniform(-np.pi, np.pi, (B, M, 3))
   f = rng.standard_normal([B] + grid) + 1j * rng.standard_normal([B] + grid)
@@ -3414,7 +3414,7 @@ def test_double_precision_3d_interp_over_stacks(tfft, tol):
   off = tfft.nufft(_dev(f), _dev(pts), transform_type='type_2', tol=tol, options=_tuned('STACK_OFF')).cpu().numpy()
   assert np.array_equal(on, off)
   truth = oracle.nufft(f[2], pts[2], None, 'type_2', 'forward', tol=1e-12, sigma=2.0)
-  assert rel_l2(on[2], truth) < 3 * tol
+  assert rel_l2(on[2], truth) < max(3 * tol, 2e-12)
   g2, M = [48, 64, 40], 100_000
   pts = rng.uniform(-np.pi, np.pi, (M, 3))
   f = rng.standard_normal(g2) + 1j * rng.standard_normal(g2)
