@@ -2539,7 +2539,7 @@ __global__ __launch_bounds__(NTHREADS) void interp_point_kernel(
     // first records are requested BEFORE this tile's points are interpolated (r05's lesson from the float stack kernels:
     // a sparse tile's time is the latency of its dependent loads -- range, then record, then planes -- not their bytes)
     constexpr int LC = 16 + W - 1;
-    constexpr int TZ = W <= 6 ? 8 : 4;                      // (the host launches this form on such tiles only)
+    constexpr int TZ = (sizeof(T) == 4 || W <= 6) ? 8 : 4;  // (the host launches this form on such tiles only)
     constexpr int NPF = (LC * LC * TZ + NT - 1) / NT;       // cells of a tile's new planes per thread
     constexpr int kRng = 64;
     __shared__ int rng[2 * kRng];
@@ -2570,8 +2570,8 @@ __global__ __launch_bounds__(NTHREADS) void interp_point_kernel(
       // the next tile's new planes, NPF cells per thread, in NAMED registers (as an array indexed by an unrolled loop they
       // went to scratch memory: 80-128 bytes per lane); requested unconditionally -- behind the last tile the planes it
       // already holds are read again and dropped
-      T2 pf0, pf1, pf2, pf3, pf4, pf5, pf6, pf7;
-      static_assert(NPF <= 8, "prefetch registers");
+      T2 pf0, pf1, pf2, pf3, pf4, pf5, pf6, pf7, pf8, pf9;
+      static_assert(NPF <= 10, "prefetch registers");
       const int tn = more ? ti + 1 : ti;
       range_of(tn, &q0, &q1);
       first = sp.rec[first_index(q0, q1)];
@@ -2585,6 +2585,7 @@ __global__ __launch_bounds__(NTHREADS) void interp_point_kernel(
       };
 #define NUFFT_PF_LOAD(u) if constexpr (u < NPF) pf##u = pf_src(u); else pf##u = T2();
       NUFFT_PF_LOAD(0) NUFFT_PF_LOAD(1) NUFFT_PF_LOAD(2) NUFFT_PF_LOAD(3) NUFFT_PF_LOAD(4) NUFFT_PF_LOAD(5) NUFFT_PF_LOAD(6) NUFFT_PF_LOAD(7)
+      NUFFT_PF_LOAD(8) NUFFT_PF_LOAD(9)
 #undef NUFFT_PF_LOAD
       do_points(c0, c1, first_now);
       if (!more) break;
@@ -2607,6 +2608,7 @@ __global__ __launch_bounds__(NTHREADS) void interp_point_kernel(
       };
 #define NUFFT_PF_STORE(u) if constexpr (u < NPF) pf_dst(u, pf##u);
       NUFFT_PF_STORE(0) NUFFT_PF_STORE(1) NUFFT_PF_STORE(2) NUFFT_PF_STORE(3) NUFFT_PF_STORE(4) NUFFT_PF_STORE(5) NUFFT_PF_STORE(6) NUFFT_PF_STORE(7)
+      NUFFT_PF_STORE(8) NUFFT_PF_STORE(9)
 #undef NUFFT_PF_STORE
       __syncthreads();
     }
@@ -3700,7 +3702,7 @@ hipError_t launch_interp(const Geom& g, int method, const SortedPoints<T>& sp, i
         break;                                                                                        \
       }                                                                                               \
     }                                                                                                 \
-    if constexpr (RR == 3 && sizeof(T) == 8) {                                                        \
+    if constexpr (RR == 3 && sizeof(T) == 8) {   /* (float: measured and rejected, profiles/r06_float_interp_stack_ab.txt) */ \
       if (g.stack && sp.segs && g.tile[0] == 16 && g.tile[1] == 16) {   /* r06: over stacks of tiles */ \
         const dim3 sgrid(stack_grid_bound(g, M), grid.y);                                             \
         if (split3) {                                                                                 \

@@ -608,7 +608,8 @@ int ensure_point_capacity(nufft_hip_plan p, int64_t M, int rec_mult = 1) {
   }
   // fixed-point 3-D plans that spread over stacks of tiles (r05): the stack descriptors
   // (type-2 plans: the double-precision w <= 8 interpolation walks stacks too, r06)
-  const bool t2_stacks = p->g.fp64_stack && (p->g.wide || p->precision == NUFFT_HIP_F64);   // (and the w = 9..16 interpolation)
+  const bool t2_stacks = p->g.fp64_stack && (p->g.wide || p->precision == NUFFT_HIP_F64);   // (and the w = 9..16 interpolation; the float
+                                                                                              // interpolation over stacks lost at every density, r05 and r06)
   const bool stacks = (p->g.fixed_point || p->g.fp64_stack) && p->rank == 3 && (p->type == NUFFT_HIP_TYPE_1 || p->opts.spread_only || t2_stacks) && stack3_wanted(p->g, M);
   if (stacks) {
     const int64_t need_g = (int64_t)stack_grid_bound(p->g, M) + 1;

@@ -44,6 +44,12 @@ if __name__ == '__main__':
       for tol in (1e-6, 1e-4):
         run('type_2', [256, 256, 256], M, tol, 3, dtype=c128, tuning=TUNE['STACK_ON'])
         run('type_2', [256, 256, 256], M, tol, 3, dtype=c128, tuning=TUNE['STACK_OFF'])
+  if 'fistack' in which:   # float 3-D type 2 over stacks (on request only)
+    from tensorflow_nufft._lib import TUNE
+    for M in (1_000_000, 3_000_000, 10_000_000, 30_000_000, 100_000_000):
+      for tol in (1e-6, 1e-4):
+        run('type_2', [256, 256, 256], M, tol, 3, dtype=c64, tuning=TUNE['STACK_ON'])
+        run('type_2', [256, 256, 256], M, tol, 3, dtype=c64, tuning=TUNE['STACK_OFF'])
   if 'wideistack' in which:
     from tensorflow_nufft._lib import TUNE
     for M in (3_000_000, 10_000_000, 30_000_000):
