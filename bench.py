@@ -332,13 +332,14 @@ def other_configs(args, dev):
                  'kernel_width': int(info.kernel_width), 'fine_grid': nf[::-1], 'steps': steps, 'points': dist,
                  'dtype': 'f64' if cdtype == torch.complex128 else 'f32'}
     for st in also:   # further stages of the same pass (timing level 2 covers the dominant kernel only: a third pass)
-      if st not in tm or not tm[st][1]:
+      if not any(tm.get(k, (0, 0))[1] for k in {'fft': ['fft'], 'sort': ['sort_scatter']}.get(st, [st])):
         plan.set_timing(1); plan.get_timing()
         for _ in range(steps):
           step()
         tm = plan.get_timing()
         plan.set_timing(False)
-      out[name][st + '_ms'] = round(sum(tm[k][0] / max(tm[k][1], 1) for k in ([st] if st != 'fft' else ['fft', 'deconvolve', 'zero']) if k in tm), 4)
+      groups = {'fft': ['fft', 'deconvolve', 'zero'], 'sort': ['sort_count', 'sort_scan', 'sort_scatter']}
+      out[name][st + '_ms'] = round(sum(tm[k][0] / max(tm[k][1], 1) for k in groups.get(st, [st]) if k in tm), 4)
     if ttype == 'type_1' and rank == 3 and int(info.kernel_width) <= 8 and cdtype == torch.complex64:
       # the 3-D float fixed-point spreaders are bound by the LDS-atomic data path, not by HBM: ds_add_u64
       # wave-instructions per point of the kernel family (spread_dense3_kernel: one W x 3 x 3 lane block per
@@ -394,6 +395,11 @@ def other_configs(args, dev):
           lambda: plan_case('nonpow2_2d_type1_960_M1e7_tol1e-6', 'type_1', [960, 960], M, TOL, 15, 5, 'spread', also=('fft',)))
   guarded('c128_3d_type1_256_M1e7_tol1e-6',
           lambda: plan_case('c128_3d_type1_256_M1e7_tol1e-6', 'type_1', [256, 256, 256], 10_000_000, 1e-6, 16, 3, 'spread', cdtype=torch.complex128))
+  guarded('c128_3d_type2_256_M1e7_tol1e-6',
+          lambda: plan_case('c128_3d_type2_256_M1e7_tol1e-6', 'type_2', [256, 256, 256], 10_000_000, 1e-6, 18, 3, 'interp', cdtype=torch.complex128))
+  # a grid past 640^3 fine cells (two-level sort over 1728 super-tiles; `sort_ms` = count + scan + scatter)
+  guarded('3d_type1_384_M1e8_tol1e-4',
+          lambda: plan_case('3d_type1_384_M1e8_tol1e-4', 'type_1', [384, 384, 384], 100_000_000, 1e-4, 19, 3, 'spread', also=('sort',)))
   for k in list(out):
     if 'error' not in out[k]:
       out[k].update(pmc_traffic_of(k))
