@@ -3204,11 +3204,12 @@ def test_randomised_smooth_grids_vs_oracle(tfft):
         assert err <= 1.05 * ref_err + (1e-6 if not f64 else 1e-13), (case, rank, grid, f64, tol, M, ttype, fd, B, b, err, ref_err)
 
 
-@pytest.mark.parametrize('n', [18, 20, 24, 30, 36, 48, 50, 60, 90, 100, 150, 162, 240, 250, 270, 384, 400, 480, 486, 500, 640, 750,
-                               960, 972, 1000, 1250, 1280, 1458, 1536, 1620, 1920, 2000, 2250, 2560, 3000, 3072, 3750, 4096])
+@pytest.mark.parametrize('n', [18, 20, 24, 30, 36, 48, 50, 60, 90, 100, 150, 162, 180, 192, 240, 250, 270, 300, 320, 384, 400, 480, 486, 500, 640, 750,
+                               900, 960, 972, 1000, 1250, 1280, 1458, 1536, 1620, 1920, 2000, 2250, 2560, 3000, 3072, 3600, 3750, 4096])
 def test_every_radix_list_of_the_mixed_passes(tfft, n):
-  # one fine-grid length per radix list the factoriser produces (2 ... 6 passes, every radix, lengths up to the LDS
-  # limit): a 2-D transform [n / 2 modes x 12] in both types against rocFFT + deconvolve on the same spread / interp
+  # one fine-grid length per radix list the factoriser produces (1 ... 6 passes, every radix incl. the 12 / 15 / 16 / 20
+  # butterflies of the BIG instantiation -- 240 = 16 x 15, 400 = 20 x 20, 1920 = 16 x 15 x 8, 3600 = 20 x 15 x 12 --, lengths up
+  # to the LDS limit): a 2-D transform [n / 2 modes x 12] in both types against rocFFT + deconvolve on the same spread / interp
   # kernels, and a 1-D type 1 against the oracle
   from oracle import oracle
   rng = np.random.default_rng(n)
