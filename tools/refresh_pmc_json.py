@@ -40,5 +40,7 @@ out['nonpow2_3d_type1_240_M1e7_tol1e-6']['fft_mixed_kernel_per_pass'] = read('mi
 out['nonpow2_3d_type1_240_M1e7_tol1e-6']['note'] = 'traffic = the dominant (spread) kernel; fft_mixed_kernel_per_pass = average of the three passes of the 480^3 fine grid (x 3 = 3.2 GB: what the passes move algorithmically)'
 out['c128_3d_type1_256_M1e7_tol1e-6'] = read('c128_3d_stacks', 'spread_wave3_stack_kernel')
 out['c128_3d_type1_256_M1e7_tol1e-6']['note'] = 'complex128 over stacks: WRITE_SIZE = 2.3 x the 2.15 GB fine grid (per subproblem: 5.7 x)'
+out['c128_3d_type2_256_M1e7_tol1e-6'] = read('c128_3d_type2_stacks', 'interp_point_kernel')
+out['c128_3d_type2_256_M1e7_tol1e-6']['note'] = 'complex128 interpolation over pipelined stacks'
 json.dump(out, open(os.path.join(P, 'pmc_traffic_configs.json'), 'w'), indent=1)
 print('ok', list(out))
