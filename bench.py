@@ -340,6 +340,18 @@ def other_configs(args, dev):
         plan.set_timing(False)
       groups = {'fft': ['fft', 'deconvolve', 'zero'], 'sort': ['sort_count', 'sort_scan', 'sort_scatter']}
       out[name][st + '_ms'] = round(sum(tm[k][0] / max(tm[k][1], 1) for k in groups.get(st, [st]) if k in tm), 4)
+      if st == 'fft' and ttype == 'type_1' and cdtype == torch.complex64:
+        # the pruned type-1 passes against HBM: pass d reads what pass d - 1 kept and writes half of it (sigma = 2), the first
+        # one also stores zeros over the fine grid it read: 8 B x cells x (1 + 1 + 1/2 + 1/2 + 1/4 + 1/4 + 1/8 ...) 
+        cells = 1
+        for n in nf:
+          cells *= n
+        fb, kept = 8 * cells, float(cells)      # (the zeroing store)
+        for d in range(rank):
+          fb += 8 * kept * 1.5
+          kept *= 0.5
+        out[name]['fft_algorithmic_bytes'] = int(fb)
+        out[name]['fft_hbm_frac'] = round(fb / (out[name]['fft_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     if ttype == 'type_1' and rank == 3 and int(info.kernel_width) <= 8 and cdtype == torch.complex64:
       # the 3-D float fixed-point spreaders are bound by the LDS-atomic data path, not by HBM: ds_add_u64
       # wave-instructions per point of the kernel family (spread_dense3_kernel: one W x 3 x 3 lane block per
