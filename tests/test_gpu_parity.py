@@ -2380,7 +2380,13 @@ if len(sys.argv) > 4 and sys.argv[4] == 'host_fft_first':
   # order the r04 experiments tied the fault to (profiles/r04_first_launch.txt)
   h = torch.fft.fft2(torch.ones((192, 160), dtype=torch.complex64, device='cuda'))
   torch.cuda.synchronize()
-out = tfft.nufft(c, pts, grid_shape=grid, transform_type='type_1', tol=1e-2)
+opts = tfft.Options()
+if len(sys.argv) > 5 and sys.argv[5] == 'rocfft':
+  # (r06: a 192 x 160 fine grid runs on the library's own mixed-radix passes now; these children keep the library's
+  # rocFFT plan -- the path the fault was tied to -- in the test)
+  from tensorflow_nufft._lib import TUNE
+  opts._internal = {'tuning': TUNE['ROCFFT']}
+out = tfft.nufft(c, pts, grid_shape=grid, transform_type='type_1', tol=1e-2, options=opts)
 print('SUM', float(out.abs().sum()))
 '''
 
@@ -2398,9 +2404,10 @@ def test_first_launch_in_fresh_processes():
     # (r05: every other child lets the HOST build a rocFFT plan first -- the first call of the process through the
     # op-level entry then loads this library's module behind it; the grid is one rocFFT serves either way)
     mode = 'host_fft_first' if k % 2 else 'plain'
-    r = subprocess.run([sys.executable, '-c', _FRESH_CHILD, ROOT, PKG, '7', mode], capture_output=True, text=True,
+    fft = 'rocfft' if (k // 2) % 2 else 'own'     # (r06: half of them through the library's rocFFT plan, half through its own passes)
+    r = subprocess.run([sys.executable, '-c', _FRESH_CHILD, ROOT, PKG, '7', mode, fft], capture_output=True, text=True,
                        timeout=300)
-    assert r.returncode == 0, (k, mode, r.stderr[-1500:])
+    assert r.returncode == 0, (k, mode, fft, r.stderr[-1500:])
     sums.append(float(r.stdout.strip().splitlines()[-1].split()[1]))
   assert max(sums) - min(sums) <= 1e-4 * abs(sums[0]), sums
 
