@@ -3241,7 +3241,7 @@ def test_every_radix_list_of_the_mixed_passes(tfft, n):
 
 
 
-@pytest.mark.parametrize('tol', [1e-14, 1e-12, 1e-9, 1e-6, 1e-4, 1e-2])
+@pytest.mark.parametrize('tol', [1e-15, 1e-14, 1e-12, 1e-9, 1e-6, 1e-4, 1e-2])   # (1e-15: w = 16 on 8 x 8 x 2 tiles, chains of nine planes)
 def test_double_precision_3d_spread_over_stacks(tfft, tol):
   # r06: complex128 3-D type 1 / spread at w <= 8 walks the stacks of tiles r05 cut for the float kernels
   # (spread_wave3_stack_kernel: fp64 planes, the z halo carried in LDS, planes moved down by the tile depth 4 < w - 1:
@@ -3373,7 +3373,7 @@ def test_two_level_sort_with_partial_super_tiles(tfft, tol):
   assert float(torch.linalg.norm(got - ref) / torch.linalg.norm(ref)) < 4e-7
 
 
-@pytest.mark.parametrize('tol', [1e-14, 1e-12, 1e-9, 1e-6, 1e-4, 1e-2])
+@pytest.mark.parametrize('tol', [1e-15, 1e-14, 1e-12, 1e-9, 1e-6, 1e-4, 1e-2])
 def test_double_precision_3d_interp_over_stacks(tfft, tol):
   # r06: complex128 3-D type 2 / interp at w <= 8 walks the stacks too (interp_point_kernel<..., STACK>: the planes a tile
   # shares with the next one move down in LDS, only the tile depth's worth of new planes is read). Forced on and off:
