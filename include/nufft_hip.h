@@ -50,7 +50,7 @@ extern "C" {
  *   3  options.tuning (validated bits), options_from_proto, op_desc_from_attrs, plan_describe
  *   4  (r06) nufft_hip_build_info. Entries that arrived under version 3's number in r04 / r05 and are guaranteed from
  *      4 on: debug_sub_bounds, debug_shader_clock_mhz, debug_stacks, debug_stack_params; tuning bits FXPATCH_OFF,
- *      QFOLD_OFF, STACK_OFF / STACK_ON, FBGROUP_OFF, and r06's MIXFFT_OFF, ISPLIT_OFF / ISPLIT_ON */
+ *      QFOLD_OFF, STACK_OFF / STACK_ON, FBGROUP_OFF, and r06's MIXFFT_OFF, ISPLIT_OFF / ISPLIT_ON, DIRECT_OFF / DIRECT_ON */
 #define NUFFT_HIP_ABI_VERSION 4
 
 /* Status codes. They map onto the tensorflow::errors the reference returns. */
@@ -151,7 +151,11 @@ enum {
   NUFFT_HIP_TUNE_ISPLIT_OFF = 1 << 24,     /* 3-D interpolation: eight lanes per point (each sums one z plane of the stencil) instead of
                                               a thread per point (r06; by default at w = 7, 8 while a tile holds < 64 points on average): never / always */
   NUFFT_HIP_TUNE_ISPLIT_ON = 1 << 25,
-  NUFFT_HIP_TUNE_ALL = (1 << 26) - 1       /* every defined bit: plan creation refuses others, and both bits of a pair */
+  NUFFT_HIP_TUNE_DIRECT_OFF = 1 << 26,     /* type 2 through the one-call entry (execute_with_points, what an op invocation runs): interpolate
+                                              straight from the caller's unsorted points, no sort (r06; by default for small calls: 2-D up to
+                                              1e5 points, 3-D while a point has > 256 fine cells to itself): never / always */
+  NUFFT_HIP_TUNE_DIRECT_ON = 1 << 27,
+  NUFFT_HIP_TUNE_ALL = (1 << 28) - 1       /* every defined bit: plan creation refuses others, and both bits of a pair */
 };
 
 typedef struct nufft_hip_plan_s* nufft_hip_plan;

@@ -207,6 +207,11 @@ template <typename T>
 hipError_t launch_interp(const Geom& g, int method, const SortedPoints<T>& sp, int64_t M,
                          const T* horner, T* c, const T* fw, int batch, int64_t c_stride,
                          int64_t fw_stride, T scale, hipStream_t stream);
+// r06: interpolation straight from the caller's (unsorted) points, for small type-2 calls through the one-call entry
+bool direct_interp_supported(const Geom& g);
+template <typename T>
+hipError_t launch_interp_direct(const Geom& g, const PointsIn& in, const T* horner, T* c, const T* fw, int batch,
+                                int64_t c_stride, int64_t fw_stride, T scale, hipStream_t stream);
 // dir 1: f = fw / phihat (type-1 step 3); dir 2: fw = f / phihat, zero elsewhere (type-2 step 1).
 template <typename T>
 hipError_t launch_deconvolve(const Geom& g, int dir, T* f, T* fw, const T* const rfser[3],

@@ -2646,6 +2646,64 @@ __global__ __launch_bounds__(NTHREADS) void interp_point_kernel(
   do_points(p0, p1, sp.rec[first_index(p0, p1)]);
 }
 
+// ------------------------------------------------ interp: straight from the caller's points (r06)
+//
+// Small type-2 calls through the one-call entry: no sort at all. A thread folds its point (the sort kernels' own fold),
+// evaluates the kernel and gathers its w^rank fine cells from global memory (L2 / Infinity Cache). A call of the size of
+// the reference harness's first case (2-D, 256^2 modes, M = 2e5) spends 25 of its 50 us sorting points it interpolates once
+// (four launches of 4-8 us: EXPERIMENTS.md 11.4); below ~1e5 points the gather is cheaper than that (12.9). Results leave
+// in the caller's order: coalesced stores.
+template <typename T, int RANK>
+__global__ __launch_bounds__(256) void interp_direct_kernel(Geom g, PointsIn in, const T* __restrict__ horner, T* __restrict__ c,
+                                                            const T* __restrict__ fw, int64_t c_stride, int64_t fw_stride,
+                                                            T scale) {
+  using T2 = typename Pair<T>::type;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= in.M) return;
+  Rec<T> r;
+  bool bad = false;
+  const int tile = fold_point<T>(g, in, i, &r, &bad);
+  int t0, t1, t2;
+  tile_coords(g, tile, &t0, &t1, &t2);
+  const PointView<T> pv = {r.loc, r.z0, r.z1, r.z2, 0};
+  T k0[8], k1[8], k2[8];
+  horner8<T, RANK>(horner, g.ncoef, pv.z0, pv.z1, pv.z2, k0, k1, k2);
+  const int b0 = t0 * g.tile[0] + (int)(pv.loc & 1023);
+  const int b1 = t1 * g.tile[1] + (int)((pv.loc >> 10) & 1023);
+  const int b2 = RANK > 2 ? t2 * g.tile[2] + (int)((pv.loc >> 20) & 1023) : 0;
+  int gx[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) gx[q] = wrap1(b0 + q, g.nf[0]);
+  const int w = g.w;
+  {
+    const int y = (int)blockIdx.y;   // transform of the batch
+    const T2* inp = reinterpret_cast<const T2*>(fw) + (int64_t)y * fw_stride;
+    T sre = (T)0, sim = (T)0;
+    for (int dz = 0; dz < (RANK > 2 ? w : 1); ++dz) {
+      const int64_t zoff = RANK > 2 ? (int64_t)wrap1(b2 + dz, g.nf[2]) * g.nf[1] : 0;
+      T pre = (T)0, pim = (T)0;
+      for (int dy = 0; dy < w; ++dy) {
+        const T2* row = inp + (zoff + wrap1(b1 + dy, g.nf[1])) * (int64_t)g.nf[0];
+        T rre = (T)0, rim = (T)0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const T2 v = row[gx[q]];          // (taps beyond the width are exactly 0: the cell is read and ignored)
+          rre = fma(k0[q], v.x, rre);
+          rim = fma(k0[q], v.y, rim);
+        }
+        pre = fma(k1[dy], rre, pre);
+        pim = fma(k1[dy], rim, pim);
+      }
+      if (RANK > 2) { sre = fma(k2[dz], pre, sre); sim = fma(k2[dz], pim, sim); }
+      else { sre = pre; sim = pim; }
+    }
+    T2 out;
+    out.x = sre * scale;
+    out.y = sim * scale;
+    (reinterpret_cast<T2*>(c) + (int64_t)y * c_stride)[i] = out;
+  }
+}
+
 // ------------------------------------------------ interp: generic tile path
 
 // One workgroup per subproblem, one thread per point, gathering w^rank fine
@@ -3765,6 +3823,22 @@ template hipError_t launch_interp<float>(const Geom&, int, const SortedPoints<fl
 template hipError_t launch_interp<double>(const Geom&, int, const SortedPoints<double>&, int64_t,
                                           const double*, double*, const double*, int, int64_t,
                                           int64_t, double, hipStream_t);
+
+// Interpolation straight from unsorted points (interp_direct_kernel): rank 2 / 3, w <= 8, one point set.
+bool direct_interp_supported(const Geom& g) { return (g.rank == 2 || g.rank == 3) && g.w <= 8 && g.nitems <= 1 && !g.wide; }
+template <typename T>
+hipError_t launch_interp_direct(const Geom& g, const PointsIn& in, const T* horner, T* c, const T* fw, int batch,
+                                int64_t c_stride, int64_t fw_stride, T scale, hipStream_t stream) {
+  if (in.M == 0) return hipSuccess;
+  const dim3 grid((unsigned)((in.M + 255) / 256), (unsigned)batch);
+  if (g.rank == 2) interp_direct_kernel<T, 2><<<grid, 256, 0, stream>>>(g, in, horner, c, fw, c_stride, fw_stride, scale);
+  else interp_direct_kernel<T, 3><<<grid, 256, 0, stream>>>(g, in, horner, c, fw, c_stride, fw_stride, scale);
+  return hipGetLastError();
+}
+template hipError_t launch_interp_direct<float>(const Geom&, const PointsIn&, const float*, float*, const float*, int, int64_t,
+                                                int64_t, float, hipStream_t);
+template hipError_t launch_interp_direct<double>(const Geom&, const PointsIn&, const double*, double*, const double*, int, int64_t,
+                                                 int64_t, double, hipStream_t);
 
 template <typename T>
 hipError_t launch_deconvolve(const Geom& g, int dir, T* f, T* fw, const T* const rfser[3],

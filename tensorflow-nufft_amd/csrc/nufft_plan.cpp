@@ -249,6 +249,7 @@ struct nufft_hip_plan_s {
   int64_t cap_sub_bound = 0;
   int* fb_list = nullptr;        // fixed-point 3-D plans: count + launch slots of the subproblems left to the fp64 planes
   int64_t cap_fb_list = 0;
+  const PointsIn* direct_in = nullptr;   // r06: set for the duration of a direct (unsorted) type-2 call of the one-call entry
   int4* segs = nullptr;          // Geom::stack: [0].x = how many stacks, [1..] their descriptors (stack_plan_kernel)
   int64_t cap_segs = 0;
   TapMax taps = {};              // per-tap maxima of the fitted kernel (bound3_kernel)
@@ -851,7 +852,7 @@ int maybe_cellsort(nufft_hip_plan p, int launches) {
 
 template <typename T>
 int execute_impl(nufft_hip_plan p, void* c, void* f) {
-  if (!p->points_set) {
+  if (!p->points_set && !p->direct_in) {
     p->err = "set_points must be called before execute";
     return NUFFT_HIP_INVALID_ARGUMENT;
   }
@@ -929,8 +930,11 @@ int execute_impl(nufft_hip_plan p, void* c, void* f) {
         if (stop == STAGE_FFT) continue;
       }
       hook.begin(STAGE_INTERP);
-      HIP_TRY(p, launch_interp<T>(p->g, p->method, sp, p->M * p->nitems, (const T*)p->d_horner, cb, fw, nb,
-                                  p->M, p->fine_elems, (T)1, p->stream));
+      if (p->direct_in)   // r06: straight from the caller's points (small calls of the one-call entry)
+        HIP_TRY(p, launch_interp_direct<T>(p->g, *p->direct_in, (const T*)p->d_horner, cb, fw, nb, p->M, p->fine_elems, (T)1, p->stream));
+      else
+        HIP_TRY(p, launch_interp<T>(p->g, p->method, sp, p->M * p->nitems, (const T*)p->d_horner, cb, fw, nb,
+                                    p->M, p->fine_elems, (T)1, p->stream));
       hook.end(STAGE_INTERP);
     }
   }
@@ -1043,7 +1047,7 @@ static int configure(nufft_hip_plan* out, int type, int rank, const int64_t* gri
                                    {NUFFT_HIP_TUNE_CELLSORT_OFF, NUFFT_HIP_TUNE_CELLSORT_ON}, {NUFFT_HIP_TUNE_CELLSORT3D_OFF, NUFFT_HIP_TUNE_CELLSORT3D_ON},
                                    {NUFFT_HIP_TUNE_JOINT_OFF, NUFFT_HIP_TUNE_JOINT_ON}, {NUFFT_HIP_TUNE_STAGED_OFF, NUFFT_HIP_TUNE_STAGED_ON},
                                    {NUFFT_HIP_TUNE_SORT2_OFF, NUFFT_HIP_TUNE_SORT2_ON}, {NUFFT_HIP_TUNE_STACK_OFF, NUFFT_HIP_TUNE_STACK_ON},
-                                   {NUFFT_HIP_TUNE_ISPLIT_OFF, NUFFT_HIP_TUNE_ISPLIT_ON}};
+                                   {NUFFT_HIP_TUNE_ISPLIT_OFF, NUFFT_HIP_TUNE_ISPLIT_ON}, {NUFFT_HIP_TUNE_DIRECT_OFF, NUFFT_HIP_TUNE_DIRECT_ON}};
     for (const auto& pr : pairs)
       if ((t & pr[0]) && (t & pr[1])) return fail(NUFFT_HIP_INVALID_ARGUMENT, format("options.tuning has both bits of an OFF / ON pair (0x%x)", (unsigned)(pr[0] | pr[1])));
     if (opts_in->op_group < 0 || opts_in->op_lanes < 0) return fail(NUFFT_HIP_INVALID_ARGUMENT, "options.op_group and options.op_lanes must be >= 0");
@@ -1534,6 +1538,12 @@ int nufft_hip_set_points(nufft_hip_plan p, int64_t M, const void* x, const void*
     }                                                                       \
   } while (0)
 
+// r06, direct type-2 interpolation (tools/exp_direct_interp.py, profiles/r06_direct_interp.txt: us per tfft.nufft call, direct /
+// sorted): 2-D 256^2 modes M = 2e4 32 / 39, 1e5 35 / 41, 2e5 44 / 45, 5e5 65 / 56; 1024^2: 1e5 60 / 72, 2e5 82 / 74; 3-D 128^3: 2e4 153 / 270,
+// 1e5 267 / 268, 2e5 469 / 278; 64^3: 2e4 80 / 67 -- in 2-D up to 1e5 points, in 3-D while a point has > 256 fine cells to itself
+constexpr int64_t kDirectMaxPoints2d = 100000;
+constexpr int64_t kDirectCellsPerPoint3d = 256;
+
 int nufft_hip_execute_with_points(nufft_hip_plan p, int64_t M, const void* x, const void* y,
                                   const void* z, int64_t stride, void* c, void* f) {
   NUFFT_REQUIRE_DEVICE_PLAN(p);
@@ -1552,6 +1562,33 @@ int nufft_hip_execute_with_points(nufft_hip_plan p, int64_t M, const void* x, co
   // one type-1 transform: the sort can carry the strengths inside the records
   const bool fuse = type1 && p->ntransf == 1 && p->precision == NUFFT_HIP_F32 && c &&
                     fused_sort_supported(p->g, p->method, p->precision, M);
+  // r06: a small type-2 call interpolates straight from these points -- no sort (four launches) for points that are
+  // used once
+  if (!type1 && !p->opts.spread_only && M > 0 && direct_interp_supported(p->g) && p->stop_after < 0 &&
+      !(p->opts.check_points_range && p->opts.points_range != NUFFT_HIP_RANGE_INFINITE) &&
+      p->opts.spread_method == NUFFT_HIP_METHOD_AUTO) {
+    const int mode = tune_mode(p->g, NUFFT_HIP_TUNE_DIRECT_OFF, NUFFT_HIP_TUNE_DIRECT_ON);
+    const bool small = p->rank == 2 ? M <= kDirectMaxPoints2d : M * kDirectCellsPerPoint3d <= (int64_t)p->fine_elems;
+    if (mode > 0 || (mode < 0 && small)) {
+      int rc = ensure_fixed_workspace(p);
+      if (rc) return rc;
+      PointsIn in;
+      in.pts[0] = x; in.pts[1] = p->rank > 1 ? y : x; in.pts[2] = p->rank > 2 ? z : x;
+      in.stride = stride;
+      in.M = in.M_item = M;
+      in.blocks_per_item = 1;
+      in.range_mode = p->opts.points_range;
+      in.check_range = 0;
+      in.strengths = nullptr;
+      in.aos = 0;
+      p->M = M;
+      p->points_set = false;   // (nothing of these points stays in the plan)
+      p->direct_in = &in;
+      rc = p->precision == NUFFT_HIP_F32 ? execute_impl<float>(p, c, f) : execute_impl<double>(p, c, f);
+      p->direct_in = nullptr;
+      return rc;
+    }
+  }
   int rc = p->precision == NUFFT_HIP_F32 ? set_points_impl<float>(p, M, x, y, z, stride, fuse ? c : nullptr)
                                          : set_points_impl<double>(p, M, x, y, z, stride);
   if (rc) return rc;

@@ -24,7 +24,7 @@ METHOD_AUTO, METHOD_TILE_GENERIC, METHOD_TILE_WAVE, METHOD_POINT_GLOBAL = 0, 1, 
 TUNE = {name: 1 << bit for bit, name in enumerate((
     'NO_FUSED', 'GROUP_OFF', 'GROUP_ON', 'SPARSE_OFF', 'SPARSE_ON', 'CELLSORT_OFF', 'CELLSORT_ON', 'CELLSORT3D_OFF',
     'CELLSORT3D_ON', 'ROCFFT', 'NO_WIDE', 'NO_LINE', 'JOINT_OFF', 'JOINT_ON', 'STAGED_OFF', 'STAGED_ON',
-    'SORT2_OFF', 'SORT2_ON', 'FXPATCH_OFF', 'QFOLD_OFF', 'STACK_OFF', 'STACK_ON', 'FBGROUP_OFF', 'MIXFFT_OFF', 'ISPLIT_OFF', 'ISPLIT_ON'))}
+    'SORT2_OFF', 'SORT2_ON', 'FXPATCH_OFF', 'QFOLD_OFF', 'STACK_OFF', 'STACK_ON', 'FBGROUP_OFF', 'MIXFFT_OFF', 'ISPLIT_OFF', 'ISPLIT_ON', 'DIRECT_OFF', 'DIRECT_ON'))}
 STAGES = ('sort_count', 'sort_scan', 'sort_scatter', 'zero', 'spread', 'fft', 'deconvolve', 'interp', 'sort_cell')
 
 

@@ -3485,3 +3485,59 @@ def test_3d_interp_eight_lanes_per_point(tfft, tol, f64):
     res[name] = sp.interp(_dev(f)).cpu().numpy()
     sp.close()
   assert rel_l2(res['ISPLIT_ON'], res['ISPLIT_OFF']) < (2e-6 if not f64 else 1e-13)
+
+
+@pytest.mark.parametrize('f64', [False, True])
+def test_small_type2_calls_interpolate_without_a_sort(tfft, f64):
+  # r06: type 2 through the one-call entry (execute_with_points = what tfft.nufft runs) on a small problem interpolates
+  # straight from the caller's unsorted points (interp_direct_kernel: fold, kernel, gather from the L2-resident fine
+  # grid; no sort). Forced on and off against the fp64 oracle and each other: ranks 2 and 3, widths 2-8, both signs,
+  # several transforms per call, points outside [-pi, pi) (EXTENDED range: folded), a strided [M, rank] layout (the
+  # op's), and by default: taken for a small call, not for a large one or a plan with several point sets.
+  import torch
+  from oracle import oracle
+  from tensorflow_nufft._lib import TUNE
+  rng = np.random.default_rng(909)
+  rdt, cdt, tdt = (np.float64, np.complex128, torch.complex128) if f64 else (np.float32, np.complex64, torch.complex64)
+  for grid, M, tol, nt, fd in (([48, 64], 30_000, 1e-6, 1, 'backward'), ([33, 47], 9_000, 1e-4, 3, 'forward'), ([256, 256], 200_000, 1e-6, 1, 'forward'),
+                               ([20, 24, 18], 20_000, 1e-6, 2, 'backward'), ([9, 31, 12], 4_000, 1e-2, 1, 'forward'), ([40, 40, 40], 50_000, 1e-5, 1, 'forward')):
+    rank = len(grid)
+    pts = rng.uniform(-3 * np.pi, 3 * np.pi, (M, rank)).astype(rdt)     # EXTENDED range: folded by the kernel
+    f = (rng.standard_normal([nt] + grid) + 1j * rng.standard_normal([nt] + grid)).astype(cdt)
+    if nt == 1:
+      f = f[0]
+    outs = {}
+    for name in ('DIRECT_ON', 'DIRECT_OFF'):
+      plan = tfft.Plan('type_2', grid, fd, tol=tol, num_transforms=nt, dtype=tdt, tuning=TUNE[name])
+      outs[name] = plan.execute_with_points(_dev(pts), _dev(f)).cpu().numpy()
+      if name == 'DIRECT_ON':
+        assert plan.sort_path() == -1          # nothing was sorted: no points stay in the plan
+        with pytest.raises(Exception):
+          plan.execute(_dev(f))
+      plan.close()
+    bar = 2e-6 if not f64 else 1e-13
+    assert rel_l2(outs['DIRECT_ON'], outs['DIRECT_OFF']) < bar, (grid, rel_l2(outs['DIRECT_ON'], outs['DIRECT_OFF']))
+    pf = ((pts.astype(np.float64) + np.pi) % (2 * np.pi) - np.pi)
+    for b in range(nt):
+      f1, o1 = (f[b], outs['DIRECT_ON'][b]) if nt > 1 else (f, outs['DIRECT_ON'])
+      truth = oracle.nufft(f1.astype(np.complex128), pf, None, 'type_2', fd, tol=1e-12, sigma=2.0)
+      e = rel_l2(o1, truth)
+      if e >= tol:
+        same = oracle.nufft(f1.astype(np.complex128), pf, None, 'type_2', fd, tol=tol, sigma=2.0)
+        assert e <= 1.05 * rel_l2(same, truth) + (1e-6 if not f64 else 1e-13), (grid, tol, e)
+  # the default: small call -> direct; through the op as well (its points arrive as one [M, rank] array)
+  grid, M = [64, 64], 50_000
+  pts = rng.uniform(-np.pi, np.pi, (M, 2)).astype(rdt)
+  f = (rng.standard_normal(grid) + 1j * rng.standard_normal(grid)).astype(cdt)
+  plan = tfft.Plan('type_2', grid, 'forward', tol=1e-6, dtype=tdt)
+  plan.execute_with_points(_dev(pts), _dev(f))
+  assert plan.sort_path() == -1
+  plan.close()
+  out = tfft.nufft(_dev(f), _dev(pts), transform_type='type_2', tol=1e-6).cpu().numpy()
+  truth = oracle.nufft(f.astype(np.complex128), pts, None, 'type_2', 'forward', tol=1e-12, sigma=2.0)
+  assert rel_l2(out, truth) < 1e-6
+  big = tfft.Plan('type_2', [512, 512], 'forward', tol=1e-6, dtype=tdt)
+  pb = _dev(rng.uniform(-np.pi, np.pi, (300_000, 2)).astype(rdt))
+  big.execute_with_points(pb, _dev((rng.standard_normal([512, 512]) + 0j).astype(cdt)))
+  assert big.sort_path() >= 0                # a large call sorts as before
+  big.close()
