@@ -1,4 +1,5 @@
-// Pruned FFT passes of the NUFFT plan for power-of-two fine grids (gfx950).
+// Pruned FFT passes of the NUFFT plan (gfx950): fft_rotate_kernel for power-of-two fine-grid dimensions up to 2048,
+// fft_mixed_kernel (r06, second half of this file) for every other even 2^a 3^b 5^c length up to 4096.
 //
 // The reference runs a full in-place FFT of the oversampled grid (cuFFT / FFTW,
 // nufft_plan.cu.cc:2147-2152, nufft_plan.cc:336) and then a separate deconvolve kernel
