@@ -17,6 +17,7 @@
 #include <list>
 #include <mutex>
 #include <numeric>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -505,10 +506,30 @@ int nufft_hip_op_compute_ex(const nufft_hip_op_desc* desc, const void* source, c
     // (a plan takes at most 4096 point sets and 65535 transforms x sets: an oversized request is cut, not refused)
     group = std::min<int64_t>(group, std::min<int64_t>(4096, 65535 / std::max<int64_t>(1, a.num_transforms)));
     if (group < 1) group = 1;
+    // (r06: the geometry of this configuration, memoised -- plan_describe builds a host plan (Gauss-Legendre rule, kernel fit):
+    // ~150 us of host time on EVERY grouped call, more than the GPU needs for a group of 16 small transforms)
     nufft_hip_plan_info pi;
-    char pe[256];
-    if (nufft_hip_plan_describe(desc->transform_type, rank, dims, desc->fft_direction, (int)a.num_transforms, tol,
-                                desc->precision, &opts, &pi, pe, sizeof(pe)) == NUFFT_HIP_OK) {
+    bool described = false;
+    {
+      static std::mutex dmu;
+      static std::map<std::string, nufft_hip_plan_info> dcache;
+      const std::string dkey = plan_key(desc, opts, a, desc->transform_type, (int)a.num_transforms, tol, nullptr, 0, false);
+      std::lock_guard<std::mutex> lk(dmu);
+      const auto it = dcache.find(dkey);
+      if (it != dcache.end()) {
+        pi = it->second;
+        described = true;
+      } else {
+        char pe[256];
+        described = nufft_hip_plan_describe(desc->transform_type, rank, dims, desc->fft_direction, (int)a.num_transforms, tol,
+                                            desc->precision, &opts, &pi, pe, sizeof(pe)) == NUFFT_HIP_OK;
+        if (described) {
+          if (dcache.size() >= 256) dcache.clear();
+          dcache[dkey] = pi;
+        }
+      }
+    }
+    if (described) {
       const double fine_bytes = (double)pi.fine_dims[0] * pi.fine_dims[1] * pi.fine_dims[2] * csize *
                                 (opts.spread_only ? 0.0 : (double)a.num_transforms);
       const int64_t ntiles = (int64_t)pi.num_tiles[0] * pi.num_tiles[1] * pi.num_tiles[2];
@@ -635,9 +656,22 @@ int nufft_hip_op_compute_ex(const nufft_hip_op_desc* desc, const void* source, c
     pfac[d2] = pfac[d2 + 1] * pts_outer[d2 + 1];
   }
   const size_t rsize = (size_t)desc->precision;
+  // (r06: the fork / join events live in a per-thread, per-device pool -- creating and destroying three of them was part
+  // of every multi-lane call's host time)
+  auto pooled_event = [&](int i, hipEvent_t* ev) {
+    static thread_local std::map<int, std::vector<hipEvent_t>> pool;
+    std::vector<hipEvent_t>& v = pool[device];
+    if ((int)v.size() <= i) v.resize(i + 1, nullptr);
+    if (!v[i]) {
+      const hipError_t e = hipEventCreateWithFlags(&v[i], hipEventDisableTiming);
+      if (e != hipSuccess) { v[i] = nullptr; return e; }
+    }
+    *ev = v[i];
+    return hipSuccess;
+  };
   hipEvent_t ev_fork = nullptr, ev_join[kMaxLanes] = {};
   if (nlanes > 1) {
-    hipError_t e = hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming);
+    hipError_t e = pooled_event(0, &ev_fork);
     if (e == hipSuccess) e = hipEventRecord(ev_fork, stream);
     for (int l = 0; l < nlanes && e == hipSuccess; ++l) e = hipStreamWaitEvent(lane_stream[l], ev_fork, 0);
     if (e != hipSuccess) return hip_fail(e);
@@ -671,7 +705,6 @@ int nufft_hip_op_compute_ex(const nufft_hip_op_desc* desc, const void* source, c
   for (int64_t gi = 0; gi < nfull && !rc; ++gi) rc = run_group(gi, plans[gi % nlanes]);
   if (rc) {
     const std::string msg = nufft_hip_last_error(plan);
-    if (ev_fork) (void)hipEventDestroy(ev_fork);
     cleanup();
     release_all();
     return fail(errbuf, errbuf_len, rc, msg);
@@ -679,13 +712,10 @@ int nufft_hip_op_compute_ex(const nufft_hip_op_desc* desc, const void* source, c
   if (nlanes > 1) {   // join: the caller's stream continues after both lanes
     hipError_t e = hipSuccess;
     for (int l = 0; l < nlanes && e == hipSuccess; ++l) {
-      e = hipEventCreateWithFlags(&ev_join[l], hipEventDisableTiming);
+      e = pooled_event(1 + l, &ev_join[l]);
       if (e == hipSuccess) e = hipEventRecord(ev_join[l], lane_stream[l]);
       if (e == hipSuccess) e = hipStreamWaitEvent(stream, ev_join[l], 0);
     }
-    (void)hipEventDestroy(ev_fork);
-    for (int l = 0; l < nlanes; ++l)
-      if (ev_join[l]) (void)hipEventDestroy(ev_join[l]);
     if (e != hipSuccess) return hip_fail(e);
   }
   if (tail != group) {   // the shorter last group, on the caller's stream

@@ -26,7 +26,21 @@ def _options_bytes(options):
   (python/ops/nufft_ops.py:118-123: `options or Options()`, always serialized)."""
   if isinstance(options, (bytes, bytearray)):
     return bytes(options)
-  return (options or nufft_options.Options()).to_proto().SerializeToString()
+  if options is None:
+    return _default_options_bytes()
+  return options.to_proto().SerializeToString()
+
+
+_DEFAULT_OPTIONS_BYTES = None
+
+
+def _default_options_bytes():
+  """Serialized default Options, built once (r06: constructing and serializing the default Options model cost ~25 us
+  of host time on every call -- as much as the plan-level call itself on a small transform)."""
+  global _DEFAULT_OPTIONS_BYTES
+  if _DEFAULT_OPTIONS_BYTES is None:
+    _DEFAULT_OPTIONS_BYTES = nufft_options.Options().to_proto().SerializeToString()
+  return _DEFAULT_OPTIONS_BYTES
 
 
 def _apply_internal_options(o, options):
@@ -216,7 +230,6 @@ def nufft(source, points, grid_shape=None, transform_type='type_2',
   if grid_shape is None and transform_type == 'type_1':
     raise ValueError("grid_shape must be provided for type-1 transforms")
   _check_enums(transform_type, fft_direction)
-  options = options or nufft_options.Options()
   needs_grad = any(isinstance(t, torch.Tensor) and t.requires_grad for t in (source, points))
   if needs_grad and torch.is_grad_enabled():
     return _NufftFunction.apply(source, points, grid_shape, transform_type, fft_direction, tol, options)
