@@ -1056,9 +1056,12 @@ __global__ __launch_bounds__(kStackPlanWaves * 64) void stack_plan_kernel(Geom g
 // the z pass over the tile's TZ layers and the last W - 1 layers of the tile before it. add_tile(i, cnt) adds the
 // weights of the stack's i-th tile to cnt[TZ][T][T + 1] (zeroed, behind a barrier; called by every thread).
 // a: TZ T L floats, b: (TZ + W - 1) L L floats, wmax: NT / 64 floats. Returns the maximum in every thread.
-template <int W, int TZ, int NT, typename AddTile>
+struct NoPrefetch { __device__ __forceinline__ void operator()(int) const {} };
+// pre_tile(i): called before the filter passes of tile i - 1 (and once up front with 0) -- a place to request tile i's
+// point range and first records so that their latency hides behind those passes (r06)
+template <int W, int TZ, int NT, typename AddTile, typename PreTile = NoPrefetch>
 __device__ __forceinline__ float stack_filter_max(int nz, AddTile add_tile, uint32_t* cnt, float* a, float* b, float* wmax,
-                                                  const float (&km)[W], int tid) {
+                                                  const float (&km)[W], int tid, PreTile pre_tile = PreTile()) {
   constexpr int T = kDenseTile, L = T + W - 1, CP = T + 1, H = W - 1, NS = TZ + H;
   static_assert(H <= TZ, "the z halo must end inside the next tile");
   // b: a circular buffer of TZ + H layers -- tile i's layer z in slot (i TZ + z) mod NS, so that the last H layers of
@@ -1066,11 +1069,13 @@ __device__ __forceinline__ float stack_filter_max(int nz, AddTile add_tile, uint
   // buffers of TZ layers made 54 KB, two per CU)
   float best = 0.f;
   int s0 = 0;   // slot of this tile's layer 0
+  pre_tile(0);
   for (int i = 0; i <= nz; ++i) {   // (i == nz: the halo planes behind the last tile)
     if (i < nz) {
       for (int q = tid; q < TZ * T * CP; q += NT) cnt[q] = 0u;
       __syncthreads();
       add_tile(i, cnt);
+      if (i + 1 < nz) pre_tile(i + 1);
       __syncthreads();
       count_filter_xy<W, TZ, NT, NS>(cnt, a, b, km, tid, s0);
     }
@@ -1136,19 +1141,44 @@ __global__ __launch_bounds__(kBoundThreads) void bound3_stack_kernel(Geom g, con
   float km[W];
 #pragma unroll
   for (int t = 0; t < W; ++t) km[t] = taps.k[t];
-  float m = stack_filter_max<W, TZ, NT>(d.nz, [&](int i, uint32_t* c) {
-    int p0 = d.p0, p1 = d.p1;
-    if (p0 < 0) {
+  // r06: the tiles' point ranges are read up front and every thread's first record of tile i + 1 is requested before
+  // the filter passes of tile i: the two dependent loads at the head of a tile (range, then records) were exposed
+  // once per tile -- at ~76 points per tile most of this kernel's time (sort_cell stage 0.40 ms at 256^3 / M = 1e7)
+  constexpr int kRng = 32;
+  __shared__ int rng[2 * kRng];
+  if (d.p0 < 0) {
+    for (int i = tid; i < d.nz && i < kRng; i += NT) {
       const int t = stack_tile_index(g, cc, d.z0 + i);
-      p0 = tile_start[t];
-      p1 = tile_start[t + 1];
+      rng[2 * i] = tile_start[t];
+      rng[2 * i + 1] = tile_start[t + 1];
     }
-    for (int j = p0 + tid; j < p1; j += NT) {
+  }
+  __syncthreads();
+  auto range_of = [&](int i, int* q0, int* q1) {
+    if (d.p0 >= 0) { *q0 = d.p0; *q1 = d.p1; return; }
+    if (i < kRng) { *q0 = rng[2 * i]; *q1 = rng[2 * i + 1]; return; }
+    const int t = stack_tile_index(g, cc, d.z0 + i);
+    *q0 = tile_start[t];
+    *q1 = tile_start[t + 1];
+  };
+  uint32_t nx0 = 0u, nx1 = 0u, nx2 = 0u;   // the start-cell bits of this thread's first record of the next tile
+  float m = stack_filter_max<W, TZ, NT>(d.nz, [&](int i, uint32_t* c) {
+    int p0, p1;
+    range_of(i, &p0, &p1);
+    if (p0 + tid < p1) atomicAdd(&c[((nx2 >> 28) * T + (nx1 >> 28)) * CP + (nx0 >> 28)], 1u);   // (requested by pre_tile(i))
+    for (int j = p0 + tid + NT; j < p1; j += NT) {
       const Rec<float>& r = rec_at(rec, j, rec_stride);
       const uint32_t l0 = r.loc >> 28, l1 = __float_as_uint(r.z0) >> 28, l2 = __float_as_uint(r.z1) >> 28;
       atomicAdd(&c[(l2 * T + l1) * CP + l0], 1u);
     }
-  }, cnt, a, b, wmax, km, tid);
+  }, cnt, a, b, wmax, km, tid, [&](int i) {
+    int p0, p1;
+    range_of(i, &p0, &p1);
+    if (p0 + tid < p1) {
+      const Rec<float>& r = rec_at(rec, p0 + tid, rec_stride);
+      nx0 = r.loc; nx1 = __float_as_uint(r.z0); nx2 = __float_as_uint(r.z1);
+    }
+  });
   if (tid == 0) {
     m *= 1.0001f;   // (float sums of non-negative terms)
     if (m > g.fx_bound_limit) {
